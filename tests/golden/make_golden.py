@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE (read-only, /root/reference).
+
+Runs only in the build container (the reference never travels).  Usage:
+
+    python tests/golden/make_golden.py            # both flavours
+    python tests/golden/make_golden.py portable   # one flavour, in-process (expects the env below)
+
+Two flavours are written ("Oracle and the two reference flavours"):
+
+* ``portable`` -- NumPy's SIMD dispatch disabled (NPY_DISABLE_CPU_FEATURES) so arctan2/arctan/tan/arccos
+  are glibc libm and argpartition/argsort are NumPy's portable C loops.  This is what the reference
+  computes on a CPU without AVX2/AVX-512 and what a C restatement linked against the same glibc can match
+  bit for bit.  These fixtures are the parity gate.
+* ``native``   -- default dispatch on this container's Sapphire-Rapids vCPUs (Intel SVML loops, x86-simd-sort).
+  float32 arctan2 differs from glibc's in 40 % of inputs by one float32 ULP here, i.e. the reference's own
+  output is machine-dependent at that level; tests report mismatch counts against this flavour.
+
+What is stored is data only: inputs and the reference's outputs.
+"""
+import os
+import random
+import subprocess
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REF = Path("/root/reference")
+DISABLE = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
+
+if __name__ == "__main__" and len(sys.argv) == 1:
+    for flavour in ("portable", "native"):
+        env = dict(os.environ, MPLBACKEND="Agg")
+        if flavour == "portable":
+            env["NPY_DISABLE_CPU_FEATURES"] = DISABLE
+        else:
+            env.pop("NPY_DISABLE_CPU_FEATURES", None)
+        subprocess.check_call([sys.executable, __file__, flavour], env=env)
+    sys.exit(0)
+
+FLAVOUR = sys.argv[1]
+os.environ.setdefault("MPLBACKEND", "Agg")
+import numpy as np  # noqa: E402
+
+sys.path.insert(0, str(REF))
+sys.path.insert(0, str(HERE.parent.parent))
+for name in ("lib", "lib.OpenPCDet", "lib.OpenPCDet.pcdet", "lib.OpenPCDet.pcdet.utils",
+             "lib.OpenPCDet.pcdet.utils.calibration_kitti"):
+    m = types.ModuleType(name)
+    m.__path__ = []
+    sys.modules[name] = m
+sys.modules["lib.OpenPCDet.pcdet.utils"].calibration_kitti = sys.modules["lib.OpenPCDet.pcdet.utils.calibration_kitti"]
+
+import scipy  # noqa: E402
+import sklearn  # noqa: E402
+import tools.snowfall.geometry as g  # noqa: E402
+import tools.snowfall.sampling as smp  # noqa: E402
+import tools.snowfall.simulation as sim  # noqa: E402
+import tools.wet_ground.augmentation as wet  # noqa: E402
+import tools.wet_ground.phy_equations as phy  # noqa: E402
+import yaml  # noqa: E402
+
+from lidar_snow_sim_amd.synthetic import synthetic_sweep  # noqa: E402
+
+META = dict(flavour=FLAVOUR, python=sys.version.split()[0], numpy=np.__version__, scipy=scipy.__version__,
+            sklearn=sklearn.__version__, npy_disable=os.environ.get("NPY_DISABLE_CPU_FEATURES", ""))
+BEAM_DIV = float(np.degrees(3e-3))          # precompute.py:104, pointcloud_viewer.py:2809
+PREFIX = "gunn_x_y"
+LASERS = yaml.safe_load(open(REF / "calib" / "20171102_64E_S3.yaml"))["lasers"]
+
+
+def save(name, **arrays):
+    out = HERE / f"{name}_{FLAVOUR}.npz"
+    np.savez_compressed(out, meta=np.array(repr(META)), **arrays)
+    print(f"  wrote {out.name}: {out.stat().st_size / 1024:.0f} KiB")
+
+
+def flatten_dicts(dicts):
+    cnt = np.array([len(d) for d in dicts], np.int64)
+    keys = np.array([k for d in dicts for k in d.keys()], np.int64)
+    rj = np.array([float(v[0]) for d in dicts for v in d.values()], np.float64)
+    ratio = np.array([float(v[1]) for d in dicts for v in d.values()], np.float64)
+    return cnt, keys, rj, ratio
+
+
+def make_tables():
+    """4 gunn tables at 2.5 mm/h @ 1.6 m/s with R0 = 40 m, one 0.5 mm/h @ 2.0 m/s table with R0 = 30 m."""
+    occ, rate = smp.compute_occupancy(2.5, 1.6), smp.snowfall_rate_to_rainfall_rate(2.5, 1.6)
+    tabs = [smp.dart_throwing(occ, rate, 40.0, np.random.default_rng(43 + i), "gunn") for i in range(4)]
+    occ, rate = smp.compute_occupancy(0.5, 2.0), smp.snowfall_rate_to_rainfall_rate(0.5, 2.0)
+    dense = smp.dart_throwing(occ, rate, 30.0, np.random.default_rng(7), "gunn")
+    return tabs, dense
+
+
+def write_table_files(root, tables):
+    """<root>/training/snowflakes/npy/<prefix>_<1..64>.npy, the 4 tables reused round-robin (sim:324-325)."""
+    d = Path(root) / "training" / "snowflakes" / "npy"
+    d.mkdir(parents=True, exist_ok=True)
+    for line in range(1, 65):
+        np.save(d / f"{PREFIX}_{line}.npy", tables[(line - 1) % len(tables)])
+
+
+def small_frame(beams_per_channel, seed, dtype, intensity="lambert"):
+    """A channel-major sub-sampling of the 64 x 2048 synthetic sweep, incl. beams next to azimuth 0 (Q9)."""
+    full = synthetic_sweep(64, 2048, seed=seed, intensity=intensity, dtype=np.float64).reshape(64, 2048, 5)
+    rng = np.random.default_rng(seed)
+    cols = np.sort(rng.choice(2048, beams_per_channel - 4, replace=False))
+    cols = np.concatenate((cols, [1023, 1024, 1025, 0]))    # azimuth ~ +-1e-4, +-3e-3 rad and ~ -pi
+    pc = full[:, cols, :].reshape(-1, 5)
+    return pc.astype(dtype)
+
+
+def main():
+    print(f"[{FLAVOUR}] numpy {np.__version__}, disable='{META['npy_disable']}'")
+    rng = np.random.default_rng(2024)
+    tabs, dense = make_tables()
+    if FLAVOUR == "portable":
+        np.savez_compressed(HERE / "tables.npz", **{f"t{i}": t for i, t in enumerate(tabs)}, dense=dense)
+    else:  # the sampler only uses sqrt/cos/sin/exponential: identical in both flavours or we want to know
+        ref = np.load(HERE / "tables.npz")
+        same = all(np.array_equal(ref[f"t{i}"], t) for i, t in enumerate(tabs)) and np.array_equal(ref["dense"], dense)
+        print("  tables identical across flavours:", same)
+        if not same:
+            tabs = [ref[f"t{i}"] for i in range(4)]
+            dense = ref["dense"]
+
+    # ---- L0 scalar helpers -----------------------------------------------------------------------
+    rs = np.array([0.5, 1.0, 1.5, 2.0, 2.5, 10.0])
+    vt = np.array([0.2, 0.6, 1.0, 1.6, 2.0])
+    grid = np.array([(a, b) for a in rs for b in vt])
+    xs = np.concatenate((np.linspace(0.5, 1.5, 41), [0.9, 1.0, 3.0, 50.0]))
+    rp_args = np.array([(229.5 / (1e-6 / np.pi), 1e-6 / np.pi, q, R, rj, 1e-8)
+                        for q in (0.1, 1.0) for rj in (0.95, 5.0, 33.3) for R in (rj, rj + 0.7, rj + 1.5, rj + 2.9)])
+    save("L0_helpers", grid=grid,
+         occupancy=np.array([smp.compute_occupancy(a, b) for a, b in grid]),
+         rain=np.array([smp.snowfall_rate_to_rainfall_rate(a, b) for a, b in grid]),
+         snow=np.array([smp.rainfall_rate_to_snowfall_rate(a * 7, b) for a, b in grid]),
+         gunn=np.array([smp.gunn_marshall(a * 7) for a in rs]), sekhon=np.array([smp.sekhon_srivastava(a * 7) for a in rs]),
+         xsi_in=xs, xsi=np.array([sim.xsi(v) for v in xs], np.float64),
+         rp_args=rp_args, rp=np.array([sim.received_power(*a) for a in rp_args]))
+
+    # ---- L1 geometry -----------------------------------------------------------------------------
+    disks = tabs[0][rng.choice(len(tabs[0]), 400, replace=False)].copy()
+    extra = np.array([[0.004, 3.0, 0.004],      # |x| == r: one tangent vertical (geometry.py:163)
+                      [-0.006, -2.0, 0.006],
+                      [5.0, 1e-4, 0.004],       # straddles the 0 / 2pi seam
+                      [5.0, -1e-4, 0.004],
+                      [0.3, 0.31, 0.01], [-0.42, 0.05, 0.009], [0.0, 7.0, 0.003], [-9.0, 0.0, 0.002]])
+    disks = np.concatenate((disks, extra))
+    phi = np.arctan2(disks[:, 1], disks[:, 0])
+    phi[phi < 0] += 2 * np.pi
+    ta, tb = g.tangents_from_origin(disks)
+    tang = g.tangent_lines_to_tangent_angles((ta, tb), phi.copy())
+    ang = np.column_stack((rng.uniform(0, 2 * np.pi, 64), rng.uniform(0, 2 * np.pi, 64)))
+    ang[0] = [np.pi / 2, 3 * np.pi / 2]
+    la, lb = g.angles_to_lines(ang)
+    dist = g.distances_of_points_to_lines(disks[:, :2], la[5, np.newaxis].T, lb[5, np.newaxis].T, np.zeros((2, 1)))
+    fwd = g.do_angles_intersect_particles(ang[5, 0], disks[:, :2])
+    save("L1_geometry", disks=disks, phi=phi, rho=np.linalg.norm([disks[:, 0], disks[:, 1]], axis=0),
+         tang_a=ta, tang_b=tb, tangent_angles=tang, angles=ang, line_a=la, line_b=lb, dist5=dist, fwd5=fwd)
+
+    # ---- L2 compute_occlusion_dict ---------------------------------------------------------------
+    cases = []
+    eps = 1e-3
+    cases.append(((2 * np.pi - eps, 2 * eps), np.array([[2 * np.pi - 0.4 * eps, 2 * np.pi - 0.0 * eps - 1e-9, 10.0]]), 30.0, np.degrees(3 * eps)))
+    cases.append(((2 * np.pi - eps, 2 * eps), np.array([[0.2 * eps, 0.8 * eps, 10.0]]), 30.0, np.degrees(3 * eps)))
+    cases.append(((2 * np.pi - eps, 2 * eps), np.array([[2 * np.pi - 0.3 * eps, 0.5 * eps, 10.0]]), 30.0, np.degrees(3 * eps)))
+    cases.append(((1.0, 1.0 + 5 * eps), np.array([[1.0 + eps, 1.0 + 2 * eps, 5.0], [1.0, 1.0 + 3 * eps, 7.0],
+                                                   [1.0 + 0.5 * eps, 1.0 + 5 * eps, 9.0], [1.0 + eps, 1.0 + 1.5 * eps, 11.0]]),
+                  30.0, np.degrees(5 * eps)))
+    for _ in range(60):
+        L = int(rng.integers(0, 14))
+        base = rng.uniform(0.01, 6.0)
+        wdt = 3e-3
+        a1 = base + rng.uniform(-0.2, 1.0, L) * wdt
+        a2 = a1 + rng.uniform(0.001, 0.6, L) * wdt
+        a1 = np.maximum(a1, base)
+        a2 = np.minimum(a2, base + wdt)
+        ok = a2 > a1
+        iv = np.column_stack((a1[ok], a2[ok], np.sort(rng.uniform(1, 40, ok.sum()))))
+        cases.append(((base, base + wdt), iv, 41.0, np.degrees(wdt)))
+    l2 = dict(n=np.array(len(cases)))
+    for i, (ba, iv, rng_m, bd) in enumerate(cases):
+        d = sim.compute_occlusion_dict(ba, iv.copy(), rng_m, bd)
+        c, k, r, q = flatten_dicts([d])
+        l2.update({f"ba{i}": np.array(ba), f"iv{i}": iv, f"range{i}": np.array(rng_m), f"bd{i}": np.array(bd),
+                   f"keys{i}": k, f"rj{i}": r, f"ratio{i}": q})
+    save("L2_occlusion_dict", **l2)
+
+    with tempfile.TemporaryDirectory() as root:
+        write_table_files(root, tabs)
+        np.save(Path(root) / "training" / "snowflakes" / "npy" / "dense_1.npy", dense)
+
+        # ---- L3 get_occlusions ---------------------------------------------------------------------
+        nb = 160
+        centre = np.concatenate((rng.uniform(0, 2 * np.pi, nb - 8),
+                                 [1e-4, 2 * np.pi - 1e-4, 1.4e-3, 2 * np.pi - 1.4e-3, 1.6e-3, 0.0, np.pi / 2, 3 * np.pi / 2]))
+        half = np.radians(BEAM_DIV / 2)
+        ba = np.column_stack((centre - half, centre + half))
+        ba[ba < 0] += 2 * np.pi
+        ba[ba > 2 * np.pi] -= 2 * np.pi
+        ranges = rng.uniform(3, 60, nb)
+        l3 = dict(beam_angles=ba, ranges=ranges, bd=np.array(BEAM_DIV))
+        for tag, fname in (("t0", f"{PREFIX}_1.npy"), ("dense", "dense_1.npy")):
+            occ = sim.get_occlusions(ba.copy(), ranges.copy(), root, fname, BEAM_DIV)
+            c, k, r, q = flatten_dicts(occ)
+            l3.update({f"{tag}_count": c, f"{tag}_keys": k, f"{tag}_rj": r, f"{tag}_ratio": q})
+        # float32 ranges (what process_single_channel really passes, sim:89, :103)
+        occ = sim.get_occlusions(ba.copy(), ranges.astype(np.float32), root, f"{PREFIX}_1.npy", BEAM_DIV)
+        c, k, r, q = flatten_dicts(occ)
+        l3.update(dict(t0f32_count=c, t0f32_keys=k, t0f32_rj=r, t0f32_ratio=q))
+        # a 10x wider beam on the dense table: long intersecting lists (beyond 32 in places)
+        bd_wide = float(np.degrees(3e-2))
+        hw = np.radians(bd_wide / 2)
+        baw = np.column_stack((centre - hw, centre + hw))
+        baw[baw < 0] += 2 * np.pi
+        baw[baw > 2 * np.pi] -= 2 * np.pi
+        occ = sim.get_occlusions(baw.copy(), ranges.copy(), root, "dense_1.npy", bd_wide)
+        c, k, r, q = flatten_dicts(occ)
+        l3.update(dict(wide_beam_angles=baw, wide_bd=np.array(bd_wide), wide_count=c, wide_keys=k, wide_rj=r, wide_ratio=q))
+        print(f"    L3 wide: max dict size {c.max()}, mean {c.mean():.1f}")
+        save("L3_get_occlusions", **l3)
+
+        # ---- L4 process_single_channel --------------------------------------------------------------
+        order = list(range(64))
+        l4 = dict(order=np.array(order), bd=np.array(BEAM_DIV))
+        for dt in (np.float32, np.float64):
+            pc = small_frame(40, seed=1001, dtype=dt)
+            tag = np.dtype(dt).name
+            l4[f"pc_{tag}"] = pc
+            for ch in (0, 14, 22, 34, 53, 56, 63):
+                diff, idx, out = sim.process_single_channel(root, PREFIX, pc.copy(), BEAM_DIV, order, LASERS, ch)
+                l4[f"{tag}_ch{ch}_diff"] = np.array(diff, np.float64)
+                l4[f"{tag}_ch{ch}_idx"] = idx
+                l4[f"{tag}_ch{ch}_out"] = out
+        # dense table through channel 5 (long scatterer lists)
+        pc = small_frame(40, seed=1002, dtype=np.float32)
+        diff, idx, out = sim.process_single_channel(root, "dense", pc.copy(), BEAM_DIV, [0] * 64, LASERS, 5)
+        l4.update(dense_pc=pc, dense_diff=np.array(diff, np.float64), dense_idx=idx, dense_out=out)
+        # far targets (grid end, sim:146-149), near targets (xsi ramp under NEP 50, sim:553-569), wide beams
+        def ring(n, r_lo, r_hi, ch, seed, dt):
+            rr = np.random.default_rng(seed)
+            az = rr.uniform(-np.pi, np.pi, n)
+            el = rr.uniform(-0.3, 0.03, n)
+            rg = rr.uniform(r_lo, r_hi, n)
+            return np.column_stack((rg * np.cos(el) * np.cos(az), rg * np.cos(el) * np.sin(az), rg * np.sin(el),
+                                    rr.integers(1, 255, n), np.full(n, ch))).astype(dt)
+        rr = np.random.default_rng(5)
+        nr, na = rr.uniform(0.25, 0.95, 300), rr.uniform(0, 2 * np.pi, 300)
+        near_tab = np.column_stack((nr * np.cos(na), nr * np.sin(na), rr.uniform(1e-3, 5e-3, 300)))
+        np.save(Path(root) / "training" / "snowflakes" / "npy" / "nearflakes_1.npy", near_tab)
+        l4["nearflakes_xyr"] = near_tab
+        for tag, (lo, hi, ch, bd, pref, dt) in dict(far=(88.0, 119.9, 10, BEAM_DIV, PREFIX, np.float32),
+                                                    far64=(88.0, 119.9, 58, BEAM_DIV, PREFIX, np.float64),
+                                                    wide=(15.0, 60.0, 20, bd_wide, "dense", np.float32),
+                                                    wide64=(15.0, 60.0, 41, bd_wide, "dense", np.float64),
+                                                    near=(0.86, 1.25, 3, bd_wide, "nearflakes", np.float32),
+                                                    near64=(0.86, 1.25, 3, bd_wide, "nearflakes", np.float64)).items():
+            pc = ring(48, lo, hi, ch, 77, dt)
+            diff, idx, out = sim.process_single_channel(root, pref, pc.copy(), bd, [0] * 64, LASERS, ch)
+            l4.update({f"{tag}_pc": pc, f"{tag}_bd": np.array(bd), f"{tag}_ch": np.array(ch), f"{tag}_table": np.array(pref),
+                       f"{tag}_diff": np.array(diff, np.float64), f"{tag}_out": out})
+            print(f"    L4 {tag}: labels {np.bincount(out[:, 4].astype(int), minlength=3)}")
+        save("L4_process_single_channel", **l4)
+
+        # ---- L5 augment ----------------------------------------------------------------------------
+        l5 = dict(bd=np.array(BEAM_DIV))
+        case = 0
+        for dt in (np.float32, np.float64):
+            for shuffle, seed in ((True, 3), (False, 0)):
+                for plane in (None, ([0.0, 0.0, -1.0], -1.7)):
+                    pc = small_frame(28, seed=1100 + case, dtype=dt)
+                    # ride a source-index column through augment (the reference only touches columns 0..4)
+                    pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(dt)
+                    random.seed(seed)
+                    order = list(range(64))
+                    if shuffle:
+                        random.shuffle(order)
+                    random.seed(seed)
+                    orig_plane = sim.calculate_plane
+                    if plane is not None:
+                        sim.calculate_plane = lambda _pc, _p=plane: (np.asarray(_p[0]), _p[1])
+                    try:
+                        stats, aug = sim.augment(pc6, PREFIX, BEAM_DIV, shuffle=shuffle, show_progressbar=False,
+                                                 only_camera_fov=False, noise_floor=0.7, root_path=root)
+                    finally:
+                        sim.calculate_plane = orig_plane
+                    l5.update({f"c{case}_pc": pc, f"c{case}_order": np.array(order),
+                               f"c{case}_plane_w": np.array([0, 0, 1.0] if plane is None else plane[0]),
+                               f"c{case}_plane_h": np.array(-1.55 if plane is None else plane[1]),
+                               f"c{case}_injected": np.array(plane is not None),
+                               f"c{case}_stats": np.array(stats, np.int64), f"c{case}_aug": aug[:, :5],
+                               f"c{case}_src": aug[:, 5].astype(np.int64)})
+                    print(f"    L5 case {case}: {np.dtype(dt).name} shuffle={shuffle} plane={'inj' if plane else 'fallback'} "
+                          f"stats={tuple(int(s) for s in stats)} labels={np.bincount(aug[:, 4].astype(int), minlength=3)}")
+                    case += 1
+        # Q5: channel ids >= 64 are never processed and keep their id in the label column
+        pc = small_frame(8, seed=1200, dtype=np.float32)
+        pc[-5:, 4] = 70
+        pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(np.float32)
+        sim.calculate_plane = lambda _pc: (np.asarray([0.0, 0.0, -1.0]), -1.7)
+        try:
+            stats, aug = sim.augment(pc6, PREFIX, BEAM_DIV, shuffle=False, only_camera_fov=False, root_path=root)
+        finally:
+            sim.calculate_plane = orig_plane
+        l5.update(q5_pc=pc, q5_stats=np.array(stats, np.int64), q5_aug=aug[:, :5], q5_src=aug[:, 5].astype(np.int64))
+        l5["n_cases"] = np.array(case)
+        save("L5_augment", **l5)
+
+    # ---- L6 wet ground -----------------------------------------------------------------------------
+    l6 = {}
+    case = 0
+    for dt in (np.float32, np.float64):
+        for flat in (False, True):
+            for replace in (True, False):
+                pc = small_frame(48, seed=1300 + case, dtype=dt)
+                wet.calculate_plane = lambda _pc: (np.asarray([0.0, 0.0, -1.0]), -1.7)
+                kw = dict(water_height=0.0008, pavement_depth=0.001, noise_floor=0.7, power_factor=15,
+                          estimation_method="linear", flat_earth=flat, debug=False, delta=0.5, replace=replace)
+                out = wet.ground_water_augmentation(pc.copy(), **kw)
+                l6.update({f"c{case}_pc": pc, f"c{case}_flat": np.array(flat), f"c{case}_replace": np.array(replace),
+                           f"c{case}_out": out})
+                print(f"    L6 case {case}: {np.dtype(dt).name} flat={flat} replace={replace} {pc.shape} -> {out.shape} {out.dtype}")
+                case += 1
+    # estimate_laser_parameters on its own
+    pc = small_frame(48, seed=1400, dtype=np.float32)
+    wv = np.asarray([0.0, 0.0, -1.0])
+    grd = np.abs(pc[:, :3] @ wv - 1.7) < 0.5
+    gp = pc[grd]
+    angle = np.arccos((gp[:, :3] @ wv) / (np.linalg.norm(gp[:, :3], axis=1) * np.linalg.norm(wv)))
+    rel, thr, p, _ = wet.estimate_laser_parameters(gp, angle, noise_floor=0.7, debug=False)
+    l6.update(elp_pc=gp, elp_angle=angle, elp_rel=rel, elp_thr=thr, elp_p=np.array(p))
+    ang = np.linspace(0.01, 1.55, 64)
+    rho = np.linspace(0.05, 1.0, 64)
+    l6.update(fres_angle=ang, fres_rho=rho, fres=np.array(phy.total_transmittance_from_ground(ang, rho=rho)))
+    l6["n_cases"] = np.array(case)
+    save("L6_wet_ground", **l6)
+
+    # ---- L7 dart_throwing --------------------------------------------------------------------------
+    l7 = {}
+    for i, (rs_, vt_, mode, r0, seed) in enumerate(((2.5, 1.6, "gunn", 8.0, 11), (0.5, 2.0, "sekhon", 6.0, 12),
+                                                     (10.0, 1.6, "gunn", 12.0, 13))):
+        occ, rate = smp.compute_occupancy(rs_, vt_), smp.snowfall_rate_to_rainfall_rate(rs_, vt_)
+        t = smp.dart_throwing(occ, rate, r0, np.random.default_rng(seed), mode)
+        l7.update({f"t{i}": t, f"args{i}": np.array([occ, rate, r0, seed]), f"mode{i}": np.array(mode)})
+    occ, rate = smp.compute_occupancy(2.5, 1.6), smp.snowfall_rate_to_rainfall_rate(2.5, 1.6)
+    t = smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(42), "gunn")
+    l7.update(big_count=np.array(len(t)), big_sum=t.sum(axis=0), big_args=np.array([occ, rate, 80.0, 42]),
+              big_head=t[:64], big_tail=t[-64:])
+    print(f"    L7: R0=80 table has {len(t)} flakes")
+    save("L7_dart_throwing", **l7)
+
+
+main()
