@@ -1,0 +1,165 @@
+/*
+ * snowgpu.h -- C ABI of libsnowgpu.so, the MI355X (gfx950) snowfall-augmentation engine.
+ *
+ * This is the drop-in boundary for ONE hot path of SysCV/LiDAR_snow_sim: the per-beam snow
+ * scattering simulation behind
+ *     tools/snowfall/simulation.py::augment                 (simulation.py:427-544)
+ *       -> process_single_channel                           (simulation.py:50-194)
+ *       -> get_occlusions / compute_occlusion_dict          (simulation.py:298-424, :231-295)
+ *       -> tools/snowfall/geometry.py                       (geometry.py:14-223)
+ *       -> received_power / xsi                             (simulation.py:547-569)
+ * plus the noise-threshold prepass it shares with the wet-ground model
+ *     tools/wet_ground/augmentation.py::estimate_laser_parameters (augmentation.py:195-266)
+ * and the wet-ground intensity model itself
+ *     tools/wet_ground/augmentation.py::ground_water_augmentation (augmentation.py:25-161).
+ *
+ * The reference is pure Python/NumPy and has no FFI; what a maintainer binds instead of its
+ * Python loops is shown in INTEGRATION.md (a ctypes stub).  All pointers are caller-owned,
+ * little-endian, C-order.  No C++ exception crosses this boundary: every entry point returns
+ * an int status (0 = ok) and snowgpu_last_error() returns a message for the last failure.
+ *
+ * Conventions shared by every entry point
+ *   rows      : (x, y, z, intensity, channel) per point, float32 (dtype 0) or float64 (dtype 1)
+ *               -- the STF .bin row the reference reads (precompute.py:78) and returns
+ *   frames    : a batch is n_frames frames concatenated; frame f owns rows
+ *               [frame_offsets[f], frame_offsets[f+1])
+ *   labels    : output column 4 is the reference's label: 0 unchanged, 1 attenuated,
+ *               2 scattered (simulation.py:160, :174, :192); rows whose channel is not an
+ *               integer in [0, n_lasers) are never simulated and keep their channel value there
+ *               (simulation.py:480-483, quirk Q5)
+ *   order     : output rows are in the reference's order -- sorted by channel
+ *               (simulation.py:447), STABLY here (the reference's argsort is unstable, so its
+ *               within-channel order is implementation-defined); out_src returns, per output
+ *               row, the index of the input row it came from (frame-local)
+ */
+#ifndef SNOWGPU_H
+#define SNOWGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct snowgpu_ctx snowgpu_ctx;
+
+enum {
+    SNOWGPU_OK = 0,
+    SNOWGPU_E_INVALID = 1,      /* bad argument (null pointer, negative size, unknown table id) */
+    SNOWGPU_E_HIP = 2,          /* a HIP runtime call failed; see snowgpu_last_error */
+    SNOWGPU_E_TABLE = 3,        /* particle table the reference could not process either
+                                   (disk containing the origin, non-finite row) */
+    SNOWGPU_E_RANGE = 4,        /* a simulated point has range >= ~120 m: the reference raises
+                                   IndexError there (simulation.py:146-149, quirk Q6) */
+    SNOWGPU_E_CHANNELS = 5,     /* channel column holds values other than integers in [0, 255]
+                                   and no explicit permutation was supplied */
+    SNOWGPU_E_OVERFLOW = 6,     /* more than SNOWGPU_MAX_FLAKES_PER_BEAM flakes intersect one beam */
+    SNOWGPU_E_GROUND = 7,       /* fewer than 3 ground points: the reference raises TypeError
+                                   (simulation.py:462 on None, quirk Q7) */
+    SNOWGPU_E_NO_DEVICE = 8     /* no HIP device / device index out of range */
+};
+
+#define SNOWGPU_MAX_FLAKES_PER_BEAM 63
+#define SNOWGPU_MAX_LASERS 256
+#define SNOWGPU_RANGE_BINS 1230  /* M_extended, simulation.py:113 */
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* One context per (device, host thread).  Owns a HIP stream, the uploaded tables and all scratch. */
+int snowgpu_create(int device, snowgpu_ctx **out);
+void snowgpu_destroy(snowgpu_ctx *ctx);
+const char *snowgpu_last_error(const snowgpu_ctx *ctx);
+/* "snowgpu <version> gfx950 ..." -- also usable without a device to check the library loads. */
+const char *snowgpu_version(void);
+
+/* Replaces yaml.safe_load(calib/20171102_64E_S3.yaml) + the per-channel constants of
+ * simulation.py:72-76, :123-126.  focal_offset[c] = (1 - focal_distance[c]*100/13100)**2 is
+ * computed by the caller exactly as the reference does (Python float arithmetic). */
+int snowgpu_set_lasers(snowgpu_ctx *ctx, int n_lasers, const double *focal_slope,
+                       const double *focal_offset, const int32_t *min_intensity,
+                       const int32_t *max_intensity);
+
+/* Replaces np.load(<prefix>_<line>.npy) (simulation.py:324-330) and hoists the per-flake,
+ * beam-independent work of get_occlusions (simulation.py:351-354; geometry.py:138-190, :32-80)
+ * out of the frame loop: rows are (x, y, disk radius) float64.  table_id is a small non-negative
+ * integer chosen by the caller; uploading again under the same id replaces the table. */
+int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t n_flakes);
+int snowgpu_table_count(const snowgpu_ctx *ctx);
+
+/* The 1230-entry range grid of simulation.py:106-116 as the library computes it (for tests). */
+int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/*
+ * snowgpu_augment_batch -- augment() (simulation.py:427-544, only_camera_fov=False) for a batch of
+ * frames whose rows live in HOST memory.
+ *
+ *   table_ids  n_frames x n_lasers: the table feeding channel c of frame f, i.e. the id the caller
+ *              uploaded `<prefix>_<order[c]+1>.npy` under (simulation.py:70, :78, :482-486)
+ *   beam_divergence_deg  as passed to augment() (degrees; simulation.py:96-97)
+ *   thr_poly   n_frames x 3 quadratic (p0, p1, p2) of the per-point noise threshold over range
+ *              (simulation.py:467-469), or NULL to run the prepass (simulation.py:449-467) on the
+ *              device with plane (plane_w[3], plane_h) per frame: n_frames x 4 doubles (wx, wy, wz, h)
+ *   noise_floor  augment()'s noise_floor (only used by the device prepass)
+ *   perm       optional n_total int32 permutation (frame-local source row of each channel-sorted
+ *              position); NULL = stable counting sort by channel on the device
+ *   out_rows   capacity n_total rows (worst case: nothing removed); compacted per frame, frame f
+ *              starts at row frame_offsets[f]
+ *   out_src    n_total int32: frame-local input row of each output row
+ *   out_counts n_frames: rows kept per frame
+ *   out_stats  n_frames x 3: num_attenuated, num_removed, avg_intensity_diff (simulation.py:525-542)
+ *   out_thr_poly optional n_frames x 3: the threshold polynomial actually used
+ */
+int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets,
+                          const void *rows, int dtype, const int32_t *table_ids,
+                          double beam_divergence_deg, const double *thr_poly,
+                          const double *plane, double noise_floor, const int32_t *perm,
+                          void *out_rows, int32_t *out_src, int64_t *out_counts,
+                          int64_t *out_stats, double *out_thr_poly);
+
+/*
+ * Same computation with every array already in DEVICE memory (hipMalloc'ed by the caller, e.g. a
+ * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
+ * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
+ * the entry point bench.py times.  d_status (device int32[4]) receives {error code, first bad
+ * global row, overflow beams, reserved}; check it after synchronising the stream.
+ */
+int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total,
+                                 const int64_t *d_frame_offsets, const void *d_rows, int dtype,
+                                 const int32_t *d_table_ids, double beam_divergence_deg,
+                                 const double *d_thr_poly, const double *d_plane, double noise_floor,
+                                 const int32_t *d_perm, void *d_out_rows, int32_t *d_out_src,
+                                 int64_t *d_out_counts, int64_t *d_out_stats, double *d_out_thr_poly,
+                                 int32_t *d_status, void *stream);
+
+/*
+ * Debug/parity tap: the occlusion dicts of get_occlusions (simulation.py:298-424) for the rows of
+ * ONE frame, in the channel-sorted order, flattened: count[i] entries for sorted row i stored at
+ * [i*cap, i*cap + count[i]) of rj / ratio, near -> far, hard target last.  Host pointers.
+ */
+int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows, int dtype,
+                             const int32_t *table_ids, double beam_divergence_deg, int cap,
+                             int32_t *count, double *rj, double *ratio, int32_t *sorted_src);
+
+/* ---- wet ground ---------------------------------------------------------------------------- */
+
+/*
+ * ground_water_augmentation() (tools/wet_ground/augmentation.py:25-161, estimation_method
+ * 'linear', debug off) for a batch of frames in host memory.  Output rows are float64 whatever
+ * the input dtype (augmentation.py:150), ordered [non-ground rows ; kept ground rows]
+ * (augmentation.py:151-152).  A frame with fewer than 1000 ground rows is returned unchanged
+ * (augmentation.py:51-52) with out_flags[f] = 1.
+ *   plane  n_frames x 4 (wx, wy, wz, h)
+ */
+int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets,
+                             const void *rows, int dtype, const double *plane,
+                             double water_height, double pavement_depth, double noise_floor,
+                             double power_factor, int flat_earth, double delta, int replace,
+                             double *out_rows, int32_t *out_src, int64_t *out_counts,
+                             int32_t *out_flags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNOWGPU_H */

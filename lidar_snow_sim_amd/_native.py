@@ -1,0 +1,206 @@
+"""ctypes binding of libsnowgpu.so (include/snowgpu.h).  No compute happens in this file.
+
+The library is hand-written HIP for gfx950; it is built in-tree by ``python -m lidar_snow_sim_amd.build``
+(or ``__graft_entry__.build()``).  If it is missing every entry point raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_LIB_PATH = Path(__file__).resolve().parent / "libsnowgpu.so"
+_lib = None
+_lock = threading.Lock()
+
+E_OK, E_INVALID, E_HIP, E_TABLE, E_RANGE, E_CHANNELS, E_OVERFLOW, E_GROUND, E_NO_DEVICE = range(9)
+
+EXPORTS = [
+    "snowgpu_create", "snowgpu_destroy", "snowgpu_last_error", "snowgpu_version", "snowgpu_set_lasers",
+    "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
+    "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
+]
+
+
+class SnowGPUError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsnowgpu error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    """Load libsnowgpu.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not _LIB_PATH.exists():
+                raise RuntimeError(
+                    f"{_LIB_PATH} is missing: the HIP extension has not been built. Run "
+                    "`python -m lidar_snow_sim_amd.build` (needs hipcc). There is no CPU fallback.")
+            L = ctypes.CDLL(str(_LIB_PATH))
+            vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+            L.snowgpu_create.restype = ctypes.c_int
+            L.snowgpu_create.argtypes = [ctypes.c_int, ctypes.POINTER(vp)]
+            L.snowgpu_destroy.restype = None
+            L.snowgpu_destroy.argtypes = [vp]
+            L.snowgpu_last_error.restype = ctypes.c_char_p
+            L.snowgpu_last_error.argtypes = [vp]
+            L.snowgpu_version.restype = ctypes.c_char_p
+            L.snowgpu_version.argtypes = []
+            L.snowgpu_set_lasers.restype = ctypes.c_int
+            L.snowgpu_set_lasers.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
+            L.snowgpu_upload_table.restype = ctypes.c_int
+            L.snowgpu_upload_table.argtypes = [vp, ctypes.c_int, vp, i64]
+            L.snowgpu_table_count.restype = ctypes.c_int
+            L.snowgpu_table_count.argtypes = [vp]
+            L.snowgpu_range_grid.restype = ctypes.c_int
+            L.snowgpu_range_grid.argtypes = [vp]
+            L.snowgpu_augment_batch.restype = ctypes.c_int
+            L.snowgpu_augment_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp,
+                                                vp, vp, vp, vp, vp]
+            L.snowgpu_augment_batch_device.restype = ctypes.c_int
+            L.snowgpu_augment_batch_device.argtypes = [vp, ctypes.c_int, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp,
+                                                       dbl, vp, vp, vp, vp, vp, vp, vp, vp]
+            L.snowgpu_debug_occlusions.restype = ctypes.c_int
+            L.snowgpu_debug_occlusions.argtypes = [vp, i64, vp, ctypes.c_int, vp, dbl, ctypes.c_int, vp, vp, vp, vp]
+            L.snowgpu_wet_ground_batch.restype = ctypes.c_int
+            L.snowgpu_wet_ground_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, dbl, dbl, dbl,
+                                                   ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp]
+            _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+def _dtype_code(dt):
+    if dt == np.float32:
+        return 0
+    if dt == np.float64:
+        return 1
+    raise TypeError(f"rows must be float32 or float64, not {dt}")
+
+
+def range_grid():
+    out = np.zeros(1230)
+    rc = lib().snowgpu_range_grid(_p(out))
+    if rc:
+        raise SnowGPUError(rc, "snowgpu_range_grid")
+    return out
+
+
+class Context:
+    """One libsnowgpu context = one device + one stream + its uploaded tables."""
+
+    def __init__(self, device: int = 0):
+        self._L = lib()
+        h = ctypes.c_void_p()
+        rc = self._L.snowgpu_create(int(device), ctypes.byref(h))
+        self._h = h
+        self.device = int(device)
+        if rc:
+            msg = self._L.snowgpu_last_error(h).decode() if h else "no usable HIP device"
+            if h:
+                self._L.snowgpu_destroy(h)
+                self._h = None
+            raise SnowGPUError(rc, msg)
+        self.n_lasers = 0
+        self._call_lock = threading.Lock()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.snowgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise SnowGPUError(rc, self._L.snowgpu_last_error(self._h).decode())
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_lasers(self, focal_slope, focal_offset, min_intensity, max_intensity):
+        fs = np.ascontiguousarray(focal_slope, np.float64)
+        fo = np.ascontiguousarray(focal_offset, np.float64)
+        mi = np.ascontiguousarray(min_intensity, np.int32)
+        ma = np.ascontiguousarray(max_intensity, np.int32)
+        self._check(self._L.snowgpu_set_lasers(self._h, len(fs), _p(fs), _p(fo), _p(mi), _p(ma)))
+        self.n_lasers = len(fs)
+
+    def upload_table(self, table_id: int, xyr):
+        t = np.ascontiguousarray(xyr, np.float64)
+        if t.ndim != 2 or t.shape[1] != 3:
+            raise ValueError("a particle table is K x 3 (x, y, disk radius)")
+        self._check(self._L.snowgpu_upload_table(self._h, int(table_id), _p(t), t.shape[0]))
+
+    def augment_batch(self, rows, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None,
+                      noise_floor=0.7, perm=None, want_thr=False):
+        """rows: N_total x 5 (float32/float64), frame_offsets: n_frames + 1, table_ids: n_frames x n_lasers.
+
+        Returns (out_rows [N_total x 5, only the first counts[f] rows of each frame slot are valid],
+                 out_src, counts, stats[n_frames x 3], thr_poly or None)."""
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf = len(off) - 1
+        tids = np.ascontiguousarray(table_ids, np.int32).reshape(nf, -1)
+        if tids.shape[1] != self.n_lasers:
+            raise ValueError("table_ids must be n_frames x n_lasers")
+        n = int(off[-1])
+        out_rows = np.empty((n, 5), rows.dtype)
+        out_src = np.empty(n, np.int32)
+        counts = np.zeros(nf, np.int64)
+        stats = np.zeros((nf, 3), np.int64)
+        thr = None if thr_poly is None else np.ascontiguousarray(thr_poly, np.float64).reshape(nf, 3)
+        pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        pm = None if perm is None else np.ascontiguousarray(perm, np.int32)
+        out_thr = np.zeros((nf, 3)) if want_thr else None
+        with self._call_lock:
+            rc = self._L.snowgpu_augment_batch(self._h, nf, _p(off), _p(rows), code, _p(tids), float(beam_divergence),
+                                               _p(thr), _p(pl), float(noise_floor), _p(pm), _p(out_rows), _p(out_src),
+                                               _p(counts), _p(stats), _p(out_thr))
+            self._check(rc)
+        return out_rows, out_src, counts, stats, out_thr
+
+    def debug_occlusions(self, rows, table_ids, beam_divergence, cap=64):
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        n = rows.shape[0]
+        tids = np.ascontiguousarray(table_ids, np.int32).reshape(-1)
+        count = np.zeros(n, np.int32)
+        rj = np.zeros((n, cap))
+        ratio = np.zeros((n, cap))
+        src = np.zeros(n, np.int32)
+        with self._call_lock:
+            self._check(self._L.snowgpu_debug_occlusions(self._h, n, _p(rows), code, _p(tids), float(beam_divergence),
+                                                         int(cap), _p(count), _p(rj), _p(ratio), _p(src)))
+        return count, rj, ratio, src
+
+    def wet_ground_batch(self, rows, frame_offsets, plane, water_height, pavement_depth, noise_floor, power_factor,
+                         flat_earth, delta, replace):
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf = len(off) - 1
+        n = int(off[-1])
+        pl = np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        out_rows = np.empty((n, 5), np.float64)
+        out_src = np.empty(n, np.int32)
+        counts = np.zeros(nf, np.int64)
+        flags = np.zeros(nf, np.int32)
+        with self._call_lock:
+            self._check(self._L.snowgpu_wet_ground_batch(self._h, nf, _p(off), _p(rows), code, _p(pl), float(water_height),
+                                                         float(pavement_depth), float(noise_floor), float(power_factor),
+                                                         int(bool(flat_earth)), float(delta), int(bool(replace)),
+                                                         _p(out_rows), _p(out_src), _p(counts), _p(flags)))
+        return out_rows, out_src, counts, flags

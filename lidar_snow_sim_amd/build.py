@@ -1,0 +1,60 @@
+"""Build libsnowgpu.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m lidar_snow_sim_amd.build [--force]
+
+The shared library lands next to the package (lidar_snow_sim_amd/libsnowgpu.so); it is git-ignored
+but travels to the GPU box with the working tree.
+"""
+from __future__ import annotations
+
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libsnowgpu.so"
+SOURCES = ["snowgpu_kernels.hip", "snowgpu_prepass.hip", "snowgpu_api.cpp"]
+# -ffp-contract=off: every decision of the reference is made on separately rounded float64/float32
+# operations (NumPy never fuses a multiply into an add); a contracted FMA would change them.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(exe).exists():
+        raise RuntimeError("hipcc not found: libsnowgpu.so cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [p for p in CSRC.glob("*") if p.is_file()] + [PKG.parent / "include" / "snowgpu.h"]
+    return any(p.stat().st_mtime > t for p in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> Path:
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    (CSRC / "_obj").mkdir(exist_ok=True)
+    for src in SOURCES:
+        obj = CSRC / "_obj" / (src.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(str(obj))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

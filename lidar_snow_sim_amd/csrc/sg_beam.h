@@ -1,0 +1,302 @@
+// sg_beam.h -- one LiDAR beam of the snowfall simulation, one thread per beam.
+//
+// Replaces, for one row of the point cloud, the Python loops
+//   process_single_channel   simulation.py:50-194   (loop over beams :118, power loop :137-149)
+//   get_occlusions           simulation.py:298-424  (loop over beams :338, O(K) NumPy per beam)
+//   compute_occlusion_dict   simulation.py:231-295
+//   geometry.*               geometry.py:14-223
+//   received_power / xsi     simulation.py:547-569
+//
+// MI355X shape of the work
+//   * the flake table is filed under 2048 azimuth bins (3.07 mrad, one beam width), each bin sorted
+//     by range; a beam only visits the bins its wedge touches and stops at the first flake beyond
+//     the hard target, so it tests ~20 candidates instead of ~18 000 -- the exact predicates of the
+//     reference are then evaluated on that conservative superset, which leaves the result unchanged;
+//   * the per-beam lists (near -> far intervals, later the scatterer list) live in LDS, strided by
+//     the block size so that lane l always hits bank l whatever its private index is;
+//   * everything that decides a label is float64 with no FMA contraction, and the float32 parts the
+//     reference computes in the input dtype (range, beam azimuth, hard-target window) are float32.
+#pragma once
+#include "sg_math.h"
+
+template <typename T> struct SgReal;
+template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
+template <> struct SgReal<double> { static constexpr bool is_f32 = false; };
+
+struct SgBeamOut {
+    double x, y, z;   // possibly moved point (label 2)
+    double intensity; // un-rounded output intensity
+    double label;     // 0 / 1 / 2
+    int overflow;     // list capacity exceeded: nothing else is valid
+    int range_error;  // window beyond the 1230-bin grid (reference: IndexError)
+    double diff2;     // 2 * (0.9 * max_intensity - new_i) for label 1, else 0
+};
+
+__device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
+{
+    // theta may be slightly outside [0, 2 pi] after adding a margin
+    if (theta < 0) theta += SG_TWO_PI;
+    if (theta >= SG_TWO_PI) theta -= SG_TWO_PI;
+    int b = (int)floor(theta * inv_w);
+    if (b < 0) b = 0;
+    if (b >= nb) b = nb - 1;
+    return b;
+}
+
+// LDS views: element j of this thread's private array lives at base[j * STRIDE + tid].
+#define SG_A1(j) s_a1[(j) * STRIDE + tid]
+#define SG_A2(j) s_a2[(j) * STRIDE + tid]
+#define SG_RHO(j) s_rho[(j) * STRIDE + tid]
+#define SG_RATIO(j) s_ratio[(j) * STRIDE + tid]
+
+template <typename T, int LMAX, int STRIDE>
+__device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, const SgTable tab,
+                                        const SgLasers *__restrict__ las, const double *__restrict__ s_rgrid,
+                                        double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
+                                        double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
+                                        int32_t *dbg_count, double *dbg_rj, double *dbg_ratio)
+{
+    constexpr bool F32 = SgReal<T>::is_f32;
+    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0;
+    out.x = (double)px; out.y = (double)py; out.z = (double)pz; out.intensity = (double)pint; out.label = 0.0;
+
+    // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
+    T d_t;
+    double theta_c;
+    if constexpr (F32) {
+        d_t = sqrtf((px * px + py * py) + pz * pz);             // :89 np.linalg.norm in float32
+        float tc = sg_atan2f(py, px);                           // :91
+        if (tc < 0) tc = tc + (float)SG_TWO_PI;                 // :92 float32 add
+        theta_c = (double)tc;
+    } else {
+        d_t = sqrt((px * px + py * py) + pz * pz);
+        theta_c = atan2(py, px);
+        if (theta_c < 0) theta_c = theta_c + SG_TWO_PI;
+    }
+    const double d = (double)d_t;
+    const double half = (beam_div_deg / 2) * (SG_PI / 180.0);   // np.radians(beam_divergence / 2)
+    double theta_r = theta_c - half;                            // :96
+    double theta_l = theta_c + half;                            // :97
+    if (theta_r < 0) theta_r = theta_r + SG_TWO_PI;             // :100
+    if (theta_l < 0) theta_l = theta_l + SG_TWO_PI;
+    if (theta_r > SG_TWO_PI) theta_r = theta_r - SG_TWO_PI;     // :101
+    if (theta_l > SG_TWO_PI) theta_l = theta_l - SG_TWO_PI;
+
+    // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
+    double ar, br, al, bl;
+    if (theta_r == SG_PI / 2 || theta_r == 3 * SG_PI / 2) { ar = 1.0; br = 0.0; } else { ar = -tan(theta_r); br = 1.0; }
+    if (theta_l == SG_PI / 2 || theta_l == 3 * SG_PI / 2) { al = 1.0; bl = 0.0; } else { al = -tan(theta_l); bl = 1.0; }
+    const double den_r = sqrt(ar * ar + br * br);               // geometry.py:133
+    const double den_l = sqrt(al * al + bl * bl);
+    const bool wrap = theta_r > theta_l;                        // simulation.py:361
+
+    // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
+    int L = 0;
+    {
+        const int nb = (int)tab.n_bins;
+        const int b_lo = sg_bin_of(theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        int span = b_hi - b_lo;
+        if (span < 0) span += nb;
+        int b = b_lo;
+        for (int s = 0; s <= span && !out.overflow; ++s) {
+            const uint32_t e1 = tab.bin_start[b + 1];
+            for (uint32_t e = tab.bin_start[b]; e < e1; ++e) {
+                const SgEntry *f = tab.entries + e;
+                const double rho = f->rho;
+                if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
+                const uint32_t flags = f->flags;
+                if (s > 0 && !(flags & 1u)) continue;           // already met in an earlier bin
+                const double phi = f->phi, fx = f->x, fy = f->y, fr = f->r;
+                const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
+                                 || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
+                                 || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
+                const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
+                const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
+                const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
+                const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
+                if (!(centre || hit_r || hit_l)) continue;      // :389
+                if (L == LMAX) { out.overflow = 1; break; }
+                const double na1 = hit_r ? theta_r : f->t0;     // geometry.py:26
+                const double na2 = hit_l ? theta_l : f->t1;     // geometry.py:27
+                int p = L;                                      // insertion sort by rho (:413-417)
+                while (p > 0 && SG_RHO(p - 1) > rho) {
+                    SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
+                    --p;
+                }
+                SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
+                ++L;
+            }
+            if (++b == nb) b = 0;
+        }
+    }
+    if (out.overflow) return;
+
+    // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------
+    // The reference sorts the unique endpoints, gives every elementary slot to the nearest flake
+    // covering it and sums the slot widths per owner.  Owner of the slot starting at endpoint e is
+    // the first (nearest) j with a1_j <= e < a2_j, so each owner's sum can be produced by walking
+    // the endpoints inside its own interval -- no sorted endpoint array, no assignment array.
+    double ra = theta_r, la = theta_l;
+    if (ra > la) {                                              // :260-263
+        ra = ra - SG_TWO_PI;
+        for (int j = 0; j < L; ++j) {
+            const double a1 = SG_A1(j);
+            if (a1 > SG_A2(j)) SG_A1(j) = a1 - SG_TWO_PI;
+        }
+    }
+    const double delta = beam_div_deg * (SG_PI / 180.0);        // np.radians(beam_divergence), :289
+    int S = 0;                                                  // scatterers kept (dict entries before -1)
+    double e_min = ra < la ? ra : la, e_max = ra < la ? la : ra;
+    SgNpSum acc;
+    for (int j = 0; j < L; ++j) {
+        const double lo = SG_A1(j), hi = SG_A2(j);
+        if (lo < e_min) e_min = lo;
+        if (hi < e_min) e_min = hi;
+        if (lo > e_max) e_max = lo;
+        if (hi > e_max) e_max = hi;
+        bool made = false;
+        acc.reset();
+        double e = lo;
+        while (e < hi) {                                        // slots i1 .. i2-1 (:277-282)
+            bool pre = false;
+            double nxt = hi;
+            for (int q = 0; q < L; ++q) {
+                const double q1 = SG_A1(q), q2 = SG_A2(q);
+                if (q < j && q1 <= e && e < q2) pre = true;     // a nearer flake already owns it (:284)
+                if (q1 > e && q1 < nxt) nxt = q1;
+                if (q2 > e && q2 < nxt) nxt = q2;
+            }
+            if (ra > e && ra < nxt) nxt = ra;
+            if (la > e && la < nxt) nxt = la;
+            if (!pre) { acc.push(nxt - e); made = true; }       // :266 diffs, :285-286
+            e = nxt;
+        }
+        if (made) {                                             // :288-290
+            const double ratio = sg_clip01(acc.result() / delta);
+            const double rho = SG_RHO(j);
+            SG_RHO(S) = rho;                                    // S <= j: in-place compaction
+            SG_RATIO(S) = ratio;
+            ++S;
+        }
+    }
+    {   // the hard target gets every slot nobody claimed (:292-293)
+        acc.reset();
+        double e = e_min;
+        while (e < e_max) {
+            bool pre = false;
+            double nxt = e_max;
+            for (int q = 0; q < L; ++q) {
+                const double q1 = SG_A1(q), q2 = SG_A2(q);
+                if (q1 <= e && e < q2) pre = true;
+                if (q1 > e && q1 < nxt) nxt = q1;
+                if (q2 > e && q2 < nxt) nxt = q2;
+            }
+            if (ra > e && ra < nxt) nxt = ra;
+            if (la > e && la < nxt) nxt = la;
+            if (!pre) acc.push(nxt - e);
+            e = nxt;
+        }
+        SG_RHO(S) = d;
+        SG_RATIO(S) = sg_clip01(acc.result() / delta);
+    }
+    const int n_dict = S + 1;
+    if (dbg_count) {
+        *dbg_count = n_dict;
+        for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
+    }
+    if (n_dict == 1) return;                                    // :133 no snowflake in this beam -> label 0
+
+    // ---- phase 3: received power on the 10 cm grid, argmax, decision (simulation.py:135-188) ---
+    const int ch = channel;
+    const int max_i = las->max_i[ch], min_i = las->min_i[ch];
+    const double c_tau = 299792458.0 * 1e-8;                    // c * tau_h
+    const double beta_0 = 1 * 1e-6 / SG_PI;                     // :108
+    const double i_snow = 0.9 * max_i;                          // :140
+    const double ca_p0 = i_snow / beta_0;                       // :141 (also used for the hard target, Q1)
+    // per scatterer: amplitude into s_a1, window [k0, k1) packed into s_a2
+    int k_min = SG_RBINS, k_max = 0;
+    for (int t = 0; t < n_dict; ++t) {
+        int k0, k1;
+        double amp;
+        const double ratio = SG_RATIO(t);
+        if (F32 && t == S) {                                    // hard target keeps its float32 range
+            const float r = (float)d_t;
+            k0 = (int)ceilf(r * 10.0f);                         // :145
+            float ee = r + (float)c_tau;                        // :146 (float32 under NEP 50)
+            ee = ee * 10.0f;
+            ee = floorf(ee) + 1.0f;
+            k1 = (int)ee;
+            const float r2 = r * r;                             // r_j ** 2 in float32 (:549)
+            amp = (((ca_p0 * beta_0) * ratio) * sg_xsi(r)) / (double)r2;
+        } else {
+            const double r = SG_RHO(t);
+            k0 = (int)ceil(r * 10);                             // :145
+            k1 = (int)(floor((r + c_tau) * 10) + 1);            // :146
+            amp = (((ca_p0 * beta_0) * ratio) * sg_xsi(r)) / (r * r);   // :549
+        }
+        if (k1 > SG_RBINS) { out.range_error = 1; k1 = SG_RBINS; }      // reference: IndexError (:149)
+        if (k0 < 0) k0 = 0;
+        SG_A1(t) = amp;
+        SG_A2(t) = __hiloint2double(k1, k0);
+        if (k0 < k_min) k_min = k0;
+        if (k1 > k_max) k_max = k1;
+    }
+    // I[k] = sum over scatterers (dict order) whose window holds k; argmax = first maximum (:151).
+    double best = 0.0;
+    int k_best = 0;
+    int t_lo = 0;                                               // first flake whose window may still hold k
+    const double tgt_packed = SG_A2(S);
+    const int tk0 = __double2loint(tgt_packed), tk1 = __double2hiint(tgt_packed);
+    for (int k = k_min; k < k_max; ++k) {
+        while (t_lo < S && k >= __double2hiint(SG_A2(t_lo))) ++t_lo;
+        const bool in_tgt = (k >= tk0 && k < tk1);
+        if (t_lo < S) {
+            const int nk0 = __double2loint(SG_A2(t_lo));
+            if (k < nk0 && !in_tgt) {                           // gap: jump to the next window start
+                int nk = nk0;
+                if (k < tk0 && tk0 < nk) nk = tk0;
+                k = nk - 1;
+                continue;
+            }
+        } else if (!in_tgt) {
+            if (k < tk0) { k = tk0 - 1; continue; }
+            break;
+        }
+        const double Rk = s_rgrid[k];
+        double sum = 0.0;                                       // :135 np.zeros
+        for (int t = t_lo; t < S; ++t) {
+            const double pk = SG_A2(t);
+            if (k < __double2loint(pk)) break;                  // flake windows start in range order
+            if (k < __double2hiint(pk)) {
+                const double sn = sin((SG_PI * (Rk - SG_RHO(t))) / c_tau);
+                sum += SG_A1(t) * (sn * sn);                    // :149
+            }
+        }
+        if (in_tgt) {
+            const double sn = sin((SG_PI * (Rk - d)) / c_tau);
+            sum += SG_A1(S) * (sn * sn);
+        }
+        if (sum > best) { best = sum; k_best = k; }
+    }
+    double i_max = best;                                        // :152
+    const double d_max = ((double)k_best / 10) - (c_tau / 2);   // :153
+    const double t1 = 1 - d_max / 120;
+    i_max += max_i * las->focal_slope[ch] * fabs(las->focal_offset[ch] - t1 * t1);   // :155
+    if (i_max < min_i) i_max = min_i;                           // :156
+    if (i_max > max_i) i_max = max_i;
+    long long new_i = (long long)i_max;                         // :162 / :182
+    if (fabs(d_max - d) < 2 * (1.0 / 10)) {                     // :158
+        out.label = 1.0;                                        // :160
+        out.diff2 = 2.0 * (i_snow - (double)new_i);             // :170 (Q2)
+    } else {
+        out.label = 2.0;                                        // :174
+        const double scale = d_max / d;                         // :176
+        out.x = (double)px * scale;                             // :178-180
+        out.y = (double)py * scale;
+        out.z = (double)pz * scale;
+    }
+    if (new_i < min_i) new_i = min_i;                           // :186
+    if (new_i > max_i) new_i = max_i;
+    out.intensity = (double)new_i;                              // :188
+}

@@ -1,0 +1,29 @@
+// sg_prepass.h -- device noise-threshold prepass (simulation.py:449-467; wet_ground/augmentation.py:195-266)
+// and the wet-ground model (wet_ground/augmentation.py:25-161).  Implemented in snowgpu_prepass.hip.
+#pragma once
+#include <stdint.h>
+
+struct SgPrepassScratch {
+    void *buf[12];
+    size_t cap[12];
+};
+
+struct SgWetParams {
+    double water_height, pavement_depth, noise_floor, power_factor, delta;
+    int flat_earth, replace;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// Returns 0, a positive hipError_t, or -1 on allocation failure.  plane: n_frames x 4 (wx, wy, wz, h).
+int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
+                   int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status,
+                   void *stream);
+int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
+               int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
+               int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream);
+void sg_prepass_release(SgPrepassScratch *s);
+#ifdef __cplusplus
+}
+#endif

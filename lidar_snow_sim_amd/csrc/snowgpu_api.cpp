@@ -1,0 +1,657 @@
+// snowgpu_api.cpp -- the C ABI of libsnowgpu.so (include/snowgpu.h): context, table filing, scratch
+// management and the launch sequence of one augment batch.  Host-side C++; every kernel lives in
+// snowgpu_kernels.hip / snowgpu_prepass.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/snowgpu.h"
+#include "sg_common.h"
+#include "sg_prepass.h"
+
+namespace {
+
+struct DeviceTable {
+    SgEntry *entries = nullptr;
+    uint32_t *bin_start = nullptr;
+    SgTable desc{};
+};
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) return (int)e;
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct snowgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<DeviceTable> tables;
+    SgTable *d_tables = nullptr;      // device mirror of the descriptors
+    size_t d_tables_cap = 0;
+    bool tables_dirty = true;
+    uint32_t max_flakes = 0;          // largest uploaded table (drives the LMAX choice)
+    SgLasers h_las{};
+    SgLasers *d_las = nullptr;
+    double *d_rgrid = nullptr;
+    int32_t *d_status = nullptr;      // 4 ints
+    // scratch shared by every batch
+    DevBuf<int32_t> tile_hist, tile_base, ovf_list, perm, ctile_cnt, ctile_base, table_ids, out_src;
+    DevBuf<uint16_t> rank;
+    DevBuf<uint8_t> keep, rows_in, rows_tmp, rows_out;
+    DevBuf<int64_t> frame_off, out_counts, out_stats;
+    DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio;
+    DevBuf<int32_t> dbg_count;
+    DevBuf<unsigned long long> diff2;
+    SgPrepassScratch prepass;
+};
+
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return SNOWGPU_E_HIP;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+#define ENSURE(ctx, buf, n)                                                                       \
+    do {                                                                                          \
+        if ((buf).ensure(n)) { (ctx)->err = "hipMalloc failed for " #buf; return SNOWGPU_E_HIP; } \
+    } while (0)
+
+static int fail(snowgpu_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// simulation.py:106-116: R = np.round(np.linspace(0, 120 + c*tau_h, 1230), 2).
+// linspace: k * step (+ 0.0), last element = stop; round(., 2): rint(v * 100) / 100.
+static void range_grid(double *out)
+{
+    const double stop = 120 + 299792458.0 * 1e-8;
+    const int num = SG_RBINS;
+    const double step = stop / (num - 1);
+    for (int k = 0; k < num; ++k) {
+        double v = (double)k * step + 0.0;
+        if (k == num - 1) v = stop;
+        out[k] = std::rint(v * 100.0) / 100.0;
+    }
+}
+
+extern "C" const char *snowgpu_version(void) { return "snowgpu 0.1.0 gfx950 (MI355X) hip"; }
+
+extern "C" int snowgpu_range_grid(double *out)
+{
+    if (!out) return SNOWGPU_E_INVALID;
+    range_grid(out);
+    return SNOWGPU_OK;
+}
+
+extern "C" const char *snowgpu_last_error(const snowgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
+{
+    if (!out) return SNOWGPU_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SNOWGPU_E_NO_DEVICE;
+    snowgpu_ctx *ctx = new snowgpu_ctx();
+    ctx->device = device;
+    *out = ctx;   // hand the context back even on failure so that last_error is readable
+    HIPCHK(ctx, hipSetDevice(device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 4));
+    double grid[SG_RBINS];
+    range_grid(grid);
+    HIPCHK(ctx, hipMemcpy(ctx->d_rgrid, grid, sizeof(grid), hipMemcpyHostToDevice));
+    ctx->h_las.n = 0;
+    return SNOWGPU_OK;
+}
+
+extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &t : ctx->tables) {
+        if (t.entries) (void)hipFree(t.entries);
+        if (t.bin_start) (void)hipFree(t.bin_start);
+    }
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_las) (void)hipFree(ctx->d_las);
+    if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->perm.release();
+    ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
+    ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
+    ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
+    ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
+    ctx->dbg_count.release(); ctx->diff2.release();
+    sg_prepass_release(&ctx->prepass);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int snowgpu_set_lasers(snowgpu_ctx *ctx, int n, const double *focal_slope, const double *focal_offset,
+                                  const int32_t *min_intensity, const int32_t *max_intensity)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n <= 0 || n > SG_MAX_LASERS || !focal_slope || !focal_offset || !min_intensity || !max_intensity)
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers: need 1..256 lasers and four arrays");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n; ++i) {
+        ctx->h_las.focal_slope[i] = focal_slope[i];
+        ctx->h_las.focal_offset[i] = focal_offset[i];
+        ctx->h_las.min_i[i] = min_intensity[i];
+        ctx->h_las.max_i[i] = max_intensity[i];
+    }
+    ctx->h_las.n = n;
+    HIPCHK(ctx, hipMemcpy(ctx->d_las, &ctx->h_las, sizeof(SgLasers), hipMemcpyHostToDevice));
+    return SNOWGPU_OK;
+}
+
+// ---- table filing --------------------------------------------------------------------------------
+// Per flake (beam-independent, hoisted out of get_occlusions' beam loop): rho, phi, the two tangent
+// angles.  Same operation order as the reference (geometry.py:138-190, :32-80; simulation.py:351-352).
+static bool forward_of(double ray, double centre)
+{
+    double d = ray - centre;
+    return (std::fabs(d) < SG_PI / 2) || (std::fabs(d - SG_TWO_PI) < SG_PI / 2) || (std::fabs(d + SG_TWO_PI) < SG_PI / 2);
+}
+
+static bool derive_flake(double x, double y, double r, SgEntry *f)
+{
+    if (!(std::isfinite(x) && std::isfinite(y) && std::isfinite(r)) || !(r > 0)) return false;
+    f->x = x; f->y = y; f->r = r;
+    f->rho = std::sqrt(x * x + y * y);
+    if (!(f->rho > r)) return false;                   // disk contains the origin: sqrt of a negative below
+    f->phi = std::atan2(y, x);
+    if (f->phi < 0) f->phi = f->phi + SG_TWO_PI;
+    double a[2], b[2];
+    const double disc = r * std::sqrt(x * x + y * y - r * r);
+    if (std::fabs(x) - r == 0) {
+        a[0] = 1.0; b[0] = 0.0;
+        a[1] = (y * y - x * x) / (2 * x * y); b[1] = -1.0;
+    } else {
+        a[0] = (-x * y + disc) / (r * r - x * x);
+        a[1] = (-x * y - disc) / (r * r - x * x);
+        b[0] = b[1] = -1.0;
+    }
+    double ang[2];
+    for (int i = 0; i < 2; ++i) {
+        double ray1 = std::atan(-a[i] / b[i]);
+        double ray2 = ray1 + SG_PI;
+        if (ray1 < 0) ray1 = ray1 + SG_TWO_PI;
+        ray1 = std::fabs(ray1);
+        if (b[i] == 0) { ray1 = SG_PI / 2; ray2 = 3 * SG_PI / 2; }
+        const bool ok1 = forward_of(ray1, f->phi), ok2 = forward_of(ray2, f->phi);
+        if (ok1 == ok2) return false;                  // the reference would raise / mis-align (geometry.py:72)
+        ang[i] = ok1 ? ray1 : ray2;
+    }
+    const double lo = std::min(ang[0], ang[1]), hi = std::max(ang[0], ang[1]);
+    if (hi - lo > SG_PI) { f->t0 = hi; f->t1 = lo; } else { f->t0 = lo; f->t1 = hi; }
+    return true;
+}
+
+static int bin_of(double theta, double inv_w, int nb)
+{
+    theta = std::fmod(theta, SG_TWO_PI);
+    if (theta < 0) theta += SG_TWO_PI;
+    int b = (int)std::floor(theta * inv_w);
+    if (b < 0) b = 0;
+    if (b >= nb) b = nb - 1;
+    return b;
+}
+
+extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t k)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (table_id < 0 || table_id > (1 << 20) || k < 0 || (k > 0 && !xyr))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_upload_table: bad table id or size");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int nb = SG_NBINS;
+    const double inv_w = nb / SG_TWO_PI;
+    std::vector<SgEntry> fl((size_t)k);
+    std::vector<int> b0((size_t)k), span((size_t)k);
+    std::vector<uint32_t> count((size_t)nb + 1, 0);
+    for (int64_t i = 0; i < k; ++i) {
+        if (!derive_flake(xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2], &fl[(size_t)i])) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "snowgpu_upload_table: row %lld (%g, %g, %g) is not a disk clear of the origin",
+                     (long long)i, xyr[3 * i], xyr[3 * i + 1], xyr[3 * i + 2]);
+            return fail(ctx, SNOWGPU_E_TABLE, buf);
+        }
+        SgEntry &f = fl[(size_t)i];
+        f.src = (uint32_t)i;
+        const double alpha = std::asin(std::min(1.0, f.r / f.rho));
+        const double lo = f.phi - alpha - SG_BIN_MARGIN, hi = f.phi + alpha + SG_BIN_MARGIN;
+        int s;
+        if (hi - lo >= SG_TWO_PI - 2.0 / inv_w) { b0[(size_t)i] = 0; s = nb; }
+        else {
+            const int bl = bin_of(lo, inv_w, nb), bh = bin_of(hi, inv_w, nb);
+            b0[(size_t)i] = bl;
+            s = bh - bl;
+            if (s < 0) s += nb;
+            s += 1;
+        }
+        span[(size_t)i] = s;
+        for (int t = 0; t < s; ++t) count[(size_t)((b0[(size_t)i] + t) % nb)]++;
+    }
+    std::vector<uint32_t> start((size_t)nb + 1, 0);
+    for (int b = 0; b < nb; ++b) start[(size_t)b + 1] = start[(size_t)b] + count[(size_t)b];
+    const size_t n_entries = start[(size_t)nb];
+    if (n_entries > (size_t)64 * (size_t)std::max<int64_t>(k, 1) + 4096)
+        return fail(ctx, SNOWGPU_E_TABLE, "snowgpu_upload_table: flakes so close to the sensor that they cover most azimuths");
+    std::vector<SgEntry> entries(n_entries);
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (int64_t i = 0; i < k; ++i) {
+        for (int t = 0; t < span[(size_t)i]; ++t) {
+            const int b = (b0[(size_t)i] + t) % nb;
+            SgEntry e = fl[(size_t)i];
+            e.flags = (t == 0) ? 1u : 0u;
+            entries[fill[(size_t)b]++] = e;
+        }
+    }
+    uint32_t max_bin = 0;
+    for (int b = 0; b < nb; ++b) {
+        std::sort(entries.begin() + start[(size_t)b], entries.begin() + start[(size_t)b + 1],
+                  [](const SgEntry &p, const SgEntry &q) { return p.rho < q.rho || (p.rho == q.rho && p.src < q.src); });
+        max_bin = std::max(max_bin, start[(size_t)b + 1] - start[(size_t)b]);
+    }
+    if ((size_t)table_id >= ctx->tables.size()) ctx->tables.resize((size_t)table_id + 1);
+    DeviceTable &dt = ctx->tables[(size_t)table_id];
+    if (dt.entries) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(dt.entries); dt.entries = nullptr; }
+    if (dt.bin_start) { (void)hipFree(dt.bin_start); dt.bin_start = nullptr; }
+    HIPCHK(ctx, hipMalloc((void **)&dt.entries, std::max<size_t>(n_entries, 1) * sizeof(SgEntry)));
+    HIPCHK(ctx, hipMalloc((void **)&dt.bin_start, ((size_t)nb + 1) * sizeof(uint32_t)));
+    if (n_entries) HIPCHK(ctx, hipMemcpy(dt.entries, entries.data(), n_entries * sizeof(SgEntry), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dt.bin_start, start.data(), ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    dt.desc.entries = dt.entries;
+    dt.desc.bin_start = dt.bin_start;
+    dt.desc.n_bins = (uint32_t)nb;
+    dt.desc.n_entries = (uint32_t)n_entries;
+    dt.desc.inv_bin_w = inv_w;
+    dt.desc.n_flakes = (uint32_t)k;
+    dt.desc.max_bin = max_bin;
+    ctx->tables_dirty = true;
+    ctx->max_flakes = std::max(ctx->max_flakes, (uint32_t)k);
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_table_count(const snowgpu_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int n = 0;
+    for (auto &t : ctx->tables) n += t.entries != nullptr;
+    return n;
+}
+
+static int sync_tables(snowgpu_ctx *ctx)
+{
+    if (!ctx->tables_dirty) return SNOWGPU_OK;
+    const size_t n = std::max<size_t>(ctx->tables.size(), 1);
+    if (n > ctx->d_tables_cap) {
+        if (ctx->d_tables) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(ctx->d_tables); }
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_tables, n * sizeof(SgTable)));
+        ctx->d_tables_cap = n;
+    }
+    std::vector<SgTable> h(n);
+    for (size_t i = 0; i < ctx->tables.size(); ++i) h[i] = ctx->tables[i].desc;
+    HIPCHK(ctx, hipMemcpy(ctx->d_tables, h.data(), n * sizeof(SgTable), hipMemcpyHostToDevice));
+    ctx->tables_dirty = false;
+    return SNOWGPU_OK;
+}
+
+// Expected flakes per beam ~ K * delta / (2 pi); pick the per-thread list capacity of the fast pass.
+static int choose_lmax(const snowgpu_ctx *ctx, double beam_div_deg)
+{
+    const double expect = (double)ctx->max_flakes * (beam_div_deg * (SG_PI / 180.0)) / SG_TWO_PI;
+    if (expect <= 9.5) return 16;
+    if (expect <= 20.0) return 32;
+    return SG_LCAP;
+}
+
+// ---- the batch launch sequence (everything on device pointers) --------------------------------------
+struct BatchDev {
+    int n_frames;
+    int64_t n_total;
+    int64_t max_frame;   // rows of the largest frame (host knowledge; n_total is a safe bound)
+    const int64_t *frame_off;
+    const void *rows;
+    int dtype;
+    const int32_t *table_ids;
+    double beam_div_deg;
+    const double *thr_poly;   // may be null -> prepass with plane
+    const double *plane;
+    double noise_floor;
+    const int32_t *perm;      // may be null -> device sort
+    void *out_rows;
+    int32_t *out_src;
+    int64_t *out_counts;
+    int64_t *out_stats;
+    double *out_thr_poly;     // may be null
+    int32_t *status;
+    hipStream_t stream;
+    // debug tap
+    int32_t *dbg_count = nullptr;
+    double *dbg_rj = nullptr, *dbg_ratio = nullptr;
+    int dbg_cap = 0;
+    int32_t *perm_out = nullptr;   // where the permutation actually used lives (device)
+};
+
+static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
+{
+    if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
+    if (b.beam_div_deg <= 0 || b.beam_div_deg >= 45.0)
+        return fail(ctx, SNOWGPU_E_INVALID, "beam divergence must be in (0, 45) degrees");
+    int rc = sync_tables(ctx);
+    if (rc) return rc;
+    const size_t esz = b.dtype == 0 ? 4 : 8;
+    const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
+    const size_t n = (size_t)b.n_total;
+    hipStream_t st = b.stream;
+    HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 4, st));
+    {
+        const int32_t minus1 = -1;   // status[1] = first offending row, -1 = none
+        HIPCHK(ctx, hipMemcpyAsync(b.status + 1, &minus1, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(b.out_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
+        HIPCHK(ctx, hipMemsetAsync(b.out_stats, 0, sizeof(int64_t) * 3 * (size_t)b.n_frames, st));
+        return SNOWGPU_OK;
+    }
+    // 1. channel sort (simulation.py:447)
+    const int32_t *perm = b.perm;
+    if (!perm) {
+        ENSURE(ctx, ctx->tile_hist, (size_t)b.n_frames * (size_t)max_tiles * 256);
+        ENSURE(ctx, ctx->tile_base, (size_t)b.n_frames * (size_t)max_tiles * 256);
+        ENSURE(ctx, ctx->rank, n);
+        ENSURE(ctx, ctx->perm, n);
+        int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
+                               ctx->rank.p, ctx->perm.p, b.status, max_tiles, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
+        perm = ctx->perm.p;
+    }
+    b.perm_out = const_cast<int32_t *>(perm);
+    // 2. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial
+    const double *thr = b.thr_poly;
+    if (!thr) {
+        if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
+        ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
+        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.max_frame, b.plane,
+                               b.noise_floor, ctx->thr_poly.p, b.status, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+        thr = ctx->thr_poly.p;
+    }
+    if (b.out_thr_poly)
+        HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
+    // 3. beams
+    ENSURE(ctx, ctx->rows_tmp, n * 5 * esz);
+    ENSURE(ctx, ctx->keep, n);
+    ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
+    const int32_t ovf_cap = (int32_t)std::min<size_t>(n, (size_t)1 << 22);
+    ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
+    HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
+    SgBeamArgs a{};
+    a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
+    a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
+    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.thr_poly = thr; a.tmp_rows = ctx->rows_tmp.p;
+    a.keep = ctx->keep.p; a.status = b.status; a.ovf_list = ctx->ovf_list.p; a.ovf_cap = ovf_cap;
+    a.work_list = nullptr; a.work_count = nullptr; a.diff2 = ctx->diff2.p;
+    a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
+    const int lmax = choose_lmax(ctx, b.beam_div_deg);
+    int e = sg_launch_beams(&a, b.dtype, lmax, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
+    if (lmax < SG_LCAP) {
+        // overflow pass: beams with more intersecting flakes than the fast list holds.  The count lives on
+        // the device; the grid is sized for a bounded number of overflow beams and further ones are reported.
+        SgBeamArgs o = a;
+        o.work_list = ctx->ovf_list.p;
+        o.work_count = b.status + 2;
+        o.ovf_cap = std::min<int32_t>(ovf_cap, 1 << 16);
+        e = sg_launch_beams(&o, b.dtype, SG_LCAP, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("overflow launch: ") + hipGetErrorString((hipError_t)e));
+    }
+    // 4. round + noise-floor filter + compaction + stats (simulation.py:516-530)
+    ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles);
+    ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles);
+    e = sg_launch_compact(ctx->rows_tmp.p, b.dtype, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+                          ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
+                          ctx->diff2.p, max_tiles, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
+    return SNOWGPU_OK;
+}
+
+static int status_to_error(snowgpu_ctx *ctx, const int32_t st[4])
+{
+    char buf[200];
+    if (st[2] > (1 << 16)) {
+        snprintf(buf, sizeof buf, "%d beams overflowed the fast flake list (more than the overflow pass handles)", st[2]);
+        return fail(ctx, SNOWGPU_E_OVERFLOW, buf);
+    }
+    switch (st[0]) {
+    case 0: return SNOWGPU_OK;
+    case SNOWGPU_E_RANGE:
+        snprintf(buf, sizeof buf, "index out of bounds for the %d-bin range grid: a simulated point lies at >= ~120 m (sorted row %d)", SG_RBINS, st[1]);
+        return fail(ctx, SNOWGPU_E_RANGE, buf);
+    case SNOWGPU_E_CHANNELS:
+        return fail(ctx, SNOWGPU_E_CHANNELS, "channel column holds values other than integers in [0, 255]; pass an explicit permutation");
+    case SNOWGPU_E_OVERFLOW:
+        snprintf(buf, sizeof buf, "more than %d flakes intersect one beam (sorted row %d)", SG_LCAP, st[1]);
+        return fail(ctx, SNOWGPU_E_OVERFLOW, buf);
+    case SNOWGPU_E_GROUND:
+        return fail(ctx, SNOWGPU_E_GROUND, "fewer than 3 ground points in a frame");
+    case SNOWGPU_E_INVALID:
+        return fail(ctx, SNOWGPU_E_INVALID, "a table id in table_ids was never uploaded");
+    default:
+        snprintf(buf, sizeof buf, "device status %d", st[0]);
+        return fail(ctx, SNOWGPU_E_INVALID, buf);
+    }
+}
+
+extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, const int64_t *d_frame_offsets,
+                                            const void *d_rows, int dtype, const int32_t *d_table_ids,
+                                            double beam_divergence_deg, const double *d_thr_poly, const double *d_plane,
+                                            double noise_floor, const int32_t *d_perm, void *d_out_rows, int32_t *d_out_src,
+                                            int64_t *d_out_counts, int64_t *d_out_stats, double *d_out_thr_poly,
+                                            int32_t *d_status, void *stream)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || n_total < 0 || !d_frame_offsets || (n_total > 0 && !d_rows) || !d_table_ids || !d_out_rows ||
+        !d_out_src || !d_out_counts || !d_out_stats || !d_status || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_batch_device: null pointer or bad dtype");
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    BatchDev b{};
+    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = n_total; b.frame_off = d_frame_offsets; b.rows = d_rows;
+    b.dtype = dtype; b.table_ids = d_table_ids; b.beam_div_deg = beam_divergence_deg; b.thr_poly = d_thr_poly;
+    b.plane = d_plane; b.noise_floor = noise_floor; b.perm = d_perm; b.out_rows = d_out_rows; b.out_src = d_out_src;
+    b.out_counts = d_out_counts; b.out_stats = d_out_stats; b.out_thr_poly = d_out_thr_poly; b.status = d_status;
+    b.stream = stream ? (hipStream_t)stream : ctx->stream;
+    return run_batch(ctx, b);
+}
+
+static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                      const int32_t *table_ids, double beam_div_deg, const double *thr_poly, const double *plane,
+                      double noise_floor, const int32_t *perm, void *out_rows, int32_t *out_src, int64_t *out_counts,
+                      int64_t *out_stats, double *out_thr_poly, int dbg_cap, int32_t *dbg_count, double *dbg_rj,
+                      double *dbg_ratio, int32_t *perm_out)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !frame_offsets || !table_ids || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_batch: null pointer or bad dtype");
+    if (frame_offsets[0] != 0) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets[0] must be 0");
+    int64_t max_frame = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets must be non-decreasing");
+        max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    }
+    const int64_t n_total = frame_offsets[n_frames];
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    if (n_total > 0 && (!rows || !out_rows || !out_src)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    if (!out_counts || !out_stats) return fail(ctx, SNOWGPU_E_INVALID, "null count/stat buffers");
+    if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total;
+    const size_t row_bytes = n * 5 * esz;
+    hipStream_t st = ctx->stream;
+    ENSURE(ctx, ctx->rows_in, std::max<size_t>(row_bytes, 8));
+    ENSURE(ctx, ctx->rows_out, std::max<size_t>(row_bytes, 8));
+    ENSURE(ctx, ctx->out_src, std::max<size_t>(n, 1));
+    ENSURE(ctx, ctx->frame_off, (size_t)n_frames + 1);
+    ENSURE(ctx, ctx->out_counts, (size_t)n_frames);
+    ENSURE(ctx, ctx->out_stats, (size_t)n_frames * 3);
+    ENSURE(ctx, ctx->table_ids, (size_t)n_frames * (size_t)ctx->h_las.n);
+    ENSURE(ctx, ctx->thr_poly, (size_t)n_frames * 3);
+    ENSURE(ctx, ctx->plane, (size_t)n_frames * 4);
+    if (row_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * (size_t)n_frames * (size_t)ctx->h_las.n, hipMemcpyHostToDevice, st));
+    // the user polynomial goes to its own buffer so that the prepass scratch (ctx->thr_poly) stays free
+    DevBuf<double> user_thr;
+    const double *d_thr = nullptr;
+    if (thr_poly) {
+        if (user_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for thr_poly");
+        HIPCHK(ctx, hipMemcpyAsync(user_thr.p, thr_poly, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+        d_thr = user_thr.p;
+    } else if (plane) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    }
+    DevBuf<int32_t> user_perm;
+    if (perm) {
+        if (user_perm.ensure(std::max<size_t>(n, 1))) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for perm");
+        if (n) HIPCHK(ctx, hipMemcpyAsync(user_perm.p, perm, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    }
+    DevBuf<double> d_out_thr;
+    if (out_thr_poly && d_out_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
+    BatchDev b{};
+    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = max_frame; b.frame_off = ctx->frame_off.p; b.rows = ctx->rows_in.p;
+    b.dtype = dtype; b.table_ids = ctx->table_ids.p; b.beam_div_deg = beam_div_deg; b.thr_poly = d_thr;
+    b.plane = (!thr_poly && plane) ? ctx->plane.p : nullptr; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
+    b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = ctx->out_counts.p; b.out_stats = ctx->out_stats.p;
+    b.out_thr_poly = out_thr_poly ? d_out_thr.p : nullptr; b.status = ctx->d_status; b.stream = st;
+    if (dbg_count) {
+        ENSURE(ctx, ctx->dbg_count, std::max<size_t>(n, 1));
+        ENSURE(ctx, ctx->dbg_rj, std::max<size_t>(n * (size_t)dbg_cap, 1));
+        ENSURE(ctx, ctx->dbg_ratio, std::max<size_t>(n * (size_t)dbg_cap, 1));
+        HIPCHK(ctx, hipMemsetAsync(ctx->dbg_count.p, 0, sizeof(int32_t) * std::max<size_t>(n, 1), st));
+        b.dbg_count = ctx->dbg_count.p; b.dbg_rj = ctx->dbg_rj.p; b.dbg_ratio = ctx->dbg_ratio.p; b.dbg_cap = dbg_cap;
+    }
+    int rc = run_batch(ctx, b);
+    int32_t status[4] = {0, -1, 0, 0};
+    if (rc == SNOWGPU_OK) {
+        HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        if (row_bytes) {
+            HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, row_bytes, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        }
+        if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, d_out_thr.p, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        if (dbg_count && n) {
+            HIPCHK(ctx, hipMemcpyAsync(dbg_count, ctx->dbg_count.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(dbg_rj, ctx->dbg_rj.p, sizeof(double) * n * (size_t)dbg_cap, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(dbg_ratio, ctx->dbg_ratio.p, sizeof(double) * n * (size_t)dbg_cap, hipMemcpyDeviceToHost, st));
+        }
+        if (perm_out && n && b.perm_out) HIPCHK(ctx, hipMemcpyAsync(perm_out, b.perm_out, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    }
+    hipError_t se = hipStreamSynchronize(st);
+    user_thr.release(); user_perm.release(); d_out_thr.release();
+    if (rc != SNOWGPU_OK) return rc;
+    if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    return status_to_error(ctx, status);
+}
+
+extern "C" int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                     const int32_t *table_ids, double beam_divergence_deg, const double *thr_poly,
+                                     const double *plane, double noise_floor, const int32_t *perm, void *out_rows,
+                                     int32_t *out_src, int64_t *out_counts, int64_t *out_stats, double *out_thr_poly)
+{
+    return host_batch(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_divergence_deg, thr_poly, plane, noise_floor,
+                      perm, out_rows, out_src, out_counts, out_stats, out_thr_poly, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows, int dtype, const int32_t *table_ids,
+                                        double beam_divergence_deg, int cap, int32_t *count, double *rj, double *ratio,
+                                        int32_t *sorted_src)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_rows < 0 || cap <= 0 || !count || !rj || !ratio || !sorted_src) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_debug_occlusions: bad arguments");
+    const int64_t off[2] = {0, n_rows};
+    const double thr[3] = {0.0, 0.0, -1.0};   // keep everything
+    const size_t esz = dtype == 0 ? 4 : 8;
+    std::vector<unsigned char> out_rows((size_t)n_rows * 5 * esz + 8);
+    std::vector<int32_t> out_src((size_t)n_rows + 1);
+    int64_t cnt = 0, stats[3];
+    return host_batch(ctx, 1, off, rows, dtype, table_ids, beam_divergence_deg, thr, nullptr, 0.7, nullptr, out_rows.data(),
+                      out_src.data(), &cnt, stats, nullptr, cap, count, rj, ratio, sorted_src);
+}
+
+extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                        const double *plane, double water_height, double pavement_depth, double noise_floor,
+                                        double power_factor, int flat_earth, double delta, int replace, double *out_rows,
+                                        int32_t *out_src, int64_t *out_counts, int32_t *out_flags)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !frame_offsets || !plane || !out_counts || !out_flags || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_wet_ground_batch: null pointer or bad dtype");
+    int64_t max_frame = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets must be non-decreasing");
+        max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    }
+    const int64_t n_total = frame_offsets[n_frames];
+    if (n_total > 0 && (!rows || !out_rows || !out_src)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total;
+    hipStream_t st = ctx->stream;
+    ENSURE(ctx, ctx->rows_in, std::max<size_t>(n * 5 * esz, 8));
+    ENSURE(ctx, ctx->rows_out, std::max<size_t>(n * 5 * 8, 8));
+    ENSURE(ctx, ctx->out_src, std::max<size_t>(n, 1));
+    ENSURE(ctx, ctx->frame_off, (size_t)n_frames + 1);
+    ENSURE(ctx, ctx->out_counts, (size_t)n_frames);
+    ENSURE(ctx, ctx->plane, (size_t)n_frames * 4);
+    ENSURE(ctx, ctx->dbg_count, (size_t)n_frames);   // reused as the per-frame "returned unchanged" flags
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t) * 4, st));
+    SgWetParams wp{};
+    wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
+    wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, max_frame, ctx->plane.p, &wp,
+                       (double *)ctx->rows_out.p, ctx->out_src.p, ctx->out_counts.p, ctx->dbg_count.p, ctx->d_status, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(out_flags, ctx->dbg_count.p, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return SNOWGPU_OK;
+}

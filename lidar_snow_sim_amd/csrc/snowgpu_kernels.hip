@@ -1,0 +1,397 @@
+// snowgpu_kernels.hip -- gfx950 kernels of the snowfall-augmentation engine and their launch wrappers.
+//
+//   k_sort_*     stable counting sort of every frame's rows by channel         (simulation.py:447)
+//   k_beams      one thread per beam: occlusion + received power + decision    (simulation.py:50-424)
+//   k_compact_*  round, noise-floor filter, stable stream compaction, stats    (simulation.py:516-530)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see lidar_snow_sim_amd/build.py).
+#include <hip/hip_runtime.h>
+#include "sg_beam.h"
+
+#define SG_BLOCK 256
+
+__device__ __forceinline__ int sg_find_frame(const int64_t *__restrict__ off, int n_frames, int64_t g)
+{
+    int lo = 0, hi = n_frames - 1;   // largest f with off[f] <= g
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ unsigned long long sg_lanemask_lt()
+{
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable counting sort by channel, per frame.  grid = (tiles per frame, frames), 256 threads, a tile
+// is 1024 consecutive rows; wave w owns rows [256 w, 256 w + 256) of the tile in 4 rounds of 64 so
+// that "earlier row" == "earlier (wave, round, lane)".
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
+                                                        int32_t *__restrict__ tile_hist, uint16_t *__restrict__ rank,
+                                                        int32_t *__restrict__ status, int64_t max_tiles)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    __shared__ volatile int cnt[4][256];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 4 * 256; i += SG_BLOCK) ((volatile int *)cnt)[i] = 0;
+    __syncthreads();
+    int my_bucket[4], my_rank[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + w * 256 + q * 64 + lane;
+        const bool valid = r < n;
+        int bucket = -1;
+        if (valid) {
+            const T c = rows[(base + r) * 5 + 4];
+            const int ci = (int)c;
+            if ((T)ci == c && ci >= 0 && ci < 256) bucket = ci;
+            else { atomicCAS(&status[0], 0, 5 /* SNOWGPU_E_CHANNELS */); bucket = 255; }
+        }
+        my_bucket[q] = bucket;
+        my_rank[q] = 0;
+        unsigned long long todo = __ballot(valid);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int v = __shfl(bucket, leader);
+            const unsigned long long m = __ballot(valid && bucket == v);
+            const int before = cnt[w][v];
+            if (valid && bucket == v) my_rank[q] = before + __popcll(m & sg_lanemask_lt());
+            if (lane == leader) cnt[w][v] = before + __popcll(m);
+            todo &= ~m;
+        }
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + w * 256 + q * 64 + lane;
+        if (r < n) {
+            int off = my_rank[q];
+            for (int ww = 0; ww < w; ++ww) off += cnt[ww][my_bucket[q]];
+            rank[base + r] = (uint16_t)off;
+        }
+    }
+    int32_t *h = tile_hist + ((int64_t)f * max_tiles + blockIdx.x) * 256;
+    h[tid] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+}
+
+// One block per frame, thread v owns bucket v: tile_base[t][v] = (rows of smaller buckets) + (rows of
+// bucket v in earlier tiles).
+__global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restrict__ frame_off,
+                                                        const int32_t *__restrict__ tile_hist,
+                                                        int32_t *__restrict__ tile_base, int64_t max_tiles)
+{
+    const int f = blockIdx.x, v = threadIdx.x;
+    const int64_t n = frame_off[f + 1] - frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    const int32_t *h = tile_hist + (int64_t)f * max_tiles * 256;
+    int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
+    int total = 0;
+    for (int64_t t = 0; t < tiles; ++t) total += h[t * 256 + v];
+    __shared__ int s[256];
+    s[v] = total;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan over the 256 buckets
+        int add = v >= d ? s[v - d] : 0;
+        __syncthreads();
+        s[v] += add;
+        __syncthreads();
+    }
+    int run = s[v] - total;
+    for (int64_t t = 0; t < tiles; ++t) { b[t * 256 + v] = run; run += h[t * 256 + v]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
+                                                           const int32_t *__restrict__ tile_base,
+                                                           const uint16_t *__restrict__ rank, int32_t *__restrict__ perm,
+                                                           int64_t max_tiles)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const int32_t *b = tile_base + ((int64_t)f * max_tiles + blockIdx.x) * 256;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
+        if (r < n) {
+            const T c = rows[(base + r) * 5 + 4];
+            int ci = (int)c;
+            if (!((T)ci == c && ci >= 0 && ci < 256)) ci = 255;
+            perm[base + b[ci] + rank[base + r]] = (int32_t)r;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The per-beam kernel.  Dynamic LDS: range grid (1230 doubles) + four per-thread lists.
+template <typename T, int LMAX, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *s_rgrid = (double *)smem;
+    double *s_a1 = s_rgrid + SG_RBINS + 2;            // keep 16-byte alignment: 1232 doubles
+    double *s_a2 = s_a1 + LMAX * BLOCK;
+    double *s_rho = s_a2 + LMAX * BLOCK;
+    double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SG_RBINS; i += BLOCK) s_rgrid[i] = a.rgrid[i];
+    __syncthreads();
+
+    int64_t g;
+    if (a.work_list) {
+        const int64_t w = (int64_t)blockIdx.x * BLOCK + tid;
+        int cnt = *a.work_count;
+        if (cnt > a.ovf_cap) cnt = a.ovf_cap;
+        if (w >= cnt) return;
+        g = a.work_list[w];
+    } else {
+        g = (int64_t)blockIdx.x * BLOCK + tid;
+        if (g >= a.n_total) return;
+    }
+    const int f = sg_find_frame(a.frame_off, a.n_frames, g);
+    const int64_t fbase = a.frame_off[f];
+    const int64_t src = fbase + a.perm[g];
+    const T *row = (const T *)a.rows + src * 5;
+    const T px = row[0], py = row[1], pz = row[2], pint = row[3], pch = row[4];
+    const int n_las = a.las->n;
+    const int ch = (int)pch;
+    const bool simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;   // simulation.py:80, :482 (Q5)
+
+    SgBeamOut o;
+    o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = (double)pint; o.label = (double)pch;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0;
+    if (simulated) {
+        const int tid_table = a.table_ids[(int64_t)f * n_las + ch];
+        if (tid_table < 0 || tid_table >= a.n_tables || a.tables[tid_table].entries == nullptr) {
+            atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
+            return;
+        }
+        const SgTable tab = a.tables[tid_table];
+        int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+        double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
+        double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
+        sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
+                                s_ratio, tid, o, a.dbg_cap, dc, drj, dra);
+        if (o.overflow) {
+            if (LMAX >= SG_LCAP) {
+                atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+                atomicCAS(&a.status[1], -1, (int32_t)g);
+            } else {
+                const int slot = atomicAdd(&a.status[2], 1);
+                if (slot < a.ovf_cap) a.ovf_list[slot] = (int32_t)g;
+            }
+            return;                                   // the overflow pass writes this row
+        }
+        if (o.range_error) {
+            atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+            atomicCAS(&a.status[1], -1, (int32_t)g);
+        }
+    }
+    // ---- frame-level epilogue (simulation.py:516-520) -------------------------------------------
+    T *orow = (T *)a.tmp_rows + g * 5;
+    T oi;
+    if constexpr (SgReal<T>::is_f32) {
+        orow[0] = (float)o.x; orow[1] = (float)o.y; orow[2] = (float)o.z;   // :178-180 store float64 -> float32
+        oi = rintf((float)o.intensity);                                     // :516 np.round (half to even)
+    } else {
+        orow[0] = o.x; orow[1] = o.y; orow[2] = o.z;
+        oi = rint(o.intensity);
+    }
+    orow[3] = oi;
+    orow[4] = (T)o.label;
+    // per-point threshold on the ORIGINAL range (:465, :469): p0 * d^2 + p1 * d + p2, d^2 in the row dtype
+    T dd;
+    if constexpr (SgReal<T>::is_f32) dd = sqrtf((px * px + py * py) + pz * pz);
+    else dd = sqrt((px * px + py * py) + pz * pz);
+    const T dd2 = dd * dd;
+    const double *p = a.thr_poly + (int64_t)f * 3;
+    const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
+    const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
+    a.keep[g] = keep ? 1 : 0;
+    if (o.diff2 != 0.0) atomicAdd(&a.diff2[f], (unsigned long long)(long long)o.diff2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stable compaction of kept rows, per frame.
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const uint8_t *__restrict__ keep,
+                                                            const int64_t *__restrict__ frame_off,
+                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    int c = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
+        if (r < n && keep[base + r]) ++c;
+    }
+    __shared__ int s[4];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
+                                                           const int32_t *__restrict__ tile_cnt,
+                                                           int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
+                                                           int64_t *__restrict__ out_stats, int64_t max_tiles)
+{
+    const int f = blockIdx.x;
+    const int64_t n = frame_off[f + 1] - frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    if (threadIdx.x == 0) {                      // <= a few hundred tiles per frame: a serial scan is fine
+        int run = 0;
+        for (int64_t t = 0; t < tiles; ++t) {
+            tile_base[(int64_t)f * max_tiles + t] = run;
+            run += tile_cnt[(int64_t)f * max_tiles + t];
+        }
+        out_counts[f] = run;
+        out_stats[f * 3 + 0] = 0;                // num_attenuated: filled by k_compact_scatter
+        out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522)
+        out_stats[f * 3 + 2] = 0;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ tmp_rows, const uint8_t *__restrict__ keep,
+                                                              const int32_t *__restrict__ perm,
+                                                              const int64_t *__restrict__ frame_off,
+                                                              const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
+                                                              int32_t *__restrict__ out_src, int64_t *__restrict__ out_stats,
+                                                              int64_t max_tiles)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    __shared__ int wave_cnt[4][4];               // [round][wave]
+    const int tid = threadIdx.x, w = tid >> 6;
+    bool k[4];
+    int pre[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + tid;
+        k[q] = (r < n) && keep[base + r];
+        const unsigned long long m = __ballot(k[q]);
+        pre[q] = __popcll(m & sg_lanemask_lt());
+        if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
+    }
+    __syncthreads();
+    int run = tile_base[(int64_t)f * max_tiles + blockIdx.x];
+    int att = 0;
+    for (int q = 0; q < 4; ++q) {
+        int off = run;
+        for (int ww = 0; ww < w; ++ww) off += wave_cnt[q][ww];
+        if (k[q]) {
+            const int64_t r = base + tile0 + q * SG_BLOCK + tid;
+            const int64_t dst = base + off + pre[q];
+            const T *s = tmp_rows + r * 5;
+            T *d = out_rows + dst * 5;
+            const T lab = s[4];
+            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; d[4] = lab;
+            out_src[dst] = perm[r];
+            if (lab == (T)1) ++att;              // simulation.py:525
+        }
+        run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+    }
+    for (int o = 32; o > 0; o >>= 1) att += __shfl_down(att, o);
+    if ((tid & 63) == 0 && att) atomicAdd((unsigned long long *)&out_stats[f * 3 + 0], (unsigned long long)att);
+}
+
+__global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const int64_t att = out_stats[f * 3 + 0];
+    const double diff_sum = (double)(long long)diff2[f] / 2.0;
+    out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // simulation.py:527-530 int()
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers (C linkage, called from snowgpu_api.cpp)
+
+#define SG_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        hipError_t e__ = hipGetLastError();                \
+        if (e__ != hipSuccess) return (int)e__;            \
+    } while (0)
+
+extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
+                              int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
+                              int64_t max_tiles, void *stream)
+{
+    (void)n_total;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_sort_hist<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, status, max_tiles);
+    else hipLaunchKernelGGL(k_sort_hist<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, status, max_tiles);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_sort_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_hist, tile_base, max_tiles);
+    SG_CHECK_LAUNCH();
+    if (dtype == 0) hipLaunchKernelGGL(k_sort_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_base, rank, perm, max_tiles);
+    else hipLaunchKernelGGL(k_sort_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_base, rank, perm, max_tiles);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int LMAX, int BLOCK>
+static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * ((SG_RBINS + 2) + (size_t)BLOCK * (2 * LMAX + 2 * (LMAX + 1)));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL((k_beams<T, LMAX, BLOCK>), dim3(blocks), dim3(BLOCK), lds, st, *a);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+// lmax: 16 (fast path, 256-thread blocks), 32 (dense tables, 128-thread blocks) or 63 (overflow pass,
+// 64-thread blocks).  With a->work_list set the grid covers a->ovf_cap work items.
+extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = a->work_list ? (int64_t)a->ovf_cap : a->n_total;
+    if (dtype == 0) {
+        if (lmax == 16) return launch_beams_t<float, 16, 256>(a, n, st);
+        if (lmax == 32) return launch_beams_t<float, 32, 128>(a, n, st);
+        return launch_beams_t<float, SG_LCAP, 64>(a, n, st);
+    } else {
+        if (lmax == 16) return launch_beams_t<double, 16, 256>(a, n, st);
+        if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
+        return launch_beams_t<double, SG_LCAP, 64>(a, n, st);
+    }
+}
+
+extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
+                                 const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
+                                 int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
+                                 int64_t *out_stats, const unsigned long long *diff2, int64_t max_tiles, void *stream)
+{
+    (void)n_total;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    hipLaunchKernelGGL(k_compact_count, grid, dim3(SG_BLOCK), 0, st, keep, frame_off, tile_cnt, max_tiles);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
+    SG_CHECK_LAUNCH();
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)tmp_rows, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
+    else
+        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)tmp_rows, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_stats_final, dim3((n_frames + 63) / 64), dim3(64), 0, st, n_frames, out_stats, diff2);
+    SG_CHECK_LAUNCH();
+    return 0;
+}

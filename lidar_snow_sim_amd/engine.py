@@ -1,0 +1,110 @@
+"""Per-device engine: one libsnowgpu context, the HDL-64E S3 laser table and the particle-table cache.
+
+Host logic only -- every number the simulation produces comes out of libsnowgpu.so.
+"""
+from __future__ import annotations
+
+import json
+import threading
+from pathlib import Path
+
+import numpy as np
+
+from . import _native
+
+_DATA = Path(__file__).resolve().parent / "data" / "hdl64e_s3_lasers.json"
+_engines = {}
+_engines_lock = threading.Lock()
+
+
+def load_lasers(path=None):
+    """The per-laser dicts the reference gets from yaml.safe_load(calib/20171102_64E_S3.yaml)['lasers']
+    (tools/snowfall/simulation.py:474-480), reduced to the three fields the simulation reads (:72-76)."""
+    d = json.loads(Path(path or _DATA).read_text())
+    return [{"focal_distance": fd, "focal_slope": fs, **({} if mi is None else {"min_intensity": mi})}
+            for fd, fs, mi in zip(d["focal_distance"], d["focal_slope"], d["min_intensity"])]
+
+
+def laser_constants(lasers):
+    """(focal_slope, focal_offset, min_intensity, max_intensity) per channel -- simulation.py:72-76, :123-126."""
+    fs, fo, mi, ma = [], [], [], []
+    for ch, info in enumerate(lasers):
+        focal_distance = info["focal_distance"] * 100                  # :74
+        fs.append(float(info["focal_slope"]))                          # :75
+        fo.append((1 - focal_distance / 13100) ** 2)                   # :76 (Python float arithmetic, as there)
+        mi.append(int(info.get("min_intensity", 0)))                   # :72
+        ma.append(230 if (ch % 64) in (53, 55, 56, 58) else 255)       # :123-126
+    return fs, fo, mi, ma
+
+
+class Engine:
+    def __init__(self, device: int = 0, lasers=None):
+        self.ctx = _native.Context(device)
+        self.device = device
+        self.lasers = load_lasers() if lasers is None else lasers
+        self.ctx.set_lasers(*laser_constants(self.lasers))
+        self._tables = {}          # key -> table id
+        self._next_id = 0
+        self._lock = threading.Lock()
+
+    @property
+    def n_lasers(self):
+        return len(self.lasers)
+
+    def set_lasers(self, lasers):
+        self.lasers = lasers
+        self.ctx.set_lasers(*laser_constants(lasers))
+
+    def table_id(self, key, loader):
+        """Device table id for `key`, uploading `loader()` (K x 3 float64) the first time."""
+        with self._lock:
+            tid = self._tables.get(key)
+            if tid is None:
+                tid = self._next_id
+                self.ctx.upload_table(tid, loader())
+                self._tables[key] = tid
+                self._next_id += 1
+            return tid
+
+    def table_ids_from_files(self, particle_file_prefix, order, root_path=None):
+        """The reference's lookup (simulation.py:78, :324-329): channel c reads <prefix>_<order[c]+1>.npy."""
+        if root_path:
+            base = Path(root_path) / "training" / "snowflakes" / "npy"
+        else:
+            base = particle_dir()
+        ids = []
+        for ch in range(self.n_lasers):
+            path = base / f"{particle_file_prefix}_{order[ch] + 1}.npy"
+            ids.append(self.table_id(("file", str(path)), lambda p=path: np.load(str(p))))
+        return ids
+
+    def table_ids_from_arrays(self, particles, order):
+        """particles: sequence (index = line - 1) of K x 3 arrays; channel c uses particles[order[c]]."""
+        ids = []
+        for ch in range(self.n_lasers):
+            arr = particles[order[ch]]
+            ids.append(self.table_id(("array", id(arr), arr.shape[0]), lambda a=arr: a))
+        return ids
+
+
+_particle_dir = None
+
+
+def particle_dir() -> Path:
+    """Default directory of the <prefix>_<line>.npy tables: <repo root>/npy, the reference's rule
+    (Path(__file__).parent.parent.parent / 'npy', simulation.py:327)."""
+    return _particle_dir or (Path(__file__).resolve().parent.parent / "npy")
+
+
+def set_particle_dir(path):
+    global _particle_dir
+    _particle_dir = None if path is None else Path(path)
+
+
+def get_engine(device: int = 0) -> Engine:
+    with _engines_lock:
+        eng = _engines.get(device)
+        if eng is None:
+            eng = Engine(device)
+            _engines[device] = eng
+        return eng

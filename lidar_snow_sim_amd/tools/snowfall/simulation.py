@@ -1,0 +1,159 @@
+"""Snowfall augmentation of LiDAR sweeps on MI355X.
+
+Drop-in for tools/snowfall/simulation.py::augment (simulation.py:427-544): same name, positional
+arguments, defaults, return shape and exception types, so that
+
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+
+replaces ``from tools.snowfall.simulation import augment`` at the reference's call sites
+(pointcloud_viewer.py:2807-2810, :2865-2868; tools/snowfall/precompute.py:103-104).
+
+This module is host logic only: argument handling, the channel permutation drawn from Python's global
+``random`` exactly as the reference does (:482-486), particle-table lookup (:78, :324-329) and the
+optional camera-FOV crop.  The simulation itself -- channel sort, noise-threshold prepass, per-beam
+occlusion and received-power integration, noise-floor filter, compaction, statistics -- runs in
+libsnowgpu.so (hand-written HIP for gfx950).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import random
+from typing import Sequence, Tuple
+
+import numpy as np
+
+from ... import _native
+from ... import engine as _engine
+from ..wet_ground.augmentation import noise_threshold_poly
+from ..wet_ground.planes import calculate_plane
+
+PI = np.pi
+
+
+def _as_rows(pc) -> np.ndarray:
+    pc = np.asarray(pc)
+    if pc.ndim != 2 or pc.shape[1] < 5:
+        raise ValueError("pc must be N x 5 (x, y, z, intensity, channel)")
+    if pc.dtype not in (np.float32, np.float64):
+        pc = pc.astype(np.float64)
+    return pc
+
+
+def _raise_like_reference(err: _native.SnowGPUError):
+    """Map library status codes onto the exception types the reference raises (SURVEY 8 b, 'Errors')."""
+    if err.code == _native.E_RANGE:
+        raise IndexError(str(err)) from err            # simulation.py:149 (quirk Q6)
+    if err.code == _native.E_GROUND:
+        raise TypeError(str(err)) from err             # simulation.py:462 on None (quirk Q7)
+    if err.code == _native.E_TABLE:
+        raise ValueError(str(err)) from err
+    raise err
+
+
+def _needs_host_perm(ch: np.ndarray) -> bool:
+    """The device counting sort handles integer channel values 0..255; anything else is sorted here."""
+    ci = ch.astype(np.int64, copy=False) if np.issubdtype(ch.dtype, np.integer) else None
+    if ci is None:
+        with np.errstate(invalid="ignore"):
+            ok = np.isfinite(ch) & (ch == np.floor(ch)) & (ch >= 0) & (ch <= 255)
+        return not bool(ok.all())
+    return False
+
+
+def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
+                  noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
+                  thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True):
+    """augment() for a list of frames in one launch sequence -- the throughput entry point.
+
+    frames      sequence of N_i x 5 arrays (one dtype for the whole batch)
+    planes      optional per-frame (w, h); default: calculate_plane(frame) per frame, like the reference
+    orders      optional per-frame channel permutations; default: range(64), shuffled with the global
+                `random` module when shuffle=True, one draw per frame in frame order
+    particles   optional sequence of K x 3 tables (index = line - 1) instead of <prefix>_<line>.npy files
+    thr_polys   optional per-frame (p0, p1, p2) noise-threshold polynomials (skips the prepass)
+    Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
+    """
+    eng = _engine.get_engine(device)
+    rows = [_as_rows(f) for f in frames]
+    if not rows:
+        return []
+    dt = rows[0].dtype
+    if any(r.dtype != dt for r in rows):
+        raise TypeError("all frames of a batch must share one dtype")
+    nl = eng.n_lasers
+    table_ids, polys, plane_rows = [], [], []
+    for i, r in enumerate(rows):
+        if orders is not None:
+            order = list(orders[i])
+        else:
+            order = list(range(nl))                                         # simulation.py:483
+            if shuffle:
+                random.shuffle(order)                                       # simulation.py:485-486
+        if particles is not None:
+            table_ids.append(eng.table_ids_from_arrays(particles, order))
+        else:
+            table_ids.append(eng.table_ids_from_files(particle_file_prefix, order, root_path))
+        if thr_polys is not None:
+            polys.append(np.asarray(thr_polys[i], np.float64))
+        else:
+            w, h = calculate_plane(r) if planes is None else planes[i]      # simulation.py:449
+            plane_rows.append([float(w[0]), float(w[1]), float(w[2]), float(h)])
+            if not device_prepass:
+                srt = r[np.argsort(r[:, 4], kind="stable")]
+                polys.append(noise_threshold_poly(srt[:, :5], w, h, noise_floor))
+    offsets = np.zeros(len(rows) + 1, np.int64)
+    offsets[1:] = np.cumsum([r.shape[0] for r in rows])
+    flat = np.concatenate([r[:, :5] for r in rows]) if len(rows) > 1 else np.ascontiguousarray(rows[0][:, :5])
+    perm = None
+    if _needs_host_perm(flat[:, 4]):
+        perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
+    try:
+        out, src, counts, stats, _ = eng.ctx.augment_batch(
+            flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
+            plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm)
+    except _native.SnowGPUError as err:
+        _raise_like_reference(err)
+    results = []
+    for i in range(len(rows)):
+        a, n = int(offsets[i]), int(counts[i])
+        aug = out[a:a + n]
+        st = (np.int64(stats[i, 0]), np.int64(stats[i, 1]), int(stats[i, 2]))
+        results.append((st, aug, src[a:a + n]) if return_src else (st, aug))
+    return results
+
+
+def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
+            show_progressbar: bool = False, only_camera_fov: bool = True, noise_floor: float = 0.7,
+            root_path: str = None, *, plane=None, order=None, particles=None, thr_poly=None, calib=None,
+            device: int = 0, return_src: bool = False, device_prepass: bool = True) -> Tuple:
+    """
+    :param pc:                      N-by-5 array containing original pointcloud (x, y, z, intensity, channel).
+    :param particle_file_prefix:    Prefix of the particle tables, f'{mode}_{rain_rate}_{occupancy}'.
+    :param beam_divergence:         Beam divergence in degrees.
+    :param shuffle:                 Flag if order of sampled snowflakes should be shuffled.
+    :param show_progressbar:        Accepted for compatibility; there is nothing to show.
+    :param only_camera_fov:         Flag if the camera field of view (FOV) filter should be applied
+                                    (needs `calib=`, see lidar_snow_sim_amd.calibration).
+    :param noise_floor:             Noise floor threshold.
+    :param root_path:               Optional root path of <root>/training/snowflakes/npy.
+
+    :return:                        ((num_attenuated, num_removed, avg_intensity_diff), N'-by-5 array)
+
+    Keyword-only extras: plane=(w, h), order=<permutation>, particles=<tables>, thr_poly, calib, device,
+    return_src (append the source-row index of every output row to the result).
+    """
+    res = augment_batch([pc], particle_file_prefix, beam_divergence, shuffle=shuffle, noise_floor=noise_floor,
+                        root_path=root_path, planes=None if plane is None else [plane],
+                        orders=None if order is None else [order], particles=particles,
+                        thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=True,
+                        device_prepass=device_prepass)[0]
+    (num_att, num_removed, avg), aug_pc, src = res
+    if only_camera_fov:                                                     # simulation.py:532-540
+        from ...calibration import get_calib, get_fov_flag
+        cal = get_calib() if calib is None else calib
+        pts_rect = cal.lidar_to_rect(aug_pc[:, 0:3])
+        fov_flag = get_fov_flag(pts_rect, (1024, 1920), cal)
+        num_removed = num_removed + np.logical_not(fov_flag).sum()
+        aug_pc = aug_pc[fov_flag]
+        src = src[fov_flag]
+    stats = num_att, num_removed, avg
+    return (stats, aug_pc, src) if return_src else (stats, aug_pc)

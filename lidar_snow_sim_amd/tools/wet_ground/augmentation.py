@@ -1,0 +1,88 @@
+"""Wet-ground augmentation and the laser-parameter estimate it shares with the snowfall path.
+
+Mirror of tools/wet_ground/augmentation.py: ``ground_water_augmentation`` (:25-161) and
+``estimate_laser_parameters`` (:195-266).  The per-point model (incident angles, Fresnel chain,
+intensity rewrite, adaptive noise-threshold drop, [non-ground ; kept ground] reordering) runs in
+libsnowgpu.so; this file is argument handling.  `estimate_laser_parameters` is also kept as a host
+function because it is part of the reference's importable surface (simulation.py:24).
+"""
+import numpy as np
+
+from ... import engine as _engine
+from .planes import calculate_plane
+
+
+def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, power_factor=15, noise_floor=0.7,
+                              debug=True, estimation_method='linear'):
+    """(relative_output_intensity, adaptive_noise_threshold, p, stat_values) -- augmentation.py:195-266.
+
+    Host (NumPy/SciPy) version of the estimate, 'linear' mode.  The per-row minimum of the 50 x 2555
+    histogram is taken as the FIRST minimum of the row, which is what ``np.argpartition(hist, 2)[:, 0]``
+    (:236) returns through NumPy's portable selection code; NumPy's AVX2/AVX-512 builds return a
+    different one of the three smallest bins, so the reference's own answer is
+    machine-dependent there and this mirror pins the portable one.
+    """
+    from scipy.stats import linregress
+    if estimation_method != 'linear':
+        raise NotImplementedError("only estimation_method='linear' is reproducible (the 'poly' branch of the "
+                                  "reference draws from the unseeded global NumPy RNG, augmentation.py:171-192)")
+    normalized = pointcloud_planes[:, 3] / np.cos(calculated_indicent_angle)       # :207
+    distance = np.linalg.norm(pointcloud_planes[:, :3], axis=1)                    # :208
+    if len(normalized) < 3:                                                        # :213-214
+        return None, None, None, None
+    reg = linregress(distance, normalized)                                         # :216
+    p = [reg[0], reg[1]]
+    stat_values = reg[2:]
+    relative_output_intensity = power_factor * (p[0] * distance + p[1])            # :221
+    hist, xedges, yedges = np.histogram2d(distance, normalized, bins=(50, 2555),
+                                          range=((10, 70), (5, np.abs(np.max(normalized)))))   # :232-233
+    hist[hist == 0] = len(pointcloud_planes)                                       # :234-235
+    ymins = np.argmin(hist, axis=1)                                                # :236 (see docstring)
+    min_vals = yedges[ymins]                                                       # :237
+    sel = np.where(min_vals > 5)[0]                                                # :238
+    min_vals = min_vals[sel]
+    x = (xedges[sel] + xedges[sel + 1]) / 2                                        # :240-241
+    pmin = linregress(x, min_vals) if len(min_vals) > 3 else p                     # :248-251
+    adaptive_noise_threshold = noise_floor * (pmin[0] * distance + pmin[1])        # :252-253
+    return relative_output_intensity, adaptive_noise_threshold, p, stat_values
+
+
+def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7):
+    """Quadratic (p0, p1, p2) of the per-point noise threshold over range -- simulation.py:450-467 (host)."""
+    w = np.asarray(w)
+    height = np.matmul(pc_sorted[:, :3], w) + h
+    ground = np.logical_and(height < 0.5, height > -0.5)
+    pc_ground = pc_sorted[ground]
+    angle = np.arccos(np.divide(np.matmul(pc_ground[:, :3], w),
+                                np.linalg.norm(pc_ground[:, :3], axis=1) * np.linalg.norm(w)))
+    _, thr, _, _ = estimate_laser_parameters(pc_ground, angle, noise_floor=noise_floor, debug=False)
+    if thr is None:
+        raise TypeError("unsupported operand type(s) for *=: 'NoneType' and 'float' "
+                        "(fewer than 3 ground points, simulation.py:462)")
+    thr = thr * np.cos(angle)
+    return np.polyfit(np.linalg.norm(pc_ground[:, :3], axis=1), thr, 2)
+
+
+def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0012, noise_floor=0.7, power_factor=15,
+                              estimation_method='linear', flat_earth=False, debug=True, delta=0.5, replace=True,
+                              *, plane=None, device=0, return_src=False):
+    """Drop-in for tools/wet_ground/augmentation.py::ground_water_augmentation (:25-161).
+
+    `debug` is accepted and ignored (the reference's debug branch only draws matplotlib figures).
+    Extra keyword-only arguments: plane=(w, h) to skip the plane estimate, device, return_src.
+    Returns a float64 N' x 5 array (:150); the input object itself when fewer than 1000 ground rows
+    exist (:51-52).
+    """
+    if estimation_method != 'linear':
+        raise NotImplementedError("only estimation_method='linear' is reproducible (augmentation.py:171-192)")
+    pc = np.asarray(pointcloud)
+    rows = pc if pc.dtype in (np.float32, np.float64) else pc.astype(np.float64)
+    w, h = calculate_plane(rows) if plane is None else plane
+    eng = _engine.get_engine(device)
+    out, src, counts, flags = eng.ctx.wet_ground_batch(
+        np.ascontiguousarray(rows[:, :5]), [0, rows.shape[0]], [[w[0], w[1], w[2], h]], water_height,
+        pavement_depth, noise_floor, power_factor, flat_earth, delta, replace)
+    if flags[0]:
+        return (pointcloud, np.arange(rows.shape[0])) if return_src else pointcloud
+    n = int(counts[0])
+    return (out[:n], src[:n]) if return_src else out[:n]

@@ -1,0 +1,170 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors."""
+import numpy as np
+import pytest
+
+from conftest import canonical
+
+pytestmark = pytest.mark.gpu
+
+PLANE = (np.array([0.0, 0.0, -1.0]), -1.7)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from lidar_snow_sim_amd import engine
+    return engine.get_engine(0)
+
+
+@pytest.fixture(scope="module")
+def so():
+    from oracle import snow_oracle
+    return snow_oracle
+
+
+def _tables64(tables):
+    return [tables["t"][i % 4] for i in range(64)]
+
+
+def test_library_is_the_hip_build(eng):
+    from lidar_snow_sim_amd import _native
+    assert b"gfx950" in _native.lib().snowgpu_version()
+    assert eng.ctx.handle
+
+
+@pytest.mark.parametrize("tag", ["float32", "float64"])
+def test_occlusion_dicts_match_oracle(eng, so, golden, tables, tag):
+    """get_occlusions / compute_occlusion_dict on the L4 inputs: scatterer lists bit for bit."""
+    d = golden("L4_process_single_channel")
+    pc = d[f"pc_{tag}"]
+    tl = _tables64(tables)
+    tids = eng.table_ids_from_arrays(tl, list(range(64)))
+    cnt, rj, ratio, src = eng.ctx.debug_occlusions(pc, tids, float(d["bd"]))
+    assert np.array_equal(pc[src, 4], np.sort(pc[:, 4], kind="stable"))
+    las = so.load_lasers()
+    bad = 0
+    for ch in range(64):
+        rows = np.where(pc[:, 4] == ch)[0]
+        _, _, (c0, k0, r0, q0) = so.process_single_channel(pc[rows], tl[ch], float(d["bd"]), las, ch, dump=True)
+        pos = np.where(pc[src, 4] == ch)[0]
+        assert np.array_equal(src[pos], rows)
+        start = np.concatenate(([0], np.cumsum(c0)))
+        for i, p in enumerate(pos):
+            n = int(c0[i])
+            ok = cnt[p] == n and np.array_equal(rj[p, :n], r0[start[i]:start[i] + n])
+            if tag == "float32":
+                ok = ok and np.array_equal(ratio[p, :n], q0[start[i]:start[i] + n])
+            else:
+                # float64 rows: the beam azimuth is a float64 atan2 -- OCML's and glibc's differ in the last
+                # bit for some inputs, which moves ratios by ~1e-16 of a beam (no float32 rounding to hide in)
+                ok = ok and np.allclose(ratio[p, :n], q0[start[i]:start[i] + n], rtol=0, atol=1e-12)
+            bad += not ok
+    assert bad == 0
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_L5_augment_matches_reference(eng, golden, tables, case):
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    d = golden("L5_augment")
+    pc = d[f"c{case}_pc"]
+    plane = (d[f"c{case}_plane_w"], float(d[f"c{case}_plane_h"]))
+    stats, aug, src = augment(pc, "unused", float(d["bd"]), only_camera_fov=False, plane=plane,
+                              order=list(d[f"c{case}_order"]), particles=_tables64(tables), return_src=True,
+                              device_prepass=False)
+    assert tuple(int(s) for s in stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+    a1, s1 = canonical(aug, src)
+    a2, s2 = canonical(d[f"c{case}_aug"], d[f"c{case}_src"])
+    assert np.array_equal(s1, s2)                              # bit-exact kept-point indices
+    assert a1.dtype == a2.dtype
+    assert np.array_equal(a1[:, 4], a2[:, 4])                  # bit-exact labels
+    assert np.array_equal(a1[:, 3], a2[:, 3])                  # intensities are integers: exact
+    np.testing.assert_allclose(a1[:, :3], a2[:, :3], rtol=1e-6 if pc.dtype == np.float32 else 1e-12, atol=0)
+    # output order: channel-sorted, stable
+    assert np.array_equal(src, s1[np.argsort(pc[s1, 4], kind="stable")])
+
+
+def test_Q5_unsimulated_channels(eng, golden, tables):
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    d = golden("L5_augment")
+    stats, aug, src = augment(d["q5_pc"], "unused", float(d["bd"]), shuffle=False, only_camera_fov=False, plane=PLANE,
+                              particles=_tables64(tables), return_src=True, device_prepass=False)
+    assert tuple(int(s) for s in stats) == tuple(int(v) for v in d["q5_stats"])
+    a1, _ = canonical(aug, src)
+    a2, _ = canonical(d["q5_aug"], d["q5_src"])
+    assert np.array_equal(a1, a2)
+
+
+@pytest.mark.parametrize("tag", ["far", "far64", "wide", "wide64", "near", "near64", "dense"])
+def test_L4_special_channels(eng, so, golden, tables, tag):
+    """Grid end, xsi ramp under NEP 50, lists beyond the 16/32-entry fast paths."""
+    d = golden("L4_process_single_channel")
+    if tag == "dense":
+        pc, ch, bd, tab, ref = d["dense_pc"], 5, float(d["bd"]), tables["dense"], d["dense_out"]
+        pc = pc[pc[:, 4] == ch]
+    else:
+        pc, ch, bd, ref = d[f"{tag}_pc"], int(d[f"{tag}_ch"]), float(d[f"{tag}_bd"]), d[f"{tag}_out"]
+        tab = {"dense": tables["dense"], "nearflakes": d["nearflakes_xyr"]}.get(str(d[f"{tag}_table"]), tables["t"][0])
+    tids = [eng.table_id(("array", id(tab), tab.shape[0]), lambda: tab)] * 64
+    off = np.array([0, pc.shape[0]])
+    out, src, counts, stats, _ = eng.ctx.augment_batch(pc, off, [tids], bd, thr_poly=[[0.0, 0.0, -1.0]])
+    assert counts[0] == pc.shape[0]                            # threshold -1: nothing is filtered
+    got = np.empty_like(out)
+    got[src] = out
+    exp = ref.copy()
+    exp[:, 3] = np.round(exp[:, 3])
+    assert np.array_equal(got[:, 4], exp[:, 4])
+    assert np.array_equal(got[:, 3], exp[:, 3])
+    np.testing.assert_allclose(got[:, :3], exp[:, :3], rtol=1e-6 if pc.dtype == np.float32 else 1e-12, atol=0)
+    diff = float(d[f"{tag}_diff"])
+    n_att = int((exp[:, 4] == 1).sum())
+    assert int(stats[0, 0]) == n_att
+    assert int(stats[0, 2]) == (int(diff / n_att) if n_att else 0)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_synthetic_frame_against_oracle(eng, so, tables, dtype):
+    """A 64 x 128 sub-sweep at production beam divergence: every row against the CPU oracle."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    full = synthetic_sweep(64, 2048, seed=1003, intensity="lambert", dtype=np.float64).reshape(64, 2048, 5)
+    pc = full[:, ::16, :].reshape(-1, 5).astype(dtype)
+    rng = np.random.default_rng(5)
+    pc = pc[rng.permutation(pc.shape[0])]                      # unsorted input: exercises the device sort
+    order = list(rng.permutation(64))
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    s0, a0, src0 = so.augment(pc, tl, bd, order, plane=PLANE)
+    s1, a1, src1 = augment(pc, "unused", bd, only_camera_fov=False, plane=PLANE, order=order, particles=tl,
+                           return_src=True, device_prepass=False)
+    assert tuple(int(v) for v in s1) == tuple(int(v) for v in s0)
+    assert np.array_equal(src1, src0)                          # same rows kept, same (stable) order
+    assert np.array_equal(a1[:, 3:], a0[:, 3:])
+    np.testing.assert_allclose(a1[:, :3], a0[:, :3], rtol=1e-6 if dtype == np.float32 else 1e-12, atol=0)
+
+
+def test_empty_and_ragged_batch(eng, so, tables):
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    full = synthetic_sweep(64, 2048, seed=1004, intensity="lambert").reshape(64, 2048, 5)
+    f0 = full[:, ::64, :].reshape(-1, 5)
+    f1 = np.zeros((0, 5), np.float32)
+    f2 = full[:7, 5::100, :].reshape(-1, 5)
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    polys = [[0.0, 0.01, 2.0]] * 3
+    orders = [list(range(64))] * 3
+    res = augment_batch([f0, f1, f2], "unused", bd, particles=tl, orders=orders, thr_polys=polys, return_src=True)
+    for f, (st, aug, src) in zip((f0, f1, f2), res):
+        if f.shape[0] == 0:
+            assert aug.shape == (0, 5) and tuple(int(v) for v in st) == (0, 0, 0)
+            continue
+        s0, a0, src0 = so.augment(f, tl, bd, orders[0], thr_poly=np.array(polys[0]))
+        assert tuple(int(v) for v in st) == tuple(int(v) for v in s0)
+        assert np.array_equal(src, src0) and np.array_equal(aug[:, 3:], a0[:, 3:])
+
+
+def test_range_beyond_grid_raises_index_error(eng, tables):
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    pc = np.array([[125.0, 1.0, 0.0, 30.0, 3.0], [10.0, 1.0, -1.0, 30.0, 3.0]], np.float32)
+    with pytest.raises(IndexError):
+        augment(pc, "unused", float(np.degrees(3e-2)), only_camera_fov=False, particles=_tables64(tables),
+                thr_poly=[0.0, 0.0, 0.0], shuffle=False)
