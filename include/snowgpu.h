@@ -122,11 +122,12 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
  * Same computation with every array already in DEVICE memory (hipMalloc'ed by the caller, e.g. a
  * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
- * the entry point bench.py times.  d_status (device int32[4]) receives {error code, first bad
+ * the entry point bench.py times.  max_frame_rows = rows of the largest frame (sizes the per-frame grids;
+ * 0 = unknown, n_total is used).  d_status (device int32[4]) receives {error code, first bad
  * global row, overflow beams, reserved}; check it after synchronising the stream.
  */
 int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total,
-                                 const int64_t *d_frame_offsets, const void *d_rows, int dtype,
+                                 int64_t max_frame_rows, const int64_t *d_frame_offsets, const void *d_rows, int dtype,
                                  const int32_t *d_table_ids, double beam_divergence_deg,
                                  const double *d_thr_poly, const double *d_plane, double noise_floor,
                                  const int32_t *d_perm, void *d_out_rows, int32_t *d_out_src,
@@ -141,6 +142,14 @@ int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total
 int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows, int dtype,
                              const int32_t *table_ids, double beam_divergence_deg, int cap,
                              int32_t *count, double *rj, double *ratio, int32_t *sorted_src);
+
+/* ---- measurement hooks ------------------------------------------------------------------------ */
+
+/* Record a HIP event pair around every launch of the per-beam kernel (the dominant kernel) on the stream
+ * it is launched on, for up to max_launches launches.  snowgpu_profile_end synchronises that stream and
+ * returns the summed kernel time in milliseconds and the number of launches timed. */
+int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches);
+int snowgpu_profile_end(snowgpu_ctx *ctx, double *beam_kernel_ms, int *n_launches);
 
 /* ---- wet ground ---------------------------------------------------------------------------- */
 

@@ -21,6 +21,7 @@ EXPORTS = [
     "snowgpu_create", "snowgpu_destroy", "snowgpu_last_error", "snowgpu_version", "snowgpu_set_lasers",
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
+    "snowgpu_profile_begin", "snowgpu_profile_end",
 ]
 
 
@@ -61,13 +62,17 @@ def lib():
             L.snowgpu_augment_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp,
                                                 vp, vp, vp, vp, vp]
             L.snowgpu_augment_batch_device.restype = ctypes.c_int
-            L.snowgpu_augment_batch_device.argtypes = [vp, ctypes.c_int, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp,
+            L.snowgpu_augment_batch_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp,
                                                        dbl, vp, vp, vp, vp, vp, vp, vp, vp]
             L.snowgpu_debug_occlusions.restype = ctypes.c_int
             L.snowgpu_debug_occlusions.argtypes = [vp, i64, vp, ctypes.c_int, vp, dbl, ctypes.c_int, vp, vp, vp, vp]
             L.snowgpu_wet_ground_batch.restype = ctypes.c_int
             L.snowgpu_wet_ground_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, dbl, dbl, dbl,
                                                    ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp]
+            L.snowgpu_profile_begin.restype = ctypes.c_int
+            L.snowgpu_profile_begin.argtypes = [vp, ctypes.c_int]
+            L.snowgpu_profile_end.restype = ctypes.c_int
+            L.snowgpu_profile_end.argtypes = [vp, vp, vp]
             _lib = L
     return _lib
 
@@ -171,6 +176,26 @@ class Context:
                                                _p(counts), _p(stats), _p(out_thr))
             self._check(rc)
         return out_rows, out_src, counts, stats, out_thr
+
+    def augment_batch_device(self, n_frames, n_total, max_frame_rows, d_frame_off, d_rows, dtype_code, d_table_ids, beam_divergence,
+                             d_thr_poly, d_plane, noise_floor, d_perm, d_out_rows, d_out_src, d_out_counts,
+                             d_out_stats, d_out_thr, d_status, stream=0):
+        """Raw device-pointer entry (ints from tensor.data_ptr()); asynchronous on `stream`."""
+        vp = ctypes.c_void_p
+        rc = self._L.snowgpu_augment_batch_device(self._h, int(n_frames), int(n_total), int(max_frame_rows), vp(d_frame_off), vp(d_rows),
+                                                  int(dtype_code), vp(d_table_ids), float(beam_divergence),
+                                                  vp(d_thr_poly or None), vp(d_plane or None), float(noise_floor),
+                                                  vp(d_perm or None), vp(d_out_rows), vp(d_out_src), vp(d_out_counts),
+                                                  vp(d_out_stats), vp(d_out_thr or None), vp(d_status), vp(stream or None))
+        self._check(rc)
+
+    def profile_begin(self, max_launches):
+        self._check(self._L.snowgpu_profile_begin(self._h, int(max_launches)))
+
+    def profile_end(self):
+        ms, n = ctypes.c_double(0.0), ctypes.c_int(0)
+        self._check(self._L.snowgpu_profile_end(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def debug_occlusions(self, rows, table_ids, beam_divergence, cap=64):
         rows = np.ascontiguousarray(rows)

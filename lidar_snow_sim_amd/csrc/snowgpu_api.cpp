@@ -63,7 +63,12 @@ struct snowgpu_ctx {
     DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio;
     DevBuf<int32_t> dbg_count;
     DevBuf<unsigned long long> diff2;
-    SgPrepassScratch prepass;
+    SgPrepassScratch prepass{};
+    // measurement hooks (snowgpu_profile_begin / _end)
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    int ev_used = 0;
+    bool prof = false;
+    hipStream_t prof_stream = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -152,6 +157,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
     ctx->dbg_count.release(); ctx->diff2.release();
     sg_prepass_release(&ctx->prepass);
+    for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
+    for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -402,7 +409,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (!thr) {
         if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
-        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.max_frame, b.plane,
+        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
                                b.noise_floor, ctx->thr_poly.p, b.status, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         thr = ctx->thr_poly.p;
@@ -424,7 +431,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.work_list = nullptr; a.work_count = nullptr; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     const int lmax = choose_lmax(ctx, b.beam_div_deg);
+    const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
+    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = sg_launch_beams(&a, b.dtype, lmax, st);
+    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     if (lmax < SG_LCAP) {
         // overflow pass: beams with more intersecting flakes than the fast list holds.  The count lives on
@@ -473,7 +483,8 @@ static int status_to_error(snowgpu_ctx *ctx, const int32_t st[4])
     }
 }
 
-extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, const int64_t *d_frame_offsets,
+extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
+                                            const int64_t *d_frame_offsets,
                                             const void *d_rows, int dtype, const int32_t *d_table_ids,
                                             double beam_divergence_deg, const double *d_thr_poly, const double *d_plane,
                                             double noise_floor, const int32_t *d_perm, void *d_out_rows, int32_t *d_out_src,
@@ -487,7 +498,8 @@ extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int6
     if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     BatchDev b{};
-    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = n_total; b.frame_off = d_frame_offsets; b.rows = d_rows;
+    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = (max_frame_rows > 0 && max_frame_rows <= n_total) ? max_frame_rows : n_total;
+    b.frame_off = d_frame_offsets; b.rows = d_rows;
     b.dtype = dtype; b.table_ids = d_table_ids; b.beam_div_deg = beam_divergence_deg; b.thr_poly = d_thr_poly;
     b.plane = d_plane; b.noise_floor = noise_floor; b.perm = d_perm; b.out_rows = d_out_rows; b.out_src = d_out_src;
     b.out_counts = d_out_counts; b.out_stats = d_out_stats; b.out_thr_poly = d_out_thr_poly; b.status = d_status;
@@ -611,6 +623,40 @@ extern "C" int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const 
                       out_src.data(), &cnt, stats, nullptr, cap, count, rj, ratio, sorted_src);
 }
 
+extern "C" int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches)
+{
+    if (!ctx || max_launches <= 0) return SNOWGPU_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    while ((int)ctx->ev_start.size() < max_launches) {
+        hipEvent_t a, b;
+        HIPCHK(ctx, hipEventCreate(&a));
+        HIPCHK(ctx, hipEventCreate(&b));
+        ctx->ev_start.push_back(a);
+        ctx->ev_stop.push_back(b);
+    }
+    ctx->ev_used = 0;
+    ctx->prof = true;
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_profile_end(snowgpu_ctx *ctx, double *beam_kernel_ms, int *n_launches)
+{
+    if (!ctx || !beam_kernel_ms || !n_launches) return SNOWGPU_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->prof = false;
+    double sum = 0.0;
+    if (ctx->ev_used > 0) HIPCHK(ctx, hipEventSynchronize(ctx->ev_stop[(size_t)ctx->ev_used - 1]));
+    for (int i = 0; i < ctx->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_start[(size_t)i], ctx->ev_stop[(size_t)i]));
+        sum += ms;
+    }
+    *beam_kernel_ms = sum;
+    *n_launches = ctx->ev_used;
+    ctx->ev_used = 0;
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                                         const double *plane, double water_height, double pavement_depth, double noise_floor,
                                         double power_factor, int flat_earth, double delta, int replace, double *out_rows,
@@ -643,7 +689,7 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
-    int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, max_frame, ctx->plane.p, &wp,
+    int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, n_total, max_frame, ctx->plane.p, &wp,
                        (double *)ctx->rows_out.p, ctx->out_src.p, ctx->out_counts.p, ctx->dbg_count.p, ctx->d_status, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
     HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));

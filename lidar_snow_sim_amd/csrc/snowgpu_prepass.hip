@@ -1,6 +1,605 @@
-// snowgpu_prepass.hip -- placeholder, replaced below by the real device prepass / wet-ground kernels.
+// snowgpu_prepass.hip -- the frame-level prepass and the wet-ground model on gfx950.
+//
+//   noise-threshold prepass   simulation.py:449-467 + wet_ground/augmentation.py:195-266 ('linear')
+//   wet-ground augmentation   wet_ground/augmentation.py:25-161 + wet_ground/phy_equations.py:35-108
+//
+// Both start from the same per-frame estimate (estimate_laser_parameters): ground rows by plane distance,
+// incident angle, I / cos(angle) against range, a least-squares line, a 50 x 2555 (range x normalised
+// intensity) histogram whose per-range-row sparsest occupied bin gives the noise line.  The reference does
+// this with NumPy/SciPy calls on the host; here it is a chain of small kernels, one grid row per frame,
+// whose floating-point reductions run in a fixed order (tile partials -> ordered final sum) so that a
+// batch is reproducible run to run.  The reductions are float64; they agree with NumPy's to ~1e-12, not
+// bit for bit (NumPy's own summation order depends on its build) -- see DESIGN.md "prepass tolerance".
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include "sg_common.h"
 #include "sg_prepass.h"
-extern "C" int sg_prepass_run(SgPrepassScratch *, const void *, int, const int64_t *, int, int64_t, const double *, double, double *, int32_t *, void *) { return -1; }
-extern "C" int sg_wet_run(SgPrepassScratch *, const void *, int, const int64_t *, int, int64_t, const double *, const SgWetParams *, double *, int32_t *, int64_t *, int32_t *, int32_t *, void *) { return -1; }
-extern "C" void sg_prepass_release(SgPrepassScratch *) {}
+
+#define PB 256
+#define HX 50     /* range rows of the histogram (augmentation.py:232) */
+#define HY 2555   /* normalised-intensity bins */
+
+struct PreFrame {          // per-frame state shared by the kernels
+    double n_ground;       // ground rows
+    double xmean, ymean;   // mean range / mean normalised intensity
+    double ymax;           // max normalised intensity (histogram range, augmentation.py:233)
+    double p0, p1;         // linregress(dist, normalised)            augmentation.py:216-219
+    double pmin0, pmin1;   // noise line                              augmentation.py:248-251
+    double poly[3];        // simulation.py:467
+    int32_t unchanged;     // wet path: < 1000 ground rows (augmentation.py:51-52)
+    int32_t pad;
+};
+
+struct PreArgs {
+    const void *rows;
+    const int64_t *frame_off;
+    int n_frames;
+    int64_t max_tiles;
+    const double *plane;   // n_frames x 4
+    double delta;          // ground band half width (0.5 in the snowfall path)
+    int flat_earth;        // wet: incident angle from -z (augmentation.py:61-63)
+    double noise_floor, power_factor;
+    // per-row scratch (n_total)
+    double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle; g_norm = NaN for non-ground rows
+    // per-tile partials: [frame][tile][k]
+    double *part;          // 12 doubles per tile
+    int32_t *hist;         // [frame][HX][HY]
+    double *rowmin;        // [frame][HX]  yedges[argmin] or -1
+    PreFrame *fr;
+    int32_t *status;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o));
+    return v;
+}
+// block reduction of K values in a fixed order: lanes -> waves -> wave 0
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *smem /* 4*K */)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) for (int k = 0; k < K; ++k) smem[w * K + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < K; ++k) v[k] = ((smem[k] + smem[K + k]) + smem[2 * K + k]) + smem[3 * K + k];
+}
+
+// ---- P1: ground rows, incident angle, normalised intensity; tile partials (count, sum x, sum y, max y) ------
+template <typename T>
+__global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const double *pl = a.plane + 4 * f;
+    const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
+    const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);              // np.linalg.norm(w)
+    const T *rows = (const T *)a.rows;
+    double v[3] = {0.0, 0.0, 0.0};
+    double ymax = -INFINITY;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        if (r >= n) continue;
+        const T *p = rows + (base + r) * 5;
+        const T x = p[0], y = p[1], z = p[2], inten = p[3];
+        const double dot = ((double)x * w0 + (double)y * w1) + (double)z * w2;   // np.matmul(pc[:, :3], w)
+        const double hog = dot + h;
+        double gn = NAN, gd = 0.0, ga = 0.0;
+        if (hog < a.delta && hog > -a.delta) {                           // simulation.py:450-451 / augmentation.py:46-47
+            T nrm;
+            if constexpr (sizeof(T) == 4) nrm = sqrtf((x * x + y * y) + z * z);
+            else nrm = sqrt((x * x + y * y) + z * z);
+            double c;
+            if (a.flat_earth) c = -((double)z / ((double)nrm * 1.0));    // augmentation.py:61-63
+            else c = dot / ((double)nrm * wn);                           // simulation.py:454-455
+            ga = acos(c);
+            gn = (double)inten / cos(ga);                                // augmentation.py:207
+            gd = (double)nrm;                                            // augmentation.py:208
+            v[0] += 1.0; v[1] += gd; v[2] += gn;
+            ymax = fmax(ymax, gn);
+        }
+        a.g_dist[base + r] = gd; a.g_norm[base + r] = gn; a.g_ang[base + r] = ga;
+    }
+    __shared__ double sm[12];
+    __shared__ double smax[4];
+    block_sum<3>(v, sm);
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = ymax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * 12;
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+        o[3] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
+}
+
+// ---- P2: per frame: counts, means, max ------------------------------------------------------------------------
+__global__ void k_pre_means(PreArgs a, int min_ground, int err_code)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    double c = 0, sx = 0, sy = 0, ym = -INFINITY;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
+        c += p[0]; sx += p[1]; sy += p[2]; ym = fmax(ym, p[3]);
+    }
+    PreFrame &fr = a.fr[f];
+    fr.n_ground = c;
+    fr.xmean = c > 0 ? sx / c : 0.0;
+    fr.ymean = c > 0 ? sy / c : 0.0;
+    fr.ymax = fabs(ym);                                                  // np.abs(np.max(...)), augmentation.py:233
+    fr.unchanged = 0;
+    if (c < (double)min_ground) {
+        if (err_code) atomicCAS(&a.status[0], 0, err_code);              // snowfall: TypeError in the reference (Q7)
+        fr.unchanged = 1;                                                // wet: frame returned unchanged
+    }
+}
+
+// searchsorted(edges, v, side='right') - 1 on edges = linspace(lo, hi, nb + 1), last edge inclusive
+// (np.histogramdd).  Edge k is k * step + lo, the last one exactly hi.
+__device__ __forceinline__ int hist_bin(double v, double lo, double hi, int nb)
+{
+    if (!(v >= lo) || !(v <= hi)) return -1;
+    const double step = (hi - lo) / nb;
+    int k = (int)floor((v - lo) / step);
+    if (k < 0) k = 0;
+    if (k > nb) k = nb;
+    // settle against the edge values NumPy compares with
+    while (k > 0 && !(((k == nb) ? hi : (double)k * step + lo) <= v)) --k;
+    while (k < nb && (((k + 1 == nb) ? hi : (double)(k + 1) * step + lo) <= v)) ++k;
+    if (k >= nb) k = nb - 1;                                             // v == last edge
+    return k;
+}
+
+// ---- P3: centred second moments (np.cov inside linregress) + the 50 x 2555 histogram ----------------------------
+__global__ __launch_bounds__(PB) void k_pre_moments(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const PreFrame fr = a.fr[f];
+    double v[2] = {0.0, 0.0};
+    int32_t *hist = a.hist + (int64_t)f * HX * HY;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        if (r >= n) continue;
+        const double gn = a.g_norm[base + r];
+        if (gn != gn) continue;
+        const double gd = a.g_dist[base + r];
+        const double dx = gd - fr.xmean, dy = gn - fr.ymean;
+        v[0] += dx * dx; v[1] += dx * dy;
+        const int bx = hist_bin(gd, 10.0, 70.0, HX);                     // augmentation.py:232-233
+        const int by = hist_bin(gn, 5.0, fr.ymax, HY);
+        if (bx >= 0 && by >= 0) atomicAdd(&hist[bx * HY + by], 1);
+    }
+    __shared__ double sm[8];
+    block_sum<2>(v, sm);
+    if (threadIdx.x == 0) {
+        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * 12;
+        o[4] = v[0]; o[5] = v[1];
+    }
+}
+
+// ---- P4: per range row, the sparsest occupied bin (first one on ties) ------------------------------------------
+// hist[hist == 0] = len(ground); ymins = argpartition(hist, 2, axis=1)[:, 0]  (augmentation.py:234-236).  NumPy's
+// portable selection leaves the FIRST minimum there (argmin); an all-empty row gives bin 0.
+__global__ __launch_bounds__(PB) void k_pre_rowmin(PreArgs a)
+{
+    const int f = blockIdx.y, row = blockIdx.x;
+    const int32_t *h = a.hist + ((int64_t)f * HX + row) * HY;
+    const PreFrame fr = a.fr[f];
+    const int ng = (int)fr.n_ground;
+    int best = 0x7fffffff, bidx = 0x7fffffff;
+    for (int b = threadIdx.x; b < HY; b += PB) {
+        int c = h[b];
+        if (c == 0) c = ng;
+        if (c < best) { best = c; bidx = b; }                            // ascending b per thread: first minimum
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ob = __shfl_down(best, o), oi = __shfl_down(bidx, o);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    __shared__ int sb[4], si[4];
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sb[w] < best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
+        const double step = (fr.ymax - 5.0) / HY;
+        const double edge = (bidx == HY) ? fr.ymax : (double)bidx * step + 5.0;   // yedges[ymins], augmentation.py:237
+        a.rowmin[(int64_t)f * HX + row] = edge;
+    }
+}
+
+// linregress(x, y) for a handful of points: slope = cov / var, intercept = ymean - slope * xmean
+__device__ __forceinline__ void small_linregress(const double *x, const double *y, int n, double &slope, double &icpt)
+{
+    double xm = 0, ym = 0;
+    for (int i = 0; i < n; ++i) { xm += x[i]; ym += y[i]; }
+    xm /= n; ym /= n;
+    double sxx = 0, sxy = 0;
+    for (int i = 0; i < n; ++i) { sxx += (x[i] - xm) * (x[i] - xm); sxy += (x[i] - xm) * (y[i] - ym); }
+    slope = (sxy / n) / (sxx / n);
+    icpt = ym - slope * xm;
+}
+
+// ---- P5: the two lines ----------------------------------------------------------------------------------------
+__global__ void k_pre_lines(PreArgs a, int xmean_f32)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    PreFrame &fr = a.fr[f];
+    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    double sxx = 0, sxy = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
+        sxx += p[4]; sxy += p[5];
+    }
+    const double ng = fr.n_ground;
+    double slope = 0, icpt = 0;
+    if (ng >= 3) {
+        slope = (sxy / ng) / (sxx / ng);                                 // scipy linregress: ssxym / ssxm
+        // np.mean of a float32 column is a float32; the intercept is ymean - slope * xmean (augmentation.py:216)
+        const double xm = xmean_f32 ? (double)(float)fr.xmean : fr.xmean;
+        icpt = fr.ymean - slope * xm;
+    }
+    fr.p0 = slope; fr.p1 = icpt;
+    // min_vals > 5 (augmentation.py:238), x = centres of the surviving range rows (:240-241)
+    double xs[HX], ys[HX];
+    int m = 0;
+    const double xstep = (70.0 - 10.0) / HX;
+    for (int r = 0; r < HX; ++r) {
+        const double mv = a.rowmin[(int64_t)f * HX + r];
+        if (mv > 5) {
+            const double e0 = (double)r * xstep + 10.0;
+            const double e1 = (r + 1 == HX) ? 70.0 : (double)(r + 1) * xstep + 10.0;
+            xs[m] = (e0 + e1) / 2; ys[m] = mv; ++m;
+        }
+    }
+    if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
+    else { fr.pmin0 = slope; fr.pmin1 = icpt; }                          // :250-251
+}
+
+// ---- P6: normal-equation partials of polyfit(ground_dist, thr * cos(angle), 2) (simulation.py:462-467) ----------
+template <typename T>
+__global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const PreFrame fr = a.fr[f];
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        if (r >= n) continue;
+        const double gn = a.g_norm[base + r];
+        if (gn != gn) continue;
+        const double gd = a.g_dist[base + r];
+        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * cos(a.g_ang[base + r]);   // augmentation.py:252-253, simulation.py:462
+        // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
+        double a2;
+        if constexpr (sizeof(T) == 4) { const float xf = (float)gd; a2 = (double)(xf * xf); }
+        else a2 = gd * gd;
+        const double a1 = gd;
+        v[0] += a2 * a2; v[1] += a2 * a1; v[2] += a2; v[3] += a1 * a1; v[4] += a1;
+        v[5] += a2 * y; v[6] += a1 * y; v[7] += y; v[8] += 1.0;
+    }
+    __shared__ double sm[36];
+    block_sum<9>(v, sm);
+    if (threadIdx.x == 0) {
+        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * 12;
+        for (int k = 0; k < 9; ++k) o[k] = v[k];
+    }
+}
+
+// ---- P7: solve the 3 x 3 system (columns scaled by their norms, as np.polyfit does) ------------------------------
+__global__ void k_pre_poly_solve(PreArgs a, double *thr_poly)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t t = 0; t < tiles; ++t) {
+        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
+        for (int k = 0; k < 9; ++k) s[k] += p[k];
+    }
+    double *out = thr_poly + 3 * f;
+    if (s[8] < 3) { out[0] = out[1] = out[2] = 0.0; return; }
+    const double c2 = sqrt(s[0]), c1 = sqrt(s[3]), c0 = sqrt(s[8]);
+    double G[3][4] = {{s[0] / (c2 * c2), s[1] / (c2 * c1), s[2] / (c2 * c0), s[5] / c2},
+                      {s[1] / (c1 * c2), s[3] / (c1 * c1), s[4] / (c1 * c0), s[6] / c1},
+                      {s[2] / (c0 * c2), s[4] / (c0 * c1), s[8] / (c0 * c0), s[7] / c0}};
+    for (int i = 0; i < 3; ++i) {                                        // Gaussian elimination, partial pivoting
+        int piv = i;
+        for (int r = i + 1; r < 3; ++r) if (fabs(G[r][i]) > fabs(G[piv][i])) piv = r;
+        if (piv != i) for (int k = 0; k < 4; ++k) { const double t = G[i][k]; G[i][k] = G[piv][k]; G[piv][k] = t; }
+        for (int r = i + 1; r < 3; ++r) {
+            const double m = G[r][i] / G[i][i];
+            for (int k = i; k < 4; ++k) G[r][k] -= m * G[i][k];
+        }
+    }
+    double x[3];
+    for (int i = 2; i >= 0; --i) {
+        double t = G[i][3];
+        for (int k = i + 1; k < 3; ++k) t -= G[i][k] * x[k];
+        x[i] = t / G[i][i];
+    }
+    out[0] = x[0] / c2; out[1] = x[1] / c1; out[2] = x[2] / c0;
+    a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
+}
+
+// ================================================================================================================
+// wet ground (augmentation.py:88-159; phy_equations.py:35-108)
+
+struct Fresnel { double rs, ts, rp, tp, aout; };
+__device__ __forceinline__ Fresnel fresnel_power(double ain, double n_in, double n_out)   // phy_equations.py:35-67
+{
+    Fresnel r;
+    double s = sin(ain) * n_in / n_out;
+    s = s < -1 ? -1 : (s > 1 ? 1 : s);
+    r.aout = asin(s);
+    const double ci = cos(ain), co = cos(r.aout);
+    const double frac = ci * n_in / n_out / co;
+    const double rs = (n_in * ci - n_out * co) / (n_in * ci + n_out * co);
+    const double ts = 2 * n_in * ci / (n_in * ci + n_out * co);
+    const double rp = (n_out * ci - n_in * co) / (n_out * ci + n_in * co);
+    const double tp = 2 * n_in * ci / (n_out * ci + n_in * co);
+    r.rs = rs * rs; r.ts = ts * ts / frac; r.rp = rp * rp; r.tp = tp * tp / frac;
+    return r;
+}
+
+struct WetArgs {
+    PreArgs p;
+    double water_height, pavement_depth;
+    int replace;
+    uint8_t *cls;          // per row: 1 = non-ground, 2 = kept ground, 0 = dropped
+    double *new_i;         // per row: rewritten intensity
+    int32_t *tile_cnt;     // [frame][tile][2]
+    int32_t *tile_base;    // [frame][tile][2]
+    double *out_rows;
+    int32_t *out_src;
+    int64_t *out_counts;
+    int32_t *out_flags;
+};
+
+template <typename T>
+__global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
+{
+    const PreArgs &a = w.p;
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const PreFrame fr = a.fr[f];
+    const T *rows = (const T *)a.rows;
+    int cnt_a = 0, cnt_b = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        if (r >= n) continue;
+        uint8_t cls;
+        double ni = 0.0;
+        const double gn = a.g_norm[base + r];
+        if (fr.unchanged) { cls = 1; }                                   // frame returned as is (augmentation.py:51-52)
+        else if (gn != gn) { cls = 1; }
+        else {
+            const double gd = a.g_dist[base + r], ang = a.g_ang[base + r];
+            const double gc = cos(ang);
+            const double inten = (double)rows[(base + r) * 5 + 3];
+            const double rel = a.power_factor * (fr.p0 * gd + fr.p1);    // :221
+            const double thr = a.noise_floor * (fr.pmin0 * gd + fr.pmin1);   // :252-253
+            const double refl = inten / gc / rel;                        // :90
+            double rho = refl < 0.05 ? 0.05 : (refl > 1 ? 1 : refl);     // :109 np.clip(reflectivities, 0.05, 1)
+            const Fresnel aw = fresnel_power(ang, 1.0003, 1.33);         // phy_equations.py:81
+            const Fresnel wa = fresnel_power(aw.aout, 1.33, 1.0003);     // :83
+            const double ts = aw.ts * rho * wa.ts / (1 - rho * wa.rs);   // :86
+            const double tp = aw.tp * rho * wa.tp / (1 - rho * wa.rp);   // :89
+            const double t = fmax(tp, ts);                               // augmentation.py:119
+            double fw = w.water_height / w.pavement_depth;               // :122
+            fw = fw < 0 ? 0 : (fw > 1 ? 1 : fw);
+            const double tw = (1 - fw) * refl + fw * t / ang;            // :123
+            double v = rel * gc * tw;                                    // :126
+            v = v < 0 ? 0 : (v > inten ? inten : v);                     // np.clip(., 0, intensity)
+            const double lim = thr * gc;
+            if (v < lim) v = 0;                                          // :128, :131
+            ni = v;
+            cls = (v > lim) ? 2 : 0;                                     // :146
+        }
+        w.cls[base + r] = cls;
+        w.new_i[base + r] = ni;
+        cnt_a += cls == 1; cnt_b += cls == 2;
+    }
+    __shared__ int sa[4], sb[4];
+    for (int o = 32; o > 0; o >>= 1) { cnt_a += __shfl_down(cnt_a, o); cnt_b += __shfl_down(cnt_b, o); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = cnt_a; sb[threadIdx.x >> 6] = cnt_b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int32_t *o = w.tile_cnt + ((int64_t)f * a.max_tiles + blockIdx.x) * 2;
+        o[0] = sa[0] + sa[1] + sa[2] + sa[3];
+        o[1] = sb[0] + sb[1] + sb[2] + sb[3];
+    }
+}
+
+__global__ void k_wet_scan(WetArgs w)
+{
+    const PreArgs &a = w.p;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    int na = 0, nb = 0;
+    for (int64_t t = 0; t < tiles; ++t) {
+        const int32_t *c = w.tile_cnt + ((int64_t)f * a.max_tiles + t) * 2;
+        int32_t *b = w.tile_base + ((int64_t)f * a.max_tiles + t) * 2;
+        b[0] = na; b[1] = nb; na += c[0]; nb += c[1];
+    }
+    for (int64_t t = 0; t < tiles; ++t) w.tile_base[((int64_t)f * a.max_tiles + t) * 2 + 1] += na;   // ground after non-ground
+    w.out_counts[f] = na + nb;
+    w.out_flags[f] = a.fr[f].unchanged;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
+{
+    const PreArgs &a = w.p;
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const T *rows = (const T *)a.rows;
+    const int unchanged = a.fr[f].unchanged;
+    __shared__ int wc[4][4][2];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+    uint8_t c[4];
+    int pre[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + tid;
+        c[q] = r < n ? w.cls[base + r] : 0;
+        const unsigned long long ma = __ballot(c[q] == 1), mb = __ballot(c[q] == 2);
+        pre[q] = c[q] == 1 ? __popcll(ma & lt) : __popcll(mb & lt);
+        if ((tid & 63) == 0) { wc[q][wv][0] = __popcll(ma); wc[q][wv][1] = __popcll(mb); }
+    }
+    __syncthreads();
+    const int32_t *tb = w.tile_base + ((int64_t)f * a.max_tiles + blockIdx.x) * 2;
+    int run[2] = {tb[0], tb[1]};
+    for (int q = 0; q < 4; ++q) {
+        if (c[q]) {
+            const int k = c[q] - 1;
+            int off = run[k];
+            for (int ww = 0; ww < wv; ++ww) off += wc[q][ww][k];
+            const int64_t r = base + tile0 + q * PB + tid;
+            const int64_t dst = base + off + pre[q];
+            const T *s = rows + r * 5;
+            double *d = w.out_rows + dst * 5;
+            d[0] = (double)s[0]; d[1] = (double)s[1]; d[2] = (double)s[2];
+            d[3] = (c[q] == 2) ? w.new_i[r] : (double)s[3];              // augmentation.py:151-153
+            double lab = (double)s[4];
+            if (!unchanged) {
+                if (w.replace) lab = 0.0;                                // :155-156
+                if (c[q] == 2) lab = 1.0;                                // :159
+            }
+            d[4] = lab;
+            w.out_src[dst] = (int32_t)(r - base);
+        }
+        for (int k = 0; k < 2; ++k) run[k] += wc[q][0][k] + wc[q][1][k] + wc[q][2][k] + wc[q][3][k];
+    }
+}
+
+// ================================================================================================================
+// host side
+
+enum { B_GDIST = 0, B_GNORM, B_GCOS, B_PART, B_HIST, B_ROWMIN, B_FRAME, B_CLS, B_NEWI, B_TCNT, B_TBASE, B_N };
+
+static int ensure(SgPrepassScratch *s, int i, size_t bytes)
+{
+    if (bytes <= s->cap[i]) return 0;
+    if (s->buf[i]) (void)hipFree(s->buf[i]);
+    s->buf[i] = nullptr; s->cap[i] = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&s->buf[i], want) != hipSuccess) return -1;
+    s->cap[i] = want;
+    return 0;
+}
+
+extern "C" void sg_prepass_release(SgPrepassScratch *s)
+{
+    for (int i = 0; i < 12; ++i) { if (s->buf[i]) (void)hipFree(s->buf[i]); s->buf[i] = nullptr; s->cap[i] = 0; }
+}
+
+#define LCHK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total, int64_t max_frame, int min_ground,
+                    int err_code, hipStream_t st)
+{
+    const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
+    a.max_tiles = max_tiles;
+    const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)a.n_frames;
+    if (ensure(s, B_GDIST, n * 8) || ensure(s, B_GNORM, n * 8) || ensure(s, B_GCOS, n * 8) ||
+        ensure(s, B_PART, nf * (size_t)max_tiles * 12 * 8) || ensure(s, B_HIST, nf * HX * HY * 4) ||
+        ensure(s, B_ROWMIN, nf * HX * 8) || ensure(s, B_FRAME, nf * sizeof(PreFrame)))
+        return -1;
+    a.g_dist = (double *)s->buf[B_GDIST]; a.g_norm = (double *)s->buf[B_GNORM]; a.g_ang = (double *)s->buf[B_GCOS];
+    a.part = (double *)s->buf[B_PART]; a.hist = (int32_t *)s->buf[B_HIST]; a.rowmin = (double *)s->buf[B_ROWMIN];
+    a.fr = (PreFrame *)s->buf[B_FRAME];
+    hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((unsigned)max_tiles, (unsigned)a.n_frames);
+    const unsigned fb = (unsigned)((a.n_frames + 63) / 64);
+    if (dtype == 0) hipLaunchKernelGGL(k_pre_ground<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_pre_ground<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_means, dim3(fb), dim3(64), 0, st, a, min_ground, err_code);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_moments, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)a.n_frames), dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_lines, dim3(fb), dim3(64), 0, st, a, dtype == 0 ? 1 : 0);
+    LCHK();
+    return 0;
+}
+
+extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
+                              int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
+                              int32_t *status, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    PreArgs a{};
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0;
+    a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
+    int rc = estimate(s, a, dtype, n_total, max_frame, 3, 7 /* SNOWGPU_E_GROUND */, st);
+    if (rc) return rc;
+    dim3 grid((unsigned)a.max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_pre_poly_part<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_pre_poly_part<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_poly_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, thr_poly);
+    LCHK();
+    return 0;
+}
+
+extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
+                          int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
+                          int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    WetArgs w{};
+    PreArgs &a = w.p;
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = wp->delta;
+    a.flat_earth = wp->flat_earth; a.noise_floor = wp->noise_floor; a.power_factor = wp->power_factor; a.status = status;
+    int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, st);
+    if (rc) return rc;
+    const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)n_frames;
+    if (ensure(s, B_CLS, n) || ensure(s, B_NEWI, n * 8) || ensure(s, B_TCNT, nf * (size_t)a.max_tiles * 2 * 4) ||
+        ensure(s, B_TBASE, nf * (size_t)a.max_tiles * 2 * 4))
+        return -1;
+    w.water_height = wp->water_height; w.pavement_depth = wp->pavement_depth; w.replace = wp->replace;
+    w.cls = (uint8_t *)s->buf[B_CLS]; w.new_i = (double *)s->buf[B_NEWI];
+    w.tile_cnt = (int32_t *)s->buf[B_TCNT]; w.tile_base = (int32_t *)s->buf[B_TBASE];
+    w.out_rows = out_rows; w.out_src = out_src; w.out_counts = out_counts; w.out_flags = out_flags;
+    dim3 grid((unsigned)a.max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_wet_apply<float>, grid, dim3(PB), 0, st, w);
+    else hipLaunchKernelGGL(k_wet_apply<double>, grid, dim3(PB), 0, st, w);
+    LCHK();
+    hipLaunchKernelGGL(k_wet_scan, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, w);
+    LCHK();
+    if (dtype == 0) hipLaunchKernelGGL(k_wet_scatter<float>, grid, dim3(PB), 0, st, w);
+    else hipLaunchKernelGGL(k_wet_scatter<double>, grid, dim3(PB), 0, st, w);
+    LCHK();
+    return 0;
+}

@@ -168,3 +168,92 @@ def test_range_beyond_grid_raises_index_error(eng, tables):
     with pytest.raises(IndexError):
         augment(pc, "unused", float(np.degrees(3e-2)), only_camera_fov=False, particles=_tables64(tables),
                 thr_poly=[0.0, 0.0, 0.0], shuffle=False)
+
+
+# ---- device prepass (simulation.py:449-467 on the GPU) ---------------------------------------------------------
+@pytest.mark.parametrize("case", range(8))
+def test_L5_augment_device_prepass(eng, golden, tables, case):
+    """Same L5 fixtures with the noise-threshold prepass on the device: the polynomial agrees with the
+    NumPy/SciPy one to 1e-7 relative (different summation order and least-squares solver) and the kept
+    rows / labels / intensities are the reference's."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import noise_threshold_poly
+    d = golden("L5_augment")
+    pc = d[f"c{case}_pc"]
+    plane = (d[f"c{case}_plane_w"], float(d[f"c{case}_plane_h"]))
+    order = list(d[f"c{case}_order"])
+    tl = _tables64(tables)
+    tids = eng.table_ids_from_arrays(tl, order)
+    _, _, _, _, thr = eng.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], float(d["bd"]),
+                                            plane=[[*plane[0], plane[1]]], want_thr=True)
+    srt = pc[np.argsort(pc[:, 4], kind="stable")]
+    host = noise_threshold_poly(srt, plane[0], plane[1], 0.7)
+    dist = np.linspace(3, 80, 50)
+    # float64 rows: 1e-12.  float32 rows: np.polyfit builds its Vandermonde matrix in float32 and divides it by
+    # float32 column norms before the float64 solve, which perturbs ITS answer by ~1e-6 in threshold units (and
+    # differently for every row order); the device solves the same normal equations in float64.
+    tol = dict(rtol=1e-5, atol=1e-4) if pc.dtype == np.float32 else dict(rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(np.polyval(thr[0], dist), np.polyval(host, dist), **tol)
+    stats, aug, src = augment(pc, "unused", float(d["bd"]), only_camera_fov=False, plane=plane, order=order,
+                              particles=tl, return_src=True)
+    assert tuple(int(s) for s in stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+    a1, s1 = canonical(aug, src)
+    a2, s2 = canonical(d[f"c{case}_aug"], d[f"c{case}_src"])
+    assert np.array_equal(s1, s2) and np.array_equal(a1[:, 3:], a2[:, 3:])
+
+
+def test_too_few_ground_points_raise_type_error(eng, tables):
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    pc = np.array([[10.0, 1.0, 5.0, 30.0, 3.0], [12.0, 1.0, 6.0, 30.0, 3.0]], np.float32)   # nothing near the plane
+    with pytest.raises(TypeError):
+        augment(pc, "unused", float(np.degrees(3e-3)), only_camera_fov=False, particles=_tables64(tables),
+                plane=PLANE, shuffle=False)
+
+
+# ---- wet ground (wet_ground/augmentation.py:25-161 on the GPU) --------------------------------------------------
+@pytest.mark.parametrize("case", range(8))
+def test_L6_wet_ground(eng, golden, case):
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import ground_water_augmentation
+    d = golden("L6_wet_ground")
+    pc = d[f"c{case}_pc"]
+    out, src = ground_water_augmentation(pc, water_height=0.0008, pavement_depth=0.001, noise_floor=0.7, power_factor=15,
+                                         estimation_method="linear", flat_earth=bool(d[f"c{case}_flat"]), debug=False,
+                                         delta=0.5, replace=bool(d[f"c{case}_replace"]), plane=PLANE, return_src=True)
+    ref = d[f"c{case}_out"]
+    assert out.dtype == np.float64 and out.shape == ref.shape            # same rows kept, float64 output (Q10)
+    assert np.array_equal(out[:, [0, 1, 2, 4]], ref[:, [0, 1, 2, 4]])   # [non-ground ; kept ground] order, labels
+    if pc.dtype == np.float64:
+        np.testing.assert_allclose(out[:, 3], ref[:, 3], rtol=1e-9, atol=0)
+    else:
+        # float32 rows: scipy's linregress takes np.mean of the float32 range column (a float32 pairwise sum) for
+        # the intercept; the laser-power line nearly cancels at short range on these frames, which amplifies that
+        # one rounding to ~1e-3 of the rewritten intensity.  See DESIGN.md "wet ground, float32 mean".
+        np.testing.assert_allclose(out[:, 3], ref[:, 3], rtol=5e-3, atol=0)
+    assert np.array_equal(pc[src, :3].astype(np.float64), out[:, :3])
+
+
+def test_wet_ground_returns_input_below_1000_ground_rows(eng, golden):
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import ground_water_augmentation
+    d = golden("L6_wet_ground")
+    pc = d["c0_pc"][:900]
+    out = ground_water_augmentation(pc, plane=PLANE, debug=False)
+    assert out is pc                                                     # augmentation.py:51-52
+
+
+def test_chained_snow_then_wet_like_the_viewer(eng, so, golden, tables):
+    """pointcloud_viewer.py:2807-2821: augment(...) then ground_water_augmentation(..., replace=False)."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import ground_water_augmentation
+    d = golden("L6_wet_ground")
+    pc = d["c0_pc"]
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    order = list(range(64))
+    stats, aug = augment(pc, "unused", bd, only_camera_fov=False, plane=PLANE, order=order, particles=tl)
+    out = ground_water_augmentation(aug, water_height=0.0008, pavement_depth=0.001, noise_floor=0.7, power_factor=15,
+                                    flat_earth=False, debug=False, delta=0.5, replace=False, plane=PLANE)
+    s0, a0, _ = so.augment(pc, tl, bd, order, plane=PLANE)
+    o0 = so.ground_water_augmentation(a0, water_height=0.0008, pavement_depth=0.001, flat_earth=False, replace=False, plane=PLANE)
+    assert out.shape == o0.shape and np.array_equal(out[:, 4], o0[:, 4])
+    np.testing.assert_allclose(out[:, :3], o0[:, :3], rtol=1e-6, atol=0)
+    np.testing.assert_allclose(out[:, 3], o0[:, 3], rtol=5e-3, atol=0)
