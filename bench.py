@@ -94,7 +94,7 @@ def main():
     out_src = torch.empty(n_total, dtype=torch.int32, device=dev)
     out_counts = torch.zeros(F, dtype=torch.int64, device=dev)
     out_stats = torch.zeros(F, 3, dtype=torch.int64, device=dev)
-    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    status = torch.zeros(8, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -164,7 +164,7 @@ def main():
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "k_beams<float,16,256>", "avg_launch_ms": avg_ms, "launches": n_launch,
+                         "kernel": "k_beams<float,4,256>", "avg_launch_ms": avg_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "40 B/point + 24 B per flake per channel per frame (tables counted, 251.3 B/point)"},
         }

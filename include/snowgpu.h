@@ -86,6 +86,12 @@ int snowgpu_set_lasers(snowgpu_ctx *ctx, int n_lasers, const double *focal_slope
 int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t n_flakes);
 int snowgpu_table_count(const snowgpu_ctx *ctx);
 
+/* Validation switch for the received-power term A * sin^2(pi (R - r) / (c tau_h)) (simulation.py:549).
+ * 0 (default): the engine's own sine (one reduction step + odd polynomial, < 1 ULP) and a multiplication by
+ * 1 / (c tau_h); 1: the device math library's sin and a true division, operation for operation what NumPy
+ * evaluates.  Both modes give the same labels / intensities (tests/test_gpu_parity.py); mode 1 is ~3x slower. */
+int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
+
 /* The 1230-entry range grid of simulation.py:106-116 as the library computes it (for tests). */
 int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
 
@@ -123,8 +129,8 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
  * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
  * the entry point bench.py times.  max_frame_rows = rows of the largest frame (sizes the per-frame grids;
- * 0 = unknown, n_total is used).  d_status (device int32[4]) receives {error code, first bad
- * global row, overflow beams, reserved}; check it after synchronising the stream.
+ * 0 = unknown, n_total is used).  d_status (device int32[8]) receives {error code, first bad
+ * global row, beams handed to the 2nd / 3rd / (unused) list capacity, reserved...}; check it after synchronising the stream.
  */
 int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total,
                                  int64_t max_frame_rows, const int64_t *d_frame_offsets, const void *d_rows, int dtype,

@@ -21,7 +21,7 @@ EXPORTS = [
     "snowgpu_create", "snowgpu_destroy", "snowgpu_last_error", "snowgpu_version", "snowgpu_set_lasers",
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
-    "snowgpu_profile_begin", "snowgpu_profile_end",
+    "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
             L.snowgpu_wet_ground_batch.restype = ctypes.c_int
             L.snowgpu_wet_ground_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, dbl, dbl, dbl,
                                                    ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp]
+            L.snowgpu_set_exact_math.restype = ctypes.c_int
+            L.snowgpu_set_exact_math.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_begin.restype = ctypes.c_int
             L.snowgpu_profile_begin.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_end.restype = ctypes.c_int
@@ -188,6 +190,9 @@ class Context:
                                                   vp(d_perm or None), vp(d_out_rows), vp(d_out_src), vp(d_out_counts),
                                                   vp(d_out_stats), vp(d_out_thr or None), vp(d_status), vp(stream or None))
         self._check(rc)
+
+    def set_exact_math(self, on: bool):
+        self._check(self._L.snowgpu_set_exact_math(self._h, int(bool(on))))
 
     def profile_begin(self, max_launches):
         self._check(self._L.snowgpu_profile_begin(self._h, int(max_launches)))

@@ -30,6 +30,9 @@ struct SgBeamOut {
     int overflow;     // list capacity exceeded: nothing else is valid
     int range_error;  // window beyond the 1230-bin grid (reference: IndexError)
     double diff2;     // 2 * (0.9 * max_intensity - new_i) for label 1, else 0
+    int has_power;    // >= 1 flake kept: the received-power phase has work for this beam
+    int n_flakes;     // scatterers before the hard target (the target sits at index n_flakes)
+    int k_min, k_max; // union of the scatterers' bin windows
 };
 
 __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
@@ -49,6 +52,8 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 #define SG_RHO(j) s_rho[(j) * STRIDE + tid]
 #define SG_RATIO(j) s_ratio[(j) * STRIDE + tid]
 
+// Phases 1-2 and 3a for one beam (per lane).  Leaves the scatterer list in this lane's LDS column:
+// s_a1[t] amplitude, s_a2[t] packed (k1, k0), s_rho[t] range, t = 0 .. n_flakes (hard target last).
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, const SgTable tab,
                                         const SgLasers *__restrict__ las, const double *__restrict__ s_rgrid,
@@ -57,7 +62,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                                         int32_t *dbg_count, double *dbg_rj, double *dbg_ratio)
 {
     constexpr bool F32 = SgReal<T>::is_f32;
-    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0;
+    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.k_min = 0; out.k_max = 0;
     out.x = (double)px; out.y = (double)py; out.z = (double)pz; out.intensity = (double)pint; out.label = 0.0;
 
     // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
@@ -207,14 +212,13 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     }
     if (n_dict == 1) return;                                    // :133 no snowflake in this beam -> label 0
 
-    // ---- phase 3: received power on the 10 cm grid, argmax, decision (simulation.py:135-188) ---
+    // ---- phase 3a (per lane): amplitude and bin window of every scatterer (simulation.py:137-146) --------
     const int ch = channel;
-    const int max_i = las->max_i[ch], min_i = las->min_i[ch];
+    const int max_i = las->max_i[ch];
     const double c_tau = 299792458.0 * 1e-8;                    // c * tau_h
     const double beta_0 = 1 * 1e-6 / SG_PI;                     // :108
     const double i_snow = 0.9 * max_i;                          // :140
     const double ca_p0 = i_snow / beta_0;                       // :141 (also used for the hard target, Q1)
-    // per scatterer: amplitude into s_a1, window [k0, k1) packed into s_a2
     int k_min = SG_RBINS, k_max = 0;
     for (int t = 0; t < n_dict; ++t) {
         int k0, k1;
@@ -242,47 +246,164 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         if (k0 < k_min) k_min = k0;
         if (k1 > k_max) k_max = k1;
     }
-    // I[k] = sum over scatterers (dict order) whose window holds k; argmax = first maximum (:151).
-    double best = 0.0;
-    int k_best = 0;
-    int t_lo = 0;                                               // first flake whose window may still hold k
-    const double tgt_packed = SG_A2(S);
-    const int tk0 = __double2loint(tgt_packed), tk1 = __double2hiint(tgt_packed);
-    for (int k = k_min; k < k_max; ++k) {
-        while (t_lo < S && k >= __double2hiint(SG_A2(t_lo))) ++t_lo;
-        const bool in_tgt = (k >= tk0 && k < tk1);
-        if (t_lo < S) {
-            const int nk0 = __double2loint(SG_A2(t_lo));
-            if (k < nk0 && !in_tgt) {                           // gap: jump to the next window start
-                int nk = nk0;
-                if (k < tk0 && tk0 < nk) nk = tk0;
-                k = nk - 1;
+    out.n_flakes = S;
+    out.k_min = k_min;
+    out.k_max = k_max;
+    out.has_power = 1;
+}
+
+// sin(u) for u in [-0.3, 3.5]: one step of reduction against pi (hi + lo) and the odd Taylor polynomial to
+// x^21 on [-pi/2, pi/2] (truncation 1.3e-18 relative, < 1 ULP overall).  The sign is dropped by the caller's
+// square.  glibc's sin, which NumPy calls, is correctly rounded almost everywhere, so this agrees with it to
+// the last bit or one next to it; see DESIGN.md "phase 3 arithmetic".
+__device__ __forceinline__ double sg_sin_0_pi(double u)
+{
+    const double PI_HI = 3.141592653589793, PI_LO = 1.2246467991473532e-16;
+    double x = u;
+    if (u > 1.5707963267948966) x = (u - PI_HI) - PI_LO;
+    const double x2 = x * x;
+    double p = -1.9572941063391263e-20;                // -1/21!
+    p = __builtin_fma(p, x2, 8.2206352466243295e-18);  //  1/19!
+    p = __builtin_fma(p, x2, -2.8114572543455206e-15); // -1/17!
+    p = __builtin_fma(p, x2, 7.6471637318198164e-13);  //  1/15!
+    p = __builtin_fma(p, x2, -1.6059043836821613e-10); // -1/13!
+    p = __builtin_fma(p, x2, 2.5052108385441720e-08);  //  1/11!
+    p = __builtin_fma(p, x2, -2.7557319223985893e-06); // -1/9!
+    p = __builtin_fma(p, x2, 1.9841269841269841e-04);  //  1/7!
+    p = __builtin_fma(p, x2, -8.3333333333333332e-03); // -1/5!
+    p = __builtin_fma(p, x2, 1.6666666666666666e-01);  //  1/3!  (sign applied below)
+    return __builtin_fma(-(x * x2), p, x);
+}
+
+// A * sin^2(pi (R - r) / (c tau_h))  (simulation.py:549)
+template <bool EXACT>
+__device__ __forceinline__ double sg_power_term(double amp, double Rk, double r)
+{
+    const double c_tau = 299792458.0 * 1e-8;
+    double sn;
+    if (EXACT) sn = sin((SG_PI * (Rk - r)) / c_tau);
+    else sn = sg_sin_0_pi((SG_PI * (Rk - r)) * (1.0 / c_tau));
+    return amp * (sn * sn);
+}
+
+// ---- phase 3b (cooperative): received power on the 10 cm grid and its first maximum (simulation.py:135-151) --
+// Each half-wave (32 lanes) takes the beams of its own 32 lanes one at a time and spreads the range bins of
+// that beam over its lanes -- a scatterer's window is 31 bins, so one chunk holds it.  For every bin the
+// contributions are added in dict order (flakes near -> far, hard target last), exactly the order in which the
+// reference's `i[k] += ...` loop visits them; bins nobody touches stay 0.  The list of the beam being worked on
+// is read from the owning lane's LDS column (same address across the half-wave: a broadcast); the beam's
+// scalars come over v_readlane, the half-wave argmax over DPP row operations -- no LDS round trips for either.
+
+// value of `v` in lane (half * 32 + i), i wave-uniform
+__device__ __forceinline__ int sg_bcast_half(int v, int i, bool upper)
+{
+    const int lo = __builtin_amdgcn_readlane(v, i), hi = __builtin_amdgcn_readlane(v, 32 + i);
+    return upper ? hi : lo;
+}
+
+template <int CTRL> __device__ __forceinline__ int sg_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL> __device__ __forceinline__ void sg_argmax_step_dpp(double &bv, int &bk)
+{
+    const double ov = __hiloint2double(sg_dpp<CTRL>(__double2hiint(bv)), sg_dpp<CTRL>(__double2loint(bv)));
+    const int ok = sg_dpp<CTRL>(bk);
+    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+}
+// max value, smallest bin on ties, over the 32 lanes of a half-wave; every lane ends with the result
+__device__ __forceinline__ void sg_argmax_half(double &bv, int &bk)
+{
+    sg_argmax_step_dpp<0xB1>(bv, bk);     // quad_perm [1,0,3,2]: lane ^ 1
+    sg_argmax_step_dpp<0x4E>(bv, bk);     // quad_perm [2,3,0,1]: lane ^ 2
+    sg_argmax_step_dpp<0x124>(bv, bk);    // row_ror:4 within the 16-lane row
+    sg_argmax_step_dpp<0x128>(bv, bk);    // row_ror:8
+    const double ov = __shfl_xor(bv, 16);  // the other 16-lane row of this half
+    const int ok = __shfl_xor(bk, 16);
+    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+}
+
+// R[k] of simulation.py:116 without a table: n = rint(k * step * 100) is the grid value in centimetres and
+// n / 100 is recovered with one Newton step on n * 0.01 -- bit-identical to np.round(np.linspace(...), 2) for
+// all 1230 bins (checked exhaustively on the host, tests/test_host_logic.py).
+__device__ __forceinline__ double sg_range_bin(int k)
+{
+    const double step = (120 + 299792458.0 * 1e-8) / (SG_RBINS - 1);
+    const double n = rint(((double)k * step) * 100.0);
+    const double q = n * 0.01;
+    return __builtin_fma(__builtin_fma(-q, 100.0, n), 0.01, q);
+}
+
+template <int STRIDE, bool EXACT>
+__device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, int k_max, const double *__restrict__ rgrid,
+                                              const double *s_a1, const double *s_a2, const double *s_rho, int tid,
+                                              double &best, int &k_best)
+{
+    const int lane = tid & 63, sub = lane & 31;
+    const bool upper = lane >= 32;
+    const int wave_col = tid - lane;
+    best = 0.0;
+    k_best = 0;
+    const unsigned long long todo = __ballot(has_power != 0);
+    const unsigned todo_any = (unsigned)(todo | (todo >> 32));       // lanes i with work in either half
+    for (int i = 0; i < 32; ++i) {
+        if (!((todo_any >> i) & 1u)) continue;                       // wave-uniform
+        if (!sg_bcast_half(has_power, i, upper)) continue;           // half-uniform
+        const int bS = sg_bcast_half(S, i, upper), bkmin = sg_bcast_half(k_min, i, upper),
+                  bkmax = sg_bcast_half(k_max, i, upper);
+        const int col = wave_col + (lane & 32) + i;
+        const double tpk = s_a2[bS * STRIDE + col];
+        const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+        const double tamp = s_a1[bS * STRIDE + col], td = s_rho[bS * STRIDE + col];
+        double lbest = 0.0;
+        int lk = 0;
+        int t_lo = 0, c = bkmin;
+        while (c < bkmax) {
+            while (t_lo < bS && __double2hiint(s_a2[t_lo * STRIDE + col]) <= c) ++t_lo;
+            const int fstart = t_lo < bS ? __double2loint(s_a2[t_lo * STRIDE + col]) : 0x7fffffff;
+            const bool tgt_hit = (tk0 < c + 32) && (tk1 > c);
+            if (fstart >= c + 32 && !tgt_hit) {              // nothing here: jump to the next window start
+                int nc = fstart;
+                if (tk0 > c && tk0 < nc) nc = tk0;
+                if (nc == 0x7fffffff) break;
+                c = nc;
                 continue;
             }
-        } else if (!in_tgt) {
-            if (k < tk0) { k = tk0 - 1; continue; }
-            break;
-        }
-        const double Rk = s_rgrid[k];
-        double sum = 0.0;                                       // :135 np.zeros
-        for (int t = t_lo; t < S; ++t) {
-            const double pk = SG_A2(t);
-            if (k < __double2loint(pk)) break;                  // flake windows start in range order
-            if (k < __double2hiint(pk)) {
-                const double sn = sin((SG_PI * (Rk - SG_RHO(t))) / c_tau);
-                sum += SG_A1(t) * (sn * sn);                    // :149
+            const int k = c + sub;
+            const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
+            double sum = 0.0;                                // :135 np.zeros
+            for (int t = t_lo; t < bS; ++t) {
+                const double pk = s_a2[t * STRIDE + col];
+                const int k0 = __double2loint(pk);
+                if (k0 >= c + 32) break;                     // flake windows start in range order
+                if (k >= k0 && k < __double2hiint(pk))
+                    sum += sg_power_term<EXACT>(s_a1[t * STRIDE + col], Rk, s_rho[t * STRIDE + col]);   // :149
             }
+            if (tgt_hit && k >= tk0 && k < tk1) sum += sg_power_term<EXACT>(tamp, Rk, td);
+            if (sum > lbest) { lbest = sum; lk = k; }        // ascending k per lane: keeps the first maximum
+            c += 32;
         }
-        if (in_tgt) {
-            const double sn = sin((SG_PI * (Rk - d)) / c_tau);
-            sum += SG_A1(S) * (sn * sn);
-        }
-        if (sum > best) { best = sum; k_best = k; }
+        sg_argmax_half(lbest, lk);                           // ties -> smaller bin: np.argmax's first maximum (:151)
+        if (sub == i) { best = lbest; k_best = lk; }
     }
+}
+
+// ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------
+template <typename T>
+__device__ __forceinline__ void sg_beam_decide(T px, T py, T pz, int channel, const SgLasers *__restrict__ las, double best,
+                                               int k_best, SgBeamOut &out)
+{
+    T d_t;
+    if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);
+    else d_t = sqrt((px * px + py * py) + pz * pz);
+    const double d = (double)d_t;
+    const int max_i = las->max_i[channel], min_i = las->min_i[channel];
+    const double c_tau = 299792458.0 * 1e-8;
+    const double i_snow = 0.9 * max_i;
     double i_max = best;                                        // :152
     const double d_max = ((double)k_best / 10) - (c_tau / 2);   // :153
     const double t1 = 1 - d_max / 120;
-    i_max += max_i * las->focal_slope[ch] * fabs(las->focal_offset[ch] - t1 * t1);   // :155
+    i_max += max_i * las->focal_slope[channel] * fabs(las->focal_offset[channel] - t1 * t1);   // :155
     if (i_max < min_i) i_max = min_i;                           // :156
     if (i_max > max_i) i_max = max_i;
     long long new_i = (long long)i_max;                         // :162 / :182

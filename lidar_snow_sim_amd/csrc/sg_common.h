@@ -57,15 +57,19 @@ struct SgBeamArgs {
     void *tmp_rows;              // channel-sorted, un-compacted result rows
     uint8_t *keep;               // per sorted row
     int32_t *status;             // [0] error code, [1] first offending sorted row, [2] overflow beams
-    int32_t *ovf_list;           // sorted positions that overflowed the fast list
+    int32_t *ovf_list;           // sorted positions that overflowed this pass's list capacity
+    int32_t *ovf_count;          // counter to bump for them (status[2] or status[3])
     int32_t ovf_cap;
     const int32_t *work_list;    // non-null: process these sorted positions (overflow pass)
     const int32_t *work_count;
+    int32_t work_cap;            // entries of work_list that may be read
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
     int32_t *dbg_count;          // optional occlusion-dict tap
     double *dbg_rj;
     double *dbg_ratio;
     int32_t dbg_cap;
+    int32_t exact_math;          // 1: libm sin + true division in the power term (validation mode)
+    unsigned long long *phase_cycles;   // optional [8]: per-wave cycle totals per phase (profiling builds of the call)
 };
 
 // Launch wrappers implemented in snowgpu_kernels.hip (hipStream_t passed as void*).

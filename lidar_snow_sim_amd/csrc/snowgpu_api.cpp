@@ -56,7 +56,7 @@ struct snowgpu_ctx {
     double *d_rgrid = nullptr;
     int32_t *d_status = nullptr;      // 4 ints
     // scratch shared by every batch
-    DevBuf<int32_t> tile_hist, tile_base, ovf_list, perm, ctile_cnt, ctile_base, table_ids, out_src;
+    DevBuf<int32_t> tile_hist, tile_base, ovf_list, ovf_list2, perm, ctile_cnt, ctile_base, table_ids, out_src;
     DevBuf<uint16_t> rank;
     DevBuf<uint8_t> keep, rows_in, rows_tmp, rows_out;
     DevBuf<int64_t> frame_off, out_counts, out_stats;
@@ -69,6 +69,8 @@ struct snowgpu_ctx {
     int ev_used = 0;
     bool prof = false;
     hipStream_t prof_stream = nullptr;
+    int exact_math = 0;
+    unsigned long long *phase_cycles = nullptr;   // device [8], experiments only
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -129,7 +131,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 8));
     double grid[SG_RBINS];
     range_grid(grid);
     HIPCHK(ctx, hipMemcpy(ctx->d_rgrid, grid, sizeof(grid), hipMemcpyHostToDevice));
@@ -150,7 +152,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_las) (void)hipFree(ctx->d_las);
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->perm.release();
+    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->ovf_list2.release(); ctx->perm.release();
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
@@ -333,13 +335,18 @@ static int sync_tables(snowgpu_ctx *ctx)
     return SNOWGPU_OK;
 }
 
-// Expected flakes per beam ~ K * delta / (2 pi); pick the per-thread list capacity of the fast pass.
-static int choose_lmax(const snowgpu_ctx *ctx, double beam_div_deg)
+// Expected flakes per beam for a target at the table's edge ~ K * delta / (2 pi); real sweeps sit well
+// below that (flakes in range scale with (d / R0)^2).  The first pass runs with the smallest list that most
+// beams fit in -- its LDS footprint decides how many waves hide each other's latency -- and hands the rest
+// to the next capacity.
+static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[3], int *n_tiers)
 {
     const double expect = (double)ctx->max_flakes * (beam_div_deg * (SG_PI / 180.0)) / SG_TWO_PI;
-    if (expect <= 9.5) return 16;
-    if (expect <= 20.0) return 32;
-    return SG_LCAP;
+    int n = 0;
+    if (expect <= 12.0) tiers[n++] = 4;
+    if (expect <= 40.0) tiers[n++] = 16;
+    tiers[n++] = SG_LCAP;
+    *n_tiers = n;
 }
 
 // ---- the batch launch sequence (everything on device pointers) --------------------------------------
@@ -381,7 +388,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
-    HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
     {
         const int32_t minus1 = -1;   // status[1] = first offending row, -1 = none
         HIPCHK(ctx, hipMemcpyAsync(b.status + 1, &minus1, sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -420,32 +427,37 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->rows_tmp, n * 5 * esz);
     ENSURE(ctx, ctx->keep, n);
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
-    const int32_t ovf_cap = (int32_t)std::min<size_t>(n, (size_t)1 << 22);
+    const int32_t ovf_cap = (int32_t)std::min<size_t>(n, (size_t)1 << 24);
     ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
+    ENSURE(ctx, ctx->ovf_list2, (size_t)ovf_cap);
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
     a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
     a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.thr_poly = thr; a.tmp_rows = ctx->rows_tmp.p;
-    a.keep = ctx->keep.p; a.status = b.status; a.ovf_list = ctx->ovf_list.p; a.ovf_cap = ovf_cap;
-    a.work_list = nullptr; a.work_count = nullptr; a.diff2 = ctx->diff2.p;
+    a.keep = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
-    const int lmax = choose_lmax(ctx, b.beam_div_deg);
-    const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
-    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
-    int e = sg_launch_beams(&a, b.dtype, lmax, st);
-    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
-    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
-    if (lmax < SG_LCAP) {
-        // overflow pass: beams with more intersecting flakes than the fast list holds.  The count lives on
-        // the device; the grid is sized for a bounded number of overflow beams and further ones are reported.
-        SgBeamArgs o = a;
-        o.work_list = ctx->ovf_list.p;
-        o.work_count = b.status + 2;
-        o.ovf_cap = std::min<int32_t>(ovf_cap, 1 << 16);
-        e = sg_launch_beams(&o, b.dtype, SG_LCAP, st);
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("overflow launch: ") + hipGetErrorString((hipError_t)e));
+    a.exact_math = ctx->exact_math;
+    a.phase_cycles = ctx->phase_cycles;
+    int tiers[3], n_tiers = 0;
+    choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
+    // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
+    // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
+    int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
+    for (int t = 0; t < n_tiers; ++t) {
+        a.work_list = t == 0 ? nullptr : lists[(t - 1) & 1];
+        a.work_count = t == 0 ? nullptr : b.status + 1 + t;
+        a.work_cap = ovf_cap;
+        a.ovf_list = lists[t & 1];
+        a.ovf_count = b.status + 2 + t;
+        a.ovf_cap = ovf_cap;
+        const bool timed = t == 0 && ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
+        if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
+        int e = sg_launch_beams(&a, b.dtype, tiers[t], st);
+        if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     }
+    int e = 0;
     // 4. round + noise-floor filter + compaction + stats (simulation.py:516-530)
     ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles);
     ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles);
@@ -456,13 +468,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     return SNOWGPU_OK;
 }
 
-static int status_to_error(snowgpu_ctx *ctx, const int32_t st[4])
+static int status_to_error(snowgpu_ctx *ctx, const int32_t st[8])
 {
     char buf[200];
-    if (st[2] > (1 << 16)) {
-        snprintf(buf, sizeof buf, "%d beams overflowed the fast flake list (more than the overflow pass handles)", st[2]);
-        return fail(ctx, SNOWGPU_E_OVERFLOW, buf);
-    }
     switch (st[0]) {
     case 0: return SNOWGPU_OK;
     case SNOWGPU_E_RANGE:
@@ -574,7 +582,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         b.dbg_count = ctx->dbg_count.p; b.dbg_rj = ctx->dbg_rj.p; b.dbg_ratio = ctx->dbg_ratio.p; b.dbg_cap = dbg_cap;
     }
     int rc = run_batch(ctx, b);
-    int32_t status[4] = {0, -1, 0, 0};
+    int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
     if (rc == SNOWGPU_OK) {
         HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
@@ -621,6 +629,34 @@ extern "C" int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const 
     int64_t cnt = 0, stats[3];
     return host_batch(ctx, 1, off, rows, dtype, table_ids, beam_divergence_deg, thr, nullptr, 0.7, nullptr, out_rows.data(),
                       out_src.data(), &cnt, stats, nullptr, cap, count, rj, ratio, sorted_src);
+}
+
+extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    ctx->exact_math = on ? 1 : 0;
+    return SNOWGPU_OK;
+}
+
+extern "C" int sg_set_phase_dbg(unsigned long long *p);   // snowgpu_kernels.hip
+
+// Experiments only (not in snowgpu.h): per-phase cycle counters of the per-beam kernel.
+extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned long long *out8)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (enable) {
+        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 16 * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 16 * sizeof(unsigned long long)));
+        sg_set_phase_dbg(ctx->phase_cycles);
+    } else if (ctx->phase_cycles) {
+        HIPCHK(ctx, hipDeviceSynchronize());
+        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        sg_set_phase_dbg(nullptr);
+        (void)hipFree(ctx->phase_cycles);
+        ctx->phase_cycles = nullptr;
+    }
+    return SNOWGPU_OK;
 }
 
 extern "C" int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches)
@@ -685,7 +721,7 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t) * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t) * 8, st));
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;

@@ -133,65 +133,115 @@ template <typename T, int LMAX, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *s_rgrid = (double *)smem;
-    double *s_a1 = s_rgrid + SG_RBINS + 2;            // keep 16-byte alignment: 1232 doubles
-    double *s_a2 = s_a1 + LMAX * BLOCK;
-    double *s_rho = s_a2 + LMAX * BLOCK;
+    const double *s_rgrid = a.rgrid;                  // 9.8 KB, read with consecutive bins per lane: L1-resident
+    double *s_a1 = (double *)smem;                    // LMAX + 1 rows each: the hard target is entry n_flakes <= LMAX
+    double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
+    double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
     double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
     const int tid = threadIdx.x;
-    for (int i = tid; i < SG_RBINS; i += BLOCK) s_rgrid[i] = a.rgrid[i];
-    __syncthreads();
+    int64_t work_n = 0;
+    if (a.work_list) {                                   // overflow pass: most blocks have nothing to do
+        work_n = *a.work_count;
+        if (work_n > a.work_cap) work_n = a.work_cap;
+        if ((int64_t)blockIdx.x * BLOCK >= work_n) return;
+    }
 
-    int64_t g;
+    int64_t g = -1;
     if (a.work_list) {
         const int64_t w = (int64_t)blockIdx.x * BLOCK + tid;
-        int cnt = *a.work_count;
-        if (cnt > a.ovf_cap) cnt = a.ovf_cap;
-        if (w >= cnt) return;
-        g = a.work_list[w];
+        if (w < work_n) g = a.work_list[w];
     } else {
         g = (int64_t)blockIdx.x * BLOCK + tid;
-        if (g >= a.n_total) return;
+        if (g >= a.n_total) g = -1;
     }
-    const int f = sg_find_frame(a.frame_off, a.n_frames, g);
-    const int64_t fbase = a.frame_off[f];
-    const int64_t src = fbase + a.perm[g];
-    const T *row = (const T *)a.rows + src * 5;
-    const T px = row[0], py = row[1], pz = row[2], pint = row[3], pch = row[4];
+    const unsigned long long tcs = a.phase_cycles ? wall_clock64() : 0;
+    // No early return from here on: the received-power phase is cooperative across the wave.
+    const bool live = g >= 0;
+    int f = 0;
+    T px = 0, py = 0, pz = 0, pint = 0, pch = 0;
+    int ch = 0;
+    bool simulated = false;
     const int n_las = a.las->n;
-    const int ch = (int)pch;
-    const bool simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;   // simulation.py:80, :482 (Q5)
-
+    if (live) {
+        f = sg_find_frame(a.frame_off, a.n_frames, g);
+        const int64_t src = a.frame_off[f] + a.perm[g];
+        const T *row = (const T *)a.rows + src * 5;
+        px = row[0]; py = row[1]; pz = row[2]; pint = row[3]; pch = row[4];
+        ch = (int)pch;
+        simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;            // simulation.py:80, :482 (Q5)
+    }
+    const unsigned long long tc0 = a.phase_cycles ? wall_clock64() : 0;
     SgBeamOut o;
     o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = (double)pint; o.label = (double)pch;
-    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.k_min = 0; o.k_max = 0;
+    bool write_row = live;
     if (simulated) {
         const int tid_table = a.table_ids[(int64_t)f * n_las + ch];
         if (tid_table < 0 || tid_table >= a.n_tables || a.tables[tid_table].entries == nullptr) {
             atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
-            return;
-        }
-        const SgTable tab = a.tables[tid_table];
-        int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
-        double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
-        double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-        sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
-                                s_ratio, tid, o, a.dbg_cap, dc, drj, dra);
-        if (o.overflow) {
-            if (LMAX >= SG_LCAP) {
-                atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+            write_row = false;
+        } else {
+            const SgTable tab = a.tables[tid_table];
+            int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+            double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
+            double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
+            sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
+                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra);
+            if (o.overflow) {
+                write_row = false;                        // a later pass with a longer list writes this row
+                o.has_power = 0;
+            } else if (o.range_error) {
+                atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
                 atomicCAS(&a.status[1], -1, (int32_t)g);
-            } else {
-                const int slot = atomicAdd(&a.status[2], 1);
-                if (slot < a.ovf_cap) a.ovf_list[slot] = (int32_t)g;
             }
-            return;                                   // the overflow pass writes this row
-        }
-        if (o.range_error) {
-            atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
-            atomicCAS(&a.status[1], -1, (int32_t)g);
         }
     }
+    {   // queue the overflowed beams of this wave with ONE atomic (a per-lane atomic on a single counter
+        // serialises in L2 and stalls every other memory request behind it)
+        const unsigned long long om = __ballot(o.overflow != 0);
+        if (om) {
+            if (LMAX >= SG_LCAP) {
+                if (o.overflow) {
+                    atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+                    atomicCAS(&a.status[1], -1, (int32_t)g);
+                }
+            } else {
+                int base = 0;
+                const int leader = __ffsll((long long)om) - 1;
+                if ((tid & 63) == leader) base = atomicAdd(a.ovf_count, (int)__popcll(om));
+                base = __shfl(base, leader);
+                if (o.overflow) {
+                    const int slot = base + (int)__popcll(om & sg_lanemask_lt());
+                    if (slot < a.ovf_cap) a.ovf_list[slot] = (int32_t)g;
+                }
+            }
+        }
+    }
+    const unsigned long long tc1 = a.phase_cycles ? wall_clock64() : 0;
+    double best;
+    int k_best;
+    if (a.exact_math) sg_wave_power<BLOCK, true>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+    else sg_wave_power<BLOCK, false>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+    const unsigned long long tc2 = a.phase_cycles ? wall_clock64() : 0;
+    if (a.phase_cycles && (tid & 63) == 0) {
+        atomicAdd(&a.phase_cycles[0], tc1 - tc0);      // load + phases 1, 2, 3a
+        atomicAdd(&a.phase_cycles[1], tc2 - tc1);      // phase 3b
+        atomicAdd(&a.phase_cycles[2], 1ull);           // waves
+        atomicAdd(&a.phase_cycles[3], tc0 - tcs);      // frame lookup + row load
+    }
+    if (o.has_power) sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
+    {   // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam
+        long long d2 = write_row ? (long long)o.diff2 : 0;
+        const int f0 = __shfl(f, 0);
+        const bool same = __all(!live || f == f0);
+        if (same) {
+            for (int off = 32; off > 0; off >>= 1) d2 += __shfl_down(d2, off);
+            if ((tid & 63) == 0 && d2 != 0) atomicAdd(&a.diff2[f0], (unsigned long long)d2);
+        } else if (d2 != 0) {
+            atomicAdd(&a.diff2[f], (unsigned long long)d2);      // wave straddling two frames
+        }
+    }
+    if (!write_row) return;
     // ---- frame-level epilogue (simulation.py:516-520) -------------------------------------------
     T *orow = (T *)a.tmp_rows + g * 5;
     T oi;
@@ -213,7 +263,6 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
     const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
     a.keep[g] = keep ? 1 : 0;
-    if (o.diff2 != 0.0) atomicAdd(&a.diff2[f], (unsigned long long)(long long)o.diff2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,6 +362,8 @@ __global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, con
     out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // simulation.py:527-530 int()
 }
 
+extern "C" int sg_set_phase_dbg(unsigned long long *) { return 0; }
+
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (C linkage, called from snowgpu_api.cpp)
 
@@ -343,7 +394,7 @@ extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_
 template <typename T, int LMAX, int BLOCK>
 static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * ((SG_RBINS + 2) + (size_t)BLOCK * (2 * LMAX + 2 * (LMAX + 1)));
+    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -357,17 +408,20 @@ static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st
     return 0;
 }
 
-// lmax: 16 (fast path, 256-thread blocks), 32 (dense tables, 128-thread blocks) or 63 (overflow pass,
-// 64-thread blocks).  With a->work_list set the grid covers a->ovf_cap work items.
+// lmax = per-beam list capacity of this pass: 4 (144 B of LDS per beam: 16 waves per CU), 16, 32 or 63 (the
+// hard cap).  Beams that exceed it are queued for the next pass.  With a->work_list set the grid covers
+// a->work_cap work items and idle blocks leave at once.
 extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    const int64_t n = a->work_list ? (int64_t)a->ovf_cap : a->n_total;
+    const int64_t n = a->work_list ? (int64_t)a->work_cap : a->n_total;
     if (dtype == 0) {
+        if (lmax == 4) return launch_beams_t<float, 4, 256>(a, n, st);
         if (lmax == 16) return launch_beams_t<float, 16, 256>(a, n, st);
         if (lmax == 32) return launch_beams_t<float, 32, 128>(a, n, st);
         return launch_beams_t<float, SG_LCAP, 64>(a, n, st);
     } else {
+        if (lmax == 4) return launch_beams_t<double, 4, 256>(a, n, st);
         if (lmax == 16) return launch_beams_t<double, 16, 256>(a, n, st);
         if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
         return launch_beams_t<double, SG_LCAP, 64>(a, n, st);

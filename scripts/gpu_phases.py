@@ -1,0 +1,29 @@
+"""Experiment: per-phase cycle totals of the per-beam kernel on the bench workload (one batch)."""
+import ctypes, random, sys, time
+import numpy as np
+sys.path.insert(0, '/root/repo')
+from lidar_snow_sim_amd import _native, engine
+from lidar_snow_sim_amd.synthetic import synthetic_sweep
+sys.argv = sys.argv[:1]
+import bench
+eng = engine.get_engine(0)
+tables = bench.make_tables(64)
+F = 8
+frames, tids, planes = [], [], []
+for f in range(F):
+    pc = synthetic_sweep(64, 2048, seed=1000 + f, intensity="lambert")
+    random.seed(1000 + f); order = list(range(64)); random.shuffle(order)
+    frames.append(pc); tids.append(eng.table_ids_from_arrays(tables, order)); planes.append([0, 0, -1.0, -1.7])
+rows = np.concatenate(frames); off = np.arange(F + 1) * frames[0].shape[0]
+L = _native.lib()
+L.snowgpu_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes)
+L.snowgpu_debug_phase_cycles(eng.ctx.handle, 1, None)
+t = time.time(); eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes); dt = time.time() - t
+out = (ctypes.c_ulonglong * 16)()
+L.snowgpu_debug_phase_cycles(eng.ctx.handle, 0, out)
+v = list(out); waves = max(v[2], 1)
+print('waves', waves, 'host call', dt)
+print('per wave (100 MHz ticks x24 = cycles @2.4GHz):')
+for name, x in (('row load', v[3]), ('P1+P2+P3a', v[0]), ('P3b', v[1])):
+    print(f'  {name:16s} {x / waves:10.1f} ticks  ~{x / waves * 24:10.0f} cycles')

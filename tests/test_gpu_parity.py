@@ -257,3 +257,23 @@ def test_chained_snow_then_wet_like_the_viewer(eng, so, golden, tables):
     assert out.shape == o0.shape and np.array_equal(out[:, 4], o0[:, 4])
     np.testing.assert_allclose(out[:, :3], o0[:, :3], rtol=1e-6, atol=0)
     np.testing.assert_allclose(out[:, 3], o0[:, 3], rtol=5e-3, atol=0)
+
+
+def test_fast_sine_equals_libm_mode_on_a_full_sweep(eng, tables):
+    """64 x 2048 sweep (BASELINE config C2 shape): the engine's own sin^2 against the device libm + true
+    division (snowgpu_set_exact_math) -- same kept rows, labels and intensities."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    pc = synthetic_sweep(64, 2048, seed=1007, intensity="lambert")
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    kw = dict(only_camera_fov=False, plane=PLANE, order=list(range(64)), particles=tl, return_src=True)
+    s_fast, a_fast, src_fast = augment(pc, "unused", bd, **kw)
+    eng.ctx.set_exact_math(True)
+    try:
+        s_ex, a_ex, src_ex = augment(pc, "unused", bd, **kw)
+    finally:
+        eng.ctx.set_exact_math(False)
+    assert tuple(int(v) for v in s_fast) == tuple(int(v) for v in s_ex)
+    assert np.array_equal(src_fast, src_ex) and np.array_equal(a_fast, a_ex)
+    assert (a_fast[:, 4] == 1).sum() > 1000 and (a_fast[:, 4] == 2).sum() > 100
