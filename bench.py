@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="frames per batch (per GPU)")
+    ap.add_argument("--frames", type=int, default=128, help="frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
     args = ap.parse_args()
@@ -160,11 +160,12 @@ def main():
                                    "beam_divergence=3 mrad, noise_floor=0.7, float32 rows resident in HBM",
                        "frames_per_step_per_gpu": F, "points_per_frame": n_per,
                        "prepass": "host (outside the timed region)" if args.host_prepass else "device (timed)",
-                       "sharding": f"frame-parallel x{world}, no collective"},
+                       "sharding": f"frame-parallel x{world}, no collective",
+                       "beams_per_capacity_tier": [int(n_total)] + [int(v) for v in st[2:5]]},
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "k_beams<float,4,256>", "avg_launch_ms": avg_ms, "launches": n_launch,
+                         "kernel": "k_beams<float,LMAX,BLOCK> (capacity tiers 4/8/16/63, launched back to back)", "avg_launch_ms": avg_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "40 B/point + 24 B per flake per channel per frame (tables counted, 251.3 B/point)"},
         }

@@ -388,6 +388,60 @@ __device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, i
     }
 }
 
+// ---- phase 3b, per-lane form (later capacity tiers) ---------------------------------------------------------
+// When every lane of a wave carries a long list the cooperative form serialises 32 beams per half-wave and the
+// wave's latency explodes while most of the chip idles; here each lane walks its own bins.  Same sums in the
+// same order: flakes covering bin k in range order, then the hard target.  The nearest still-open flake window
+// is cached in registers, so the common one-flake-per-bin case touches no LDS.
+template <int STRIDE, bool EXACT>
+__device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const double *__restrict__ rgrid,
+                                              const double *s_a1, const double *s_a2, const double *s_rho, int tid,
+                                              double &best, int &k_best)
+{
+    best = 0.0;
+    k_best = 0;
+    const double tpk = s_a2[S * STRIDE + tid];
+    const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+    const double tamp = s_a1[S * STRIDE + tid], td = s_rho[S * STRIDE + tid];
+    int t_lo = 0;
+    double c_amp = 0.0, c_r = 0.0;
+    int c_k0 = 0x7fffffff, c_k1 = 0x7fffffff;
+    if (S > 0) {
+        const double pk = s_a2[tid];
+        c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk); c_amp = s_a1[tid]; c_r = s_rho[tid];
+    }
+    for (int k = k_min; k < k_max; ++k) {
+        while (t_lo < S && k >= c_k1) {
+            ++t_lo;
+            if (t_lo < S) {
+                const double pk = s_a2[t_lo * STRIDE + tid];
+                c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk);
+                c_amp = s_a1[t_lo * STRIDE + tid]; c_r = s_rho[t_lo * STRIDE + tid];
+            } else { c_k0 = 0x7fffffff; c_k1 = 0x7fffffff; }
+        }
+        const bool in_tgt = k >= tk0 && k < tk1;
+        if (k < c_k0 && !in_tgt) {                           // gap: jump to the next window start
+            int nk = c_k0;
+            if (k < tk0 && tk0 < nk) nk = tk0;
+            if (nk == 0x7fffffff) break;
+            k = nk - 1;
+            continue;
+        }
+        const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
+        double sum = 0.0;                                    // :135 np.zeros
+        if (k >= c_k0) {
+            sum += sg_power_term<EXACT>(c_amp, Rk, c_r);     // :149
+            for (int t = t_lo + 1; t < S; ++t) {
+                const double pk = s_a2[t * STRIDE + tid];
+                if (k < __double2loint(pk)) break;           // flake windows start in range order
+                if (k < __double2hiint(pk)) sum += sg_power_term<EXACT>(s_a1[t * STRIDE + tid], Rk, s_rho[t * STRIDE + tid]);
+            }
+        }
+        if (in_tgt) sum += sg_power_term<EXACT>(tamp, Rk, td);
+        if (sum > best) { best = sum; k_best = k; }          // ascending k: first maximum (:151)
+    }
+}
+
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------
 template <typename T>
 __device__ __forceinline__ void sg_beam_decide(T px, T py, T pz, int channel, const SgLasers *__restrict__ las, double best,

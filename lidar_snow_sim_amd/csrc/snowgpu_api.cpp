@@ -339,11 +339,12 @@ static int sync_tables(snowgpu_ctx *ctx)
 // below that (flakes in range scale with (d / R0)^2).  The first pass runs with the smallest list that most
 // beams fit in -- its LDS footprint decides how many waves hide each other's latency -- and hands the rest
 // to the next capacity.
-static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[3], int *n_tiers)
+static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[4], int *n_tiers)
 {
     const double expect = (double)ctx->max_flakes * (beam_div_deg * (SG_PI / 180.0)) / SG_TWO_PI;
     int n = 0;
     if (expect <= 12.0) tiers[n++] = 4;
+    if (expect <= 24.0) tiers[n++] = 8;
     if (expect <= 40.0) tiers[n++] = 16;
     tiers[n++] = SG_LCAP;
     *n_tiers = n;
@@ -439,7 +440,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
     a.phase_cycles = ctx->phase_cycles;
-    int tiers[3], n_tiers = 0;
+    int tiers[4], n_tiers = 0;
     choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
     // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
@@ -451,10 +452,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.ovf_list = lists[t & 1];
         a.ovf_count = b.status + 2 + t;
         a.ovf_cap = ovf_cap;
-        const bool timed = t == 0 && ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
-        if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
+        // measurement hooks: one event pair around ALL capacity tiers of the per-beam kernel
+        const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
+        if (timed && t == 0) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
         int e = sg_launch_beams(&a, b.dtype, tiers[t], st);
-        if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
+        if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     }
     int e = 0;

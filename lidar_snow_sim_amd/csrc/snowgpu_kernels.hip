@@ -6,6 +6,7 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see lidar_snow_sim_amd/build.py).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "sg_beam.h"
 
 #define SG_BLOCK 256
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // The per-beam kernel.  Dynamic LDS: range grid (1230 doubles) + four per-thread lists.
-template <typename T, int LMAX, int BLOCK>
+template <typename T, int LMAX, int BLOCK, bool LIST>
 __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -139,19 +140,21 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
     double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
     const int tid = threadIdx.x;
-    int64_t work_n = 0;
-    if (a.work_list) {                                   // overflow pass: most blocks have nothing to do
+    // Direct mode: one block per 256 consecutive channel-sorted rows.  List mode (a later capacity tier): the
+    // number of queued beams is only known on the device, so a small fixed grid strides over the queue -- a block
+    // with this much LDS cannot share its CU, and thousands of empty ones would each cost a dispatch slot.
+    int64_t work_n = a.n_total;
+    if (LIST) {
         work_n = *a.work_count;
         if (work_n > a.work_cap) work_n = a.work_cap;
-        if ((int64_t)blockIdx.x * BLOCK >= work_n) return;
     }
-
+    const int64_t stride = LIST ? (int64_t)gridDim.x * BLOCK : work_n;      // direct mode: exactly one trip
+    for (int64_t chunk = (int64_t)blockIdx.x * BLOCK; chunk < work_n; chunk += stride) {
     int64_t g = -1;
-    if (a.work_list) {
-        const int64_t w = (int64_t)blockIdx.x * BLOCK + tid;
-        if (w < work_n) g = a.work_list[w];
+    if (LIST) {
+        if (chunk + tid < work_n) g = a.work_list[chunk + tid];
     } else {
-        g = (int64_t)blockIdx.x * BLOCK + tid;
+        g = chunk + tid;
         if (g >= a.n_total) g = -1;
     }
     const unsigned long long tcs = a.phase_cycles ? wall_clock64() : 0;
@@ -220,8 +223,16 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const unsigned long long tc1 = a.phase_cycles ? wall_clock64() : 0;
     double best;
     int k_best;
-    if (a.exact_math) sg_wave_power<BLOCK, true>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
-    else sg_wave_power<BLOCK, false>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+    if constexpr (LMAX <= 4) {       // sparse first tier: bins of one beam spread over a half-wave
+        if (a.exact_math) sg_wave_power<BLOCK, true>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+        else sg_wave_power<BLOCK, false>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+    } else {                         // dense later tiers: every lane walks its own bins
+        best = 0.0; k_best = 0;
+        if (o.has_power) {
+            if (a.exact_math) sg_lane_power<BLOCK, true>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+            else sg_lane_power<BLOCK, false>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+        }
+    }
     const unsigned long long tc2 = a.phase_cycles ? wall_clock64() : 0;
     if (a.phase_cycles && (tid & 63) == 0) {
         atomicAdd(&a.phase_cycles[0], tc1 - tc0);      // load + phases 1, 2, 3a
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             atomicAdd(&a.diff2[f], (unsigned long long)d2);      // wave straddling two frames
         }
     }
-    if (!write_row) return;
+    if (!write_row) continue;
     // ---- frame-level epilogue (simulation.py:516-520) -------------------------------------------
     T *orow = (T *)a.tmp_rows + g * 5;
     T oi;
@@ -263,6 +274,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
     const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
     a.keep[g] = keep ? 1 : 0;
+    }   // chunk loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -391,21 +403,34 @@ extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_
     return 0;
 }
 
-template <typename T, int LMAX, int BLOCK>
-static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
+template <typename T, int LMAX, int BLOCK, bool LIST>
+static int launch_beams_tl(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK, LIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
+    unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
     if (blocks == 0) return 0;
-    hipLaunchKernelGGL((k_beams<T, LMAX, BLOCK>), dim3(blocks), dim3(BLOCK), lds, st, *a);
+    if (LIST) {                                          // list mode: at most what the chip can hold at once
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
+        blocks = std::min(blocks, (unsigned)cus * per_cu);
+    }
+    hipLaunchKernelGGL((k_beams<T, LMAX, BLOCK, LIST>), dim3(blocks), dim3(BLOCK), lds, st, *a);
     SG_CHECK_LAUNCH();
     return 0;
+}
+
+template <typename T, int LMAX, int BLOCK>
+static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
+{
+    return a->work_list ? launch_beams_tl<T, LMAX, BLOCK, true>(a, n_threads, st)
+                        : launch_beams_tl<T, LMAX, BLOCK, false>(a, n_threads, st);
 }
 
 // lmax = per-beam list capacity of this pass: 4 (144 B of LDS per beam: 16 waves per CU), 16, 32 or 63 (the
@@ -417,11 +442,13 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
     const int64_t n = a->work_list ? (int64_t)a->work_cap : a->n_total;
     if (dtype == 0) {
         if (lmax == 4) return launch_beams_t<float, 4, 256>(a, n, st);
+        if (lmax == 8) return launch_beams_t<float, 8, 256>(a, n, st);
         if (lmax == 16) return launch_beams_t<float, 16, 256>(a, n, st);
         if (lmax == 32) return launch_beams_t<float, 32, 128>(a, n, st);
         return launch_beams_t<float, SG_LCAP, 64>(a, n, st);
     } else {
         if (lmax == 4) return launch_beams_t<double, 4, 256>(a, n, st);
+        if (lmax == 8) return launch_beams_t<double, 8, 256>(a, n, st);
         if (lmax == 16) return launch_beams_t<double, 16, 256>(a, n, st);
         if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
         return launch_beams_t<double, SG_LCAP, 64>(a, n, st);

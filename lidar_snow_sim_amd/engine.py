@@ -33,7 +33,7 @@ def laser_constants(lasers):
         fs.append(float(info["focal_slope"]))                          # :75
         fo.append((1 - focal_distance / 13100) ** 2)                   # :76 (Python float arithmetic, as there)
         mi.append(int(info.get("min_intensity", 0)))                   # :72
-        ma.append(230 if (ch % 64) in (53, 55, 56, 58) else 255)       # :123-126
+        ma.append(230 if (ch % 64) in (53, 55, 56, 58) else 255)       # :123-126 (tiled beyond 64 lasers)
     return fs, fo, mi, ma
 
 

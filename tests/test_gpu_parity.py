@@ -277,3 +277,118 @@ def test_fast_sine_equals_libm_mode_on_a_full_sweep(eng, tables):
     assert tuple(int(v) for v in s_fast) == tuple(int(v) for v in s_ex)
     assert np.array_equal(src_fast, src_ex) and np.array_equal(a_fast, a_ex)
     assert (a_fast[:, 4] == 1).sum() > 1000 and (a_fast[:, 4] == 2).sum() > 100
+
+
+def test_stream_driver_writes_reference_layout(eng, so, tables, tmp_path):
+    """tools/snowfall/precompute.py:74-106 through lidar_snow_sim_amd.stream: .bin in, .bin out, skip-if-exists."""
+    import random
+    from lidar_snow_sim_amd import stream
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    lidar = tmp_path / "lidar_hdl64_strongest"
+    lidar.mkdir()
+    ids = ["2018-02-03_00001", "2018-02-03_00002", "2018-02-04_00001"]
+    full = synthetic_sweep(64, 2048, seed=11, intensity="lambert").reshape(64, 2048, 5)
+    frames = {}
+    for i, s in enumerate(ids):
+        frames[s] = np.ascontiguousarray(full[:, i::64, :].reshape(-1, 5))
+        frames[s].tofile(lidar / f"{s}.bin")
+    combos = stream.rate_combos()[3:4]
+    prefix = f"gunn_{combos[0][0]}_{combos[0][1]}"
+    tl = _tables64(tables)
+    random.seed(5)
+    n = stream.run(lidar, ids, modes=("gunn",), combos=combos, batch=2, particles_by_prefix={prefix: tl},
+                   planes=None)
+    assert n == 3
+    random.seed(5)
+    bd = float(np.degrees(3e-3))
+    for s in ids:                                                # same global-`random` draws, frame by frame
+        order = list(range(64))
+        random.shuffle(order)
+        got = np.fromfile(stream.output_path(lidar, "gunn", combos[0][0], s), dtype=np.float32).reshape(-1, 5)
+        _, exp, _ = so.augment(frames[s], tl, bd, order, plane=None)
+        assert got.shape == exp.shape and np.array_equal(got[:, 3:], exp[:, 3:])
+    assert stream.run(lidar, ids, modes=("gunn",), combos=combos, batch=2, particles_by_prefix={prefix: tl}) == 0
+
+
+# ---- BASELINE.json configs as parity cases ------------------------------------------------------------------------
+def test_config_C1_dense_table_half_mm_per_hour(so, tables):
+    """C1: 0.5 mm/h @ 2.0 m/s (40 112 flakes per line at R0 = 80 m): the capacity tiers start at 8 entries."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    occ, rate = smp.compute_occupancy(0.5, 2.0), smp.snowfall_rate_to_rainfall_rate(0.5, 2.0)
+    tabs = [smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(42 + i), "gunn") for i in range(2)]
+    assert tabs[0].shape[0] > 39000
+    tl = [tabs[i % 2] for i in range(64)]
+    full = synthetic_sweep(64, 2048, seed=1000, intensity="lambert").reshape(64, 2048, 5)
+    pc = full[:, ::64, :].reshape(-1, 5).copy()
+    pc[:, :3] *= 1.7                                            # push targets out to ~90 m: long lists
+    order = list(range(64))
+    bd = float(np.degrees(3e-3))
+    poly = [0.0, 0.0, 3.0]
+    eng2 = engine.Engine(0)                                     # own context: max table size drives the tier choice
+    try:
+        tids = eng2.table_ids_from_arrays(tl, order)
+        out, src, counts, stats, _ = eng2.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, thr_poly=[poly])
+    finally:
+        eng2.ctx.close()
+    s0, a0, src0 = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
+    n = int(counts[0])
+    assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in s0)
+    assert np.array_equal(src[:n], src0) and np.array_equal(out[:n, 3:], a0[:, 3:])
+    assert (a0[:, 4] == 2).sum() > 20
+
+
+def test_config_C4_128_layers(so, tables):
+    """C4: 128-layer sweep, 10 mm/h tables, a 128-entry laser table made by tiling the 64-entry one (SURVEY 8 d).
+    The reference stops at 64 channels (simulation.py:474-483); the oracle is process_single_channel per channel."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+    occ, rate = smp.compute_occupancy(10.0, 1.6), smp.snowfall_rate_to_rainfall_rate(10.0, 1.6)
+    tabs = [smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(42 + i), "gunn") for i in range(2)]
+    lasers = engine.load_lasers() * 2
+    full = synthetic_sweep(128, 4096, seed=3, intensity="lambert").reshape(128, 4096, 5)
+    pc = np.ascontiguousarray(full[:, ::128, :].reshape(-1, 5))
+    bd = float(np.degrees(3e-3))
+    eng2 = engine.Engine(0, lasers=lasers)
+    try:
+        tids = [eng2.table_id(("c4", i % 2), lambda i=i: tabs[i % 2]) for i in range(128)]
+        out, src, counts, stats, _ = eng2.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, thr_poly=[[0.0, 0.0, -1.0]])
+    finally:
+        eng2.ctx.close()
+    assert counts[0] == pc.shape[0]
+    got = np.empty_like(out)
+    got[src] = out
+    las = so.load_lasers() * 2
+    diff_sum, n_att = 0.0, 0
+    for ch in range(128):
+        rows = np.where(pc[:, 4] == ch)[0]
+        # channels 64.. reuse laser ch % 64, incl. its max-intensity class (53, 55, 56, 58 -> 230)
+        d, exp = so.process_single_channel(pc[rows], tabs[ch % 2], bd, las, ch % 64)
+        assert np.array_equal(got[rows, 4], exp[:, 4]) and np.array_equal(got[rows, 3], np.round(exp[:, 3])), ch
+        np.testing.assert_allclose(got[rows, :3], exp[:, :3], rtol=1e-6, atol=0)
+        diff_sum += d
+        n_att += int((exp[:, 4] == 1).sum())
+    assert int(stats[0, 0]) == n_att and int(stats[0, 2]) == (int(diff_sum / n_att) if n_att else 0)
+
+
+def test_camera_fov_crop_textbook_projection(eng, tables):
+    """only_camera_fov=True with an explicit KITTI-style calibration (parity unpinned: SURVEY 8 c)."""
+    from lidar_snow_sim_amd.calibration import Calibration, get_fov_flag
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    cal = Calibration(P2=np.array([[700.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
+                      V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
+    full = synthetic_sweep(64, 2048, seed=21, intensity="lambert").reshape(64, 2048, 5)
+    pc = np.ascontiguousarray(full[:, ::16, :].reshape(-1, 5))
+    kw = dict(plane=PLANE, order=list(range(64)), particles=_tables64(tables), return_src=True)
+    s_all, a_all, src_all = augment(pc, "unused", float(np.degrees(3e-3)), only_camera_fov=False, **kw)
+    s_fov, a_fov, src_fov = augment(pc, "unused", float(np.degrees(3e-3)), only_camera_fov=True, calib=cal, **kw)
+    flag = get_fov_flag(cal.lidar_to_rect(a_all[:, :3]), (1024, 1920), cal)
+    assert 0 < flag.sum() < len(flag)
+    assert np.array_equal(a_fov, a_all[flag]) and np.array_equal(src_fov, src_all[flag])
+    assert int(s_fov[1]) == int(s_all[1]) + int((~flag).sum()) and s_fov[0] == s_all[0]     # simulation.py:538
+    with pytest.raises(AssertionError):                          # missing calibration file (simulation.py:35)
+        augment(pc, "unused", float(np.degrees(3e-3)), only_camera_fov=True, **kw)

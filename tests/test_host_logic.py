@@ -237,3 +237,17 @@ def test_two_rank_gloo_round_trip(tmp_path):
         line = [ln for ln in out.splitlines() if ln.startswith("RESULT")][0].split()
         assert float(line[2]) == 2.0                              # max over ranks of (1 + rank)
         assert float(line[3]) == 10.0 and float(line[4]) == 45.0  # every frame owned exactly once
+
+
+def test_stream_driver_bookkeeping(tmp_path):
+    """precompute.py's frame order, (rate, velocity) combos and output layout -- no GPU involved."""
+    from lidar_snow_sim_amd import stream
+    split = tmp_path / "s.txt"
+    split.write_text("\n".join(f"2018-02-0{d},0000{i}" for d in (1, 2) for i in range(3)) + "\n")
+    ids = stream.read_split(split)
+    srt = sorted(ids)
+    assert len(ids) == 6 and ids[:3] == srt[3:] and ids[3:] == srt[:3][::-1]     # second half, reversed first half
+    combos = stream.rate_combos()
+    assert len(combos) == 5 and int(combos[3][0]) == 34                          # 2.5 mm/h @ 1.6 m/s -> rainrate_34
+    p = stream.output_path(tmp_path / "lidar_hdl64_strongest", "gunn", combos[3][0], ids[0])
+    assert p == tmp_path / "snowfall_simulation" / "gunn" / "lidar_hdl64_strongest_rainrate_34" / f"{ids[0]}.bin"
