@@ -59,8 +59,11 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                                         const SgLasers *__restrict__ las, const double *__restrict__ s_rgrid,
                                         double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
                                         double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
-                                        int32_t *dbg_count, double *dbg_rj, double *dbg_ratio)
+                                        int32_t *dbg_count, double *dbg_rj, double *dbg_ratio,
+                                        unsigned long long *ph = nullptr)
 {
+    const unsigned long long ph0 = ph ? wall_clock64() : 0;
+    unsigned long long ph_cand = 0;
     constexpr bool F32 = SgReal<T>::is_f32;
     out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.k_min = 0; out.k_max = 0;
     out.x = (double)px; out.y = (double)py; out.z = (double)pz; out.intensity = (double)pint; out.label = 0.0;
@@ -87,6 +90,17 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     if (theta_r > SG_TWO_PI) theta_r = theta_r - SG_TWO_PI;     // :101
     if (theta_l > SG_TWO_PI) theta_l = theta_l - SG_TWO_PI;
 
+    // Azimuth bins the wedge touches.  Their offsets are requested now so that the loads fly while the two
+    // tangents below are evaluated (the compiler waits at first use, not here).
+    const int nb = (int)tab.n_bins;
+    const int b_lo = sg_bin_of(theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+    const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+    int span = b_hi - b_lo;
+    if (span < 0) span += nb;
+    const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
+    const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
+    const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
+
     // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
     double ar, br, al, bl;
     if (theta_r == SG_PI / 2 || theta_r == 3 * SG_PI / 2) { ar = 1.0; br = 0.0; } else { ar = -tan(theta_r); br = 1.0; }
@@ -98,21 +112,23 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
     int L = 0;
     {
-        const int nb = (int)tab.n_bins;
-        const int b_lo = sg_bin_of(theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
-        const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
-        int span = b_hi - b_lo;
-        if (span < 0) span += nb;
         int b = b_lo;
         for (int s = 0; s <= span && !out.overflow; ++s) {
-            const uint32_t e1 = tab.bin_start[b + 1];
-            for (uint32_t e = tab.bin_start[b]; e < e1; ++e) {
-                const SgEntry *f = tab.entries + e;
-                const double rho = f->rho;
+            uint32_t e0, e1;
+            if (s == 0) { e0 = st0; e1 = st1; }
+            else if (s == 1) { e0 = st2; e1 = st3; }
+            else { e0 = tab.bin_start[b]; e1 = tab.bin_start[b + 1]; }
+            // software pipeline: the next record is requested before the current one is examined (the entry
+            // array carries one spare record at its end, so e + 1 is always readable)
+            SgEntry nxt = tab.entries[e0];
+            for (uint32_t e = e0; e < e1; ++e) {
+                const SgEntry f = nxt;
+                nxt = tab.entries[e + 1];
+                ++ph_cand;
+                const double rho = f.rho;
                 if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
-                const uint32_t flags = f->flags;
-                if (s > 0 && !(flags & 1u)) continue;           // already met in an earlier bin
-                const double phi = f->phi, fx = f->x, fy = f->y, fr = f->r;
+                if (s > 0 && !(f.flags & 1u)) continue;         // already met in an earlier bin
+                const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
                 const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
                                  || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
                                  || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
@@ -122,8 +138,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                 const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
                 if (!(centre || hit_r || hit_l)) continue;      // :389
                 if (L == LMAX) { out.overflow = 1; break; }
-                const double na1 = hit_r ? theta_r : f->t0;     // geometry.py:26
-                const double na2 = hit_l ? theta_l : f->t1;     // geometry.py:27
+                const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26
+                const double na2 = hit_l ? theta_l : f.t1;      // geometry.py:27
                 int p = L;                                      // insertion sort by rho (:413-417)
                 while (p > 0 && SG_RHO(p - 1) > rho) {
                     SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
@@ -136,6 +152,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         }
     }
     if (out.overflow) return;
+    const unsigned long long ph1 = ph ? wall_clock64() : 0;
 
     // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------
     // The reference sorts the unique endpoints, gives every elementary slot to the nearest flake
@@ -206,6 +223,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         SG_RATIO(S) = sg_clip01(acc.result() / delta);
     }
     const int n_dict = S + 1;
+    const unsigned long long ph2 = ph ? wall_clock64() : 0;
     if (dbg_count) {
         *dbg_count = n_dict;
         for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
@@ -250,6 +268,10 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     out.k_min = k_min;
     out.k_max = k_max;
     out.has_power = 1;
+    if (ph && (tid & 63) == 0) {
+        atomicAdd(&ph[1], ph1 - ph0); atomicAdd(&ph[2], ph2 - ph1); atomicAdd(&ph[3], wall_clock64() - ph2);
+        atomicAdd(&ph[6], (unsigned long long)L); atomicAdd(&ph[7], ph_cand);
+    }
 }
 
 // sin(u) for u in [-0.3, 3.5]: one step of reduction against pi (hi + lo) and the odd Taylor polynomial to
@@ -352,18 +374,29 @@ __device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, i
         const int bS = sg_bcast_half(S, i, upper), bkmin = sg_bcast_half(k_min, i, upper),
                   bkmax = sg_bcast_half(k_max, i, upper);
         const int col = wave_col + (lane & 32) + i;
+        // the hard target and the nearest flake: six independent LDS reads, one round trip
         const double tpk = s_a2[bS * STRIDE + col];
-        const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
         const double tamp = s_a1[bS * STRIDE + col], td = s_rho[bS * STRIDE + col];
+        const double fpk = s_a2[col];
+        double c_amp = s_a1[col], c_r = s_rho[col];
+        const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+        int c_k0 = 0x7fffffff, c_k1 = 0x7fffffff;          // window of the nearest flake not yet passed (entry t_lo)
+        if (bS > 0) { c_k0 = __double2loint(fpk); c_k1 = __double2hiint(fpk); }
         double lbest = 0.0;
         int lk = 0;
         int t_lo = 0, c = bkmin;
         while (c < bkmax) {
-            while (t_lo < bS && __double2hiint(s_a2[t_lo * STRIDE + col]) <= c) ++t_lo;
-            const int fstart = t_lo < bS ? __double2loint(s_a2[t_lo * STRIDE + col]) : 0x7fffffff;
+            while (t_lo < bS && c_k1 <= c) {                 // half-wave uniform
+                ++t_lo;
+                if (t_lo < bS) {
+                    const double pk = s_a2[t_lo * STRIDE + col];
+                    c_amp = s_a1[t_lo * STRIDE + col]; c_r = s_rho[t_lo * STRIDE + col];
+                    c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk);
+                } else { c_k0 = 0x7fffffff; c_k1 = 0x7fffffff; }
+            }
             const bool tgt_hit = (tk0 < c + 32) && (tk1 > c);
-            if (fstart >= c + 32 && !tgt_hit) {              // nothing here: jump to the next window start
-                int nc = fstart;
+            if (c_k0 >= c + 32 && !tgt_hit) {                // nothing here: jump to the next window start
+                int nc = c_k0;
                 if (tk0 > c && tk0 < nc) nc = tk0;
                 if (nc == 0x7fffffff) break;
                 c = nc;
@@ -372,12 +405,15 @@ __device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, i
             const int k = c + sub;
             const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
             double sum = 0.0;                                // :135 np.zeros
-            for (int t = t_lo; t < bS; ++t) {
-                const double pk = s_a2[t * STRIDE + col];
-                const int k0 = __double2loint(pk);
-                if (k0 >= c + 32) break;                     // flake windows start in range order
-                if (k >= k0 && k < __double2hiint(pk))
-                    sum += sg_power_term<EXACT>(s_a1[t * STRIDE + col], Rk, s_rho[t * STRIDE + col]);   // :149
+            if (c_k0 < c + 32) {
+                if (k >= c_k0 && k < c_k1) sum += sg_power_term<EXACT>(c_amp, Rk, c_r);             // :149
+                for (int t = t_lo + 1; t < bS; ++t) {        // further flakes whose windows reach into this chunk
+                    const double pk = s_a2[t * STRIDE + col];
+                    const int k0 = __double2loint(pk);
+                    if (k0 >= c + 32) break;                 // flake windows start in range order
+                    if (k >= k0 && k < __double2hiint(pk))
+                        sum += sg_power_term<EXACT>(s_a1[t * STRIDE + col], Rk, s_rho[t * STRIDE + col]);
+                }
             }
             if (tgt_hit && k >= tk0 && k < tk1) sum += sg_power_term<EXACT>(tamp, Rk, td);
             if (sum > lbest) { lbest = sum; lk = k; }        // ascending k per lane: keeps the first maximum
@@ -391,54 +427,74 @@ __device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, i
 // ---- phase 3b, per-lane form (later capacity tiers) ---------------------------------------------------------
 // When every lane of a wave carries a long list the cooperative form serialises 32 beams per half-wave and the
 // wave's latency explodes while most of the chip idles; here each lane walks its own bins.  Same sums in the
-// same order: flakes covering bin k in range order, then the hard target.  The nearest still-open flake window
-// is cached in registers, so the common one-flake-per-bin case touches no LDS.
-template <int STRIDE, bool EXACT>
+// same order: flakes covering bin k in range order, then the hard target.  These tiers run at one or two waves
+// per SIMD, where a float64 dependency chain (the sine polynomial) costs its full latency per step; NB
+// consecutive bins are therefore carried together -- NB independent chains per scatterer.
+template <int STRIDE, bool EXACT, int NB = 8>
 __device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const double *__restrict__ rgrid,
                                               const double *s_a1, const double *s_a2, const double *s_rho, int tid,
                                               double &best, int &k_best)
 {
     best = 0.0;
     k_best = 0;
+    const int INF = 0x7fffffff;
     const double tpk = s_a2[S * STRIDE + tid];
     const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
     const double tamp = s_a1[S * STRIDE + tid], td = s_rho[S * STRIDE + tid];
-    int t_lo = 0;
-    double c_amp = 0.0, c_r = 0.0;
-    int c_k0 = 0x7fffffff, c_k1 = 0x7fffffff;
+    int t_lo = 0, lo_k0 = INF, lo_k1 = INF;       // nearest flake whose window has not been passed yet
+    double lo_amp = 0.0, lo_r = 0.0;
     if (S > 0) {
         const double pk = s_a2[tid];
-        c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk); c_amp = s_a1[tid]; c_r = s_rho[tid];
+        lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); lo_amp = s_a1[tid]; lo_r = s_rho[tid];
     }
-    for (int k = k_min; k < k_max; ++k) {
-        while (t_lo < S && k >= c_k1) {
+    int k = k_min;
+    while (k < k_max) {
+        while (t_lo < S && k >= lo_k1) {                     // pass windows that end at or before k
             ++t_lo;
             if (t_lo < S) {
                 const double pk = s_a2[t_lo * STRIDE + tid];
-                c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk);
-                c_amp = s_a1[t_lo * STRIDE + tid]; c_r = s_rho[t_lo * STRIDE + tid];
-            } else { c_k0 = 0x7fffffff; c_k1 = 0x7fffffff; }
+                lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk);
+                lo_amp = s_a1[t_lo * STRIDE + tid]; lo_r = s_rho[t_lo * STRIDE + tid];
+            } else { lo_k0 = INF; lo_k1 = INF; }
         }
-        const bool in_tgt = k >= tk0 && k < tk1;
-        if (k < c_k0 && !in_tgt) {                           // gap: jump to the next window start
-            int nk = c_k0;
+        const bool tgt_hit = (tk0 < k + NB) && (tk1 > k);
+        if (lo_k0 >= k + NB && !tgt_hit) {                    // gap: jump to the next window start
+            int nk = lo_k0;
             if (k < tk0 && tk0 < nk) nk = tk0;
-            if (nk == 0x7fffffff) break;
-            k = nk - 1;
+            if (nk == INF) break;
+            k = nk;
             continue;
         }
-        const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
-        double sum = 0.0;                                    // :135 np.zeros
-        if (k >= c_k0) {
-            sum += sg_power_term<EXACT>(c_amp, Rk, c_r);     // :149
+        double R[NB], sm[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int kk = k + i;
+            R[i] = EXACT ? rgrid[kk < SG_RBINS ? kk : SG_RBINS - 1] : sg_range_bin(kk);
+            sm[i] = 0.0;                                     // :135 np.zeros
+        }
+        if (lo_k0 < k + NB) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (k + i >= lo_k0 && k + i < lo_k1) sm[i] += sg_power_term<EXACT>(lo_amp, R[i], lo_r);   // :149
             for (int t = t_lo + 1; t < S; ++t) {
                 const double pk = s_a2[t * STRIDE + tid];
-                if (k < __double2loint(pk)) break;           // flake windows start in range order
-                if (k < __double2hiint(pk)) sum += sg_power_term<EXACT>(s_a1[t * STRIDE + tid], Rk, s_rho[t * STRIDE + tid]);
+                const int q0 = __double2loint(pk), q1 = __double2hiint(pk);
+                if (q0 >= k + NB) break;                      // flake windows start in range order
+                const double amp = s_a1[t * STRIDE + tid], r = s_rho[t * STRIDE + tid];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+                    if (k + i >= q0 && k + i < q1) sm[i] += sg_power_term<EXACT>(amp, R[i], r);
             }
         }
-        if (in_tgt) sum += sg_power_term<EXACT>(tamp, Rk, td);
-        if (sum > best) { best = sum; k_best = k; }          // ascending k: first maximum (:151)
+        if (tgt_hit) {
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                if (k + i >= tk0 && k + i < tk1) sm[i] += sg_power_term<EXACT>(tamp, R[i], td);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (sm[i] > best) { best = sm[i]; k_best = k + i; }   // ascending k: first maximum (:151)
+        k += NB;
     }
 }
 

@@ -275,7 +275,8 @@ extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double
     const size_t n_entries = start[(size_t)nb];
     if (n_entries > (size_t)64 * (size_t)std::max<int64_t>(k, 1) + 4096)
         return fail(ctx, SNOWGPU_E_TABLE, "snowgpu_upload_table: flakes so close to the sensor that they cover most azimuths");
-    std::vector<SgEntry> entries(n_entries);
+    std::vector<SgEntry> entries(n_entries + 1);   // + one spare record: the scan prefetches entry e + 1
+    std::memset(&entries[n_entries], 0, sizeof(SgEntry));
     std::vector<uint32_t> fill(start.begin(), start.end() - 1);
     for (int64_t i = 0; i < k; ++i) {
         for (int t = 0; t < span[(size_t)i]; ++t) {
@@ -287,7 +288,7 @@ extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double
     }
     uint32_t max_bin = 0;
     for (int b = 0; b < nb; ++b) {
-        std::sort(entries.begin() + start[(size_t)b], entries.begin() + start[(size_t)b + 1],
+        std::sort(entries.begin() + (ptrdiff_t)start[(size_t)b], entries.begin() + (ptrdiff_t)start[(size_t)b + 1],
                   [](const SgEntry &p, const SgEntry &q) { return p.rho < q.rho || (p.rho == q.rho && p.src < q.src); });
         max_bin = std::max(max_bin, start[(size_t)b + 1] - start[(size_t)b]);
     }
@@ -295,9 +296,9 @@ extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double
     DeviceTable &dt = ctx->tables[(size_t)table_id];
     if (dt.entries) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(dt.entries); dt.entries = nullptr; }
     if (dt.bin_start) { (void)hipFree(dt.bin_start); dt.bin_start = nullptr; }
-    HIPCHK(ctx, hipMalloc((void **)&dt.entries, std::max<size_t>(n_entries, 1) * sizeof(SgEntry)));
+    HIPCHK(ctx, hipMalloc((void **)&dt.entries, (n_entries + 1) * sizeof(SgEntry)));
     HIPCHK(ctx, hipMalloc((void **)&dt.bin_start, ((size_t)nb + 1) * sizeof(uint32_t)));
-    if (n_entries) HIPCHK(ctx, hipMemcpy(dt.entries, entries.data(), n_entries * sizeof(SgEntry), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(dt.entries, entries.data(), (n_entries + 1) * sizeof(SgEntry), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(dt.bin_start, start.data(), ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
     dt.desc.entries = dt.entries;
     dt.desc.bin_start = dt.bin_start;
@@ -648,12 +649,12 @@ extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned
     if (!ctx) return SNOWGPU_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (enable) {
-        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 16 * sizeof(unsigned long long)));
-        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 16 * sizeof(unsigned long long)));
+        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 32 * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 32 * sizeof(unsigned long long)));
         sg_set_phase_dbg(ctx->phase_cycles);
     } else if (ctx->phase_cycles) {
         HIPCHK(ctx, hipDeviceSynchronize());
-        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         sg_set_phase_dbg(nullptr);
         (void)hipFree(ctx->phase_cycles);
         ctx->phase_cycles = nullptr;

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         g = chunk + tid;
         if (g >= a.n_total) g = -1;
     }
-    const unsigned long long tcs = a.phase_cycles ? wall_clock64() : 0;
+    unsigned long long *ph = a.phase_cycles ? a.phase_cycles + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3) : nullptr;
+    const unsigned long long tcs = ph ? wall_clock64() : 0;
     // No early return from here on: the received-power phase is cooperative across the wave.
     const bool live = g >= 0;
     int f = 0;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         ch = (int)pch;
         simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;            // simulation.py:80, :482 (Q5)
     }
-    const unsigned long long tc0 = a.phase_cycles ? wall_clock64() : 0;
+    const unsigned long long tc0 = ph ? wall_clock64() : 0;
     SgBeamOut o;
     o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = (double)pint; o.label = (double)pch;
     o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.k_min = 0; o.k_max = 0;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
             double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
             sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
-                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra);
+                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph);
             if (o.overflow) {
                 write_row = false;                        // a later pass with a longer list writes this row
                 o.has_power = 0;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             }
         }
     }
-    const unsigned long long tc1 = a.phase_cycles ? wall_clock64() : 0;
+    const unsigned long long tc1 = ph ? wall_clock64() : 0;
     double best;
     int k_best;
     if constexpr (LMAX <= 4) {       // sparse first tier: bins of one beam spread over a half-wave
@@ -233,12 +234,10 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             else sg_lane_power<BLOCK, false>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
         }
     }
-    const unsigned long long tc2 = a.phase_cycles ? wall_clock64() : 0;
-    if (a.phase_cycles && (tid & 63) == 0) {
-        atomicAdd(&a.phase_cycles[0], tc1 - tc0);      // load + phases 1, 2, 3a
-        atomicAdd(&a.phase_cycles[1], tc2 - tc1);      // phase 3b
-        atomicAdd(&a.phase_cycles[2], 1ull);           // waves
-        atomicAdd(&a.phase_cycles[3], tc0 - tcs);      // frame lookup + row load
+    if (ph && (tid & 63) == 0) {
+        atomicAdd(&ph[0], tc0 - tcs);                  // frame lookup + row load
+        atomicAdd(&ph[4], wall_clock64() - tc1);       // phase 3b
+        atomicAdd(&ph[5], 1ull);                       // waves
     }
     if (o.has_power) sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
     {   // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam

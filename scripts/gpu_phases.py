@@ -20,10 +20,11 @@ L.snowgpu_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c
 eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes)
 L.snowgpu_debug_phase_cycles(eng.ctx.handle, 1, None)
 t = time.time(); eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes); dt = time.time() - t
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 L.snowgpu_debug_phase_cycles(eng.ctx.handle, 0, out)
-v = list(out); waves = max(v[2], 1)
-print('waves', waves, 'host call', dt)
-print('per wave (100 MHz ticks x24 = cycles @2.4GHz):')
-for name, x in (('row load', v[3]), ('P1+P2+P3a', v[0]), ('P3b', v[1])):
-    print(f'  {name:16s} {x / waves:10.1f} ticks  ~{x / waves * 24:10.0f} cycles')
+v = list(out)
+print('host call', dt, '(lane-0 view; 100 MHz ticks x24 = cycles @2.4 GHz)')
+for ti, name in enumerate(('tier 4', 'tier 8', 'tier 16', 'tier 63')):
+    b = v[8 * ti: 8 * ti + 8]
+    w = max(b[5], 1)
+    print(f'{name}: waves {b[5]}  load {b[0]/w*24:9.0f}  P1 {b[1]/w*24:9.0f}  P2 {b[2]/w*24:9.0f}  P3a {b[3]/w*24:9.0f}  P3b {b[4]/w*24:9.0f} cycles/wave;  lane0 mean L {b[6]/w:.2f} candidates {b[7]/w:.1f}')
