@@ -174,6 +174,21 @@ int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *fram
                              double *out_rows, int32_t *out_src, int64_t *out_counts,
                              int32_t *out_flags);
 
+/*
+ * augment() followed by ground_water_augmentation() on its output, as pointcloud_viewer.py:2807-2821 chains them
+ * (snow first, then wet with replace=False), without the intermediate cloud leaving the device.  Arguments are
+ * those of snowgpu_augment_batch followed by those of snowgpu_wet_ground_batch (wet_plane: n_frames x 4).
+ * out_stats are the snowfall statistics; out_rows (float64) / out_counts / out_flags the wet-ground result;
+ * out_src maps every final row to its row in the original input frame.
+ */
+int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows,
+                              int dtype, const int32_t *table_ids, double beam_divergence_deg,
+                              const double *thr_poly, const double *plane, double noise_floor,
+                              const int32_t *perm, const double *wet_plane, double water_height,
+                              double pavement_depth, double wet_noise_floor, double power_factor,
+                              int flat_earth, double delta, int replace, double *out_rows, int32_t *out_src,
+                              int64_t *out_counts, int64_t *out_stats, int32_t *out_flags);
+
 #ifdef __cplusplus
 }
 #endif

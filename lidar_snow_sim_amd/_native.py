@@ -21,7 +21,7 @@ EXPORTS = [
     "snowgpu_create", "snowgpu_destroy", "snowgpu_last_error", "snowgpu_version", "snowgpu_set_lasers",
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
-    "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math",
+    "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
 ]
 
 
@@ -69,6 +69,9 @@ def lib():
             L.snowgpu_wet_ground_batch.restype = ctypes.c_int
             L.snowgpu_wet_ground_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, dbl, dbl, dbl,
                                                    ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp]
+            L.snowgpu_augment_wet_batch.restype = ctypes.c_int
+            L.snowgpu_augment_wet_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp, vp,
+                                                    dbl, dbl, dbl, dbl, ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp, vp]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
             L.snowgpu_set_exact_math.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_begin.restype = ctypes.c_int
@@ -215,6 +218,32 @@ class Context:
             self._check(self._L.snowgpu_debug_occlusions(self._h, n, _p(rows), code, _p(tids), float(beam_divergence),
                                                          int(cap), _p(count), _p(rj), _p(ratio), _p(src)))
         return count, rj, ratio, src
+
+    def augment_wet_batch(self, rows, frame_offsets, table_ids, beam_divergence, wet_plane, thr_poly=None, plane=None,
+                          noise_floor=0.7, perm=None, water_height=0.001, pavement_depth=0.0012, wet_noise_floor=0.7,
+                          power_factor=15, flat_earth=False, delta=0.5, replace=False):
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf = len(off) - 1
+        tids = np.ascontiguousarray(table_ids, np.int32).reshape(nf, -1)
+        n = int(off[-1])
+        out_rows = np.empty((n, 5), np.float64)
+        out_src = np.empty(n, np.int32)
+        counts = np.zeros(nf, np.int64)
+        stats = np.zeros((nf, 3), np.int64)
+        flags = np.zeros(nf, np.int32)
+        thr = None if thr_poly is None else np.ascontiguousarray(thr_poly, np.float64).reshape(nf, 3)
+        pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        wpl = np.ascontiguousarray(wet_plane, np.float64).reshape(nf, 4)
+        pm = None if perm is None else np.ascontiguousarray(perm, np.int32)
+        with self._call_lock:
+            self._check(self._L.snowgpu_augment_wet_batch(
+                self._h, nf, _p(off), _p(rows), code, _p(tids), float(beam_divergence), _p(thr), _p(pl), float(noise_floor),
+                _p(pm), _p(wpl), float(water_height), float(pavement_depth), float(wet_noise_floor), float(power_factor),
+                int(bool(flat_earth)), float(delta), int(bool(replace)), _p(out_rows), _p(out_src), _p(counts), _p(stats),
+                _p(flags)))
+        return out_rows, out_src, counts, stats, flags
 
     def wet_ground_batch(self, rows, frame_offsets, plane, water_height, pavement_depth, noise_floor, power_factor,
                          flat_earth, delta, replace):

@@ -20,8 +20,8 @@ extern "C" {
 int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                    int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status,
                    void *stream);
-int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
-               int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
+int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
+               const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
                int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream);
 void sg_prepass_release(SgPrepassScratch *s);
 #ifdef __cplusplus

@@ -696,6 +696,64 @@ extern "C" int snowgpu_profile_end(snowgpu_ctx *ctx, double *beam_kernel_ms, int
     return SNOWGPU_OK;
 }
 
+// augment() followed by ground_water_augmentation() on its output (pointcloud_viewer.py:2807-2821), with the
+// intermediate cloud staying on the device.
+extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                         const int32_t *table_ids, double beam_divergence_deg, const double *thr_poly,
+                                         const double *plane, double noise_floor, const int32_t *perm, const double *wet_plane,
+                                         double water_height, double pavement_depth, double wet_noise_floor, double power_factor,
+                                         int flat_earth, double delta, int replace, double *out_rows, int32_t *out_src,
+                                         int64_t *out_counts, int64_t *out_stats, int32_t *out_flags)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !frame_offsets || !wet_plane || !out_counts || !out_stats || !out_flags)
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch: null pointer");
+    const int64_t n_total = frame_offsets[n_frames];
+    const size_t n = (size_t)std::max<int64_t>(n_total, 0), esz = dtype == 0 ? 4 : 8;
+    int64_t max_frame = 0;
+    for (int f = 0; f < n_frames; ++f) max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    // stage 1: snowfall, results left on the device (ctx->rows_out / out_src / out_counts)
+    std::vector<unsigned char> tmp_rows(n * 5 * esz + 8);
+    std::vector<int32_t> snow_src(n + 1);
+    std::vector<int64_t> snow_counts((size_t)n_frames);
+    int rc = host_batch(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_divergence_deg, thr_poly, plane, noise_floor, perm,
+                        tmp_rows.data(), snow_src.data(), snow_counts.data(), out_stats, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    // stage 2: wet ground on the compacted rows still resident in ctx->rows_out (frame f: rows [off[f], off[f] + count[f]))
+    hipStream_t st = ctx->stream;
+    DevBuf<double> wet_out;
+    DevBuf<int32_t> wet_src, wet_flags;
+    DevBuf<int64_t> wet_counts;
+    DevBuf<double> d_plane;
+    if (wet_out.ensure(std::max<size_t>(n * 5, 1)) || wet_src.ensure(std::max<size_t>(n, 1)) || wet_flags.ensure((size_t)n_frames) ||
+        wet_counts.ensure((size_t)n_frames) || d_plane.ensure((size_t)n_frames * 4))
+        return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed (wet stage)");
+    HIPCHK(ctx, hipMemcpyAsync(d_plane.p, wet_plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    SgWetParams wp{};
+    wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = wet_noise_floor;
+    wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    int e = sg_wet_run(&ctx->prepass, ctx->rows_out.p, dtype, ctx->frame_off.p, ctx->out_counts.p, n_frames, n_total, max_frame,
+                       d_plane.p, &wp, wet_out.p, wet_src.p, wet_counts.p, wet_flags.p, ctx->d_status, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    HIPCHK(ctx, hipMemcpyAsync(out_counts, wet_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(out_flags, wet_flags.p, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> wsrc(n + 1);
+    if (n) {
+        HIPCHK(ctx, hipMemcpyAsync(out_rows, wet_out.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(wsrc.data(), wet_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    }
+    hipError_t se = hipStreamSynchronize(st);
+    wet_out.release(); wet_src.release(); wet_flags.release(); wet_counts.release(); d_plane.release();
+    if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    // compose the source indices: wet row -> snow row -> input row
+    if (out_src)
+        for (int f = 0; f < n_frames; ++f) {
+            const int64_t b = frame_offsets[f];
+            for (int64_t i = 0; i < out_counts[f]; ++i) out_src[b + i] = snow_src[(size_t)(b + wsrc[(size_t)(b + i)])];
+        }
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                                         const double *plane, double water_height, double pavement_depth, double noise_floor,
                                         double power_factor, int flat_earth, double delta, int replace, double *out_rows,
@@ -728,7 +786,7 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
-    int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, n_total, max_frame, ctx->plane.p, &wp,
+    int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame, ctx->plane.p, &wp,
                        (double *)ctx->rows_out.p, ctx->out_src.p, ctx->out_counts.p, ctx->dbg_count.p, ctx->d_status, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
     HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));

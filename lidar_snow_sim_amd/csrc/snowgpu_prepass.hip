@@ -33,6 +33,7 @@ struct PreFrame {          // per-frame state shared by the kernels
 struct PreArgs {
     const void *rows;
     const int64_t *frame_off;
+    const int64_t *frame_cnt;   // optional: rows actually present in frame f (compacted input); else off[f+1] - off[f]
     int n_frames;
     int64_t max_tiles;
     const double *plane;   // n_frames x 4
@@ -48,6 +49,11 @@ struct PreArgs {
     PreFrame *fr;
     int32_t *status;
 };
+
+__device__ __forceinline__ int64_t pre_rows(const PreArgs &a, int f)
+{
+    return a.frame_cnt ? a.frame_cnt[f] : a.frame_off[f + 1] - a.frame_off[f];
+}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -77,7 +83,7 @@ template <typename T>
 __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
 {
     const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
     const double *pl = a.plane + 4 * f;
@@ -127,7 +133,7 @@ __global__ void k_pre_means(PreArgs a, int min_ground, int err_code)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.n_frames) return;
-    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     double c = 0, sx = 0, sy = 0, ym = -INFINITY;
     for (int64_t t = 0; t < tiles; ++t) {
@@ -166,7 +172,7 @@ __device__ __forceinline__ int hist_bin(double v, double lo, double hi, int nb)
 __global__ __launch_bounds__(PB) void k_pre_moments(PreArgs a)
 {
     const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
     const PreFrame fr = a.fr[f];
@@ -241,7 +247,7 @@ __global__ void k_pre_lines(PreArgs a, int xmean_f32)
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.n_frames) return;
     PreFrame &fr = a.fr[f];
-    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     double sxx = 0, sxy = 0;
     for (int64_t t = 0; t < tiles; ++t) {
@@ -278,7 +284,7 @@ template <typename T>
 __global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
 {
     const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
     const PreFrame fr = a.fr[f];
@@ -311,7 +317,7 @@ __global__ void k_pre_poly_solve(PreArgs a, double *thr_poly)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.n_frames) return;
-    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t t = 0; t < tiles; ++t) {
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
 {
     const PreArgs &a = w.p;
     const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
     const PreFrame fr = a.fr[f];
@@ -439,7 +445,7 @@ __global__ void k_wet_scan(WetArgs w)
     const PreArgs &a = w.p;
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= a.n_frames) return;
-    const int64_t n = a.frame_off[f + 1] - a.frame_off[f];
+    const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     int na = 0, nb = 0;
     for (int64_t t = 0; t < tiles; ++t) {
@@ -457,7 +463,7 @@ __global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
 {
     const PreArgs &a = w.p;
     const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = a.frame_off[f + 1] - base;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
     const T *rows = (const T *)a.rows;
@@ -573,14 +579,14 @@ extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, 
     return 0;
 }
 
-extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
-                          int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
+extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
+                          const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
                           int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     WetArgs w{};
     PreArgs &a = w.p;
-    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = wp->delta;
+    a.rows = rows; a.frame_off = frame_off; a.frame_cnt = frame_cnt; a.n_frames = n_frames; a.plane = plane; a.delta = wp->delta;
     a.flat_earth = wp->flat_earth; a.noise_floor = wp->noise_floor; a.power_factor = wp->power_factor; a.status = status;
     int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, st);
     if (rc) return rc;

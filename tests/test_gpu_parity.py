@@ -392,3 +392,30 @@ def test_camera_fov_crop_textbook_projection(eng, tables):
     assert int(s_fov[1]) == int(s_all[1]) + int((~flag).sum()) and s_fov[0] == s_all[0]     # simulation.py:538
     with pytest.raises(AssertionError):                          # missing calibration file (simulation.py:35)
         augment(pc, "unused", float(np.degrees(3e-3)), only_camera_fov=True, **kw)
+
+
+def test_config_C3_snow_and_wet_fused_batch(eng, so, golden, tables):
+    """C3: a batch of sweeps through snowfall + wet ground in one call, the intermediate cloud staying on the device
+    (pointcloud_viewer.py:2807-2821 chains the two on the host)."""
+    d = golden("L6_wet_ground")
+    frames = [d["c0_pc"], d["c1_pc"][:2500], d["c2_pc"]]
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    order = list(range(64))
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames])))
+    tids = [eng.table_ids_from_arrays(tl, order)] * 3
+    pl = [[0.0, 0.0, -1.0, -1.7]] * 3
+    out, src, counts, stats, flags = eng.ctx.augment_wet_batch(
+        np.concatenate(frames), off, tids, bd, wet_plane=pl, plane=pl, water_height=0.0008, pavement_depth=0.001,
+        wet_noise_floor=0.7, power_factor=15, flat_earth=False, delta=0.5, replace=False)
+    for i, f in enumerate(frames):
+        s0, a0, src0 = so.augment(f, tl, bd, order, plane=PLANE)
+        o0, wsrc0 = so.ground_water_augmentation(a0, water_height=0.0008, pavement_depth=0.001, flat_earth=False,
+                                                 replace=False, plane=PLANE, return_src=True)
+        n = int(counts[i])
+        got = out[off[i]:off[i] + n]
+        assert tuple(int(v) for v in stats[i]) == tuple(int(v) for v in s0)
+        assert got.shape == o0.shape and np.array_equal(got[:, 4], o0[:, 4])
+        assert np.array_equal(src[off[i]:off[i] + n], src0[wsrc0])
+        np.testing.assert_allclose(got[:, :3], o0[:, :3], rtol=1e-6, atol=0)
+        np.testing.assert_allclose(got[:, 3], o0[:, 3], rtol=5e-3, atol=0)
