@@ -4,8 +4,8 @@
 #include <stdint.h>
 
 struct SgPrepassScratch {
-    void *buf[12];
-    size_t cap[12];
+    void *buf[16];
+    size_t cap[16];
 };
 
 struct SgWetParams {

@@ -22,12 +22,13 @@
 struct PreFrame {          // per-frame state shared by the kernels
     double n_ground;       // ground rows
     double xmean, ymean;   // mean range / mean normalised intensity
+    double xmean32;        // np.mean of the float32 range column as NumPy computes it (float32 pairwise sum)
     double ymax;           // max normalised intensity (histogram range, augmentation.py:233)
     double p0, p1;         // linregress(dist, normalised)            augmentation.py:216-219
     double pmin0, pmin1;   // noise line                              augmentation.py:248-251
     double poly[3];        // simulation.py:467
     int32_t unchanged;     // wet path: < 1000 ground rows (augmentation.py:51-52)
-    int32_t pad;
+    int32_t need_mean32;   // float32 rows and the noise line falls back to p (augmentation.py:250-251)
 };
 
 struct PreArgs {
@@ -39,6 +40,8 @@ struct PreArgs {
     const double *plane;   // n_frames x 4
     double delta;          // ground band half width (0.5 in the snowfall path)
     int flat_earth;        // wet: incident angle from -z (augmentation.py:61-63)
+    int rows_as_f64;       // wet: np.hstack with the float64 height column promotes the ground rows to float64
+                           // (augmentation.py:50), so range / mean are float64 whatever the input dtype
     double noise_floor, power_factor;
     // per-row scratch (n_total)
     double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle; g_norm = NaN for non-ground rows
@@ -46,6 +49,7 @@ struct PreArgs {
     double *part;          // 12 doubles per tile
     int32_t *hist;         // [frame][HX][HY]
     double *rowmin;        // [frame][HX]  yedges[argmin] or -1
+    float *cdist;          // ground ranges compacted in row order (float32 rows only)
     PreFrame *fr;
     int32_t *status;
 };
@@ -101,15 +105,15 @@ __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
         const double hog = dot + h;
         double gn = NAN, gd = 0.0, ga = 0.0;
         if (hog < a.delta && hog > -a.delta) {                           // simulation.py:450-451 / augmentation.py:46-47
-            T nrm;
-            if constexpr (sizeof(T) == 4) nrm = sqrtf((x * x + y * y) + z * z);
-            else nrm = sqrt((x * x + y * y) + z * z);
+            double nrm;
+            if (sizeof(T) == 4 && !a.rows_as_f64) nrm = (double)sqrtf((float)((x * x + y * y) + z * z));   // float32 norm (simulation.py:455)
+            else { const double xd = (double)x, yd = (double)y, zd = (double)z; nrm = sqrt((xd * xd + yd * yd) + zd * zd); }
             double c;
-            if (a.flat_earth) c = -((double)z / ((double)nrm * 1.0));    // augmentation.py:61-63
-            else c = dot / ((double)nrm * wn);                           // simulation.py:454-455
+            if (a.flat_earth) c = -((double)z / (nrm * 1.0));            // augmentation.py:61-63
+            else c = dot / (nrm * wn);                                   // simulation.py:454-455
             ga = acos(c);
             gn = (double)inten / cos(ga);                                // augmentation.py:207
-            gd = (double)nrm;                                            // augmentation.py:208
+            gd = nrm;                                                    // augmentation.py:208
             v[0] += 1.0; v[1] += gd; v[2] += gn;
             ymax = fmax(ymax, gn);
         }
@@ -137,18 +141,128 @@ __global__ void k_pre_means(PreArgs a, int min_ground, int err_code)
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     double c = 0, sx = 0, sy = 0, ym = -INFINITY;
     for (int64_t t = 0; t < tiles; ++t) {
-        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
+        double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
+        p[6] = c;                                                        // ground rows in earlier tiles
         c += p[0]; sx += p[1]; sy += p[2]; ym = fmax(ym, p[3]);
     }
     PreFrame &fr = a.fr[f];
     fr.n_ground = c;
     fr.xmean = c > 0 ? sx / c : 0.0;
     fr.ymean = c > 0 ? sy / c : 0.0;
+    fr.xmean32 = (double)(float)fr.xmean;   // refined by k_pre_mean32 when the value is actually used
+    fr.need_mean32 = 0;
     fr.ymax = fabs(ym);                                                  // np.abs(np.max(...)), augmentation.py:233
     fr.unchanged = 0;
     if (c < (double)min_ground) {
         if (err_code) atomicCAS(&a.status[0], 0, err_code);              // snowfall: TypeError in the reference (Q7)
         fr.unchanged = 1;                                                // wet: frame returned unchanged
+    }
+}
+
+// ---- P2b/P2c (float32 rows): np.mean(range) exactly as NumPy computes it ----------------------------------------
+// scipy.stats.linregress uses np.mean(x) of the float32 range column for the intercept (augmentation.py:216);
+// NumPy sums float32 with its pairwise scheme (blocks of <= 128 values, 8 interleaved accumulators, halves split
+// at a multiple of 8) and divides in float32.  On frames where the laser-power line nearly cancels that rounding
+// is visible in the rewritten intensities, so it is reproduced operation for operation: the ground ranges are
+// first compacted in row order, then one block per frame walks NumPy's recursion.
+__global__ __launch_bounds__(PB) void k_pre_gather(PreArgs a)
+{
+    const int f = blockIdx.y;
+    if (!a.fr[f].need_mean32) return;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    __shared__ int wc[4][4];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+    bool g[4];
+    int pre[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + tid;
+        const double gn = r < n ? a.g_norm[base + r] : NAN;
+        g[q] = gn == gn;
+        const unsigned long long m = __ballot(g[q]);
+        pre[q] = __popcll(m & lt);
+        if ((tid & 63) == 0) wc[q][wv] = __popcll(m);
+    }
+    __syncthreads();
+    int run = (int)a.part[((int64_t)f * a.max_tiles + blockIdx.x) * 12 + 6];
+    for (int q = 0; q < 4; ++q) {
+        int off = run;
+        for (int ww = 0; ww < wv; ++ww) off += wc[q][ww];
+        if (g[q]) a.cdist[base + off + pre[q]] = (float)a.g_dist[base + tile0 + q * PB + tid];
+        run += wc[q][0] + wc[q][1] + wc[q][2] + wc[q][3];
+    }
+}
+
+__device__ __forceinline__ float np_leaf_sum_f32(const float *v, int n)     // n <= 128
+{
+    if (n < 8) {
+        float res = -0.0f;
+        for (int i = 0; i < n; ++i) res += v[i];
+        return res;
+    }
+    float r[8];
+    for (int j = 0; j < 8; ++j) r[j] = v[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; ++j) r[j] += v[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += v[i];
+    return res;
+}
+
+__global__ __launch_bounds__(PB) void k_pre_mean32(PreArgs a, int *leaf_buf, int max_leaves)
+{
+    const int f = blockIdx.x;
+    const int n = (int)a.fr[f].n_ground;
+    if (n <= 0 || !a.fr[f].need_mean32) return;
+    const float *v = a.cdist + a.frame_off[f];
+    int *leaf_off = leaf_buf + (int64_t)f * 3 * max_leaves;      // per frame: offsets, lengths, sums (as float bits)
+    int *leaf_len = leaf_off + max_leaves;
+    float *leaf_sum = (float *)(leaf_len + max_leaves);
+    const int PW_MAX_LEAVES = max_leaves;
+    __shared__ int n_leaves;
+    if (threadIdx.x == 0) {                     // depth-first walk of pairwise_sum's recursion: leaves in order
+        int stack_off[40], stack_len[40], sp = 0, nl = 0;
+        stack_off[0] = 0; stack_len[0] = n; sp = 1;
+        while (sp > 0 && nl < PW_MAX_LEAVES) {
+            --sp;
+            const int o = stack_off[sp], l = stack_len[sp];
+            if (l <= 128) { leaf_off[nl] = o; leaf_len[nl] = l; ++nl; }
+            else {
+                int n2 = l / 2;
+                n2 -= n2 % 8;
+                stack_off[sp] = o + n2; stack_len[sp] = l - n2; ++sp;        // right half: visited second
+                stack_off[sp] = o; stack_len[sp] = n2; ++sp;                 // left half: visited first
+            }
+        }
+        n_leaves = nl;
+    }
+    __syncthreads();                            // (global writes of this block are visible to it after the barrier)
+    for (int i = threadIdx.x; i < n_leaves; i += PB) leaf_sum[i] = np_leaf_sum_f32(v + leaf_off[i], leaf_len[i]);
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {                     // sum(l) = sum(left) + sum(right): post-order over the same tree
+        // explicit evaluation stack: entries are either pending sizes (>= 0) or the "add" marker (-1)
+        int cmd[96], sp = 0, next_leaf = 0, vs = 0;
+        float val[48];
+        cmd[sp++] = n;
+        while (sp > 0) {
+            const int c = cmd[--sp];
+            if (c == -1) { const float r = val[--vs]; const float l = val[--vs]; val[vs++] = l + r; }
+            else if (c <= 128) { val[vs++] = leaf_sum[next_leaf++]; }
+            else {
+                int n2 = c / 2;
+                n2 -= n2 % 8;
+                cmd[sp++] = -1; cmd[sp++] = c - n2; cmd[sp++] = n2;          // evaluate left, then right, then add
+            }
+        }
+        const float total = 0.0f + val[0];      // np.add.reduce: identity + pairwise sum
+        PreFrame &fr = a.fr[f];
+        fr.xmean32 = (double)(total / (float)n);                             // _mean: float32 true_divide
+        fr.p1 = fr.ymean - fr.p0 * fr.xmean32;                               // linregress intercept (augmentation.py:216)
+        fr.pmin1 = fr.p1;                                                    // pmin = p (:250-251)
     }
 }
 
@@ -259,7 +373,7 @@ __global__ void k_pre_lines(PreArgs a, int xmean_f32)
     if (ng >= 3) {
         slope = (sxy / ng) / (sxx / ng);                                 // scipy linregress: ssxym / ssxm
         // np.mean of a float32 column is a float32; the intercept is ymean - slope * xmean (augmentation.py:216)
-        const double xm = xmean_f32 ? (double)(float)fr.xmean : fr.xmean;
+        const double xm = xmean_f32 ? fr.xmean32 : fr.xmean;
         icpt = fr.ymean - slope * xm;
     }
     fr.p0 = slope; fr.p1 = icpt;
@@ -276,7 +390,7 @@ __global__ void k_pre_lines(PreArgs a, int xmean_f32)
         }
     }
     if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
-    else { fr.pmin0 = slope; fr.pmin1 = icpt; }                          // :250-251
+    else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
 }
 
 // ---- P6: normal-equation partials of polyfit(ground_dist, thr * cos(angle), 2) (simulation.py:462-467) ----------
@@ -509,7 +623,7 @@ __global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
 // ================================================================================================================
 // host side
 
-enum { B_GDIST = 0, B_GNORM, B_GCOS, B_PART, B_HIST, B_ROWMIN, B_FRAME, B_CLS, B_NEWI, B_TCNT, B_TBASE, B_N };
+enum { B_GDIST = 0, B_GNORM, B_GCOS, B_PART, B_HIST, B_ROWMIN, B_FRAME, B_CLS, B_NEWI, B_TCNT, B_TBASE, B_CDIST, B_LEAF, B_N };
 
 static int ensure(SgPrepassScratch *s, int i, size_t bytes)
 {
@@ -524,24 +638,25 @@ static int ensure(SgPrepassScratch *s, int i, size_t bytes)
 
 extern "C" void sg_prepass_release(SgPrepassScratch *s)
 {
-    for (int i = 0; i < 12; ++i) { if (s->buf[i]) (void)hipFree(s->buf[i]); s->buf[i] = nullptr; s->cap[i] = 0; }
+    for (int i = 0; i < 16; ++i) { if (s->buf[i]) (void)hipFree(s->buf[i]); s->buf[i] = nullptr; s->cap[i] = 0; }
 }
 
 #define LCHK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
 
 static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total, int64_t max_frame, int min_ground,
-                    int err_code, hipStream_t st)
+                    int err_code, bool exact_f32_mean, hipStream_t st)
 {
     const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
     a.max_tiles = max_tiles;
     const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)a.n_frames;
     if (ensure(s, B_GDIST, n * 8) || ensure(s, B_GNORM, n * 8) || ensure(s, B_GCOS, n * 8) ||
         ensure(s, B_PART, nf * (size_t)max_tiles * 12 * 8) || ensure(s, B_HIST, nf * HX * HY * 4) ||
-        ensure(s, B_ROWMIN, nf * HX * 8) || ensure(s, B_FRAME, nf * sizeof(PreFrame)))
+        ensure(s, B_ROWMIN, nf * HX * 8) || ensure(s, B_FRAME, nf * sizeof(PreFrame)) || (dtype == 0 && ensure(s, B_CDIST, n * 4)))
         return -1;
     a.g_dist = (double *)s->buf[B_GDIST]; a.g_norm = (double *)s->buf[B_GNORM]; a.g_ang = (double *)s->buf[B_GCOS];
     a.part = (double *)s->buf[B_PART]; a.hist = (int32_t *)s->buf[B_HIST]; a.rowmin = (double *)s->buf[B_ROWMIN];
     a.fr = (PreFrame *)s->buf[B_FRAME];
+    a.cdist = (float *)s->buf[B_CDIST];
     hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)max_tiles, (unsigned)a.n_frames);
@@ -551,12 +666,23 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
     LCHK();
     hipLaunchKernelGGL(k_pre_means, dim3(fb), dim3(64), 0, st, a, min_ground, err_code);
     LCHK();
+
     hipLaunchKernelGGL(k_pre_moments, grid, dim3(PB), 0, st, a);
     LCHK();
     hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)a.n_frames), dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_pre_lines, dim3(fb), dim3(64), 0, st, a, dtype == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_pre_lines, dim3(fb), dim3(64), 0, st, a, (dtype == 0 && !a.rows_as_f64) ? 1 : 0);
     LCHK();
+    if (dtype == 0 && exact_f32_mean) {
+        // only frames whose noise line fell back to p = linregress(range, I / cos) need the float32 mean; the two
+        // kernels below leave at once for every other frame
+        const int max_leaves = (int)(max_frame / 64 + 8);      // pairwise leaves hold 65..128 values
+        if (ensure(s, B_LEAF, nf * 3 * (size_t)max_leaves * 4)) return -1;
+        hipLaunchKernelGGL(k_pre_gather, grid, dim3(PB), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)a.n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        LCHK();
+    }
     return 0;
 }
 
@@ -568,7 +694,7 @@ extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, 
     PreArgs a{};
     a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0;
     a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
-    int rc = estimate(s, a, dtype, n_total, max_frame, 3, 7 /* SNOWGPU_E_GROUND */, st);
+    int rc = estimate(s, a, dtype, n_total, max_frame, 3, 7 /* SNOWGPU_E_GROUND */, true, st);
     if (rc) return rc;
     dim3 grid((unsigned)a.max_tiles, (unsigned)n_frames);
     if (dtype == 0) hipLaunchKernelGGL(k_pre_poly_part<float>, grid, dim3(PB), 0, st, a);
@@ -587,8 +713,8 @@ extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, cons
     WetArgs w{};
     PreArgs &a = w.p;
     a.rows = rows; a.frame_off = frame_off; a.frame_cnt = frame_cnt; a.n_frames = n_frames; a.plane = plane; a.delta = wp->delta;
-    a.flat_earth = wp->flat_earth; a.noise_floor = wp->noise_floor; a.power_factor = wp->power_factor; a.status = status;
-    int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, st);
+    a.flat_earth = wp->flat_earth; a.rows_as_f64 = 1; a.noise_floor = wp->noise_floor; a.power_factor = wp->power_factor; a.status = status;
+    int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, false, st);
     if (rc) return rc;
     const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)n_frames;
     if (ensure(s, B_CLS, n) || ensure(s, B_NEWI, n * 8) || ensure(s, B_TCNT, nf * (size_t)a.max_tiles * 2 * 4) ||
