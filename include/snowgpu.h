@@ -129,7 +129,7 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
  * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
  * the entry point bench.py times.  max_frame_rows = rows of the largest frame (sizes the per-frame grids;
- * 0 = unknown, n_total is used).  d_status (device int32[8]) receives {error code, first bad
+ * 0 = unknown, n_total is used; when max_frame_rows * n_frames == n_total all frames are taken to be that size).  d_status (device int32[8]) receives {error code, first bad
  * global row, beams handed to the 2nd / 3rd / (unused) list capacity, reserved...}; check it after synchronising the stream.
  */
 int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total,

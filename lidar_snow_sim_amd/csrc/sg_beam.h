@@ -100,6 +100,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
     const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
     const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
+    // touch the first record of the second bin now: its 64-byte line is then on its way while the first bin is scanned
+    const double first_rho1 = tab.entries[st2].rho;
 
     // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
     double ar, br, al, bl;
@@ -121,6 +123,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             // software pipeline: the next record is requested before the current one is examined (the entry
             // array carries one spare record at its end, so e + 1 is always readable)
             SgEntry nxt = tab.entries[e0];
+            if (s == 1) nxt.rho = first_rho1;
             for (uint32_t e = e0; e < e1; ++e) {
                 const SgEntry f = nxt;
                 nxt = tab.entries[e + 1];

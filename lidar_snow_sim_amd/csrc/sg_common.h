@@ -46,6 +46,7 @@ struct SgBeamArgs {
     const int64_t *frame_off;    // n_frames + 1
     int32_t n_frames;
     int64_t n_total;
+    int64_t uniform_rows;        // > 0: every frame has this many rows (frame = position / uniform_rows)
     const int32_t *perm;         // channel-sorted position (global) -> frame-local source row
     const SgTable *tables;
     int32_t n_tables;

@@ -356,6 +356,7 @@ struct BatchDev {
     int n_frames;
     int64_t n_total;
     int64_t max_frame;   // rows of the largest frame (host knowledge; n_total is a safe bound)
+    int64_t uniform_rows = 0;   // > 0 when the host knows that all frames have this many rows
     const int64_t *frame_off;
     const void *rows;
     int dtype;
@@ -435,6 +436,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
+    a.uniform_rows = b.uniform_rows;
     a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
     a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.thr_poly = thr; a.tmp_rows = ctx->rows_tmp.p;
     a.keep = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
@@ -510,7 +512,8 @@ extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int6
     HIPCHK(ctx, hipSetDevice(ctx->device));
     BatchDev b{};
     b.n_frames = n_frames; b.n_total = n_total; b.max_frame = (max_frame_rows > 0 && max_frame_rows <= n_total) ? max_frame_rows : n_total;
-    b.frame_off = d_frame_offsets; b.rows = d_rows;
+    b.frame_off = d_frame_offsets;
+    b.uniform_rows = (max_frame_rows > 0 && max_frame_rows * (int64_t)n_frames == n_total) ? max_frame_rows : 0; b.rows = d_rows;
     b.dtype = dtype; b.table_ids = d_table_ids; b.beam_div_deg = beam_divergence_deg; b.thr_poly = d_thr_poly;
     b.plane = d_plane; b.noise_floor = noise_floor; b.perm = d_perm; b.out_rows = d_out_rows; b.out_src = d_out_src;
     b.out_counts = d_out_counts; b.out_stats = d_out_stats; b.out_thr_poly = d_out_thr_poly; b.status = d_status;
@@ -573,6 +576,11 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     if (out_thr_poly && d_out_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
     BatchDev b{};
     b.n_frames = n_frames; b.n_total = n_total; b.max_frame = max_frame; b.frame_off = ctx->frame_off.p; b.rows = ctx->rows_in.p;
+    {
+        bool uni = max_frame > 0;
+        for (int f = 0; f < n_frames && uni; ++f) uni = (frame_offsets[f + 1] - frame_offsets[f]) == max_frame;
+        b.uniform_rows = uni ? max_frame : 0;
+    }
     b.dtype = dtype; b.table_ids = ctx->table_ids.p; b.beam_div_deg = beam_div_deg; b.thr_poly = d_thr;
     b.plane = (!thr_poly && plane) ? ctx->plane.p : nullptr; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
     b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = ctx->out_counts.p; b.out_stats = ctx->out_stats.p;

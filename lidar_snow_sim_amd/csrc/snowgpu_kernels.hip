@@ -130,6 +130,8 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // The per-beam kernel.  Dynamic LDS: range grid (1230 doubles) + four per-thread lists.
+// Second launch-bound argument = waves per SIMD the register allocator must leave room for: the 4-entry tier
+// keeps 16 waves per CU resident (its LDS footprint allows exactly that), later tiers are LDS-limited anyway.
 template <typename T, int LMAX, int BLOCK, bool LIST>
 __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 {
