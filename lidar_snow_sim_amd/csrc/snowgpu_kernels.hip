@@ -408,17 +408,19 @@ template <typename T, int LMAX, int BLOCK, bool LIST>
 static int launch_beams_tl(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};                       // per device: several contexts may live in one process
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
         hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK, LIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
     if (blocks == 0) return 0;
     if (LIST) {                                          // list mode: at most what the chip can hold at once
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
         const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
         blocks = std::min(blocks, (unsigned)cus * per_cu);
     }

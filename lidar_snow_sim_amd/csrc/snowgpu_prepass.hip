@@ -132,30 +132,58 @@ __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
     }
 }
 
-// ---- P2: per frame: counts, means, max ------------------------------------------------------------------------
-__global__ void k_pre_means(PreArgs a, int min_ground, int err_code)
+// One wave per frame: lane l sums tiles l, l + 64, ... in order, then the 64 lane totals are combined by a fixed
+// shuffle tree -- deterministic, and ~64x shorter than one thread walking every tile.
+template <int K>
+__device__ __forceinline__ void frame_sums(const double *part, int64_t tiles, const int (&col)[K], double (&out)[K])
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (int k = 0; k < K; ++k) out[k] = 0.0;
+    for (int64_t t = lane; t < tiles; t += 64)
+        for (int k = 0; k < K; ++k) out[k] += part[t * 12 + col[k]];
+    for (int k = 0; k < K; ++k) {
+        for (int o = 32; o > 0; o >>= 1) out[k] += __shfl_xor(out[k], o);
+    }
+}
+
+// ---- P2: per frame: counts, means, max ------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_pre_means(PreArgs a, int min_ground, int err_code)
+{
+    const int f = blockIdx.x;
     if (f >= a.n_frames) return;
+    const int lane = threadIdx.x;
     const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    double c = 0, sx = 0, sy = 0, ym = -INFINITY;
-    for (int64_t t = 0; t < tiles; ++t) {
-        double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
-        p[6] = c;                                                        // ground rows in earlier tiles
-        c += p[0]; sx += p[1]; sy += p[2]; ym = fmax(ym, p[3]);
+    double *part = a.part + (int64_t)f * a.max_tiles * 12;
+    // exclusive prefix of the per-tile ground counts (exact: integers), max of the per-tile maxima
+    double run = 0.0, ym = -INFINITY;
+    for (int64_t t0 = 0; t0 < tiles; t0 += 64) {
+        const int64_t t = t0 + lane;
+        const double c = t < tiles ? part[t * 12 + 0] : 0.0;
+        if (t < tiles) ym = fmax(ym, part[t * 12 + 3]);
+        double inc = c;                                          // inclusive scan across the wave
+        for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (t < tiles) part[t * 12 + 6] = run + inc - c;         // ground rows in earlier tiles
+        run += __shfl(inc, 63);
     }
-    PreFrame &fr = a.fr[f];
-    fr.n_ground = c;
-    fr.xmean = c > 0 ? sx / c : 0.0;
-    fr.ymean = c > 0 ? sy / c : 0.0;
-    fr.xmean32 = (double)(float)fr.xmean;   // refined by k_pre_mean32 when the value is actually used
-    fr.need_mean32 = 0;
-    fr.ymax = fabs(ym);                                                  // np.abs(np.max(...)), augmentation.py:233
-    fr.unchanged = 0;
-    if (c < (double)min_ground) {
-        if (err_code) atomicCAS(&a.status[0], 0, err_code);              // snowfall: TypeError in the reference (Q7)
-        fr.unchanged = 1;                                                // wet: frame returned unchanged
+    for (int o = 32; o > 0; o >>= 1) ym = fmax(ym, __shfl_xor(ym, o));
+    const int cols[2] = {1, 2};
+    double sums[2];
+    frame_sums<2>(part, tiles, cols, sums);
+    if (lane == 0) {
+        const double c = run;
+        PreFrame &fr = a.fr[f];
+        fr.n_ground = c;
+        fr.xmean = c > 0 ? sums[0] / c : 0.0;
+        fr.ymean = c > 0 ? sums[1] / c : 0.0;
+        fr.xmean32 = (double)(float)fr.xmean;   // refined by k_pre_mean32 when the value is actually used
+        fr.need_mean32 = 0;
+        fr.ymax = fabs(ym);                                              // np.abs(np.max(...)), augmentation.py:233
+        fr.unchanged = 0;
+        if (c < (double)min_ground) {
+            if (err_code) atomicCAS(&a.status[0], 0, err_code);          // snowfall: TypeError in the reference (Q7)
+            fr.unchanged = 1;                                            // wet: frame returned unchanged
+        }
     }
 }
 
@@ -356,18 +384,18 @@ __device__ __forceinline__ void small_linregress(const double *x, const double *
 }
 
 // ---- P5: the two lines ----------------------------------------------------------------------------------------
-__global__ void k_pre_lines(PreArgs a, int xmean_f32)
+__global__ __launch_bounds__(64) void k_pre_lines(PreArgs a, int xmean_f32)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
     if (f >= a.n_frames) return;
     PreFrame &fr = a.fr[f];
     const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    double sxx = 0, sxy = 0;
-    for (int64_t t = 0; t < tiles; ++t) {
-        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
-        sxx += p[4]; sxy += p[5];
-    }
+    const int cols[2] = {4, 5};
+    double mom[2];
+    frame_sums<2>(a.part + (int64_t)f * a.max_tiles * 12, tiles, cols, mom);
+    if (threadIdx.x != 0) return;
+    const double sxx = mom[0], sxy = mom[1];
     const double ng = fr.n_ground;
     double slope = 0, icpt = 0;
     if (ng >= 3) {
@@ -427,17 +455,16 @@ __global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
 }
 
 // ---- P7: solve the 3 x 3 system (columns scaled by their norms, as np.polyfit does) ------------------------------
-__global__ void k_pre_poly_solve(PreArgs a, double *thr_poly)
+__global__ __launch_bounds__(64) void k_pre_poly_solve(PreArgs a, double *thr_poly)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.x;
     if (f >= a.n_frames) return;
     const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t t = 0; t < tiles; ++t) {
-        const double *p = a.part + ((int64_t)f * a.max_tiles + t) * 12;
-        for (int k = 0; k < 9; ++k) s[k] += p[k];
-    }
+    const int cols[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
+    double s[9];
+    frame_sums<9>(a.part + (int64_t)f * a.max_tiles * 12, tiles, cols, s);
+    if (threadIdx.x != 0) return;
     double *out = thr_poly + 3 * f;
     if (s[8] < 3) { out[0] = out[1] = out[2] = 0.0; return; }
     const double c2 = sqrt(s[0]), c1 = sqrt(s[3]), c0 = sqrt(s[8]);
@@ -660,18 +687,17 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
     hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)max_tiles, (unsigned)a.n_frames);
-    const unsigned fb = (unsigned)((a.n_frames + 63) / 64);
     if (dtype == 0) hipLaunchKernelGGL(k_pre_ground<float>, grid, dim3(PB), 0, st, a);
     else hipLaunchKernelGGL(k_pre_ground<double>, grid, dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_pre_means, dim3(fb), dim3(64), 0, st, a, min_ground, err_code);
+    hipLaunchKernelGGL(k_pre_means, dim3((unsigned)a.n_frames), dim3(64), 0, st, a, min_ground, err_code);
     LCHK();
 
     hipLaunchKernelGGL(k_pre_moments, grid, dim3(PB), 0, st, a);
     LCHK();
     hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)a.n_frames), dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_pre_lines, dim3(fb), dim3(64), 0, st, a, (dtype == 0 && !a.rows_as_f64) ? 1 : 0);
+    hipLaunchKernelGGL(k_pre_lines, dim3((unsigned)a.n_frames), dim3(64), 0, st, a, (dtype == 0 && !a.rows_as_f64) ? 1 : 0);
     LCHK();
     if (dtype == 0 && exact_f32_mean) {
         // only frames whose noise line fell back to p = linregress(range, I / cos) need the float32 mean; the two
@@ -700,7 +726,7 @@ extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, 
     if (dtype == 0) hipLaunchKernelGGL(k_pre_poly_part<float>, grid, dim3(PB), 0, st, a);
     else hipLaunchKernelGGL(k_pre_poly_part<double>, grid, dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_pre_poly_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, thr_poly);
+    hipLaunchKernelGGL(k_pre_poly_solve, dim3((unsigned)n_frames), dim3(64), 0, st, a, thr_poly);
     LCHK();
     return 0;
 }
