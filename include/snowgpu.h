@@ -86,6 +86,17 @@ int snowgpu_set_lasers(snowgpu_ctx *ctx, int n_lasers, const double *focal_slope
 int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t n_flakes);
 int snowgpu_table_count(const snowgpu_ctx *ctx);
 
+/* dart_throwing (tools/snowfall/sampling.py:90-194) on the device: same process (uniform-area centres, Exp(scale)
+ * sphere diameters truncated at 20 mm, disk = slice at uniform height, no disk over the origin, no overlaps in dart
+ * order, stop when the occupied area reaches occupancy_ratio * pi * r_0^2), NOT the same random stream (Philox4x32-10
+ * keyed by (seed, dart index) instead of a sequential NumPy Generator) -- statistical parity, see DESIGN.md.
+ *   diameter_scale_mm  = 10 / rate_parameter with rate_parameter = gunn_marshall(rate) or sekhon_srivastava(rate)
+ *                        (sampling.py:108-115, :154)
+ *   table_id >= 0      file the table under that id (as snowgpu_upload_table does); -1: only return the rows
+ *   xyr_out / cap      optional host buffer for the K x 3 rows; *n_out = K */
+int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm,
+                         double r_0, uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out);
+
 /* Validation switch for the received-power term A * sin^2(pi (R - r) / (c tau_h)) (simulation.py:549).
  * 0 (default): the engine's own sine (one reduction step + odd polynomial, < 1 ULP) and a multiplication by
  * 1 / (c tau_h); 1: the device math library's sin and a true division, operation for operation what NumPy

@@ -22,6 +22,7 @@ EXPORTS = [
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
+    "snowgpu_sample_table",
 ]
 
 
@@ -72,6 +73,8 @@ def lib():
             L.snowgpu_augment_wet_batch.restype = ctypes.c_int
             L.snowgpu_augment_wet_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp, vp,
                                                     dbl, dbl, dbl, dbl, ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp, vp]
+            L.snowgpu_sample_table.restype = ctypes.c_int
+            L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
             L.snowgpu_set_exact_math.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_begin.restype = ctypes.c_int
@@ -193,6 +196,19 @@ class Context:
                                                   vp(d_perm or None), vp(d_out_rows), vp(d_out_src), vp(d_out_counts),
                                                   vp(d_out_stats), vp(d_out_thr or None), vp(d_status), vp(stream or None))
         self._check(rc)
+
+    def sample_table(self, table_id, occupancy_ratio, diameter_scale_mm, r_0, seed, want_rows=True):
+        """Sample a snowflake table on the device; returns the K x 3 rows (or K when want_rows is False)."""
+        n = ctypes.c_int64(0)
+        self._check(self._L.snowgpu_sample_table(self._h, int(table_id), float(occupancy_ratio), float(diameter_scale_mm),
+                                                 float(r_0), ctypes.c_uint64(int(seed)), None, 0, ctypes.byref(n)))
+        if not want_rows:
+            return n.value
+        out = np.empty((n.value, 3), np.float64)
+        # same seed -> same table: the second call only fetches the rows
+        self._check(self._L.snowgpu_sample_table(self._h, -1, float(occupancy_ratio), float(diameter_scale_mm), float(r_0),
+                                                 ctypes.c_uint64(int(seed)), _p(out), n.value, ctypes.byref(n)))
+        return out
 
     def set_exact_math(self, on: bool):
         self._check(self._L.snowgpu_set_exact_math(self._h, int(bool(on))))

@@ -642,6 +642,49 @@ extern "C" int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const 
                       out_src.data(), &cnt, stats, nullptr, cap, count, rj, ratio, sorted_src);
 }
 
+extern "C" int sg_sample_table(double occupancy, double scale_mm, double R0, uint64_t seed, int64_t n_cand, double *d_xyr,
+                               int64_t cap, int64_t *n_rows, void *stream);   // snowgpu_sampler.hip
+
+extern "C" int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm, double r_0,
+                                    uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (!(occupancy_ratio > 0) || !(occupancy_ratio < 0.05) || !(diameter_scale_mm > 0) || !(r_0 > 0.05) || !(r_0 <= 500.0) || !n_out)
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: need 0 < occupancy < 0.05, scale > 0, 0.05 < R0 <= 500 m");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const double target = occupancy_ratio * SG_PI * r_0 * r_0;
+    const double s_m = diameter_scale_mm / 1000.0;
+    const double mean_area = SG_PI * s_m * s_m / 3.0;         // E[pi r^2], r^2 = d^2/4 - h^2, h ~ U(-d/2, d/2), d ~ Exp(s)
+    int64_t n_cand = (int64_t)(1.3 * target / mean_area) + 4096;
+    std::vector<double> host;
+    int64_t rows = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (n_cand > ((int64_t)1 << 27)) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: table would exceed 2^27 candidates");
+        DevBuf<double> d_xyr;
+        if (d_xyr.ensure((size_t)n_cand * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for the sampled table");
+        int rc = sg_sample_table(occupancy_ratio, diameter_scale_mm, r_0, seed, n_cand, d_xyr.p, n_cand, &rows, ctx->stream);
+        if (rc == -2 && attempt < 4) { d_xyr.release(); n_cand *= 2; continue; }     // not enough darts: throw more
+        if (rc != 0) {
+            d_xyr.release();
+            if (rc > 0) return fail(ctx, SNOWGPU_E_HIP, std::string("sampler: ") + hipGetErrorString((hipError_t)rc));
+            return fail(ctx, SNOWGPU_E_TABLE, rc == -3 ? "sampler: a dart overlaps more than 4 earlier darts (occupancy too high for this sampler)"
+                                                       : "sampler: acceptance did not settle / target area not reached");
+        }
+        host.resize((size_t)rows * 3);
+        hipError_t e = rows ? hipMemcpy(host.data(), d_xyr.p, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost) : hipSuccess;
+        d_xyr.release();
+        if (e != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("sampler copy: ") + hipGetErrorString(e));
+        break;
+    }
+    *n_out = rows;
+    if (xyr_out) {
+        if (cap < rows) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: output buffer too small (see *n_out)");
+        std::memcpy(xyr_out, host.data(), sizeof(double) * 3 * (size_t)rows);
+    }
+    if (table_id >= 0) return snowgpu_upload_table(ctx, table_id, host.data(), rows);
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
 {
     if (!ctx) return SNOWGPU_E_INVALID;

@@ -91,3 +91,19 @@ def dart_throwing(occupancy_ratio: float, precipitation_rate: float, R_0: float,
         out.append((x, y, radius))
         grid.setdefault((cx, cy), []).append((x, y, radius))
     return np.array(out, dtype=np.float64).reshape(-1, 3)
+
+
+def dart_throwing_device(occupancy_ratio: float, precipitation_rate: float, R_0: float, seed: int,
+                         distribution: str = 'gunn', device: int = 0, table_id: int = -1) -> np.ndarray:
+    """dart_throwing on the GPU (libsnowgpu `snowgpu_sample_table`): the same sampling process driven by a
+    counter-based Philox stream instead of a sequential NumPy Generator, so tables are statistically -- not bit for
+    bit -- those of `dart_throwing`.  With table_id >= 0 the table is also filed on the device under that id."""
+    if distribution == 'sekhon':
+        rate_parameter = sekhon_srivastava(precipitation_rate)
+    elif distribution == 'gunn':
+        rate_parameter = gunn_marshall(precipitation_rate)
+    else:
+        raise NotImplementedError('Distribution model unknown.')
+    from ... import engine
+    eng = engine.get_engine(device)
+    return eng.ctx.sample_table(table_id, occupancy_ratio, (1 / rate_parameter) * 10, R_0, seed)

@@ -1,0 +1,83 @@
+"""-m gpu: the on-device snowflake sampler against the reference's sampling process (statistical parity)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def smp():
+    from lidar_snow_sim_amd.tools.snowfall import sampling
+    return sampling
+
+
+def _params(smp, rs, vt):
+    return smp.compute_occupancy(rs, vt), smp.snowfall_rate_to_rainfall_rate(rs, vt)
+
+
+def test_device_table_is_a_valid_dart_throw(smp):
+    """Every invariant of sampling.py:142-183 on a full-size table (2.5 mm/h @ 1.6 m/s, R0 = 80 m)."""
+    from scipy.spatial import cKDTree
+    occ, rate = _params(smp, 2.5, 1.6)
+    t = smp.dart_throwing_device(occ, rate, 80.0, seed=7, distribution="gunn")
+    x, y, r = t[:, 0], t[:, 1], t[:, 2]
+    assert t.shape[1] == 3 and np.isfinite(t).all()
+    assert (x * x + y * y <= 80.0 ** 2).all()                    # inside the domain (:145)
+    assert (x * x + y * y > r * r).all()                         # no disk over the origin (:166)
+    assert (r > 0).all() and (r <= 0.010).all()                  # diameters are cut at 20 mm (:153)
+    pairs = cKDTree(t[:, :2]).query_pairs(0.0201, output_type="ndarray")
+    if len(pairs):                                               # no overlaps (:170-174)
+        dist = np.hypot(x[pairs[:, 0]] - x[pairs[:, 1]], y[pairs[:, 0]] - y[pairs[:, 1]])
+        assert (dist > r[pairs[:, 0]] + r[pairs[:, 1]]).all()
+    target = occ * np.pi * 80.0 ** 2
+    area = np.cumsum(np.pi * r * r)                              # stop rule (:142): the last dart is the one that fills it
+    assert area[-1] >= target and area[-2] < target
+
+
+def test_device_table_matches_the_reference_distribution(smp):
+    """Counts, radii and radial density against tables thrown with the reference's own sequential sampler."""
+    from scipy.stats import ks_2samp, kstest
+    occ, rate = _params(smp, 2.5, 1.6)
+    ref = [smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(100 + i), "gunn") for i in range(3)]
+    dev = [smp.dart_throwing_device(occ, rate, 80.0, seed=100 + i, distribution="gunn") for i in range(3)]
+    k_ref, k_dev = np.mean([len(t) for t in ref]), np.mean([len(t) for t in dev])
+    assert abs(k_dev - k_ref) / k_ref < 0.03                     # ~18 000 flakes either way
+    r_ref, r_dev = np.concatenate([t[:, 2] for t in ref]), np.concatenate([t[:, 2] for t in dev])
+    assert abs(r_dev.mean() - r_ref.mean()) / r_ref.mean() < 0.02
+    assert ks_2samp(r_ref, r_dev).pvalue > 1e-3                  # same radius law
+    rho2 = np.concatenate([t[:, 0] ** 2 + t[:, 1] ** 2 for t in dev]) / 80.0 ** 2
+    assert kstest(rho2, "uniform").pvalue > 1e-3                 # uniform in area
+    phi = np.concatenate([np.arctan2(t[:, 1], t[:, 0]) for t in dev])
+    assert kstest((phi + np.pi) / (2 * np.pi), "uniform").pvalue > 1e-3
+
+
+def test_device_sampler_is_deterministic_per_seed_and_mode(smp):
+    occ, rate = _params(smp, 1.0, 1.6)
+    a = smp.dart_throwing_device(occ, rate, 30.0, seed=5, distribution="gunn")
+    b = smp.dart_throwing_device(occ, rate, 30.0, seed=5, distribution="gunn")
+    c = smp.dart_throwing_device(occ, rate, 30.0, seed=6, distribution="gunn")
+    d = smp.dart_throwing_device(occ, rate, 30.0, seed=5, distribution="sekhon")
+    assert np.array_equal(a, b) and not np.array_equal(a[:50], c[:50]) and len(d) != len(a)
+    with pytest.raises(NotImplementedError):
+        smp.dart_throwing_device(occ, rate, 30.0, seed=5, distribution="sekhon_srivastava")
+
+
+def test_sampled_tables_feed_the_simulation(smp):
+    """Tables made on the device, filed on the device, used by augment -- and the CPU oracle agrees on those tables."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from oracle import snow_oracle as so
+    occ, rate = _params(smp, 2.5, 1.6)
+    eng = engine.get_engine(0)
+    tabs = [smp.dart_throwing_device(occ, rate, 40.0, seed=900 + i) for i in range(2)]
+    tl = [tabs[i % 2] for i in range(64)]
+    full = synthetic_sweep(64, 2048, seed=31, intensity="lambert").reshape(64, 2048, 5)
+    pc = np.ascontiguousarray(full[:, ::32, :].reshape(-1, 5))
+    order = list(range(64))
+    bd = float(np.degrees(3e-3))
+    tids = eng.table_ids_from_arrays(tl, order)
+    out, src, counts, stats, _ = eng.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, plane=[[0, 0, -1.0, -1.7]])
+    s0, a0, src0 = so.augment(pc, tl, bd, order, plane=([0.0, 0.0, -1.0], -1.7))
+    n = int(counts[0])
+    assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in s0)
+    assert np.array_equal(src[:n], src0) and np.array_equal(out[:n, 3:], a0[:, 3:])
