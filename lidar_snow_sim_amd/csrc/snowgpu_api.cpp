@@ -60,7 +60,8 @@ struct snowgpu_ctx {
     DevBuf<uint16_t> rank;
     DevBuf<uint8_t> keep, rows_in, rows_tmp, rows_out;
     DevBuf<int64_t> frame_off, out_counts, out_stats;
-    DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio;
+    DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio, user_thr, out_thr;
+    DevBuf<int32_t> user_perm;
     DevBuf<int32_t> dbg_count;
     DevBuf<unsigned long long> diff2;
     SgPrepassScratch prepass{};
@@ -157,7 +158,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
-    ctx->dbg_count.release(); ctx->diff2.release();
+    ctx->dbg_count.release(); ctx->diff2.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
     sg_prepass_release(&ctx->prepass);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
@@ -558,7 +559,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * (size_t)n_frames * (size_t)ctx->h_las.n, hipMemcpyHostToDevice, st));
     // the user polynomial goes to its own buffer so that the prepass scratch (ctx->thr_poly) stays free
-    DevBuf<double> user_thr;
+    DevBuf<double> &user_thr = ctx->user_thr;
     const double *d_thr = nullptr;
     if (thr_poly) {
         if (user_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for thr_poly");
@@ -567,12 +568,12 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     } else if (plane) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
     }
-    DevBuf<int32_t> user_perm;
+    DevBuf<int32_t> &user_perm = ctx->user_perm;
     if (perm) {
         if (user_perm.ensure(std::max<size_t>(n, 1))) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for perm");
         if (n) HIPCHK(ctx, hipMemcpyAsync(user_perm.p, perm, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
     }
-    DevBuf<double> d_out_thr;
+    DevBuf<double> &d_out_thr = ctx->out_thr;
     if (out_thr_poly && d_out_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
     BatchDev b{};
     b.n_frames = n_frames; b.n_total = n_total; b.max_frame = max_frame; b.frame_off = ctx->frame_off.p; b.rows = ctx->rows_in.p;
@@ -611,7 +612,6 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         if (perm_out && n && b.perm_out) HIPCHK(ctx, hipMemcpyAsync(perm_out, b.perm_out, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     }
     hipError_t se = hipStreamSynchronize(st);
-    user_thr.release(); user_perm.release(); d_out_thr.release();
     if (rc != SNOWGPU_OK) return rc;
     if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
     return status_to_error(ctx, status);

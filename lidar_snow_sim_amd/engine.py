@@ -101,10 +101,12 @@ def set_particle_dir(path):
     _particle_dir = None if path is None else Path(path)
 
 
-def get_engine(device: int = 0) -> Engine:
+def get_engine(device: int = 0, slot: int = 0) -> Engine:
+    """The engine of `device`.  `slot` > 0 gives further independent contexts (own stream and scratch) on the same
+    device, e.g. two of them driven by two host threads overlap one batch's copies with the other's kernels."""
     with _engines_lock:
-        eng = _engines.get(device)
+        eng = _engines.get((device, slot))
         if eng is None:
             eng = Engine(device)
-            _engines[device] = eng
+            _engines[(device, slot)] = eng
         return eng

@@ -61,7 +61,7 @@ def _needs_host_perm(ch: np.ndarray) -> bool:
 
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
-                  thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True):
+                  thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch)
@@ -72,7 +72,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     thr_polys   optional per-frame (p0, p1, p2) noise-threshold polynomials (skips the prepass)
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
     """
-    eng = _engine.get_engine(device)
+    eng = _engine.get_engine(device, slot)
     rows = [_as_rows(f) for f in frames]
     if not rows:
         return []

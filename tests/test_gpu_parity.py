@@ -438,3 +438,66 @@ def test_noise_line_fallback_uses_numpy_float32_mean(eng, tables):
     host = noise_threshold_poly(srt, PLANE[0], PLANE[1], 0.7)
     dist = np.linspace(3, 10, 20)
     np.testing.assert_allclose(np.polyval(thr[0], dist), np.polyval(host, dist), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_frames_tables_and_divergences(so, seed):
+    """Random tables (incl. flakes close to the sensor), random beam divergences (1-30 mrad), random channel mixes,
+    ranges from 0.8 m to 119 m, unsorted rows, float32 and float64: every row against the CPU oracle."""
+    from lidar_snow_sim_amd import engine
+    rng = np.random.default_rng(1000 + seed)
+    n_tab = 3
+    tabs = []
+    for _ in range(n_tab):
+        k = int(rng.integers(200, 6000))
+        rho = np.sqrt(rng.uniform(0.3 ** 2, 70.0 ** 2, k))
+        rho[: k // 20] = rng.uniform(0.3, 2.0, k // 20)             # a crowd of near flakes: wide angular intervals
+        phi = rng.uniform(0, 2 * np.pi, k)
+        r = np.minimum(rng.exponential(1.5e-3, k) + 1e-4, 0.01)
+        tabs.append(np.column_stack((rho * np.cos(phi), rho * np.sin(phi), r)))
+    tl = [tabs[i % n_tab] for i in range(64)]
+    n = 1500
+    az = rng.uniform(-np.pi, np.pi, n)
+    az[:40] = rng.uniform(-4e-3, 4e-3, 40)                          # around the 0 / 2 pi seam (Q9)
+    az[40:60] = np.pi / 2 + rng.uniform(-2e-3, 2e-3, 20)            # around a vertical beam limit
+    el = rng.uniform(-0.4, 0.05, n)
+    d = np.exp(rng.uniform(np.log(0.8), np.log(119.0), n))
+    pc = np.column_stack((d * np.cos(el) * np.cos(az), d * np.cos(el) * np.sin(az), d * np.sin(el),
+                          rng.integers(0, 256, n), rng.integers(0, 64, n)))
+    dtype = np.float32 if seed % 2 == 0 else np.float64
+    pc = pc.astype(dtype)
+    bd = float(np.degrees(rng.choice([1e-3, 3e-3, 8e-3, 3e-2])))
+    order = list(rng.permutation(64))
+    poly = [0.002, -0.1, 12.0]
+    eng2 = engine.Engine(0)
+    try:
+        tids = eng2.table_ids_from_arrays(tl, order)
+        try:
+            out, src, counts, stats, _ = eng2.ctx.augment_batch(pc, [0, n], [tids], bd, thr_poly=[poly])
+        except Exception as e:                                       # > 63 flakes in one beam is a documented limit
+            assert "flakes intersect one beam" in str(e)
+            pytest.skip("beam with more than 63 flakes in this draw")
+    finally:
+        eng2.ctx.close()
+    s0, a0, src0 = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
+    m = int(counts[0])
+    assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in s0)
+    assert np.array_equal(src[:m], src0)
+    assert np.array_equal(out[:m, 3:], a0[:, 3:])
+    np.testing.assert_allclose(out[:m, :3], a0[:, :3], rtol=1e-6 if dtype == np.float32 else 1e-12, atol=0)
+
+
+def test_error_paths_report_instead_of_computing_garbage(eng, tables):
+    from lidar_snow_sim_amd import _native
+    with pytest.raises(_native.SnowGPUError) as e:                   # a disk over the origin: sqrt(< 0) in geometry.py:161
+        eng.ctx.upload_table(900, np.array([[0.001, 0.001, 0.01]]))
+    assert e.value.code == _native.E_TABLE
+    pc = np.array([[10.0, 1.0, -1.0, 30.0, 3.0]] * 8, np.float32)
+    with pytest.raises(_native.SnowGPUError) as e:                   # table id never uploaded
+        eng.ctx.augment_batch(pc, [0, 8], [[12345] * 64], float(np.degrees(3e-3)), thr_poly=[[0, 0, 0.0]])
+    assert e.value.code == _native.E_INVALID
+    with pytest.raises(_native.SnowGPUError):                        # beam divergence outside (0, 45) degrees
+        eng.ctx.augment_batch(pc, [0, 8], [eng.table_ids_from_arrays(_tables64(tables), list(range(64)))], 60.0,
+                              thr_poly=[[0, 0, 0.0]])
+    with pytest.raises(TypeError):                                   # integer rows
+        eng.ctx.augment_batch(pc.astype(np.int32), [0, 8], [[0] * 64], 0.17, thr_poly=[[0, 0, 0.0]])
