@@ -169,7 +169,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "40 B/point + 24 B per flake per channel per frame (tables counted, 251.3 B/point)"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0, N = 1 only
             from oracle import snow_oracle as so
             random.seed(1000)
             order = list(range(64))
