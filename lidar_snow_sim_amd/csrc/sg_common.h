@@ -47,10 +47,12 @@ struct SgBeamArgs {
     int32_t n_frames;
     int64_t n_total;
     int64_t uniform_rows;        // > 0: every frame has this many rows (frame = position / uniform_rows)
+    float inv_uniform_rows;
     const int32_t *perm;         // channel-sorted position (global) -> frame-local source row
     const SgTable *tables;
     int32_t n_tables;
     const int32_t *table_ids;    // n_frames x n_lasers
+    const SgTable *frame_tables; // n_frames x n_lasers resolved descriptors (entries == nullptr: unknown table id)
     const SgLasers *las;
     const double *rgrid;         // SG_RBINS
     double beam_div_deg;
@@ -81,6 +83,7 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, void *stream);
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,

@@ -64,6 +64,7 @@ struct snowgpu_ctx {
     DevBuf<int32_t> user_perm;
     DevBuf<int32_t> dbg_count;
     DevBuf<unsigned long long> diff2;
+    DevBuf<SgTable> frame_tables;
     SgPrepassScratch prepass{};
     // measurement hooks (snowgpu_profile_begin / _end)
     std::vector<hipEvent_t> ev_start, ev_stop;
@@ -158,7 +159,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
-    ctx->dbg_count.release(); ctx->diff2.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
+    ctx->dbg_count.release(); ctx->diff2.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
     sg_prepass_release(&ctx->prepass);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
@@ -435,10 +436,18 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
     ENSURE(ctx, ctx->ovf_list2, (size_t)ovf_cap);
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
+    const int64_t n_ft = (int64_t)b.n_frames * ctx->h_las.n;
+    ENSURE(ctx, ctx->frame_tables, (size_t)n_ft);
+    {
+        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
+    }
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
-    a.uniform_rows = b.uniform_rows;
+    a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
+    a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
+    a.frame_tables = ctx->frame_tables.p;
     a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.thr_poly = thr; a.tmp_rows = ctx->rows_tmp.p;
     a.keep = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;

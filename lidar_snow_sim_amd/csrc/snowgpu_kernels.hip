@@ -169,7 +169,14 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     bool simulated = false;
     const int n_las = a.las->n;
     if (live) {
-        f = sg_find_frame(a.frame_off, a.n_frames, g);
+        if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
+            const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
+            int fe = (int)((float)gu * a.inv_uniform_rows);
+            if (fe >= a.n_frames) fe = a.n_frames - 1;
+            while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
+            while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
+            f = fe;
+        } else f = sg_find_frame(a.frame_off, a.n_frames, g);
         const int64_t src = a.frame_off[f] + a.perm[g];
         const T *row = (const T *)a.rows + src * 5;
         px = row[0]; py = row[1]; pz = row[2]; pint = row[3]; pch = row[4];
@@ -182,12 +189,11 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.k_min = 0; o.k_max = 0;
     bool write_row = live;
     if (simulated) {
-        const int tid_table = a.table_ids[(int64_t)f * n_las + ch];
-        if (tid_table < 0 || tid_table >= a.n_tables || a.tables[tid_table].entries == nullptr) {
+        const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
+        if (tab.entries == nullptr) {
             atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
             write_row = false;
         } else {
-            const SgTable tab = a.tables[tid_table];
             int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
             double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
             double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
@@ -373,6 +379,27 @@ __global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, con
     const int64_t att = out_stats[f * 3 + 0];
     const double diff_sum = (double)(long long)diff2[f] / 2.0;
     out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // simulation.py:527-530 int()
+}
+
+// table_ids[frame][channel] -> the table descriptor itself, so that a beam needs one load instead of two dependent ones
+__global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_tables, const int32_t *__restrict__ table_ids,
+                                 int64_t n, SgTable *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = table_ids[i];
+    SgTable d{};
+    if (t >= 0 && t < n_tables) d = tables[t];
+    out[i] = d;
+}
+
+extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out,
+                                        void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_resolve_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tables, n_tables,
+                       table_ids, n, out);
+    return (int)hipGetLastError();
 }
 
 extern "C" int sg_set_phase_dbg(unsigned long long *) { return 0; }
