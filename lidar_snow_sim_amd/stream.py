@@ -47,38 +47,61 @@ def output_path(lidar_folder: Path, mode: str, rainfall_rate: float, sample_id: 
 
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
         batch: int = 32, calib=None, device: int = 0, rank: int = 0, world: int = 1, particles_by_prefix=None,
-        planes=None) -> int:
-    """Process this rank's share of `sample_ids`; returns the number of files written."""
+        planes=None, workers: int = 1) -> int:
+    """Process this rank's share of `sample_ids`; returns the number of files written.
+
+    workers > 1: that many host threads, each with its own engine context (stream + scratch) on `device`, take
+    batches in turn -- file reads, H2D/D2H copies and file writes of one batch overlap the kernels of another.
+    The channel permutations are drawn from the global `random` in the main thread, frame by frame in processing
+    order (as the reference's sequential loop would), so the output does not depend on `workers`."""
+    import random
+    from concurrent.futures import ThreadPoolExecutor
     lidar_folder = Path(lidar_folder)
     combos = rate_combos() if combos is None else combos
     ids = list(sample_ids)
     mine = [ids[i] for i in sdist.shard_indices(len(ids), rank, world)]
-    written = 0
+    n_lasers = 64
+
+    def do_chunk(job):
+        slot, mode, rainfall_rate, prefix, chunk, orders = job
+        frames = []
+        for s in chunk:
+            pts = np.fromfile(str(lidar_folder / f'{s}.bin'), dtype=np.float32).reshape(-1, 5)       # :78
+            if calib is not None:                                                                    # :96-99
+                from .calibration import get_fov_flag
+                pts = pts[get_fov_flag(calib.lidar_to_rect(pts[:, 0:3]), (1024, 1920), calib)]
+            frames.append(pts)
+        results = augment_batch(frames, prefix, float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
+                                particles=None if particles_by_prefix is None else particles_by_prefix[prefix],
+                                planes=planes, orders=orders, device=device, slot=slot)
+        for s, (stats, aug) in zip(chunk, results):
+            if calib is not None:                                        # augment()'s only_camera_fov default
+                from .calibration import get_fov_flag
+                aug = aug[get_fov_flag(calib.lidar_to_rect(aug[:, 0:3]), (1024, 1920), calib)]
+            out = output_path(lidar_folder, mode, rainfall_rate, s)
+            out.parent.mkdir(parents=True, exist_ok=True)
+            aug.astype(np.float32).tofile(out)                           # :106
+        return len(chunk)
+
+    jobs = []
     for mode in modes:
         for rainfall_rate, occupancy in combos:
             prefix = f'{mode}_{rainfall_rate}_{occupancy}'                      # precompute.py:101
             todo = [s for s in mine if not output_path(lidar_folder, mode, rainfall_rate, s).is_file()]   # :91-92
             for b0 in range(0, len(todo), batch):
                 chunk = todo[b0:b0 + batch]
-                frames = []
-                for s in chunk:
-                    pts = np.fromfile(str(lidar_folder / f'{s}.bin'), dtype=np.float32).reshape(-1, 5)   # :78
-                    if calib is not None:                                        # :96-99
-                        from .calibration import get_fov_flag
-                        pts = pts[get_fov_flag(calib.lidar_to_rect(pts[:, 0:3]), (1024, 1920), calib)]
-                    frames.append(pts)
-                results = augment_batch(frames, prefix, float(np.degrees(3e-3)), shuffle=True, root_path=particle_root,
-                                        particles=None if particles_by_prefix is None else particles_by_prefix[prefix],
-                                        planes=planes, device=device)
-                for s, (stats, aug) in zip(chunk, results):
-                    if calib is not None:                                        # augment()'s only_camera_fov default
-                        from .calibration import get_fov_flag
-                        aug = aug[get_fov_flag(calib.lidar_to_rect(aug[:, 0:3]), (1024, 1920), calib)]
-                    out = output_path(lidar_folder, mode, rainfall_rate, s)
-                    out.parent.mkdir(parents=True, exist_ok=True)
-                    aug.astype(np.float32).tofile(out)                           # :106
-                    written += 1
-    return written
+                orders = []
+                for _ in chunk:                                          # simulation.py:483-486, one draw per frame
+                    order = list(range(n_lasers))
+                    random.shuffle(order)
+                    orders.append(order)
+                jobs.append((len(jobs) % max(workers, 1), mode, rainfall_rate, prefix, chunk, orders))
+    if workers <= 1:
+        return sum(do_chunk(j) for j in jobs)
+    # one thread per slot so that a context is never used by two threads at once
+    per_slot = [[j for j in jobs if j[0] == w] for w in range(workers)]
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return sum(pool.map(lambda js: sum(do_chunk(j) for j in js), per_slot))
 
 
 def main(argv=None):
@@ -88,6 +111,7 @@ def main(argv=None):
     ap.add_argument('--particles', default=None, help='root_path holding training/snowflakes/npy/<prefix>_<line>.npy')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--calib', default=None, help='KITTI-style calibration file for the camera-FOV crop')
+    ap.add_argument('--workers', type=int, default=2, help='host threads (engine contexts) per GPU')
     args = ap.parse_args(argv)
     rank, local_rank, world = sdist.env_rank_world()
     calib = None
@@ -95,7 +119,7 @@ def main(argv=None):
         from .calibration import Calibration
         calib = Calibration(args.calib)
     n = run(args.lidar, read_split(args.split), particle_root=args.particles, batch=args.batch, calib=calib,
-            device=local_rank, rank=rank, world=world)
+            device=local_rank, rank=rank, world=world, workers=args.workers)
     print(f'rank {rank}/{world}: wrote {n} files')
 
 

@@ -308,6 +308,14 @@ def test_stream_driver_writes_reference_layout(eng, so, tables, tmp_path):
         _, exp, _ = so.augment(frames[s], tl, bd, order, plane=None)
         assert got.shape == exp.shape and np.array_equal(got[:, 3:], exp[:, 3:])
     assert stream.run(lidar, ids, modes=("gunn",), combos=combos, batch=2, particles_by_prefix={prefix: tl}) == 0
+    # two host threads / engine contexts: same files
+    first = {s: np.fromfile(stream.output_path(lidar, "gunn", combos[0][0], s), dtype=np.float32) for s in ids}
+    for s in ids:
+        stream.output_path(lidar, "gunn", combos[0][0], s).unlink()
+    random.seed(5)
+    assert stream.run(lidar, ids, modes=("gunn",), combos=combos, batch=1, particles_by_prefix={prefix: tl}, workers=2) == 3
+    for s in ids:
+        assert np.array_equal(np.fromfile(stream.output_path(lidar, "gunn", combos[0][0], s), dtype=np.float32), first[s])
 
 
 # ---- BASELINE.json configs as parity cases ------------------------------------------------------------------------
