@@ -60,7 +60,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                                         double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
                                         double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
                                         int32_t *dbg_count, double *dbg_rj, double *dbg_ratio,
-                                        unsigned long long *ph = nullptr)
+                                        unsigned long long *ph = nullptr, bool EXACT_TAN = false)
 {
     const unsigned long long ph0 = ph ? wall_clock64() : 0;
     unsigned long long ph_cand = 0;
@@ -105,8 +105,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
 
     // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
     double ar, br, al, bl;
-    if (theta_r == SG_PI / 2 || theta_r == 3 * SG_PI / 2) { ar = 1.0; br = 0.0; } else { ar = -tan(theta_r); br = 1.0; }
-    if (theta_l == SG_PI / 2 || theta_l == 3 * SG_PI / 2) { al = 1.0; bl = 0.0; } else { al = -tan(theta_l); bl = 1.0; }
+    if (theta_r == SG_PI / 2 || theta_r == 3 * SG_PI / 2) { ar = 1.0; br = 0.0; } else { ar = -(EXACT_TAN ? tan(theta_r) : sg_tan_0_2pi(theta_r)); br = 1.0; }
+    if (theta_l == SG_PI / 2 || theta_l == 3 * SG_PI / 2) { al = 1.0; bl = 0.0; } else { al = -(EXACT_TAN ? tan(theta_l) : sg_tan_0_2pi(theta_l)); bl = 1.0; }
     const double den_r = sqrt(ar * ar + br * br);               // geometry.py:133
     const double den_l = sqrt(al * al + bl * bl);
     const bool wrap = theta_r > theta_l;                        // simulation.py:361
@@ -330,22 +330,28 @@ template <int CTRL> __device__ __forceinline__ int sg_dpp(int v)
 {
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
 }
-template <int CTRL> __device__ __forceinline__ void sg_argmax_step_dpp(double &bv, int &bk)
+template <int CTRL> __device__ __forceinline__ double sg_dpp_f64(double v)
 {
-    const double ov = __hiloint2double(sg_dpp<CTRL>(__double2hiint(bv)), sg_dpp<CTRL>(__double2loint(bv)));
-    const int ok = sg_dpp<CTRL>(bk);
-    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+    return __hiloint2double(sg_dpp<CTRL>(__double2hiint(v)), sg_dpp<CTRL>(__double2loint(v)));
 }
-// max value, smallest bin on ties, over the 32 lanes of a half-wave; every lane ends with the result
+// max value, smallest bin on ties, over the 32 lanes of a half-wave; every lane ends with the result.
+// Two plain reductions (max of the values, then min of the bins that hold it) are cheaper than carrying the pair.
 __device__ __forceinline__ void sg_argmax_half(double &bv, int &bk)
 {
-    sg_argmax_step_dpp<0xB1>(bv, bk);     // quad_perm [1,0,3,2]: lane ^ 1
-    sg_argmax_step_dpp<0x4E>(bv, bk);     // quad_perm [2,3,0,1]: lane ^ 2
-    sg_argmax_step_dpp<0x124>(bv, bk);    // row_ror:4 within the 16-lane row
-    sg_argmax_step_dpp<0x128>(bv, bk);    // row_ror:8
-    const double ov = __shfl_xor(bv, 16);  // the other 16-lane row of this half
-    const int ok = __shfl_xor(bk, 16);
-    if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+    double m = bv;
+    m = fmax(m, sg_dpp_f64<0xB1>(m));     // quad_perm [1,0,3,2]: lane ^ 1
+    m = fmax(m, sg_dpp_f64<0x4E>(m));     // quad_perm [2,3,0,1]: lane ^ 2
+    m = fmax(m, sg_dpp_f64<0x124>(m));    // row_ror:4 within the 16-lane row
+    m = fmax(m, sg_dpp_f64<0x128>(m));    // row_ror:8
+    m = fmax(m, __shfl_xor(m, 16));       // the other 16-lane row of this half
+    int k = (bv == m) ? bk : 0x7fffffff;
+    k = min(k, sg_dpp<0xB1>(k));
+    k = min(k, sg_dpp<0x4E>(k));
+    k = min(k, sg_dpp<0x124>(k));
+    k = min(k, sg_dpp<0x128>(k));
+    k = min(k, __shfl_xor(k, 16));
+    bv = m;
+    bk = k;
 }
 
 // R[k] of simulation.py:116 without a table: n = rint(k * step * 100) is the grid value in centimetres and

@@ -159,3 +159,46 @@ __device__ __forceinline__ double sg_xsi(float R)
     y = y + (float)b;
     return (double)y;
 }
+
+// ---------------------------------------------------------------------------------------------
+// tan(theta) for theta in [0, 2 pi] (beam-limit slopes, geometry.py:94): quadrant reduction against pi/2 in
+// three parts, sine and cosine polynomials on [-pi/4, pi/4] (fdlibm's kernel coefficients), one division.
+// About 40 float64 instructions instead of the device math library's general-range tan, within 2 ULP of it;
+// the slope only enters the point-line distance test (geometry.py:131-135), where a last-bit difference moves the
+// distance by 1e-16 relative -- the same order as glibc's tan vs any other libm.
+__device__ __forceinline__ double sg_tan_0_2pi(double theta)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;   // fdlibm split of pi/2
+    const double PIO2_2 = 6.07710050630396597660e-11, PIO2_2T = 2.02226624879595063154e-21;
+    const double fn = rint(theta * TWO_OVER_PI);                 // 0 .. 4
+    const int n = (int)fn;
+    double r = theta - fn * PIO2_1;
+    double w = fn * PIO2_1T;
+    double x = r - w;
+    // second step keeps ~118 bits of pi/2: enough for every theta this close to a multiple of pi/2
+    {
+        const double t = r;
+        w = fn * PIO2_2;
+        r = t - w;
+        w = fn * PIO2_2T - ((t - r) - w);
+        x = r - w;
+    }
+    const double tail = (r - x) - w;
+    const double z = x * x;
+    // __kernel_sin
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double v = z * x;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    const double sn = x - ((z * (0.5 * tail - v * rs) - tail) - v * S1);
+    // __kernel_cos
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z;
+    const double ww = 1.0 - hz;
+    const double cs = ww + (((1.0 - ww) - hz) + (z * rc - x * tail));
+    // tan(x + n pi/2) = sin/cos for even n, -cos/sin for odd n
+    return (n & 1) ? -(cs / sn) : (sn / cs);
+}

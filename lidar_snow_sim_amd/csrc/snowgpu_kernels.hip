@@ -198,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
             double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
             sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
-                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph);
+                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph, a.exact_math != 0);
             if (o.overflow) {
                 write_row = false;                        // a later pass with a longer list writes this row
                 o.has_power = 0;
