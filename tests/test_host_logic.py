@@ -251,3 +251,42 @@ def test_stream_driver_bookkeeping(tmp_path):
     assert len(combos) == 5 and int(combos[3][0]) == 34                          # 2.5 mm/h @ 1.6 m/s -> rainrate_34
     p = stream.output_path(tmp_path / "lidar_hdl64_strongest", "gunn", combos[3][0], ids[0])
     assert p == tmp_path / "snowfall_simulation" / "gunn" / "lidar_hdl64_strongest_rainrate_34" / f"{ids[0]}.bin"
+
+
+def test_own_tangent_is_within_two_ulp_of_libm():
+    """sg_tan_0_2pi (csrc/sg_math.h) restated with NumPy float64 operations (no fused multiply-adds, as the kernels
+    are built with -ffp-contract=off): <= 2 ULP from libm's tan on [0, 2 pi], including next to pi/2 and 3 pi/2."""
+    import math
+
+    def sg_tan(theta):
+        two_over_pi = 6.36619772367581382433e-01
+        p1, p2, p2t = 1.57079632673412561417e+00, 6.07710050630396597660e-11, 2.02226624879595063154e-21
+        fn = np.rint(theta * two_over_pi)
+        n = fn.astype(int)
+        r = theta - fn * p1
+        t = r
+        w = fn * p2
+        r = t - w
+        w = fn * p2t - ((t - r) - w)
+        x = r - w
+        tail = (r - x) - w
+        z = x * x
+        s1, s2, s3, s4, s5, s6 = (-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                                  2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10)
+        v = z * x
+        rs = s2 + z * (s3 + z * (s4 + z * (s5 + z * s6)))
+        sn = x - ((z * (0.5 * tail - v * rs) - tail) - v * s1)
+        c1, c2, c3, c4, c5, c6 = (4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                                  -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11)
+        rc = z * (c1 + z * (c2 + z * (c3 + z * (c4 + z * (c5 + z * c6)))))
+        hz = 0.5 * z
+        ww = 1.0 - hz
+        cs = ww + (((1.0 - ww) - hz) + (z * rc - x * tail))
+        return np.where(n & 1, -(cs / sn), sn / cs)
+    rng = np.random.default_rng(0)
+    th = np.concatenate((rng.uniform(0, 2 * np.pi, 100000), np.pi / 2 + rng.uniform(-1e-3, 1e-3, 5000),
+                         3 * np.pi / 2 + rng.uniform(-1e-6, 1e-6, 5000), rng.uniform(0, 1e-3, 5000),
+                         2 * np.pi - rng.uniform(0, 1e-3, 5000)))
+    ref = np.array([math.tan(t) for t in th])
+    ulp = np.abs(sg_tan(th) - ref) / np.spacing(np.abs(ref))
+    assert ulp.max() <= 2.0
