@@ -31,11 +31,31 @@ BEAM_DIV = float(np.degrees(3e-3))
 SNOWFALL, VELOCITY = 2.5, 1.6
 
 
-def make_tables(n_lines=64):
+WORKLOADS = {   # name: (layers, azimuths, snowfall mm/h, terminal velocity m/s, range scale)  -- SURVEY 8 d
+    "C2": (64, 2048, 2.5, 1.6, 1.0),       # BASELINE.json configs[1]: the headline workload
+    "C2far": (64, 2048, 2.5, 1.6, 1.8),    # same sweep with every range stretched (clipped at 119 m): long scatterer lists
+    "C1": (64, 2048, 0.5, 2.0, 1.0),       # configs[0]'s table density (40 k flakes per line)
+    "C4": (128, 4096, 10.0, 1.6, 1.0),     # configs[3]: 128 x 4096 dense sweep, heavy snowfall, tiled laser table
+}
+
+
+def make_tables(n_lines=64, snowfall=SNOWFALL, velocity=VELOCITY, distinct=None):
     from lidar_snow_sim_amd.tools.snowfall import sampling as smp
-    occ = smp.compute_occupancy(SNOWFALL, VELOCITY)
-    rate = smp.snowfall_rate_to_rainfall_rate(SNOWFALL, VELOCITY)
-    return [smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(42 + line), "gunn") for line in range(1, n_lines + 1)]
+    occ = smp.compute_occupancy(snowfall, velocity)
+    rate = smp.snowfall_rate_to_rainfall_rate(snowfall, velocity)
+    distinct = n_lines if distinct is None else distinct
+    tabs = [smp.dart_throwing(occ, rate, 80.0, np.random.default_rng(42 + line), "gunn") for line in range(1, distinct + 1)]
+    return [tabs[i % distinct] for i in range(n_lines)]
+
+
+def make_frame(layers, azimuths, seed, scale):
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    pc = synthetic_sweep(layers, azimuths, seed=seed, intensity="lambert")
+    if scale != 1.0:
+        r = np.linalg.norm(pc[:, :3].astype(np.float64), axis=1)
+        f = np.minimum(r * scale, 119.0) / r
+        pc[:, :3] = (pc[:, :3] * f[:, None]).astype(np.float32)
+    return pc
 
 
 def main():
@@ -46,6 +66,7 @@ def main():
     ap.add_argument("--frames", type=int, default=128, help="frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 (default) is BASELINE.json's metric config")
     args = ap.parse_args()
 
     import torch
@@ -65,8 +86,11 @@ def main():
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     from lidar_snow_sim_amd.tools.wet_ground.augmentation import noise_threshold_poly
 
+    layers, azimuths, snowfall, velocity, rscale = WORKLOADS[args.workload]
     eng = engine.get_engine(local_rank)
-    tables = make_tables(64)
+    if layers != 64:                                       # SURVEY 8 d: 128-entry laser table = the 64-entry one tiled
+        eng.set_lasers(engine.load_lasers() * (layers // 64))
+    tables = make_tables(layers, snowfall, velocity, distinct=min(layers, 64))
     ktot = sum(t.shape[0] for t in tables)
     F = args.frames
     import random
@@ -74,9 +98,9 @@ def main():
     plane = ([0.0, 0.0, -1.0], -1.7)
     for f in range(F):
         seed = 1000 + rank * F + f
-        pc = synthetic_sweep(64, 2048, seed=seed, intensity="lambert")
+        pc = make_frame(layers, azimuths, seed, rscale)
         random.seed(seed)
-        order = list(range(64))
+        order = list(range(layers))
         random.shuffle(order)
         frames.append(pc)
         table_ids.append(eng.table_ids_from_arrays(tables, order))
@@ -155,9 +179,10 @@ def main():
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: synthetic 64-layer x 2048-azimuth sweeps, snowfall_rate=2.5 mm/h, "
-                                   "terminal_velocity=1.6 m/s, gunn tables R0=80 m (18k flakes/line), "
-                                   "beam_divergence=3 mrad, noise_floor=0.7, float32 rows resident in HBM",
+            "config": {"workload": f"{args.workload}: synthetic {layers}-layer x {azimuths}-azimuth sweeps, snowfall_rate={snowfall} mm/h, "
+                                   f"terminal_velocity={velocity} m/s, gunn tables R0=80 m ({ktot // layers} flakes/line), "
+                                   f"beam_divergence=3 mrad, noise_floor=0.7, float32 rows resident in HBM"
+                                   + ("" if rscale == 1.0 else f", ranges x{rscale} (clipped at 119 m)"),
                        "frames_per_step_per_gpu": F, "points_per_frame": n_per,
                        "prepass": "host (outside the timed region)" if args.host_prepass else "device (timed)",
                        "sharding": f"frame-parallel x{world}, no collective",
@@ -175,11 +200,12 @@ def main():
             same, cpu_s = True, 0.0
             for fi in range(n_cpu):
                 random.seed(1000 + fi)
-                order = list(range(64))
+                order = list(range(layers))
                 random.shuffle(order)
                 poly = noise_threshold_poly(frames[fi], plane[0], plane[1], 0.7)
                 c0 = time.perf_counter()
-                s_ref, a_ref, src_ref = so.augment(frames[fi], tables, BEAM_DIV, order, plane=plane, thr_poly=poly)
+                s_ref, a_ref, src_ref = so.augment(frames[fi], tables, BEAM_DIV, order, plane=plane, thr_poly=poly,
+                                                   lasers=so.load_lasers() * (layers // 64))
                 cpu_s += time.perf_counter() - c0
                 n0 = int(out_counts[fi].item())
                 lo = fi * n_per

@@ -111,7 +111,8 @@ def _laser_struct(lasers, channel):
     las = _Laser()
     las.channel = channel
     las.min_intensity = int(info.get("min_intensity", 0))     # sim:72
-    las.max_intensity = 230 if channel in (53, 55, 56, 58) else 255   # sim:123-126
+    las.max_intensity = 230 if (channel % 64) in (53, 55, 56, 58) else 255   # sim:123-126 (laser tables beyond 64
+    #                                 entries are the 64-entry one tiled, SURVEY 8 d: the rule tiles with them)
     las.focal_slope = float(info["focal_slope"])              # sim:75
     las.focal_offset = (1 - focal_distance / 13100) ** 2      # sim:76
     return las
