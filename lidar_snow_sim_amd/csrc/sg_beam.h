@@ -311,49 +311,6 @@ __device__ __forceinline__ double sg_power_term(double amp, double Rk, double r)
     return amp * (sn * sn);
 }
 
-// ---- phase 3b (cooperative): received power on the 10 cm grid and its first maximum (simulation.py:135-151) --
-// Each half-wave (32 lanes) takes the beams of its own 32 lanes one at a time and spreads the range bins of
-// that beam over its lanes -- a scatterer's window is 31 bins, so one chunk holds it.  For every bin the
-// contributions are added in dict order (flakes near -> far, hard target last), exactly the order in which the
-// reference's `i[k] += ...` loop visits them; bins nobody touches stay 0.  The list of the beam being worked on
-// is read from the owning lane's LDS column (same address across the half-wave: a broadcast); the beam's
-// scalars come over v_readlane, the half-wave argmax over DPP row operations -- no LDS round trips for either.
-
-// value of `v` in lane (half * 32 + i), i wave-uniform
-__device__ __forceinline__ int sg_bcast_half(int v, int i, bool upper)
-{
-    const int lo = __builtin_amdgcn_readlane(v, i), hi = __builtin_amdgcn_readlane(v, 32 + i);
-    return upper ? hi : lo;
-}
-
-template <int CTRL> __device__ __forceinline__ int sg_dpp(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL> __device__ __forceinline__ double sg_dpp_f64(double v)
-{
-    return __hiloint2double(sg_dpp<CTRL>(__double2hiint(v)), sg_dpp<CTRL>(__double2loint(v)));
-}
-// max value, smallest bin on ties, over the 32 lanes of a half-wave; every lane ends with the result.
-// Two plain reductions (max of the values, then min of the bins that hold it) are cheaper than carrying the pair.
-__device__ __forceinline__ void sg_argmax_half(double &bv, int &bk)
-{
-    double m = bv;
-    m = fmax(m, sg_dpp_f64<0xB1>(m));     // quad_perm [1,0,3,2]: lane ^ 1
-    m = fmax(m, sg_dpp_f64<0x4E>(m));     // quad_perm [2,3,0,1]: lane ^ 2
-    m = fmax(m, sg_dpp_f64<0x124>(m));    // row_ror:4 within the 16-lane row
-    m = fmax(m, sg_dpp_f64<0x128>(m));    // row_ror:8
-    m = fmax(m, __shfl_xor(m, 16));       // the other 16-lane row of this half
-    int k = (bv == m) ? bk : 0x7fffffff;
-    k = min(k, sg_dpp<0xB1>(k));
-    k = min(k, sg_dpp<0x4E>(k));
-    k = min(k, sg_dpp<0x124>(k));
-    k = min(k, sg_dpp<0x128>(k));
-    k = min(k, __shfl_xor(k, 16));
-    bv = m;
-    bk = k;
-}
-
 // R[k] of simulation.py:116 without a table: n = rint(k * step * 100) is the grid value in centimetres and
 // n / 100 is recovered with one Newton step on n * 0.01 -- bit-identical to np.round(np.linspace(...), 2) for
 // all 1230 bins (checked exhaustively on the host, tests/test_host_logic.py).
@@ -365,80 +322,50 @@ __device__ __forceinline__ double sg_range_bin(int k)
     return __builtin_fma(__builtin_fma(-q, 100.0, n), 0.01, q);
 }
 
-template <int STRIDE, bool EXACT>
-__device__ __forceinline__ void sg_wave_power(int has_power, int S, int k_min, int k_max, const double *__restrict__ rgrid,
-                                              const double *s_a1, const double *s_a2, const double *s_rho, int tid,
-                                              double &best, int &k_best)
+// ---- phase 3b (per lane): received power on the 10 cm grid and its first maximum (simulation.py:135-151) -----
+// Each lane walks the bins of its own beam.  Same sums in the same order as the reference's `i[k] += ...` loop:
+// flakes covering bin k in range order, then the hard target.
+//   * NB consecutive bins are carried together -- NB independent sine chains per scatterer;
+//   * EXACT PRUNING.  Every term is A_t * sin^2(.) <= A_t, so a bin's sum is bounded by U = sum of the amplitudes
+//     of the scatterers whose windows reach it.  The window of the largest amplitude is evaluated first (its peak
+//     sample is >= 0.997 A); after that a group of bins with U (1 + 1e-9) < best cannot hold the maximum, nor tie
+//     with it, and is skipped without evaluating a single sine.  np.argmax's "first maximum" (:151) is kept by
+//     preferring the smaller bin on equal sums, whatever the evaluation order.  On typical beams one or two of
+//     the S + 1 windows survive.
+
+// full sums of bins k .. k+NB-1 (flakes from index t_from on, then the hard target) folded into (best, k_best)
+template <int STRIDE, bool EXACT, int NB>
+__device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const double *__restrict__ rgrid, const double *s_a1,
+                                              const double *s_a2, const double *s_rho, int tid, int tk0, int tk1, double tamp,
+                                              double td, double &best, int &k_best)
 {
-    const int lane = tid & 63, sub = lane & 31;
-    const bool upper = lane >= 32;
-    const int wave_col = tid - lane;
-    best = 0.0;
-    k_best = 0;
-    const unsigned long long todo = __ballot(has_power != 0);
-    const unsigned todo_any = (unsigned)(todo | (todo >> 32));       // lanes i with work in either half
-    for (int i = 0; i < 32; ++i) {
-        if (!((todo_any >> i) & 1u)) continue;                       // wave-uniform
-        if (!sg_bcast_half(has_power, i, upper)) continue;           // half-uniform
-        const int bS = sg_bcast_half(S, i, upper), bkmin = sg_bcast_half(k_min, i, upper),
-                  bkmax = sg_bcast_half(k_max, i, upper);
-        const int col = wave_col + (lane & 32) + i;
-        // the hard target and the nearest flake: six independent LDS reads, one round trip
-        const double tpk = s_a2[bS * STRIDE + col];
-        const double tamp = s_a1[bS * STRIDE + col], td = s_rho[bS * STRIDE + col];
-        const double fpk = s_a2[col];
-        double c_amp = s_a1[col], c_r = s_rho[col];
-        const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
-        int c_k0 = 0x7fffffff, c_k1 = 0x7fffffff;          // window of the nearest flake not yet passed (entry t_lo)
-        if (bS > 0) { c_k0 = __double2loint(fpk); c_k1 = __double2hiint(fpk); }
-        double lbest = 0.0;
-        int lk = 0;
-        int t_lo = 0, c = bkmin;
-        while (c < bkmax) {
-            while (t_lo < bS && c_k1 <= c) {                 // half-wave uniform
-                ++t_lo;
-                if (t_lo < bS) {
-                    const double pk = s_a2[t_lo * STRIDE + col];
-                    c_amp = s_a1[t_lo * STRIDE + col]; c_r = s_rho[t_lo * STRIDE + col];
-                    c_k0 = __double2loint(pk); c_k1 = __double2hiint(pk);
-                } else { c_k0 = 0x7fffffff; c_k1 = 0x7fffffff; }
-            }
-            const bool tgt_hit = (tk0 < c + 32) && (tk1 > c);
-            if (c_k0 >= c + 32 && !tgt_hit) {                // nothing here: jump to the next window start
-                int nc = c_k0;
-                if (tk0 > c && tk0 < nc) nc = tk0;
-                if (nc == 0x7fffffff) break;
-                c = nc;
-                continue;
-            }
-            const int k = c + sub;
-            const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
-            double sum = 0.0;                                // :135 np.zeros
-            if (c_k0 < c + 32) {
-                if (k >= c_k0 && k < c_k1) sum += sg_power_term<EXACT>(c_amp, Rk, c_r);             // :149
-                for (int t = t_lo + 1; t < bS; ++t) {        // further flakes whose windows reach into this chunk
-                    const double pk = s_a2[t * STRIDE + col];
-                    const int k0 = __double2loint(pk);
-                    if (k0 >= c + 32) break;                 // flake windows start in range order
-                    if (k >= k0 && k < __double2hiint(pk))
-                        sum += sg_power_term<EXACT>(s_a1[t * STRIDE + col], Rk, s_rho[t * STRIDE + col]);
-                }
-            }
-            if (tgt_hit && k >= tk0 && k < tk1) sum += sg_power_term<EXACT>(tamp, Rk, td);
-            if (sum > lbest) { lbest = sum; lk = k; }        // ascending k per lane: keeps the first maximum
-            c += 32;
-        }
-        sg_argmax_half(lbest, lk);                           // ties -> smaller bin: np.argmax's first maximum (:151)
-        if (sub == i) { best = lbest; k_best = lk; }
+    double R[NB], sm[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int kk = k + i;
+        R[i] = EXACT ? rgrid[kk < SG_RBINS ? kk : SG_RBINS - 1] : sg_range_bin(kk);
+        sm[i] = 0.0;                                         // :135 np.zeros
     }
+    for (int t = t_from; t < S; ++t) {
+        const double pk = s_a2[t * STRIDE + tid];
+        const int q0 = __double2loint(pk), q1 = __double2hiint(pk);
+        if (q0 >= k + NB) break;                             // flake windows start in range order
+        if (q1 <= k) continue;
+        const double amp = s_a1[t * STRIDE + tid], r = s_rho[t * STRIDE + tid];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (k + i >= q0 && k + i < q1) sm[i] += sg_power_term<EXACT>(amp, R[i], r);   // :149
+    }
+    if (tk0 < k + NB && tk1 > k) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (k + i >= tk0 && k + i < tk1) sm[i] += sg_power_term<EXACT>(tamp, R[i], td);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+        if (sm[i] > best || (sm[i] == best && k + i < k_best)) { best = sm[i]; k_best = k + i; }   // first maximum (:151)
 }
 
-// ---- phase 3b, per-lane form (later capacity tiers) ---------------------------------------------------------
-// When every lane of a wave carries a long list the cooperative form serialises 32 beams per half-wave and the
-// wave's latency explodes while most of the chip idles; here each lane walks its own bins.  Same sums in the
-// same order: flakes covering bin k in range order, then the hard target.  These tiers run at one or two waves
-// per SIMD, where a float64 dependency chain (the sine polynomial) costs its full latency per step; NB
-// consecutive bins are therefore carried together -- NB independent chains per scatterer.
 template <int STRIDE, bool EXACT, int NB = 8>
 __device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const double *__restrict__ rgrid,
                                               const double *s_a1, const double *s_a2, const double *s_rho, int tid,
@@ -450,59 +377,45 @@ __device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const
     const double tpk = s_a2[S * STRIDE + tid];
     const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
     const double tamp = s_a1[S * STRIDE + tid], td = s_rho[S * STRIDE + tid];
-    int t_lo = 0, lo_k0 = INF, lo_k1 = INF;       // nearest flake whose window has not been passed yet
-    double lo_amp = 0.0, lo_r = 0.0;
-    if (S > 0) {
-        const double pk = s_a2[tid];
-        lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); lo_amp = s_a1[tid]; lo_r = s_rho[tid];
+    // ---- pass 1: the window of the strongest scatterer ----
+    int p0 = tk0, p1 = tk1;
+    {
+        double amax = tamp;
+        for (int t = 0; t < S; ++t) {
+            const double a = s_a1[t * STRIDE + tid];
+            if (a > amax) { amax = a; const double pk = s_a2[t * STRIDE + tid]; p0 = __double2loint(pk); p1 = __double2hiint(pk); }
+        }
     }
+    int p_end = p0;
+    for (; p_end < p1; p_end += NB)
+        sg_eval_group<STRIDE, EXACT, NB>(p_end, 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td, best, k_best);
+    // ---- pass 2: every other bin, ascending, pruned by the amplitude bound ----
+    int t_lo = 0, lo_k0 = INF, lo_k1 = INF;       // nearest flake whose window has not been passed yet
+    if (S > 0) { const double pk = s_a2[tid]; lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); }
     int k = k_min;
     while (k < k_max) {
         while (t_lo < S && k >= lo_k1) {                     // pass windows that end at or before k
             ++t_lo;
-            if (t_lo < S) {
-                const double pk = s_a2[t_lo * STRIDE + tid];
-                lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk);
-                lo_amp = s_a1[t_lo * STRIDE + tid]; lo_r = s_rho[t_lo * STRIDE + tid];
-            } else { lo_k0 = INF; lo_k1 = INF; }
+            if (t_lo < S) { const double pk = s_a2[t_lo * STRIDE + tid]; lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); }
+            else { lo_k0 = INF; lo_k1 = INF; }
         }
         const bool tgt_hit = (tk0 < k + NB) && (tk1 > k);
-        if (lo_k0 >= k + NB && !tgt_hit) {                    // gap: jump to the next window start
+        if (lo_k0 >= k + NB && !tgt_hit) {                   // gap: jump to the next window start
             int nk = lo_k0;
             if (k < tk0 && tk0 < nk) nk = tk0;
             if (nk == INF) break;
             k = nk;
             continue;
         }
-        double R[NB], sm[NB];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int kk = k + i;
-            R[i] = EXACT ? rgrid[kk < SG_RBINS ? kk : SG_RBINS - 1] : sg_range_bin(kk);
-            sm[i] = 0.0;                                     // :135 np.zeros
+        if (k >= p0 && k + NB <= p_end) { k += NB; continue; }      // these bins were summed in pass 1
+        double U = tgt_hit ? tamp : 0.0;                     // amplitude bound of this group
+        for (int t = t_lo; t < S; ++t) {
+            const double pk = s_a2[t * STRIDE + tid];
+            if (__double2loint(pk) >= k + NB) break;
+            if (__double2hiint(pk) > k) U += s_a1[t * STRIDE + tid];
         }
-        if (lo_k0 < k + NB) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                if (k + i >= lo_k0 && k + i < lo_k1) sm[i] += sg_power_term<EXACT>(lo_amp, R[i], lo_r);   // :149
-            for (int t = t_lo + 1; t < S; ++t) {
-                const double pk = s_a2[t * STRIDE + tid];
-                const int q0 = __double2loint(pk), q1 = __double2hiint(pk);
-                if (q0 >= k + NB) break;                      // flake windows start in range order
-                const double amp = s_a1[t * STRIDE + tid], r = s_rho[t * STRIDE + tid];
-#pragma unroll
-                for (int i = 0; i < NB; ++i)
-                    if (k + i >= q0 && k + i < q1) sm[i] += sg_power_term<EXACT>(amp, R[i], r);
-            }
-        }
-        if (tgt_hit) {
-#pragma unroll
-            for (int i = 0; i < NB; ++i)
-                if (k + i >= tk0 && k + i < tk1) sm[i] += sg_power_term<EXACT>(tamp, R[i], td);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            if (sm[i] > best) { best = sm[i]; k_best = k + i; }   // ascending k: first maximum (:151)
+        if (!(U * (1.0 + 1e-9) < best))
+            sg_eval_group<STRIDE, EXACT, NB>(k, t_lo, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td, best, k_best);
         k += NB;
     }
 }

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     }
     unsigned long long *ph = a.phase_cycles ? a.phase_cycles + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3) : nullptr;
     const unsigned long long tcs = ph ? wall_clock64() : 0;
-    // No early return from here on: the received-power phase is cooperative across the wave.
+    // No early return from here on: wave-wide ballots / shuffles follow (overflow queue, per-frame sums).
     const bool live = g >= 0;
     int f = 0;
     T px = 0, py = 0, pz = 0, pint = 0, pch = 0;
@@ -232,14 +232,12 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const unsigned long long tc1 = ph ? wall_clock64() : 0;
     double best;
     int k_best;
-    if constexpr (LMAX <= 4) {       // sparse first tier: bins of one beam spread over a half-wave
-        if (a.exact_math) sg_wave_power<BLOCK, true>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
-        else sg_wave_power<BLOCK, false>(o.has_power, o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
-    } else {                         // dense later tiers: every lane walks its own bins
+    {
         best = 0.0; k_best = 0;
         if (o.has_power) {
-            if (a.exact_math) sg_lane_power<BLOCK, true>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
-            else sg_lane_power<BLOCK, false>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+            constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together (register budget of the first tier: 128)
+            if (a.exact_math) sg_lane_power<BLOCK, true, NB>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
+            else sg_lane_power<BLOCK, false, NB>(o.n_flakes, o.k_min, o.k_max, s_rgrid, s_a1, s_a2, s_rho, tid, best, k_best);
         }
     }
     if (ph && (tid & 63) == 0) {
