@@ -409,13 +409,22 @@ __device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const
         }
         if (k >= p0 && k + NB <= p_end) { k += NB; continue; }      // these bins were summed in pass 1
         double U = tgt_hit ? tamp : 0.0;                     // amplitude bound of this group
+        int next_start = (tk0 >= k + NB) ? tk0 : INF;        // first window that starts beyond this group
         for (int t = t_lo; t < S; ++t) {
             const double pk = s_a2[t * STRIDE + tid];
-            if (__double2loint(pk) >= k + NB) break;
+            const int q0 = __double2loint(pk);
+            if (q0 >= k + NB) { if (q0 < next_start) next_start = q0; break; }
             if (__double2hiint(pk) > k) U += s_a1[t * STRIDE + tid];
         }
-        if (!(U * (1.0 + 1e-9) < best))
+        if (!(U * (1.0 + 1e-9) < best)) {
             sg_eval_group<STRIDE, EXACT, NB>(k, t_lo, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td, best, k_best);
+        } else {
+            // Until another window starts the set of scatterers reaching a group can only shrink, so every group up
+            // to there is bounded by the same U: skip them all at once.
+            if (next_start == INF) break;
+            const int nk = next_start - NB + 1;              // first group that touches the new window
+            if (nk > k + NB) { k = nk; continue; }
+        }
         k += NB;
     }
 }
