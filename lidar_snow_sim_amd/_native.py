@@ -6,12 +6,13 @@ The library is hand-written HIP for gfx950; it is built in-tree by ``python -m l
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from pathlib import Path
 
 import numpy as np
 
-_LIB_PATH = Path(__file__).resolve().parent / "libsnowgpu.so"
+_LIB_PATH = Path(os.environ.get("SNOWGPU_LIB") or Path(__file__).resolve().parent / "libsnowgpu.so")   # override: timing experiments
 _lib = None
 _lock = threading.Lock()
 

@@ -18,6 +18,9 @@
 //     reference computes in the input dtype (range, beam azimuth, hard-target window) are float32.
 #pragma once
 #include "sg_math.h"
+#ifndef SG_ABLATE
+#define SG_ABLATE 0   /* > 0 only in timing experiments: phases are cut out and results are wrong */
+#endif
 
 template <typename T> struct SgReal;
 template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
@@ -97,6 +100,9 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
     int span = b_hi - b_lo;
     if (span < 0) span += nb;
+#if SG_ABLATE >= 3
+    span = -1;
+#endif
     const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
     const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
     const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
@@ -112,7 +118,37 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const bool wrap = theta_r > theta_l;                        // simulation.py:361
 
     // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
+    // The exact predicates of get_occlusions (simulation.py:359-389) cost two float64 divisions per flake and a
+    // wave pays for them as long as any of its lanes has a candidate.  So the scan is split (PREFILTER): a cheap
+    // pass keeps the records that can possibly satisfy the predicates, the exact pass then runs on those only.
+    //   necessary condition: the predicates hold only if the flake's angular interval phi +- asin(r / rho) meets the
+    //   wedge, i.e. |phi - theta_c| <= half + asin(r / rho); asin(q) <= q pi / 2 on [0, 1] turns that into a product
+    //   test without a division, and 1e-7 rad of slack dwarfs every rounding error of the exact test.
+    constexpr bool PREFILTER = LMAX < SG_LCAP;                  // the last tier must not overflow on the superset
+    auto exact_test = [&](const SgEntry &f, int &L_) -> bool {  // returns false on list overflow
+        const double rho = f.rho, phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
+        const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
+                         || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
+                         || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
+        const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
+        const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
+        const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
+        const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
+        if (!(centre || hit_r || hit_l)) return true;           // :389
+        if (L_ == LMAX) return false;
+        const double na1 = hit_r ? theta_r : f.t0;              // geometry.py:26
+        const double na2 = hit_l ? theta_l : f.t1;              // geometry.py:27
+        int p = L_;                                             // insertion sort by rho (:413-417)
+        while (p > 0 && SG_RHO(p - 1) > rho) {
+            SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
+            --p;
+        }
+        SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
+        ++L_;
+        return true;
+    };
     int L = 0;
+    int C = 0;                                                  // PREFILTER: survivors, record indices in s_ratio
     {
         int b = b_lo;
         for (int s = 0; s <= span && !out.overflow; ++s) {
@@ -122,39 +158,56 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             else { e0 = tab.bin_start[b]; e1 = tab.bin_start[b + 1]; }
             // software pipeline: the next record is requested before the current one is examined (the entry
             // array carries one spare record at its end, so e + 1 is always readable)
-            SgEntry nxt = tab.entries[e0];
-            if (s == 1) nxt.rho = first_rho1;
-            for (uint32_t e = e0; e < e1; ++e) {
-                const SgEntry f = nxt;
-                nxt = tab.entries[e + 1];
-                ++ph_cand;
-                const double rho = f.rho;
-                if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
-                if (s > 0 && !(f.flags & 1u)) continue;         // already met in an earlier bin
-                const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
-                const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
-                                 || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
-                                 || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
-                const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
-                const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
-                const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
-                const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
-                if (!(centre || hit_r || hit_l)) continue;      // :389
-                if (L == LMAX) { out.overflow = 1; break; }
-                const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26
-                const double na2 = hit_l ? theta_l : f.t1;      // geometry.py:27
-                int p = L;                                      // insertion sort by rho (:413-417)
-                while (p > 0 && SG_RHO(p - 1) > rho) {
-                    SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
-                    --p;
+            if constexpr (PREFILTER) {
+                double n_rho = (s == 1) ? first_rho1 : tab.entries[e0].rho;
+                double n_phi = tab.entries[e0].phi, n_r = tab.entries[e0].r;
+                uint32_t n_flags = tab.entries[e0].flags;
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const double rho = n_rho, phi = n_phi, fr = n_r;
+                    const uint32_t flags = n_flags;
+                    n_rho = tab.entries[e + 1].rho; n_phi = tab.entries[e + 1].phi; n_r = tab.entries[e + 1].r;
+                    n_flags = tab.entries[e + 1].flags;
+                    ++ph_cand;
+                    if (!(rho < d)) break;                      // :345 (bins are sorted by rho)
+                    if (s > 0 && !(flags & 1u)) continue;       // already met in an earlier bin
+                    double dphi = phi - theta_c;
+                    dphi = dphi - SG_TWO_PI * rint(dphi * (1.0 / SG_TWO_PI));
+                    if ((fabs(dphi) - half - 1e-7) * rho > 1.5707963267948968 * fr) continue;
+                    if (C == LMAX) { out.overflow = 1; break; }
+                    SG_RATIO(C) = __hiloint2double(0, (int)e);
+                    ++C;
                 }
-                SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
-                ++L;
+            } else {
+                SgEntry nxt = tab.entries[e0];
+                if (s == 1) nxt.rho = first_rho1;
+                for (uint32_t e = e0; e < e1; ++e) {
+                    const SgEntry f = nxt;
+                    nxt = tab.entries[e + 1];
+                    ++ph_cand;
+                    if (!(f.rho < d)) break;
+                    if (s > 0 && !(f.flags & 1u)) continue;
+                    if (!exact_test(f, L)) { out.overflow = 1; break; }
+                }
             }
             if (++b == nb) b = 0;
         }
     }
     if (out.overflow) return;
+    if constexpr (PREFILTER) {
+        if (C > 0) {
+            SgEntry nxt = tab.entries[(uint32_t)__double2loint(SG_RATIO(0))];
+            for (int c = 0; c < C; ++c) {
+                const SgEntry f = nxt;
+                if (c + 1 < C) nxt = tab.entries[(uint32_t)__double2loint(SG_RATIO(c + 1))];
+                (void)exact_test(f, L);                          // C <= LMAX: cannot overflow
+            }
+        }
+    }
+    if (out.overflow) return;
+#if SG_ABLATE >= 2
+    out.intensity += (double)L + ar + al + den_r + den_l;       // timing experiments only (scripts/ablate.sh)
+    return;
+#endif
     const unsigned long long ph1 = ph ? wall_clock64() : 0;
 
     // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------
@@ -173,14 +226,18 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const double delta = beam_div_deg * (SG_PI / 180.0);        // np.radians(beam_divergence), :289
     int S = 0;                                                  // scatterers kept (dict entries before -1)
     double e_min = ra < la ? ra : la, e_max = ra < la ? la : ra;
-    SgNpSum acc;
     for (int j = 0; j < L; ++j) {
         const double lo = SG_A1(j), hi = SG_A2(j);
         if (lo < e_min) e_min = lo;
         if (hi < e_min) e_min = hi;
         if (lo > e_max) e_max = lo;
         if (hi > e_max) e_max = hi;
-        bool made = false;
+    }
+    SgNpSum acc;
+    // the slots of owner j, walked inside its own interval: exact for any number of slots (NumPy's blocked sum)
+    auto owner_walk = [&](int j, bool &made) -> double {
+        const double lo = SG_A1(j), hi = SG_A2(j);
+        made = false;
         acc.reset();
         double e = lo;
         while (e < hi) {                                        // slots i1 .. i2-1 (:277-282)
@@ -197,16 +254,59 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             if (!pre) { acc.push(nxt - e); made = true; }       // :266 diffs, :285-286
             e = nxt;
         }
-        if (made) {                                             // :288-290
-            const double ratio = sg_clip01(acc.result() / delta);
+        return acc.result();
+    };
+    double tgt_sum;
+    if constexpr (LMAX <= 16) {
+        // One walk over all elementary slots, left to right: each goes to its owner's running sum (kept in the
+        // ratio column; the slots of one owner arrive in the order of diffs[assignment == j]) or to the hard target.
+        // A running sum is NumPy's sum for fewer than 8 addends; an owner with more is redone by owner_walk.
+        unsigned long long cnt = 0;                             // 4 bits per owner, saturating at 8
+        acc.reset();
+        double e = e_min;
+        while (e < e_max) {
+            int own = -1;
+            double nxt = e_max;
+            for (int q = 0; q < L; ++q) {
+                const double q1 = SG_A1(q), q2 = SG_A2(q);
+                if (own < 0 && q1 <= e && e < q2) own = q;      // nearest flake covering the slot (:284)
+                if (q1 > e && q1 < nxt) nxt = q1;
+                if (q2 > e && q2 < nxt) nxt = q2;
+            }
+            if (ra > e && ra < nxt) nxt = ra;
+            if (la > e && la < nxt) nxt = la;
+            const double w = nxt - e;
+            if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)
+            else {
+                const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
+                SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
+                if (c < 8) cnt += 1ull << (4 * own);
+            }
+            e = nxt;
+        }
+        tgt_sum = acc.result();
+        for (int j = 0; j < L; ++j) {
+            const unsigned c = (unsigned)(cnt >> (4 * j)) & 15u;
+            if (c == 0) continue;                               // every slot already owned by nearer flakes
+            double sum = 0.0 + SG_RATIO(j);
+            if (c >= 8) { bool made; sum = owner_walk(j, made); }
             const double rho = SG_RHO(j);
             SG_RHO(S) = rho;                                    // S <= j: in-place compaction
-            SG_RATIO(S) = ratio;
+            SG_RATIO(S) = sg_clip01(sum / delta);               // :288-290
             ++S;
         }
-    }
-    {   // the hard target gets every slot nobody claimed (:292-293)
-        acc.reset();
+    } else {
+        for (int j = 0; j < L; ++j) {
+            bool made;
+            const double sum = owner_walk(j, made);
+            if (made) {                                         // :288-290
+                const double rho = SG_RHO(j);
+                SG_RHO(S) = rho;                                // S <= j: in-place compaction
+                SG_RATIO(S) = sg_clip01(sum / delta);
+                ++S;
+            }
+        }
+        acc.reset();                                            // the hard target gets every slot nobody claimed (:292-293)
         double e = e_min;
         while (e < e_max) {
             bool pre = false;
@@ -222,9 +322,10 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             if (!pre) acc.push(nxt - e);
             e = nxt;
         }
-        SG_RHO(S) = d;
-        SG_RATIO(S) = sg_clip01(acc.result() / delta);
+        tgt_sum = acc.result();
     }
+    SG_RHO(S) = d;
+    SG_RATIO(S) = sg_clip01(tgt_sum / delta);
     const int n_dict = S + 1;
     const unsigned long long ph2 = ph ? wall_clock64() : 0;
     if (dbg_count) {
@@ -366,67 +467,100 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
         if (sm[i] > best || (sm[i] == best && k + i < k_best)) { best = sm[i]; k_best = k + i; }   // first maximum (:151)
 }
 
-template <int STRIDE, bool EXACT, int NB = 8>
-__device__ __forceinline__ void sg_lane_power(int S, int k_min, int k_max, const double *__restrict__ rgrid,
-                                              const double *s_a1, const double *s_a2, const double *s_rho, int tid,
-                                              double &best, int &k_best)
+// Two stages so that the lanes of a wave spend their time in the same code:
+//   A  one step per scatterer: from bounds only, find the few bins of its window that can hold the maximum and put
+//      them (as groups of NB bins) on a short per-lane work list in LDS (s_work, WCAP slots);
+//   B  evaluate the listed groups exactly.
+// Bounds -- exact prunings: a bin that is not listed can neither hold nor tie the maximum.
+//   floor   the bin nearest to the peak of the strongest scatterer lies within 0.055 m of it (the grid step is 0.10
+//           or 0.11 m), so its sum, hence the maximum, is >= A_max cos^2(pi 0.055 / (c tau_h)) = 0.99668 A_max.
+//   zone    every term is A sin^2(.) <= A.  If a bin's sum reaches `need`, then for EACH scatterer t covering it
+//           A_t sin^2(u_t) >= need - (sum of the amplitudes of the other scatterers whose windows overlap t's),
+//           i.e. sin^2(u_t) >= q_t.  With cos^2(x) <= 1 - x^2 + x^4/3 that confines the bin to
+//           |u_t - pi/2| <= sqrt(1.26 (1 - q_t)) for q_t >= 1/2: a zone of a few bins around the peak of t.
+//           Applied to the strongest scatterer covering the bin (the others then being the weaker overlapping
+//           windows only), every bin that matters lies in such a zone; q_t < 1/2 keeps the whole window.
+// `tid` is the LDS column holding the beam's lists, `wtid` the column whose s_work slots this lane may use (the
+// kernel hands the beams that reached this phase to the first lanes of the block, see k_beams).
+template <int STRIDE, bool EXACT, int NB, int WCAP>
+__device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
+                                              const double *s_rho, double *s_work, int tid, int wtid, double &best,
+                                              int &k_best, int *stat = nullptr)
 {
     best = 0.0;
     k_best = 0;
-    const int INF = 0x7fffffff;
+    int n_iter = 0, n_eval = 0;                   // experiment counters (scripts/gpu_phases.py)
+    const double c_tau = 299792458.0 * 1e-8;
+    const double step = (120 + c_tau) / (SG_RBINS - 1);
     const double tpk = s_a2[S * STRIDE + tid];
     const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
     const double tamp = s_a1[S * STRIDE + tid], td = s_rho[S * STRIDE + tid];
-    // ---- pass 1: the window of the strongest scatterer ----
-    int p0 = tk0, p1 = tk1;
-    {
-        double amax = tamp;
-        for (int t = 0; t < S; ++t) {
-            const double a = s_a1[t * STRIDE + tid];
-            if (a > amax) { amax = a; const double pk = s_a2[t * STRIDE + tid]; p0 = __double2loint(pk); p1 = __double2hiint(pk); }
+    double amax = tamp;
+    for (int t = 0; t < S; ++t) amax = fmax(amax, s_a1[t * STRIDE + tid]);
+    const double floor_ = 0.9966 * amax;
+    int nw = 0;
+    auto flush = [&]() {
+        for (int w = 0; w < nw; ++w) {
+            ++n_eval;
+            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[w * STRIDE + wtid]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
+                                             tk1, tamp, td, best, k_best);
+        }
+        nw = 0;
+    };
+    // ---- stage A ----
+    for (int t = 0; t <= S; ++t) {                // the hard target is scatterer S
+        ++n_iter;
+        const double A = s_a1[t * STRIDE + tid];
+        if (!(A > 0.0)) continue;                 // adds nothing anywhere; the bins it covers belong to others' zones
+        const double pk = s_a2[t * STRIDE + tid];
+        const int k0 = __double2loint(pk), k1 = __double2hiint(pk);
+        // Each bin is the business of the strongest scatterer covering it (ties: the nearer one).  So this window
+        // answers only for its bins outside stronger overlapping windows -- those trim it from the left (lo_trim) or
+        // from the right (hi_trim); windows are in range order and of (almost) equal length -- and only the weaker
+        // overlapping windows can add to its bins (oth).
+        double oth = 0.0;
+        int lo_trim = k0, hi_trim = k1;
+        auto visit = [&](int j, int q0, int q1) {
+            const double Aj = s_a1[j * STRIDE + tid];
+            if (Aj > A || (Aj == A && j < t)) {
+                if (q0 <= k0) { if (q1 > lo_trim) lo_trim = q1; }
+                else if (q1 >= k1) { if (q0 < hi_trim) hi_trim = q0; }
+            } else oth += Aj;
+        };
+        for (int j = t - 1; j >= 0; --j) {
+            const double pj = s_a2[j * STRIDE + tid];
+            if (__double2hiint(pj) <= k0) break;
+            visit(j, __double2loint(pj), __double2hiint(pj));
+        }
+        for (int j = t + 1; j <= S; ++j) {
+            const double pj = s_a2[j * STRIDE + tid];
+            if (__double2loint(pj) >= k1) break;
+            visit(j, __double2loint(pj), __double2hiint(pj));
+        }
+        const double need = fmax(best, floor_);
+        if ((A + oth) * (1.0 + 1e-9) < need) continue;
+        const double q = (need * (1.0 - 1e-9) - oth * (1.0 + 1e-9)) / A;
+        int ka = k0, kb = k1 - 1;
+        if (q >= 0.5) {
+            const double om = q < 1.0 ? 1.0 - q : 0.0;
+            const double delta = (double)sqrtf((float)(1.26 * om)) * (1.0 + 1e-6) + 1e-6;
+            const double Rc = s_rho[t * STRIDE + tid] + c_tau / 2;
+            const double D = delta * (c_tau / SG_PI) + 0.006;      // + half a centimetre of grid rounding
+            const int za = (int)floor((Rc - D) * (1.0 / step)), zb = (int)ceil((Rc + D) * (1.0 / step));
+            if (za > ka) ka = za;
+            if (zb < kb) kb = zb;
+        }
+        if (lo_trim > ka) ka = lo_trim;
+        if (hi_trim - 1 < kb) kb = hi_trim - 1;
+        for (int g = ka; g <= kb; g += NB) {
+            if (nw == WCAP) flush();
+            s_work[nw * STRIDE + wtid] = __hiloint2double(0, g);
+            ++nw;
         }
     }
-    int p_end = p0;
-    for (; p_end < p1; p_end += NB)
-        sg_eval_group<STRIDE, EXACT, NB>(p_end, 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td, best, k_best);
-    // ---- pass 2: every other bin, ascending, pruned by the amplitude bound ----
-    int t_lo = 0, lo_k0 = INF, lo_k1 = INF;       // nearest flake whose window has not been passed yet
-    if (S > 0) { const double pk = s_a2[tid]; lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); }
-    int k = k_min;
-    while (k < k_max) {
-        while (t_lo < S && k >= lo_k1) {                     // pass windows that end at or before k
-            ++t_lo;
-            if (t_lo < S) { const double pk = s_a2[t_lo * STRIDE + tid]; lo_k0 = __double2loint(pk); lo_k1 = __double2hiint(pk); }
-            else { lo_k0 = INF; lo_k1 = INF; }
-        }
-        const bool tgt_hit = (tk0 < k + NB) && (tk1 > k);
-        if (lo_k0 >= k + NB && !tgt_hit) {                   // gap: jump to the next window start
-            int nk = lo_k0;
-            if (k < tk0 && tk0 < nk) nk = tk0;
-            if (nk == INF) break;
-            k = nk;
-            continue;
-        }
-        if (k >= p0 && k + NB <= p_end) { k += NB; continue; }      // these bins were summed in pass 1
-        double U = tgt_hit ? tamp : 0.0;                     // amplitude bound of this group
-        int next_start = (tk0 >= k + NB) ? tk0 : INF;        // first window that starts beyond this group
-        for (int t = t_lo; t < S; ++t) {
-            const double pk = s_a2[t * STRIDE + tid];
-            const int q0 = __double2loint(pk);
-            if (q0 >= k + NB) { if (q0 < next_start) next_start = q0; break; }
-            if (__double2hiint(pk) > k) U += s_a1[t * STRIDE + tid];
-        }
-        if (!(U * (1.0 + 1e-9) < best)) {
-            sg_eval_group<STRIDE, EXACT, NB>(k, t_lo, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td, best, k_best);
-        } else {
-            // Until another window starts the set of scatterers reaching a group can only shrink, so every group up
-            // to there is bounded by the same U: skip them all at once.
-            if (next_start == INF) break;
-            const int nk = next_start - NB + 1;              // first group that touches the new window
-            if (nk > k + NB) { k = nk; continue; }
-        }
-        k += NB;
-    }
+    // ---- stage B ----
+    flush();
+    if (stat) { stat[0] = n_iter; stat[1] = 0; stat[2] = n_eval; }
 }
 
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------

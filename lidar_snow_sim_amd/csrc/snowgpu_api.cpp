@@ -709,12 +709,12 @@ extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned
     if (!ctx) return SNOWGPU_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (enable) {
-        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 32 * sizeof(unsigned long long)));
-        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 32 * sizeof(unsigned long long)));
+        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 64 * sizeof(unsigned long long)));
+        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 64 * sizeof(unsigned long long)));
         sg_set_phase_dbg(ctx->phase_cycles);
     } else if (ctx->phase_cycles) {
         HIPCHK(ctx, hipDeviceSynchronize());
-        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         sg_set_phase_dbg(nullptr);
         (void)hipFree(ctx->phase_cycles);
         ctx->phase_cycles = nullptr;

@@ -20,7 +20,7 @@ L.snowgpu_debug_phase_cycles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c
 eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes)
 L.snowgpu_debug_phase_cycles(eng.ctx.handle, 1, None)
 t = time.time(); eng.ctx.augment_batch(rows, off, tids, bench.BEAM_DIV, plane=planes); dt = time.time() - t
-out = (ctypes.c_ulonglong * 32)()
+out = (ctypes.c_ulonglong * 64)()
 L.snowgpu_debug_phase_cycles(eng.ctx.handle, 0, out)
 v = list(out)
 print('host call', dt, '(lane-0 view; 100 MHz ticks x24 = cycles @2.4 GHz)')
@@ -28,3 +28,7 @@ for ti, name in enumerate(('tier 4', 'tier 8', 'tier 16', 'tier 63')):
     b = v[8 * ti: 8 * ti + 8]
     w = max(b[5], 1)
     print(f'{name}: waves {b[5]}  load {b[0]/w*24:9.0f}  P1 {b[1]/w*24:9.0f}  P2 {b[2]/w*24:9.0f}  P3a {b[3]/w*24:9.0f}  P3b {b[4]/w*24:9.0f} cycles/wave;  lane0 mean L {b[6]/w:.2f} candidates {b[7]/w:.1f}')
+for ti, name in enumerate(('tier 4', 'tier 8', 'tier 16', 'tier 63')):
+    b = v[32 + 8 * ti: 32 + 8 * ti + 8]
+    w = max(b[0], 1); ln = max(b[1], 1)
+    print(f'{name}: power-phase waves {b[0]} lanes/wave {b[1]/w:.1f}  per wave max: walk {b[2]/w:.1f} fine {b[3]/w:.1f} evaluated {b[4]/w:.1f};  per lane mean: walk {b[5]/ln:.1f} fine {b[6]/ln:.1f} evaluated {b[7]/ln:.1f}')
