@@ -83,6 +83,8 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, void *stream);
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
+                       int32_t *count, int32_t cap, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,

@@ -453,6 +453,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
     a.phase_cycles = ctx->phase_cycles;
+    ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);     // also the tiles of the overflow list builder
+    ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
     int tiers[4], n_tiers = 0;
     choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
@@ -469,13 +471,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
         if (timed && t == 0) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
         int e = sg_launch_beams(&a, b.dtype, tiers[t], st);
+        if (!e && t == 0 && n_tiers > 1)   // the first pass flags its overflowed beams; build the ordered list from the flags
+            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, st);
         if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     }
     int e = 0;
     // 4. round + noise-floor filter + compaction + stats (simulation.py:516-530)
-    ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles);
-    ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles);
     e = sg_launch_compact(ctx->rows_tmp.p, b.dtype, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
                           ctx->diff2.p, max_tiles, st);

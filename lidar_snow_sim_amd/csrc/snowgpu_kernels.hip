@@ -208,7 +208,12 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             }
         }
     }
-    {   // queue the overflowed beams of this wave with ONE atomic (a per-lane atomic on a single counter
+    if (!LIST && LMAX < SG_LCAP) {
+        // Direct mode: an overflowed beam is only flagged (keep[g] = 2); k_ovf_* then build the next pass's list in
+        // sorted-row order, so that the lanes of its waves stay neighbours in channel and azimuth -- one table, nearby
+        // bins.  (An atomic queue hands a wave 64 beams of as many channels, i.e. tables: every load a miss.)
+        if (o.overflow) a.keep[g] = 2;
+    } else {   // queue the overflowed beams of this wave with ONE atomic (a per-lane atomic on a single counter
         // serialises in L2 and stalls every other memory request behind it)
         const unsigned long long om = __ballot(o.overflow != 0);
         if (om) {
@@ -330,6 +335,67 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
     a.keep[g] = keep ? 1 : 0;
     }   // chunk loop
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered overflow list of the first pass: positions g with keep[g] == 2, ascending (count / scan / scatter
+// over tiles of SG_TILE positions).
+__global__ __launch_bounds__(SG_BLOCK) void k_ovf_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt)
+{
+    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
+    int c = 0;
+    if (g0 + 3 < n_total) {
+        const uint32_t v = *(const uint32_t *)(keep + g0);
+        c = ((v & 0xff) == 2) + (((v >> 8) & 0xff) == 2) + (((v >> 16) & 0xff) == 2) + ((v >> 24) == 2);
+    } else {
+        for (int q = 0; q < 4; ++q) if (g0 + q < n_total && keep[g0 + q] == 2) ++c;
+    }
+    __shared__ int s[SG_BLOCK / 64];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < SG_BLOCK / 64; ++w) t += s[w]; tile_cnt[blockIdx.x] = t; }
+}
+
+__global__ __launch_bounds__(1024) void k_ovf_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int64_t tiles,
+                                                   int32_t *__restrict__ count_out)
+{
+    __shared__ int s[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (tiles + 1023) / 1024, b0 = t * per, b1 = b0 + per < tiles ? b0 + per : tiles;
+    int sum = 0;
+    for (int64_t i = b0; i < b1; ++i) sum += tile_cnt[i];
+    s[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int add = t >= d ? s[t - d] : 0;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    int run = s[t] - sum;
+    for (int64_t i = b0; i < b1; ++i) { tile_base[i] = run; run += tile_cnt[i]; }
+    if (t == 1023) *count_out = s[t];
+}
+
+__global__ __launch_bounds__(SG_BLOCK) void k_ovf_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
+                                                          int32_t *__restrict__ list, int32_t cap)
+{
+    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
+    bool f[4];
+    int c = 0;
+    for (int q = 0; q < 4; ++q) { f[q] = g0 + q < n_total && keep[g0 + q] == 2; c += f[q]; }
+    // exclusive prefix of c over the block: wave scan + wave totals
+    int inc = c;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+    __shared__ int s[SG_BLOCK / 64];
+    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    int base = tile_base[blockIdx.x];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s[w];
+    int slot = base + inc - c;
+    for (int q = 0; q < 4; ++q)
+        if (f[q]) { if (slot < cap) list[slot] = (int32_t)(g0 + q); ++slot; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,17 +586,32 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
     const int64_t n = a->work_list ? (int64_t)a->work_cap : a->n_total;
     if (dtype == 0) {
         if (lmax == 4) return launch_beams_t<float, 4, 256>(a, n, st);
-        if (lmax == 8) return launch_beams_t<float, 8, 256>(a, n, st);
-        if (lmax == 16) return launch_beams_t<float, 16, 256>(a, n, st);
+        if (lmax == 8) return launch_beams_t<float, 8, 64>(a, n, st);
+        if (lmax == 16) return launch_beams_t<float, 16, 64>(a, n, st);
         if (lmax == 32) return launch_beams_t<float, 32, 128>(a, n, st);
         return launch_beams_t<float, SG_LCAP, 64>(a, n, st);
     } else {
         if (lmax == 4) return launch_beams_t<double, 4, 256>(a, n, st);
-        if (lmax == 8) return launch_beams_t<double, 8, 256>(a, n, st);
-        if (lmax == 16) return launch_beams_t<double, 16, 256>(a, n, st);
+        if (lmax == 8) return launch_beams_t<double, 8, 64>(a, n, st);
+        if (lmax == 16) return launch_beams_t<double, 16, 64>(a, n, st);
         if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
         return launch_beams_t<double, SG_LCAP, 64>(a, n, st);
     }
+}
+
+extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
+                                  int32_t *count, int32_t cap, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
+    if (tiles == 0) return 0;
+    hipLaunchKernelGGL(k_ovf_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ovf_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, tiles, count);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_ovf_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap);
+    SG_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
