@@ -118,37 +118,9 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const bool wrap = theta_r > theta_l;                        // simulation.py:361
 
     // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
-    // The exact predicates of get_occlusions (simulation.py:359-389) cost two float64 divisions per flake and a
-    // wave pays for them as long as any of its lanes has a candidate.  So the scan is split (PREFILTER): a cheap
-    // pass keeps the records that can possibly satisfy the predicates, the exact pass then runs on those only.
-    //   necessary condition: the predicates hold only if the flake's angular interval phi +- asin(r / rho) meets the
-    //   wedge, i.e. |phi - theta_c| <= half + asin(r / rho); asin(q) <= q pi / 2 on [0, 1] turns that into a product
-    //   test without a division, and 1e-7 rad of slack dwarfs every rounding error of the exact test.
-    constexpr bool PREFILTER = LMAX < SG_LCAP;                  // the last tier must not overflow on the superset
-    auto exact_test = [&](const SgEntry &f, int &L_) -> bool {  // returns false on list overflow
-        const double rho = f.rho, phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
-        const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
-                         || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
-                         || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
-        const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
-        const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
-        const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
-        const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
-        if (!(centre || hit_r || hit_l)) return true;           // :389
-        if (L_ == LMAX) return false;
-        const double na1 = hit_r ? theta_r : f.t0;              // geometry.py:26
-        const double na2 = hit_l ? theta_l : f.t1;              // geometry.py:27
-        int p = L_;                                             // insertion sort by rho (:413-417)
-        while (p > 0 && SG_RHO(p - 1) > rho) {
-            SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
-            --p;
-        }
-        SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
-        ++L_;
-        return true;
-    };
+    // (A split scan -- cheap angular prefilter first, the exact predicates on the survivors only -- was tried and
+    // made no difference: the scan is bound by its dependent record gathers, not by arithmetic.)
     int L = 0;
-    int C = 0;                                                  // PREFILTER: survivors, record indices in s_ratio
     {
         int b = b_lo;
         for (int s = 0; s <= span && !out.overflow; ++s) {
@@ -158,49 +130,36 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             else { e0 = tab.bin_start[b]; e1 = tab.bin_start[b + 1]; }
             // software pipeline: the next record is requested before the current one is examined (the entry
             // array carries one spare record at its end, so e + 1 is always readable)
-            if constexpr (PREFILTER) {
-                double n_rho = (s == 1) ? first_rho1 : tab.entries[e0].rho;
-                double n_phi = tab.entries[e0].phi, n_r = tab.entries[e0].r;
-                uint32_t n_flags = tab.entries[e0].flags;
-                for (uint32_t e = e0; e < e1; ++e) {
-                    const double rho = n_rho, phi = n_phi, fr = n_r;
-                    const uint32_t flags = n_flags;
-                    n_rho = tab.entries[e + 1].rho; n_phi = tab.entries[e + 1].phi; n_r = tab.entries[e + 1].r;
-                    n_flags = tab.entries[e + 1].flags;
-                    ++ph_cand;
-                    if (!(rho < d)) break;                      // :345 (bins are sorted by rho)
-                    if (s > 0 && !(flags & 1u)) continue;       // already met in an earlier bin
-                    double dphi = phi - theta_c;
-                    dphi = dphi - SG_TWO_PI * rint(dphi * (1.0 / SG_TWO_PI));
-                    if ((fabs(dphi) - half - 1e-7) * rho > 1.5707963267948968 * fr) continue;
-                    if (C == LMAX) { out.overflow = 1; break; }
-                    SG_RATIO(C) = __hiloint2double(0, (int)e);
-                    ++C;
+            SgEntry nxt = tab.entries[e0];
+            if (s == 1) nxt.rho = first_rho1;
+            for (uint32_t e = e0; e < e1; ++e) {
+                const SgEntry f = nxt;
+                nxt = tab.entries[e + 1];
+                ++ph_cand;
+                const double rho = f.rho;
+                if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
+                if (s > 0 && !(f.flags & 1u)) continue;         // already met in an earlier bin
+                const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
+                const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
+                                 || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
+                                 || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
+                const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
+                const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
+                const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
+                const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
+                if (!(centre || hit_r || hit_l)) continue;      // :389
+                if (L == LMAX) { out.overflow = 1; break; }
+                const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26
+                const double na2 = hit_l ? theta_l : f.t1;      // geometry.py:27
+                int p = L;                                      // insertion sort by rho (:413-417)
+                while (p > 0 && SG_RHO(p - 1) > rho) {
+                    SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
+                    --p;
                 }
-            } else {
-                SgEntry nxt = tab.entries[e0];
-                if (s == 1) nxt.rho = first_rho1;
-                for (uint32_t e = e0; e < e1; ++e) {
-                    const SgEntry f = nxt;
-                    nxt = tab.entries[e + 1];
-                    ++ph_cand;
-                    if (!(f.rho < d)) break;
-                    if (s > 0 && !(f.flags & 1u)) continue;
-                    if (!exact_test(f, L)) { out.overflow = 1; break; }
-                }
+                SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
+                ++L;
             }
             if (++b == nb) b = 0;
-        }
-    }
-    if (out.overflow) return;
-    if constexpr (PREFILTER) {
-        if (C > 0) {
-            SgEntry nxt = tab.entries[(uint32_t)__double2loint(SG_RATIO(0))];
-            for (int c = 0; c < C; ++c) {
-                const SgEntry f = nxt;
-                if (c + 1 < C) nxt = tab.entries[(uint32_t)__double2loint(SG_RATIO(c + 1))];
-                (void)exact_test(f, L);                          // C <= LMAX: cannot overflow
-            }
         }
     }
     if (out.overflow) return;
@@ -256,13 +215,13 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         }
         return acc.result();
     };
+    // One walk over all elementary slots, left to right: each goes to its owner's running sum (kept in the ratio
+    // column; the slots of one owner arrive in the order of diffs[assignment == j]) or to the hard target.
+    // A running sum is NumPy's sum for fewer than 8 addends; an owner with more is redone by owner_walk.
     double tgt_sum;
-    if constexpr (LMAX <= 16) {
-        // One walk over all elementary slots, left to right: each goes to its owner's running sum (kept in the
-        // ratio column; the slots of one owner arrive in the order of diffs[assignment == j]) or to the hard target.
-        // A running sum is NumPy's sum for fewer than 8 addends; an owner with more is redone by owner_walk.
-        unsigned long long cnt = 0;                             // 4 bits per owner, saturating at 8
-        acc.reset();
+    unsigned long long cnt = 0;      // LMAX <= 16: 4 bits per owner, saturating at 8; else: one "owns a slot" bit per owner
+    acc.reset();
+    {
         double e = e_min;
         while (e < e_max) {
             int own = -1;
@@ -277,52 +236,42 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             if (la > e && la < nxt) nxt = la;
             const double w = nxt - e;
             if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)
-            else {
+            else if constexpr (LMAX <= 16) {
                 const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
                 SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
                 if (c < 8) cnt += 1ull << (4 * own);
+            } else {
+                const bool first = !((cnt >> own) & 1ull);
+                SG_RATIO(own) = first ? w : SG_RATIO(own) + w;
+                cnt |= 1ull << own;
             }
             e = nxt;
         }
-        tgt_sum = acc.result();
-        for (int j = 0; j < L; ++j) {
+    }
+    tgt_sum = acc.result();
+    for (int j = 0; j < L; ++j) {
+        bool redo;
+        if constexpr (LMAX <= 16) {
             const unsigned c = (unsigned)(cnt >> (4 * j)) & 15u;
             if (c == 0) continue;                               // every slot already owned by nearer flakes
-            double sum = 0.0 + SG_RATIO(j);
-            if (c >= 8) { bool made; sum = owner_walk(j, made); }
-            const double rho = SG_RHO(j);
-            SG_RHO(S) = rho;                                    // S <= j: in-place compaction
-            SG_RATIO(S) = sg_clip01(sum / delta);               // :288-290
-            ++S;
-        }
-    } else {
-        for (int j = 0; j < L; ++j) {
-            bool made;
-            const double sum = owner_walk(j, made);
-            if (made) {                                         // :288-290
-                const double rho = SG_RHO(j);
-                SG_RHO(S) = rho;                                // S <= j: in-place compaction
-                SG_RATIO(S) = sg_clip01(sum / delta);
-                ++S;
-            }
-        }
-        acc.reset();                                            // the hard target gets every slot nobody claimed (:292-293)
-        double e = e_min;
-        while (e < e_max) {
-            bool pre = false;
-            double nxt = e_max;
+            redo = c >= 8;
+        } else {
+            if (!((cnt >> j) & 1ull)) continue;
+            // fewer than 7 endpoints strictly inside the interval -> fewer than 8 slots
+            const double lo = SG_A1(j), hi = SG_A2(j);
+            int inside = (ra > lo && ra < hi) + (la > lo && la < hi);
             for (int q = 0; q < L; ++q) {
                 const double q1 = SG_A1(q), q2 = SG_A2(q);
-                if (q1 <= e && e < q2) pre = true;
-                if (q1 > e && q1 < nxt) nxt = q1;
-                if (q2 > e && q2 < nxt) nxt = q2;
+                inside += (q1 > lo && q1 < hi) + (q2 > lo && q2 < hi);
             }
-            if (ra > e && ra < nxt) nxt = ra;
-            if (la > e && la < nxt) nxt = la;
-            if (!pre) acc.push(nxt - e);
-            e = nxt;
+            redo = inside >= 7;
         }
-        tgt_sum = acc.result();
+        double sum = 0.0 + SG_RATIO(j);
+        if (redo) { bool made; sum = owner_walk(j, made); }
+        const double rho = SG_RHO(j);
+        SG_RHO(S) = rho;                                        // S <= j: in-place compaction
+        SG_RATIO(S) = sg_clip01(sum / delta);                   // :288-290
+        ++S;
     }
     SG_RHO(S) = d;
     SG_RATIO(S) = sg_clip01(tgt_sum / delta);
@@ -480,12 +429,10 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
 //           |u_t - pi/2| <= sqrt(1.26 (1 - q_t)) for q_t >= 1/2: a zone of a few bins around the peak of t.
 //           Applied to the strongest scatterer covering the bin (the others then being the weaker overlapping
 //           windows only), every bin that matters lies in such a zone; q_t < 1/2 keeps the whole window.
-// `tid` is the LDS column holding the beam's lists, `wtid` the column whose s_work slots this lane may use (the
-// kernel hands the beams that reached this phase to the first lanes of the block, see k_beams).
 template <int STRIDE, bool EXACT, int NB, int WCAP>
 __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
-                                              const double *s_rho, double *s_work, int tid, int wtid, double &best,
-                                              int &k_best, int *stat = nullptr)
+                                              const double *s_rho, double *s_work, int tid, double &best, int &k_best,
+                                              int *stat = nullptr)
 {
     best = 0.0;
     k_best = 0;
@@ -502,7 +449,7 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
     auto flush = [&]() {
         for (int w = 0; w < nw; ++w) {
             ++n_eval;
-            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[w * STRIDE + wtid]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
+            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[w * STRIDE + tid]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
                                              tk1, tamp, td, best, k_best);
         }
         nw = 0;
@@ -554,13 +501,13 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
         if (hi_trim - 1 < kb) kb = hi_trim - 1;
         for (int g = ka; g <= kb; g += NB) {
             if (nw == WCAP) flush();
-            s_work[nw * STRIDE + wtid] = __hiloint2double(0, g);
+            s_work[nw * STRIDE + tid] = __hiloint2double(0, g);
             ++nw;
         }
     }
     // ---- stage B ----
     flush();
-    if (stat) { stat[0] = n_iter; stat[1] = 0; stat[2] = n_eval; }
+    if (stat) { stat[0] = n_iter; stat[1] = n_eval; }
 }
 
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------

@@ -235,65 +235,30 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         }
     }
     const unsigned long long tc1 = ph ? wall_clock64() : 0;
-    // ---- phase 3b: received power.  Only a fraction of the beams meets a flake, so the block first packs those
-    // beams onto its first lanes (their lists stay where they are: LDS columns are addressable by any lane) and
-    // waves left without a beam skip the phase.  s_ratio is dead after phase 3a and carries the bookkeeping:
-    // slots 0 .. LMAX-1 the per-lane work lists, slot LMAX the packed column list.
+    // ---- phase 3b: received power (per lane; s_ratio is dead after phase 3a and carries the work lists) ----
+    // (Packing the beams that reach this phase onto the first lanes of the block, so that whole waves skip it, was
+    // tried: three block barriers cost what the idle lanes did.)
     double best = 0.0;
     int k_best = 0;
     constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together (register budget of the first tier: 128)
-    const bool hp = o.has_power && SG_ABLATE < 1;
-    if constexpr (BLOCK > 64) {
-        int *s_wc = (int *)s_ratio;                           // wave w's count at int 128 w: slot 0 of its own first lane
-        int *s_col = (int *)(s_ratio + LMAX * BLOCK);         // 2 BLOCK ints
-        const unsigned long long pm = __ballot(hp);
-        if ((tid & 63) == 0) s_wc[2 * tid] = (int)__popcll(pm);
-        __syncthreads();
-        int base = 0, total = 0;
-        for (int i = 0; i < BLOCK / 64; ++i) {
-            const int c = s_wc[128 * i];
-            if (i < (tid >> 6)) base += c;
-            total += c;
-        }
-        if (hp) {
-            const int slot = base + (int)__popcll(pm & sg_lanemask_lt());
-            s_col[slot] = tid | (o.n_flakes << 8);
-        }
-        __syncthreads();
-        // Packed beam i goes to lane (i + 64 rot) mod BLOCK.  Wave w of every block sits on SIMD w of its CU, so without
-        // the per-block rotation the packed work of all resident blocks would pile up on the first SIMDs.
-        const int rot = (int)(((unsigned)(chunk / BLOCK) * 2654435761u) >> 24) & (BLOCK / 64 - 1);
-        const int vt = (tid - 64 * rot) & (BLOCK - 1);
-        if (vt < total) {
-            const int e = s_col[vt];
-            const int col = e & 255, S = e >> 8;
-            double b;
-            int kb;
-            int st[3] = {0, 0, 0};
-            if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, s_rgrid, s_a1, s_a2, s_rho, s_ratio, col, tid, b, kb);
-            else sg_lane_power<BLOCK, false, NB, LMAX>(S, s_rgrid, s_a1, s_a2, s_rho, s_ratio, col, tid, b, kb, ph ? st : nullptr);
-            if (ph) {                                         // experiment: trip counts of the two stages, per wave
-                int mx[3], sm[3];
-                for (int q = 0; q < 3; ++q) {
-                    mx[q] = st[q]; sm[q] = st[q];
-                    for (int off = 32; off > 0; off >>= 1) { mx[q] = max(mx[q], __shfl_xor(mx[q], off)); sm[q] += __shfl_xor(sm[q], off); }
-                }
-                const unsigned long long am = __ballot(1);
-                if ((tid & 63) == __ffsll((long long)am) - 1) {
-                    unsigned long long *p2 = a.phase_cycles + 32 + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3);
-                    atomicAdd(&p2[0], 1ull); atomicAdd(&p2[1], (unsigned long long)__popcll(am));
-                    atomicAdd(&p2[2], (unsigned long long)mx[0]); atomicAdd(&p2[3], (unsigned long long)mx[1]); atomicAdd(&p2[4], (unsigned long long)mx[2]);
-                    atomicAdd(&p2[5], (unsigned long long)sm[0]); atomicAdd(&p2[6], (unsigned long long)sm[1]); atomicAdd(&p2[7], (unsigned long long)sm[2]);
-                }
+    if (o.has_power && SG_ABLATE < 1) {
+        int st[2] = {0, 0};
+        if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
+        else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best, ph ? st : nullptr);
+        if (ph) {                                         // experiment: trip counts of the two stages, per wave
+            int mx[2], sm[2];
+            for (int q = 0; q < 2; ++q) {
+                mx[q] = st[q]; sm[q] = st[q];
+                for (int off = 32; off > 0; off >>= 1) { mx[q] = max(mx[q], __shfl_xor(mx[q], off)); sm[q] += __shfl_xor(sm[q], off); }
             }
-            s_a1[col] = b;                                    // the column's lists are spent: hand the result back in slot 0
-            s_a2[col] = __hiloint2double(0, kb);
+            const unsigned long long am = __ballot(1);
+            if ((tid & 63) == __ffsll((long long)am) - 1) {
+                unsigned long long *p2 = a.phase_cycles + 32 + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3);
+                atomicAdd(&p2[0], 1ull); atomicAdd(&p2[1], (unsigned long long)__popcll(am));
+                atomicAdd(&p2[2], (unsigned long long)mx[0]); atomicAdd(&p2[3], (unsigned long long)mx[1]);
+                atomicAdd(&p2[4], (unsigned long long)sm[0]); atomicAdd(&p2[5], (unsigned long long)sm[1]);
+            }
         }
-        __syncthreads();
-        if (hp) { best = s_a1[tid]; k_best = __double2loint(s_a2[tid]); }
-    } else if (hp) {
-        if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, tid, best, k_best);
-        else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, tid, best, k_best);
     }
     if (ph && (tid & 63) == 0) {
         atomicAdd(&ph[0], tc0 - tcs);                  // frame lookup + row load

@@ -31,4 +31,4 @@ for ti, name in enumerate(('tier 4', 'tier 8', 'tier 16', 'tier 63')):
 for ti, name in enumerate(('tier 4', 'tier 8', 'tier 16', 'tier 63')):
     b = v[32 + 8 * ti: 32 + 8 * ti + 8]
     w = max(b[0], 1); ln = max(b[1], 1)
-    print(f'{name}: power-phase waves {b[0]} lanes/wave {b[1]/w:.1f}  per wave max: walk {b[2]/w:.1f} fine {b[3]/w:.1f} evaluated {b[4]/w:.1f};  per lane mean: walk {b[5]/ln:.1f} fine {b[6]/ln:.1f} evaluated {b[7]/ln:.1f}')
+    print(f'{name}: power-phase waves {b[0]} lanes/wave {b[1]/w:.1f}  per wave max: scatterers {b[2]/w:.1f} groups evaluated {b[3]/w:.1f};  per lane mean: {b[4]/ln:.1f} / {b[5]/ln:.1f}')
