@@ -71,6 +71,14 @@ struct SgBeamArgs {
     double *dbg_rj;
     double *dbg_ratio;
     int32_t dbg_cap;
+    // Segment-ordered direct mode (optional, first pass): blocks walk (table, frame, channel) segments of the sorted
+    // rows, so that chip-wide one or two flake tables are in use at a time and stay in L2.  null = linear order.
+    const int32_t *seg_blk;      // n_seg + 1: first block of segment i
+    const int64_t *seg_start;    // n_seg: global sorted position of the segment's first row
+    const int32_t *seg_cnt;      // n_seg: rows
+    const int32_t *seg_frame;    // n_seg
+    const int32_t *seg_n;        // [0] = n_seg
+    int64_t grid_blocks;         // host: blocks to launch in that mode (upper bound; surplus blocks leave at once)
     int32_t exact_math;          // 1: libm sin + true division in the power term (validation mode)
     unsigned long long *phase_cycles;   // optional [8]: per-wave cycle totals per phase (profiling builds of the call)
 };
@@ -83,6 +91,9 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, void *stream);
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
+                       int n_las, int n_tables, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
+                       int32_t *seg_frame, int32_t *seg_n, void *stream);
 int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
                        int32_t *count, int32_t cap, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -57,6 +58,9 @@ struct snowgpu_ctx {
     int32_t *d_status = nullptr;      // 4 ints
     // scratch shared by every batch
     DevBuf<int32_t> tile_hist, tile_base, ovf_list, ovf_list2, perm, ctile_cnt, ctile_base, table_ids, out_src;
+    DevBuf<int32_t> seg_pair, seg_blk, seg_cnt, seg_frame, seg_n;
+    DevBuf<int64_t> seg_start;
+    bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     DevBuf<uint16_t> rank;
     DevBuf<uint8_t> keep, rows_in, rows_tmp, rows_out;
     DevBuf<int64_t> frame_off, out_counts, out_stats;
@@ -128,6 +132,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SNOWGPU_E_NO_DEVICE;
     snowgpu_ctx *ctx = new snowgpu_ctx();
     ctx->device = device;
+    { const char *lo = std::getenv("SNOWGPU_LINEAR_ORDER"); ctx->linear_order = lo && lo[0] == '1'; }
     *out = ctx;   // hand the context back even on failure so that last_error is readable
     HIPCHK(ctx, hipSetDevice(device));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -155,6 +160,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->ovf_list2.release(); ctx->perm.release();
+    ctx->seg_pair.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release();
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
@@ -460,7 +466,21 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
     // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
     int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
+    // Launch order of the first pass: by flake table (segments of the device sort) unless the caller brought the
+    // permutation (no channel histogram then) or table ids are too sparse for the segment builder.
+    if (!b.perm && !ctx->linear_order && ctx->tables.size() <= 4096 && b.n_frames <= (1 << 22) && b.n_total < ((int64_t)1 << 31)) {
+        const size_t P = (size_t)b.n_frames * 256;
+        ENSURE(ctx, ctx->seg_pair, P); ENSURE(ctx, ctx->seg_blk, P + 1); ENSURE(ctx, ctx->seg_cnt, P);
+        ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
+        int e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(),
+                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
+        a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
+        a.seg_n = ctx->seg_n.p;
+        a.grid_blocks = (b.n_total + 255) / 256 + (int64_t)P;     // every non-empty pair wastes less than one block
+    }
     for (int t = 0; t < n_tiers; ++t) {
+        if (t > 0) a.seg_blk = nullptr;
         a.work_list = t == 0 ? nullptr : lists[(t - 1) & 1];
         a.work_count = t == 0 ? nullptr : b.status + 1 + t;
         a.work_cap = ovf_cap;

@@ -150,11 +150,30 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         work_n = *a.work_count;
         if (work_n > a.work_cap) work_n = a.work_cap;
     }
-    const int64_t stride = LIST ? (int64_t)gridDim.x * BLOCK : work_n;      // direct mode: exactly one trip
-    for (int64_t chunk = (int64_t)blockIdx.x * BLOCK; chunk < work_n; chunk += stride) {
+    const int64_t stride = (int64_t)gridDim.x * BLOCK;
+    int seg_f = -1;                                   // segment-ordered direct mode: the block's frame
+    int64_t seg_g = -1;
+    if (!LIST && a.seg_blk) {
+        const int n_seg = a.seg_n[0];
+        const int blk = (int)blockIdx.x;
+        if (blk >= a.seg_blk[n_seg]) return;          // surplus block (the grid is an upper bound)
+        int lo = 0, hi = n_seg - 1;                   // last segment whose first block is <= blk
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.seg_blk[mid] <= blk) lo = mid; else hi = mid - 1;
+        }
+        const int off = (blk - a.seg_blk[lo]) * BLOCK + tid;
+        seg_f = a.seg_frame[lo];
+        if (off < a.seg_cnt[lo]) seg_g = a.seg_start[lo] + off;
+    }
+    int64_t chunk = (int64_t)blockIdx.x * BLOCK;
+    if (LIST && chunk >= work_n) return;
+    do {                                              // direct mode: exactly one trip, and the compiler must see that
     int64_t g = -1;
     if (LIST) {
         if (chunk + tid < work_n) g = a.work_list[chunk + tid];
+    } else if (seg_f >= 0) {
+        g = seg_g;
     } else {
         g = chunk + tid;
         if (g >= a.n_total) g = -1;
@@ -169,7 +188,8 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     bool simulated = false;
     const int n_las = a.las->n;
     if (live) {
-        if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
+        if (!LIST && seg_f >= 0) f = seg_f;
+        else if (a.uniform_rows > 0) {               // equal-sized frames: no search (float estimate, integer fix-up)
             const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
             int fe = (int)((float)gu * a.inv_uniform_rows);
             if (fe >= a.n_frames) fe = a.n_frames - 1;
@@ -299,7 +319,74 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
     const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
     a.keep[g] = keep ? 1 : 0;
-    }   // chunk loop
+    } while (LIST && (chunk += stride) < work_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segment order of the first pass.  A segment = the rows of one (frame, channel) pair in the channel-sorted order,
+// i.e. all beams of a frame that look up the same flake table.  Segments are ordered by table, so that the ~1000
+// blocks resident at any moment use one or two tables (2-3 MB each: L2-resident) instead of all 64 of a frame.
+// One block; n_frames * 256 pairs.  Order inside a table is whatever the LDS atomics give -- results do not depend
+// on the launch order.
+#define SG_SEG_MAXT 4096
+__global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
+                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables,
+                                                    int32_t *__restrict__ seg_pair, int32_t *__restrict__ seg_blk, int64_t *__restrict__ seg_start,
+                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n)
+{
+    __shared__ int hist[SG_SEG_MAXT + 1];
+    __shared__ int sc[1024];
+    const int t = threadIdx.x;
+    const int P = n_frames * 256, NT = n_tables;
+    auto pair_rows = [&](int p, int64_t &start) -> int {
+        const int f = p >> 8, c = p & 255;
+        const int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
+        const int64_t n = frame_off[f + 1] - frame_off[f];
+        start = frame_off[f];
+        if (n <= 0) return 0;                         // the sort wrote nothing for an empty frame
+        const int64_t s0 = b[c], s1 = c < 255 ? (int64_t)b[c + 1] : n;
+        start = frame_off[f] + s0;
+        return (int)(s1 - s0);
+    };
+    auto pair_key = [&](int p) -> int {
+        const int f = p >> 8, c = p & 255;
+        if (c >= n_las) return NT;
+        const int id = table_ids[(int64_t)f * n_las + c];
+        return (id >= 0 && id < NT) ? id : NT;
+    };
+    for (int k = t; k <= NT; k += 1024) hist[k] = 0;
+    __syncthreads();
+    for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) atomicAdd(&hist[pair_key(p)], 1); }
+    __syncthreads();
+    // exclusive scan of hist[0 .. NT]
+    const int per = (NT + 1 + 1023) / 1024;
+    int sum = 0;
+    for (int k = t * per; k < (t + 1) * per && k <= NT; ++k) sum += hist[k];
+    sc[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const int add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
+    const int n_seg = sc[1023];
+    int run = sc[t] - sum;
+    for (int k = t * per; k < (t + 1) * per && k <= NT; ++k) { const int h = hist[k]; hist[k] = run; run += h; }
+    __syncthreads();
+    for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) seg_pair[atomicAdd(&hist[pair_key(p)], 1)] = p; }
+    __threadfence_block();
+    __syncthreads();
+    // blocks per segment, exclusive prefix in segment order
+    const int per2 = (n_seg + 1023) / 1024;
+    int bsum = 0;
+    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) { int64_t st; bsum += (pair_rows(seg_pair[i], st) + SG_BLOCK - 1) / SG_BLOCK; }
+    sc[t] = bsum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const int add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
+    int brun = sc[t] - bsum;
+    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) {
+        int64_t st;
+        const int p = seg_pair[i], rows = pair_rows(p, st);
+        seg_blk[i] = brun; seg_start[i] = st; seg_cnt[i] = rows; seg_frame[i] = p >> 8;
+        brun += (rows + SG_BLOCK - 1) / SG_BLOCK;
+    }
+    if (t == 1023) { seg_blk[n_seg] = sc[1023]; seg_n[0] = n_seg; seg_n[1] = sc[1023]; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,6 +610,7 @@ static int launch_beams_tl(const SgBeamArgs *a, int64_t n_threads, hipStream_t s
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
+    if (!LIST && a->seg_blk) blocks = (unsigned)a->grid_blocks;
     if (blocks == 0) return 0;
     if (LIST) {                                          // list mode: at most what the chip can hold at once
         int cus = 256;
@@ -562,6 +650,17 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
         if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
         return launch_beams_t<double, SG_LCAP, 64>(a, n, st);
     }
+}
+
+extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
+                                  int n_las, int n_tables, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
+                                  int32_t *seg_frame, int32_t *seg_n, void *stream)
+{
+    if (n_tables > SG_SEG_MAXT) return -1;
+    hipLaunchKernelGGL(k_seg_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las,
+                       n_tables, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
+    SG_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,

@@ -509,3 +509,42 @@ def test_error_paths_report_instead_of_computing_garbage(eng, tables):
                               thr_poly=[[0, 0, 0.0]])
     with pytest.raises(TypeError):                                   # integer rows
         eng.ctx.augment_batch(pc.astype(np.int32), [0, 8], [[0] * 64], 0.17, thr_poly=[[0, 0, 0.0]])
+
+
+def test_table_ordered_launch_equals_sorted_row_order(tables, monkeypatch):
+    """The first capacity tier walks (table, frame, channel) segments; SNOWGPU_LINEAR_ORDER=1 keeps sorted-row order.
+    Same bytes either way -- ragged frames, an empty frame, channels without lasers (Q5) and rows of several
+    channels that share one table included."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    rng = np.random.default_rng(77)
+    full = synthetic_sweep(64, 2048, seed=1011, intensity="lambert").reshape(64, 2048, 5)
+    f0 = full[:, ::16, :].reshape(-1, 5).copy()
+    f1 = np.zeros((0, 5), np.float32)
+    f2 = full[3:40, 7::50, :].reshape(-1, 5).copy()
+    f2[::11, 4] = 70.0                                   # no such laser: copied through (Q5)
+    f3 = full[:, 1::32, :].reshape(-1, 5).copy()
+    rng.shuffle(f3, axis=0)
+    frames = [f0, f1, f2, f3]
+    rows = np.concatenate(frames)
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames])))
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    polys = [[0.0, 0.01, 2.0]] * 4
+    results = []
+    for linear in ("0", "1"):
+        monkeypatch.setenv("SNOWGPU_LINEAR_ORDER", linear)
+        e = engine.Engine(0)
+        try:
+            orders = [list(np.random.default_rng(5 + i).permutation(64)) for i in range(len(frames))]
+            tids = [e.table_ids_from_arrays(tl, o) for o in orders]
+            results.append(e.ctx.augment_batch(rows, off, tids, bd, thr_poly=polys))
+        finally:
+            e.ctx.close()
+    (o0, s0, c0, st0, _), (o1, s1, c1, st1, _) = results
+    assert np.array_equal(c0, c1) and np.array_equal(st0, st1)
+    for f in range(len(frames)):
+        a, m = int(off[f]), int(c0[f])
+        assert np.array_equal(s0[a:a + m], s1[a:a + m])
+        assert o0[a:a + m].tobytes() == o1[a:a + m].tobytes()
+    assert int(c0[1]) == 0 and int(c0[0]) > 0 and int(st0[:, 0].sum()) > 0
