@@ -46,6 +46,8 @@ template <typename T> struct DevBuf {
 struct snowgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;            // side stream: launch-order bookkeeping that only needs the sort, next to the prepass
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     std::vector<DeviceTable> tables;
     SgTable *d_tables = nullptr;      // device mirror of the descriptors
@@ -136,6 +138,9 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     *out = ctx;   // hand the context back even on failure so that last_error is readable
     HIPCHK(ctx, hipSetDevice(device));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 8));
@@ -169,6 +174,9 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     sg_prepass_release(&ctx->prepass);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -422,6 +430,30 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         perm = ctx->perm.p;
     }
     b.perm_out = const_cast<int32_t *>(perm);
+    // 1b. on the side stream, next to the prepass: table descriptors per (frame, channel) and the launch order of the
+    // first pass -- by flake table (segments of the device sort) unless the caller brought the
+    // permutation (no channel histogram then) or table ids are too sparse for the segment builder.
+    const int64_t n_ft = (int64_t)b.n_frames * ctx->h_las.n;
+    ENSURE(ctx, ctx->frame_tables, (size_t)n_ft);
+    const bool use_seg = !b.perm && !ctx->linear_order && ctx->tables.size() <= 4096 && b.n_frames <= (1 << 22)
+                         && b.n_total < ((int64_t)1 << 31);
+    if (use_seg) {
+        const size_t P = (size_t)b.n_frames * 256;
+        ENSURE(ctx, ctx->seg_pair, P); ENSURE(ctx, ctx->seg_blk, P + 1); ENSURE(ctx, ctx->seg_cnt, P);
+        ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    {
+        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, ctx->aux);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
+        if (use_seg) {
+            e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(),
+                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->aux);
+            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
     // 2. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial
     const double *thr = b.thr_poly;
     if (!thr) {
@@ -442,12 +474,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
     ENSURE(ctx, ctx->ovf_list2, (size_t)ovf_cap);
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
-    const int64_t n_ft = (int64_t)b.n_frames * ctx->h_las.n;
-    ENSURE(ctx, ctx->frame_tables, (size_t)n_ft);
-    {
-        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, st);
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
-    }
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
@@ -466,19 +492,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
     // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
     int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
-    // Launch order of the first pass: by flake table (segments of the device sort) unless the caller brought the
-    // permutation (no channel histogram then) or table ids are too sparse for the segment builder.
-    if (!b.perm && !ctx->linear_order && ctx->tables.size() <= 4096 && b.n_frames <= (1 << 22) && b.n_total < ((int64_t)1 << 31)) {
-        const size_t P = (size_t)b.n_frames * 256;
-        ENSURE(ctx, ctx->seg_pair, P); ENSURE(ctx, ctx->seg_blk, P + 1); ENSURE(ctx, ctx->seg_cnt, P);
-        ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
-        int e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(),
-                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, st);
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
+    if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
         a.seg_n = ctx->seg_n.p;
-        a.grid_blocks = (b.n_total + 255) / 256 + (int64_t)P;     // every non-empty pair wastes less than one block
+        a.grid_blocks = (b.n_total + 255) / 256 + (int64_t)b.n_frames * 256;   // every non-empty pair wastes less than one block
     }
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     for (int t = 0; t < n_tiers; ++t) {
         if (t > 0) a.seg_blk = nullptr;
         a.work_list = t == 0 ? nullptr : lists[(t - 1) & 1];

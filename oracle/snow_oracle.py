@@ -277,12 +277,14 @@ def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7):
 # frame driver
 
 def augment(pc, tables, beam_divergence, order, noise_floor=0.7, plane=None, lasers=None,
-            thr_poly=None, return_full=False):
+            thr_poly=None, return_full=False, threads=1):
     """sim:427-544 with only_camera_fov=False.
 
     pc      : N x 5 (x, y, z, intensity, channel), float32 or float64
     tables  : sequence of K_i x 3 float64 arrays; table ``order[channel]`` feeds ``channel`` (sim:70, :78)
     order   : permutation of range(num_lasers) (sim:482-486)
+    threads : > 1 runs the channels on a thread pool, as the reference does (sim:498 ThreadPool(cpu_count()));
+              the C calls release the GIL.  Results do not depend on it.
     Returns (stats, aug_pc, src) -- ``src[i]`` is the row of ``pc`` that produced output row i.
     """
     lasers = load_lasers() if lasers is None else lasers
@@ -297,9 +299,18 @@ def augment(pc, tables, beam_divergence, order, noise_floor=0.7, plane=None, las
     thr = thr_poly[0] * distances ** 2 + thr_poly[1] * distances + thr_poly[2]   # sim:469
     aug = pcs.copy()                                                    # sim:472
     diff_sum = 0
-    for ch in range(num_channels):                                      # sim:488-514
+
+    def one_channel(ch):
         mask = pcs[:, 4] == ch                                          # sim:80
-        d, out = process_single_channel(pcs[mask], tables[order[ch]], beam_divergence, lasers, ch)
+        return mask, process_single_channel(pcs[mask], tables[order[ch]], beam_divergence, lasers, ch)
+
+    if threads > 1:
+        from multiprocessing.pool import ThreadPool
+        with ThreadPool(threads) as pool:                               # sim:498-504
+            done = pool.map(one_channel, range(num_channels))
+    else:
+        done = map(one_channel, range(num_channels))                    # sim:488-514
+    for mask, (d, out) in done:                                         # channel order: the reference sums in this order (sim:510)
         diff_sum += d
         aug[mask] = out
     aug[:, 3] = np.round(aug[:, 3])                                     # sim:516
