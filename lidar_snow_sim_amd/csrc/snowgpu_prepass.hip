@@ -96,11 +96,16 @@ __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
     const T *rows = (const T *)a.rows;
     double v[3] = {0.0, 0.0, 0.0};
     double ymax = -INFINITY;
+    T rx[4], ry[4], rz[4], ri[4];                // all loads of the tile in flight before the first use
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const T *p = rows + (base + (r < n ? r : 0)) * 5;
+        rx[q] = p[0]; ry[q] = p[1]; rz[q] = p[2]; ri[q] = p[3];
+    }
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
         if (r >= n) continue;
-        const T *p = rows + (base + r) * 5;
-        const T x = p[0], y = p[1], z = p[2], inten = p[3];
+        const T x = rx[q], y = ry[q], z = rz[q], inten = ri[q];
         const double dot = ((double)x * w0 + (double)y * w1) + (double)z * w2;   // np.matmul(pc[:, :3], w)
         const double hog = dot + h;
         double gn = NAN, gd = 0.0, ga = 0.0;
@@ -117,7 +122,8 @@ __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
             v[0] += 1.0; v[1] += gd; v[2] += gn;
             ymax = fmax(ymax, gn);
         }
-        a.g_dist[base + r] = gd; a.g_norm[base + r] = gn; a.g_ang[base + r] = ga;
+        a.g_norm[base + r] = gn;                                         // NaN marks a non-ground row: range / angle are then never read
+        if (gn == gn) { a.g_dist[base + r] = gd; a.g_ang[base + r] = ga; }
     }
     __shared__ double sm[12];
     __shared__ double smax[4];
@@ -320,17 +326,40 @@ __global__ __launch_bounds__(PB) void k_pre_moments(PreArgs a)
     const PreFrame fr = a.fr[f];
     double v[2] = {0.0, 0.0};
     int32_t *hist = a.hist + (int64_t)f * HX * HY;
+    int key[4] = {-1, -1, -1, -1};
+    double gnv[4], gdv[4];                       // all loads of the tile in flight before the first use
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
-        if (r >= n) continue;
-        const double gn = a.g_norm[base + r];
+        gnv[q] = r < n ? a.g_norm[base + r] : NAN;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        gdv[q] = gnv[q] == gnv[q] ? a.g_dist[base + r] : 0.0;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const double gn = gnv[q];
         if (gn != gn) continue;
-        const double gd = a.g_dist[base + r];
+        const double gd = gdv[q];
         const double dx = gd - fr.xmean, dy = gn - fr.ymean;
         v[0] += dx * dx; v[1] += dx * dy;
         const int bx = hist_bin(gd, 10.0, 70.0, HX);                     // augmentation.py:232-233
         const int by = hist_bin(gn, 5.0, fr.ymax, HY);
-        if (bx >= 0 && by >= 0) atomicAdd(&hist[bx * HY + by], 1);
+        if (bx >= 0 && by >= 0) key[q] = bx * HY + by;
+    }
+    // Neighbouring rows are neighbouring azimuths of one laser: same range, similar intensity -- most lanes of a
+    // wave hit the same few bins, and same-address atomics serialise in L2.  So each distinct bin of the wave is
+    // counted by ballot and added once.
+    for (int q = 0; q < 4; ++q) {
+        int k = key[q];
+        unsigned long long todo = __ballot(k >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kl = __shfl(k, leader);
+            const unsigned long long same = __ballot(k == kl);
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[kl], (int)__popcll(same));
+            if (k == kl) k = -1;
+            todo &= ~same;
+        }
     }
     __shared__ double sm[8];
     block_sum<2>(v, sm);
@@ -431,13 +460,22 @@ __global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
     if (tile0 >= n) return;
     const PreFrame fr = a.fr[f];
     double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double gnv[4], gdv[4], gav[4];               // all loads of the tile in flight before the first use
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
-        if (r >= n) continue;
-        const double gn = a.g_norm[base + r];
+        gnv[q] = r < n ? a.g_norm[base + r] : NAN;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const bool g = gnv[q] == gnv[q];
+        gdv[q] = g ? a.g_dist[base + r] : 0.0;
+        gav[q] = g ? a.g_ang[base + r] : 0.0;
+    }
+    for (int q = 0; q < 4; ++q) {
+        const double gn = gnv[q];
         if (gn != gn) continue;
-        const double gd = a.g_dist[base + r];
-        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * cos(a.g_ang[base + r]);   // augmentation.py:252-253, simulation.py:462
+        const double gd = gdv[q];
+        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * cos(gav[q]);   // augmentation.py:252-253, simulation.py:462
         // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
         double a2;
         if constexpr (sizeof(T) == 4) { const float xf = (float)gd; a2 = (double)(xf * xf); }
