@@ -35,6 +35,7 @@
 #ifndef SNOWGPU_H
 #define SNOWGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -167,6 +168,18 @@ int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows,
  * returns the summed kernel time in milliseconds and the number of launches timed. */
 int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches);
 int snowgpu_profile_end(snowgpu_ctx *ctx, double *beam_kernel_ms, int *n_launches);
+
+/* ---- page-locked host buffers ------------------------------------------------------------------ */
+
+/*
+ * The host-pointer entries (snowgpu_augment_batch, snowgpu_wet_ground_batch, snowgpu_augment_wet_batch) accept any
+ * host memory, but only page-locked memory moves at PCIe speed and lets the copies of one context overlap the
+ * kernels of another.  snowgpu_host_alloc returns such a buffer (hipHostMalloc); read the frames into it and hand
+ * it in as `rows`, pass another one as `out_rows`.  The reference has no counterpart: its arrays never leave the host
+ * (precompute.py:78 np.fromfile -> :106 tofile).
+ */
+int snowgpu_host_alloc(snowgpu_ctx *ctx, size_t bytes, void **ptr);
+int snowgpu_host_free(snowgpu_ctx *ctx, void *ptr);
 
 /* ---- wet ground ---------------------------------------------------------------------------- */
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
-    "snowgpu_sample_table",
+    "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free",
 ]
 
 
@@ -82,6 +82,10 @@ def lib():
             L.snowgpu_profile_begin.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_end.restype = ctypes.c_int
             L.snowgpu_profile_end.argtypes = [vp, vp, vp]
+            L.snowgpu_host_alloc.restype = ctypes.c_int
+            L.snowgpu_host_alloc.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+            L.snowgpu_host_free.restype = ctypes.c_int
+            L.snowgpu_host_free.argtypes = [vp, vp]
             _lib = L
     return _lib
 
@@ -157,9 +161,25 @@ class Context:
             raise ValueError("a particle table is K x 3 (x, y, disk radius)")
         self._check(self._L.snowgpu_upload_table(self._h, int(table_id), _p(t), t.shape[0]))
 
+    def pinned_empty(self, shape, dtype):
+        """An uninitialised NumPy array in page-locked host memory (snowgpu_host_alloc); freed with the array."""
+        import weakref
+        dtype = np.dtype(dtype)
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        ptr = ctypes.c_void_p()
+        self._check(self._L.snowgpu_host_alloc(self._h, ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        L, h, addr = self._L, self._h, ptr.value
+        weakref.finalize(buf, lambda: L.snowgpu_host_free(h, ctypes.c_void_p(addr)))
+        return arr
+
     def augment_batch(self, rows, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None,
-                      noise_floor=0.7, perm=None, want_thr=False):
+                      noise_floor=0.7, perm=None, want_thr=False, out_rows=None, out_src=None):
         """rows: N_total x 5 (float32/float64), frame_offsets: n_frames + 1, table_ids: n_frames x n_lasers.
+        out_rows / out_src: optional caller-owned result buffers (at least N_total rows; pinned_empty() ones move at
+        PCIe speed and are not page-faulted in on every call).
 
         Returns (out_rows [N_total x 5, only the first counts[f] rows of each frame slot are valid],
                  out_src, counts, stats[n_frames x 3], thr_poly or None)."""
@@ -171,8 +191,15 @@ class Context:
         if tids.shape[1] != self.n_lasers:
             raise ValueError("table_ids must be n_frames x n_lasers")
         n = int(off[-1])
-        out_rows = np.empty((n, 5), rows.dtype)
-        out_src = np.empty(n, np.int32)
+        if out_rows is None:
+            out_rows = np.empty((n, 5), rows.dtype)
+        elif out_rows.dtype != rows.dtype or out_rows.ndim != 2 or out_rows.shape[1] != 5 or out_rows.shape[0] < n \
+                or not out_rows.flags.c_contiguous:
+            raise ValueError("out_rows must be a C-contiguous (>= N_total) x 5 array of the input dtype")
+        if out_src is None:
+            out_src = np.empty(n, np.int32)
+        elif out_src.dtype != np.int32 or out_src.ndim != 1 or out_src.shape[0] < n or not out_src.flags.c_contiguous:
+            raise ValueError("out_src must be a C-contiguous int32 array of >= N_total entries")
         counts = np.zeros(nf, np.int64)
         stats = np.zeros((nf, 3), np.int64)
         thr = None if thr_poly is None else np.ascontiguousarray(thr_poly, np.float64).reshape(nf, 3)

@@ -763,6 +763,24 @@ extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned
     return SNOWGPU_OK;
 }
 
+extern "C" int snowgpu_host_alloc(snowgpu_ctx *ctx, size_t bytes, void **ptr)
+{
+    if (!ctx || !ptr) return SNOWGPU_E_INVALID;
+    *ptr = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostMalloc(ptr, std::max<size_t>(bytes, 8), hipHostMallocPortable));
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_host_free(snowgpu_ctx *ctx, void *ptr)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (!ptr) return SNOWGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipHostFree(ptr));
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches)
 {
     if (!ctx || max_launches <= 0) return SNOWGPU_E_INVALID;

@@ -46,10 +46,63 @@ class Engine:
         self._tables = {}          # key -> table id
         self._next_id = 0
         self._lock = threading.Lock()
+        self.batch_lock = threading.RLock()   # one batch at a time per engine: the input staging buffer is reused
 
     @property
     def n_lasers(self):
         return len(self.lasers)
+
+    # ---- page-locked host buffers -----------------------------------------------------------------------------
+    # Host arrays cross PCIe at full speed only from page-locked memory, and a fresh NumPy array is page-faulted in
+    # while the copy runs.  So frames are staged in a reused page-locked input buffer, and results land in
+    # page-locked buffers that go back to a small pool when the arrays handed to the caller are garbage-collected
+    # (the caller still owns what it gets: nothing is overwritten while a result is alive).
+    PIN_LIMIT = 3 << 30          # bytes of result buffers that may be out with callers; beyond it: plain np.empty
+
+    def staging_in(self, n_rows, dtype):
+        """Reused page-locked n_rows x 5 input staging view (valid until the next call on this engine)."""
+        dtype = np.dtype(dtype)
+        need = int(n_rows) * 5 * dtype.itemsize
+        buf = getattr(self, "_pin_in", None)
+        if buf is None or buf.nbytes < need:
+            self._pin_in = buf = self.ctx.pinned_empty(max(need, 1 << 20) * 5 // 4, np.uint8)
+        return buf[:need].view(dtype).reshape(int(n_rows), 5)
+
+    def result_buffers(self, n_rows, dtype):
+        """(out_rows n x 5, out_src n) in page-locked memory from the pool, or pageable arrays past PIN_LIMIT."""
+        import ctypes
+        import weakref
+        dtype = np.dtype(dtype)
+        need = int(n_rows) * (5 * dtype.itemsize + 4)
+        if need == 0:
+            return np.empty((0, 5), dtype), np.empty(0, np.int32)
+        with self._lock:
+            pool = self.__dict__.setdefault("_pin_pool", [])
+            pick = None
+            for i, b in enumerate(pool):
+                if b.nbytes >= need and (pick is None or b.nbytes < pool[pick].nbytes):
+                    pick = i
+            base = pool.pop(pick) if pick is not None else None
+            if base is None:
+                out = self.__dict__.get("_pin_out", 0)
+                if out + need > self.PIN_LIMIT:
+                    return np.empty((int(n_rows), 5), dtype), np.empty(int(n_rows), np.int32)
+            self._pin_out = self.__dict__.get("_pin_out", 0) + (base.nbytes if base is not None else max(need, 1 << 20))
+        if base is None:
+            base = self.ctx.pinned_empty(max(need, 1 << 20), np.uint8)
+        # a fresh wrapper object per hand-out: when the caller's views of it die, the bytes return to the pool
+        lease = (ctypes.c_char * base.nbytes).from_address(base.ctypes.data)
+        weakref.finalize(lease, self._give_back, base)
+        flat = np.frombuffer(lease, np.uint8)
+        nb = int(n_rows) * 5 * dtype.itemsize
+        return flat[:nb].view(dtype).reshape(int(n_rows), 5), flat[nb:nb + 4 * int(n_rows)].view(np.int32)
+
+    def _give_back(self, base):
+        with self._lock:
+            self._pin_out = self.__dict__.get("_pin_out", 0) - base.nbytes
+            pool = self.__dict__.setdefault("_pin_pool", [])
+            if len(pool) < 4:
+                pool.append(base)
 
     def set_lasers(self, lasers):
         self.lasers = lasers

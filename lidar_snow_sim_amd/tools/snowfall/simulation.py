@@ -49,16 +49,6 @@ def _raise_like_reference(err: _native.SnowGPUError):
     raise err
 
 
-def _needs_host_perm(ch: np.ndarray) -> bool:
-    """The device counting sort handles integer channel values 0..255; anything else is sorted here."""
-    ci = ch.astype(np.int64, copy=False) if np.issubdtype(ch.dtype, np.integer) else None
-    if ci is None:
-        with np.errstate(invalid="ignore"):
-            ok = np.isfinite(ch) & (ch == np.floor(ch)) & (ch >= 0) & (ch <= 255)
-        return not bool(ok.all())
-    return False
-
-
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
                   thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0):
@@ -102,16 +92,28 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 polys.append(noise_threshold_poly(srt[:, :5], w, h, noise_floor))
     offsets = np.zeros(len(rows) + 1, np.int64)
     offsets[1:] = np.cumsum([r.shape[0] for r in rows])
-    flat = np.concatenate([r[:, :5] for r in rows]) if len(rows) > 1 else np.ascontiguousarray(rows[0][:, :5])
-    perm = None
-    if _needs_host_perm(flat[:, 4]):
-        perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
-    try:
-        out, src, counts, stats, _ = eng.ctx.augment_batch(
-            flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
-            plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm)
-    except _native.SnowGPUError as err:
-        _raise_like_reference(err)
+    with eng.batch_lock:
+        flat = eng.staging_in(int(offsets[-1]), dt)                              # page-locked: PCIe speed, no page faults
+        if len(rows) > 1:
+            np.concatenate([r[:, :5] for r in rows], out=flat)
+        else:
+            flat[...] = rows[0][:, :5]
+        out_rows, out_src = eng.result_buffers(int(offsets[-1]), dt)
+        # The device counting sort handles integer channel values 0..255 and reports anything else
+        # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
+        perm = None
+        for attempt in (0, 1):
+            try:
+                out, src, counts, stats, _ = eng.ctx.augment_batch(
+                    flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
+                    plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
+                    out_rows=out_rows, out_src=out_src)
+                break
+            except _native.SnowGPUError as err:
+                if attempt == 0 and err.code == _native.E_CHANNELS:
+                    perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
+                    continue
+                _raise_like_reference(err)
     results = []
     for i in range(len(rows)):
         a, n = int(offsets[i]), int(counts[i])

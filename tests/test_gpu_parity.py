@@ -548,3 +548,49 @@ def test_table_ordered_launch_equals_sorted_row_order(tables, monkeypatch):
         assert np.array_equal(s0[a:a + m], s1[a:a + m])
         assert o0[a:a + m].tobytes() == o1[a:a + m].tobytes()
     assert int(c0[1]) == 0 and int(c0[0]) > 0 and int(st0[:, 0].sum()) > 0
+
+
+def test_results_stay_valid_while_the_pool_recycles_buffers(eng, tables):
+    """Results live in page-locked buffers that return to a pool when the caller drops them: a later call must not
+    overwrite rows somebody still holds, and dropped buffers must be reused."""
+    import gc
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    fr = [synthetic_sweep(64, 128, seed=1020 + i, intensity="lambert") for i in range(3)]
+    kw = dict(particles=tl, orders=[list(range(64))] * 3, thr_polys=[[0.0, 0.01, 2.0]] * 3)
+    first = augment_batch(fr, "unused", bd, **kw)
+    snap = [a.copy() for _, a in first]
+    second = augment_batch(fr[::-1], "unused", bd, **kw)
+    for (_, a), s in zip(first, snap):
+        assert np.array_equal(a, s)
+    for (_, a), (_, b) in zip(first, second[::-1]):
+        assert np.array_equal(a, b)
+    addr = first[0][1].__array_interface__["data"][0]
+    del first, second, a, b
+    gc.collect()
+    again = augment_batch(fr, "unused", bd, **kw)
+    pool_addrs = {again[0][1].__array_interface__["data"][0]}
+    assert addr in pool_addrs or len(eng.__dict__.get("_pin_pool", [])) >= 1
+    for (_, a), s in zip(again, snap):
+        assert np.array_equal(a, s)
+
+
+def test_odd_channel_values_fall_back_to_a_host_permutation(eng, so, tables):
+    """Channel values the device counting sort does not take (non-integers, > 255, negative) make the library report
+    SNOWGPU_E_CHANNELS; the Python mirror then sorts on the host and runs the batch again.  Such rows are copied
+    through like any channel without a laser (Q5)."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    pc = synthetic_sweep(64, 96, seed=1031, intensity="lambert")
+    pc[5::37, 4] = 3.5
+    pc[7::41, 4] = 300.0
+    pc[11::43, 4] = -2.0
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    poly = [0.0, 0.01, 2.0]
+    (st, aug, src), = augment_batch([pc], "unused", bd, particles=tl, orders=[list(range(64))], thr_polys=[poly], return_src=True)
+    s0, a0, src0 = so.augment(pc, tl, bd, list(range(64)), thr_poly=np.array(poly))
+    assert tuple(int(v) for v in st) == tuple(int(v) for v in s0)
+    assert np.array_equal(src, src0) and np.array_equal(aug[:, 3:], a0[:, 3:])
