@@ -92,8 +92,9 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int64_t max_tiles_per_frame, void *stream);
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
-                       int n_las, int n_tables, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
+                       int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
                        int32_t *seg_frame, int32_t *seg_n, void *stream);
+int sg_beams_block(int lmax);
 int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
                        int32_t *count, int32_t cap, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);

@@ -442,13 +442,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->seg_pair, P); ENSURE(ctx, ctx->seg_blk, P + 1); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
     }
+    int tiers[4], n_tiers = 0;
+    choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
+    const int first_block = sg_beams_block(tiers[0]);
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     {
         int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, ctx->aux);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
         if (use_seg) {
-            e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(),
+            e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(), first_block,
                                    ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
         }
@@ -487,15 +490,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.phase_cycles = ctx->phase_cycles;
     ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);     // also the tiles of the overflow list builder
     ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
-    int tiers[4], n_tiers = 0;
-    choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
     // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
     int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
     if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
         a.seg_n = ctx->seg_n.p;
-        a.grid_blocks = (b.n_total + 255) / 256 + (int64_t)b.n_frames * 256;   // every non-empty pair wastes less than one block
+        a.grid_blocks = (b.n_total + first_block - 1) / first_block + (int64_t)b.n_frames * 256;   // every non-empty pair wastes less than one block
     }
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     for (int t = 0; t < n_tiers; ++t) {

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 // on the launch order.
 #define SG_SEG_MAXT 4096
 __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
-                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables,
+                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
                                                     int32_t *__restrict__ seg_pair, int32_t *__restrict__ seg_blk, int64_t *__restrict__ seg_start,
                                                     int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n)
 {
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
     // blocks per segment, exclusive prefix in segment order
     const int per2 = (n_seg + 1023) / 1024;
     int bsum = 0;
-    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) { int64_t st; bsum += (pair_rows(seg_pair[i], st) + SG_BLOCK - 1) / SG_BLOCK; }
+    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) { int64_t st; bsum += (pair_rows(seg_pair[i], st) + blk - 1) / blk; }
     sc[t] = bsum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { const int add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
         int64_t st;
         const int p = seg_pair[i], rows = pair_rows(p, st);
         seg_blk[i] = brun; seg_start[i] = st; seg_cnt[i] = rows; seg_frame[i] = p >> 8;
-        brun += (rows + SG_BLOCK - 1) / SG_BLOCK;
+        brun += (rows + blk - 1) / blk;
     }
     if (t == 1023) { seg_blk[n_seg] = sc[1023]; seg_n[0] = n_seg; seg_n[1] = sc[1023]; }
 }
@@ -633,6 +633,9 @@ static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st
 // lmax = per-beam list capacity of this pass: 4 (144 B of LDS per beam: 16 waves per CU), 16, 32 or 63 (the
 // hard cap).  Beams that exceed it are queued for the next pass.  With a->work_list set the grid covers
 // a->work_cap work items and idle blocks leave at once.
+// threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
+extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax == 32 ? 128 : 64); }
+
 extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -653,12 +656,12 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
 }
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
-                                  int n_las, int n_tables, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
-                                  int32_t *seg_frame, int32_t *seg_n, void *stream)
+                                  int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start,
+                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, void *stream)
 {
     if (n_tables > SG_SEG_MAXT) return -1;
     hipLaunchKernelGGL(k_seg_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las,
-                       n_tables, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
+                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
     SG_CHECK_LAUNCH();
     return 0;
 }
