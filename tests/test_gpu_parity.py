@@ -594,3 +594,50 @@ def test_odd_channel_values_fall_back_to_a_host_permutation(eng, so, tables):
     s0, a0, src0 = so.augment(pc, tl, bd, list(range(64)), thr_poly=np.array(poly))
     assert tuple(int(v) for v in st) == tuple(int(v) for v in s0)
     assert np.array_equal(src, src0) and np.array_equal(aug[:, 3:], a0[:, 3:])
+
+
+def test_full_size_batch_properties(eng, tables):
+    """BASELINE-sized sweeps (64 x 2048) in one batch, checked through properties that do not need the oracle:
+    batching invariance, run-to-run determinism, bookkeeping identities, untouched rows bit-identical to their source,
+    scattered points on the ray of their source and nearer than it."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    F, N = 8, 64 * 2048
+    frames = [synthetic_sweep(64, 2048, seed=1000 + f, intensity="lambert") for f in range(F)]
+    rows = np.concatenate(frames)
+    tl = _tables64(tables)
+    rng = np.random.default_rng(3)
+    tids = [eng.table_ids_from_arrays(tl, list(rng.permutation(64))) for _ in range(F)]
+    bd = float(np.degrees(3e-3))
+    planes = [[0.0, 0.0, -1.0, -1.7]] * F
+    off = np.arange(F + 1, dtype=np.int64) * N
+
+    def run(lo, hi):
+        o, s, c, st, _ = eng.ctx.augment_batch(rows[lo * N:hi * N], off[:hi - lo + 1], tids[lo:hi], bd, plane=planes[lo:hi])
+        return [(o[i * N:i * N + int(c[i])].copy(), s[i * N:i * N + int(c[i])].copy(), st[i].copy()) for i in range(hi - lo)]
+
+    whole = run(0, F)
+    again = run(0, F)
+    halves = run(0, F // 2) + run(F // 2, F)
+    n_moved = 0
+    for f in range(F):
+        o, s, st = whole[f]
+        for other in (again[f], halves[f]):
+            assert o.tobytes() == other[0].tobytes() and np.array_equal(s, other[1]) and np.array_equal(st, other[2])
+        assert int(st[1]) == N - o.shape[0]                                  # num_removed (simulation.py:522)
+        assert int(st[0]) == int((o[:, 4] == 1).sum())                       # num_attenuated (:525)
+        assert set(np.unique(o[:, 4])) <= {0.0, 1.0, 2.0}
+        src = frames[f][s]
+        assert np.all(np.diff(src[:, 4]) >= 0)                               # channel-sorted output order (:447)
+        same = o[:, 4] == 0
+        assert np.array_equal(o[same, :4], src[same, :4])
+        mv = o[:, 4] == 2
+        n_moved += int(mv.sum())
+        po, pi = o[mv, :3].astype(np.float64), src[mv, :3].astype(np.float64)
+        d_out, d_in = np.linalg.norm(po, axis=1), np.linalg.norm(pi, axis=1)
+        assert np.all(d_out < d_in)
+        cosang = np.einsum("ij,ij->i", po, pi) / (d_out * d_in)
+        # on the ray -- or on its mirror image: a beam whose only power comes from flakes nearer than 0.9 m (xsi = 0)
+        # has an all-zero power profile, argmax 0, d_max = -c tau / 2 and a negative scale (simulation.py:151-180)
+        assert np.all(np.abs(cosang) > 1 - 1e-6)
+        assert np.all((cosang > 0) | (np.abs(d_out - 299792458.0 * 1e-8 / 2) < 1e-5))
+    assert n_moved > 100
