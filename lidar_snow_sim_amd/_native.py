@@ -12,7 +12,7 @@ from pathlib import Path
 
 import numpy as np
 
-_LIB_PATH = Path(os.environ.get("SNOWGPU_LIB") or Path(__file__).resolve().parent / "libsnowgpu.so")   # override: timing experiments
+_LIB_PATH = Path(__file__).resolve().parent / "libsnowgpu.so"
 _lib = None
 _lock = threading.Lock()
 

@@ -18,9 +18,6 @@
 //     reference computes in the input dtype (range, beam azimuth, hard-target window) are float32.
 #pragma once
 #include "sg_math.h"
-#ifndef SG_ABLATE
-#define SG_ABLATE 0   /* > 0 only in timing experiments: phases are cut out and results are wrong */
-#endif
 
 template <typename T> struct SgReal;
 template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
@@ -100,9 +97,6 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
     int span = b_hi - b_lo;
     if (span < 0) span += nb;
-#if SG_ABLATE >= 3
-    span = -1;
-#endif
     const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
     const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
     const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
@@ -163,10 +157,6 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         }
     }
     if (out.overflow) return;
-#if SG_ABLATE >= 2
-    out.intensity += (double)L + ar + al + den_r + den_l;       // timing experiments only (scripts/ablate.sh)
-    return;
-#endif
     const unsigned long long ph1 = ph ? wall_clock64() : 0;
 
     // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         const T *row = (const T *)a.rows + src * 5;
         px = row[0]; py = row[1]; pz = row[2]; pint = row[3]; pch = row[4];
         ch = (int)pch;
-        simulated = ((T)ch == pch) && ch >= 0 && ch < n_las && SG_ABLATE < 4;   // simulation.py:80, :482 (Q5)
+        simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;            // simulation.py:80, :482 (Q5)
     }
     const unsigned long long tc0 = ph ? wall_clock64() : 0;
     SgBeamOut o;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     double best = 0.0;
     int k_best = 0;
     constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together (register budget of the first tier: 128)
-    if (o.has_power && SG_ABLATE < 1) {
+    if (o.has_power) {
         int st[2] = {0, 0};
         if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
         else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best, ph ? st : nullptr);
