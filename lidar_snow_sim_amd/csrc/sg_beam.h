@@ -137,10 +137,16 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                 const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
                                  || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
                                  || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
-                const double dist_r = fabs(((fx * ar + fy * br) + 0.0) / den_r);  // geometry.py:131-135
-                const double dist_l = fabs(((fx * al + fy * bl) + 0.0) / den_l);
-                const bool hit_r = (dist_r < fr) && sg_forward(theta_r, phi);     // :379-384
-                const bool hit_l = (dist_l < fr) && sg_forward(theta_l, phi);     // :379-385
+                // geometry.py:131-135: |a x + b y + 0| / sqrt(a^2 + b^2) < r.  The quotient is only compared, so the
+                // division is done only when the product form num < r * den cannot decide it: outside a band of
+                // 2^-48 around equality both forms agree whatever the rounding of the quotient.
+                const double num_r = fabs((fx * ar + fy * br) + 0.0), num_l = fabs((fx * al + fy * bl) + 0.0);
+                const double lim_r = fr * den_r, lim_l = fr * den_l;
+                bool near_r = num_r < lim_r, near_l = num_l < lim_l;
+                if (fabs(num_r - lim_r) <= lim_r * 3.6e-15) near_r = (num_r / den_r) < fr;
+                if (fabs(num_l - lim_l) <= lim_l * 3.6e-15) near_l = (num_l / den_l) < fr;
+                const bool hit_r = near_r && sg_forward(theta_r, phi);            // :379-384
+                const bool hit_l = near_l && sg_forward(theta_l, phi);            // :379-385
                 if (!(centre || hit_r || hit_l)) continue;      // :389
                 if (L == LMAX) { out.overflow = 1; break; }
                 const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26

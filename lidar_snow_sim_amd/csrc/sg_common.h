@@ -78,6 +78,7 @@ struct SgBeamArgs {
     const int32_t *seg_cnt;      // n_seg: rows
     const int32_t *seg_frame;    // n_seg
     const int32_t *seg_n;        // [0] = n_seg
+    const int32_t *seg_of_blk;   // grid_blocks: segment of block b (valid below seg_blk[n_seg])
     int64_t grid_blocks;         // host: blocks to launch in that mode (upper bound; surplus blocks leave at once)
     int32_t exact_math;          // 1: libm sin + true division in the power term (validation mode)
     unsigned long long *phase_cycles;   // optional [8]: per-wave cycle totals per phase (profiling builds of the call)
@@ -93,7 +94,7 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
-                       int32_t *seg_frame, int32_t *seg_n, void *stream);
+                       int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
                        int32_t *count, int32_t cap, void *stream);

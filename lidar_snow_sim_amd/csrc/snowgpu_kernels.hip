@@ -157,11 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         const int n_seg = a.seg_n[0];
         const int blk = (int)blockIdx.x;
         if (blk >= a.seg_blk[n_seg]) return;          // surplus block (the grid is an upper bound)
-        int lo = 0, hi = n_seg - 1;                   // last segment whose first block is <= blk
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (a.seg_blk[mid] <= blk) lo = mid; else hi = mid - 1;
-        }
+        const int lo = a.seg_of_blk[blk];             // one load instead of a 13-step dependent search per block
         const int off = (blk - a.seg_blk[lo]) * BLOCK + tid;
         seg_f = a.seg_frame[lo];
         if (off < a.seg_cnt[lo]) seg_g = a.seg_start[lo] + off;
@@ -332,7 +328,8 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
                                                     int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
                                                     int32_t *__restrict__ seg_pair, int32_t *__restrict__ seg_blk, int64_t *__restrict__ seg_start,
-                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n)
+                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n,
+                                                    int32_t *__restrict__ seg_of_blk)
 {
     __shared__ int hist[SG_SEG_MAXT + 1];
     __shared__ int sc[1024];
@@ -384,7 +381,9 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
         int64_t st;
         const int p = seg_pair[i], rows = pair_rows(p, st);
         seg_blk[i] = brun; seg_start[i] = st; seg_cnt[i] = rows; seg_frame[i] = p >> 8;
-        brun += (rows + blk - 1) / blk;
+        const int nb = (rows + blk - 1) / blk;
+        for (int q = 0; q < nb; ++q) seg_of_blk[brun + q] = i;
+        brun += nb;
     }
     if (t == 1023) { seg_blk[n_seg] = sc[1023]; seg_n[0] = n_seg; seg_n[1] = sc[1023]; }
 }
@@ -657,11 +656,11 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start,
-                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, void *stream)
+                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream)
 {
     if (n_tables > SG_SEG_MAXT) return -1;
     hipLaunchKernelGGL(k_seg_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las,
-                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
+                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n, seg_of_blk);
     SG_CHECK_LAUNCH();
     return 0;
 }
