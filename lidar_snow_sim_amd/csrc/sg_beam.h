@@ -54,7 +54,11 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 
 // Phases 1-2 and 3a for one beam (per lane).  Leaves the scatterer list in this lane's LDS column:
 // s_a1[t] amplitude, s_a2[t] packed (k1, k0), s_rho[t] range, t = 0 .. n_flakes (hard target last).
-template <typename T, int LMAX, int STRIDE>
+template <typename T, int LMAX, int STRIDE> __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2, double *s_rho, double *s_ratio, int tid, SgBeamOut &out);
+
+// DICT_ONLY: stop after phase 2 and leave the occlusion dict (s_rho[t], s_ratio[t], t = 0 .. n_flakes) in LDS --
+// the direct-mode pass then queues the beam for k_power instead of walking phase 3 with most lanes idle.
+template <typename T, int LMAX, int STRIDE, bool DICT_ONLY = false>
 __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, const SgTable tab,
                                         const SgLasers *__restrict__ las, const double *__restrict__ s_rgrid,
                                         double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
@@ -278,8 +282,27 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
         for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
     }
     if (n_dict == 1) return;                                    // :133 no snowflake in this beam -> label 0
+    if (ph && (tid & 63) == 0) {
+        atomicAdd(&ph[1], ph1 - ph0); atomicAdd(&ph[2], ph2 - ph1);
+        atomicAdd(&ph[6], (unsigned long long)L); atomicAdd(&ph[7], ph_cand);
+    }
+    if constexpr (DICT_ONLY) {
+        out.n_flakes = S;
+        out.has_power = 1;
+        return;
+    } else {
+        sg_beam_amp<T, LMAX, STRIDE>(d_t, S, channel, las, s_a1, s_a2, s_rho, s_ratio, tid, out);
+    }
+}
 
-    // ---- phase 3a (per lane): amplitude and bin window of every scatterer (simulation.py:137-146) --------
+// ---- phase 3a (per lane): amplitude and bin window of every scatterer (simulation.py:137-146) --------
+// In: s_rho[t], s_ratio[t] for t = 0 .. S (the hard target last, range d).  Out: s_a1[t] amplitude, s_a2[t] packed (k1, k0).
+template <typename T, int LMAX, int STRIDE>
+__device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2,
+                                            double *s_rho, double *s_ratio, int tid, SgBeamOut &out)
+{
+    constexpr bool F32 = SgReal<T>::is_f32;
+    const int n_dict = S + 1;
     const int ch = channel;
     const int max_i = las->max_i[ch];
     const double c_tau = 299792458.0 * 1e-8;                    // c * tau_h
@@ -317,10 +340,6 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     out.k_min = k_min;
     out.k_max = k_max;
     out.has_power = 1;
-    if (ph && (tid & 63) == 0) {
-        atomicAdd(&ph[1], ph1 - ph0); atomicAdd(&ph[2], ph2 - ph1); atomicAdd(&ph[3], wall_clock64() - ph2);
-        atomicAdd(&ph[6], (unsigned long long)L); atomicAdd(&ph[7], ph_cand);
-    }
 }
 
 // sin(u) for u in [-0.3, 3.5]: one step of reduction against pi (hi + lo) and the odd Taylor polynomial to

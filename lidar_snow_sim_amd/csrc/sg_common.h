@@ -80,6 +80,13 @@ struct SgBeamArgs {
     const int32_t *seg_n;        // [0] = n_seg
     const int32_t *seg_of_blk;   // grid_blocks: segment of block b (valid below seg_blk[n_seg])
     int64_t grid_blocks;         // host: blocks to launch in that mode (upper bound; surplus blocks leave at once)
+    // First-pass split: the direct-mode pass stops at the occlusion dict and queues the beams that met a flake;
+    // k_power runs the received-power phase over the queue with every lane busy.
+    const int32_t *pq_list;      // sorted positions of the queued beams, ascending (built from the keep flags 16 + n_flakes)
+    double *pq_dict;             // pq_stride doubles per sorted position: (range, ratio) x (n_flakes + 1), the hard target last
+    int32_t *pq_count;
+    int32_t pq_cap;
+    int32_t pq_stride;           // 2 * (first-pass capacity + 1)
     int32_t exact_math;          // 1: libm sin + true division in the power term (validation mode)
     unsigned long long *phase_cycles;   // optional [8]: per-wave cycle totals per phase (profiling builds of the call)
 };
@@ -92,12 +99,13 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, void *stream);
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
                        int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                       int32_t *count, int32_t cap, void *stream);
+                       int32_t *count, int32_t cap, int lo, int hi, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,

@@ -60,7 +60,9 @@ struct snowgpu_ctx {
     int32_t *d_status = nullptr;      // 4 ints
     // scratch shared by every batch
     DevBuf<int32_t> tile_hist, tile_base, ovf_list, ovf_list2, perm, ctile_cnt, ctile_base, table_ids, out_src;
-    DevBuf<int32_t> seg_pair, seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk;
+    DevBuf<int32_t> seg_pair, seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk, pq_list, ptile_cnt, ptile_base;
+    DevBuf<double> pq_dict;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     DevBuf<int64_t> seg_start;
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     DevBuf<uint16_t> rank;
@@ -141,6 +143,8 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 8));
@@ -165,7 +169,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->ovf_list2.release(); ctx->perm.release();
-    ctx->seg_pair.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release();
+    ctx->seg_pair.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->pq_list.release(); ctx->ptile_cnt.release(); ctx->ptile_base.release(); ctx->pq_dict.release();
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
@@ -176,6 +180,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_fork2) (void)hipEventDestroy(ctx->ev_fork2);
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -500,6 +506,17 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.grid_blocks = (b.n_total + first_block - 1) / first_block + (int64_t)b.n_frames * 256;   // every non-empty pair wastes less than one block
     }
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    {   // queue of the first pass: one slot per row would always do; slots carry (range, ratio) x (capacity + 1)
+        const size_t stride = 2 * ((size_t)tiers[0] + 1);
+        if (n * stride * sizeof(double) > ((size_t)32 << 30))
+            return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the received-power queue of this table density: split it");
+        if (b.n_frames >= (1 << 25)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");
+        ENSURE(ctx, ctx->pq_list, n);
+        ENSURE(ctx, ctx->ptile_cnt, (n + SG_TILE - 1) / SG_TILE + 1);
+        ENSURE(ctx, ctx->ptile_base, (n + SG_TILE - 1) / SG_TILE + 1);
+        ENSURE(ctx, ctx->pq_dict, n * stride);
+        a.pq_list = ctx->pq_list.p; a.pq_dict = ctx->pq_dict.p; a.pq_count = b.status + 6; a.pq_cap = (int32_t)n; a.pq_stride = (int32_t)stride;
+    }
     for (int t = 0; t < n_tiers; ++t) {
         if (t > 0) a.seg_blk = nullptr;
         a.work_list = t == 0 ? nullptr : lists[(t - 1) & 1];
@@ -512,8 +529,18 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
         if (timed && t == 0) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
         int e = sg_launch_beams(&a, b.dtype, tiers[t], st);
+        if (!e && t == 0) {
+            // the first pass queued the beams that met a flake: their received-power phase runs on the side stream,
+            // next to the (latency-bound, mostly empty) later capacity tiers
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork2, st));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork2, 0));
+            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 6, (int32_t)n, 16, 255, ctx->aux);
+            if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], ctx->aux);
+            HIPCHK(ctx, hipEventRecord(ctx->ev_join2, ctx->aux));
+        }
         if (!e && t == 0 && n_tiers > 1)   // the first pass flags its overflowed beams; build the ordered list from the flags
-            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, st);
+            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, 2, 2, st);
+        if (t == n_tiers - 1) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
         if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     }

@@ -128,6 +128,32 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
     }
 }
 
+// ---- frame-level epilogue of one row (simulation.py:516-520): rounded intensity, label, keep flag ----------------
+template <typename T>
+__device__ __forceinline__ void sg_store_row(const SgBeamArgs &a, int64_t g, int f, T px, T py, T pz, const SgBeamOut &o)
+{
+    T *orow = (T *)a.tmp_rows + g * 5;
+    T oi;
+    if constexpr (SgReal<T>::is_f32) {
+        orow[0] = (float)o.x; orow[1] = (float)o.y; orow[2] = (float)o.z;   // :178-180 store float64 -> float32
+        oi = rintf((float)o.intensity);                                     // :516 np.round (half to even)
+    } else {
+        orow[0] = o.x; orow[1] = o.y; orow[2] = o.z;
+        oi = rint(o.intensity);
+    }
+    orow[3] = oi;
+    orow[4] = (T)o.label;
+    // per-point threshold on the ORIGINAL range (:465, :469): p0 * d^2 + p1 * d + p2, d^2 in the row dtype
+    T dd;
+    if constexpr (SgReal<T>::is_f32) dd = sqrtf((px * px + py * py) + pz * pz);
+    else dd = sqrt((px * px + py * py) + pz * pz);
+    const T dd2 = dd * dd;
+    const double *p = a.thr_poly + (int64_t)f * 3;
+    const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
+    const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
+    a.keep[g] = keep ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The per-beam kernel.  Dynamic LDS: range grid (1230 doubles) + four per-thread lists.
 // Second launch-bound argument = waves per SIMD the register allocator must leave room for: the 4-entry tier
@@ -213,8 +239,8 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
             double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
             double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-            sg_beam<T, LMAX, BLOCK>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
-                                    s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph, a.exact_math != 0);
+            sg_beam<T, LMAX, BLOCK, !LIST>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
+                                           s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph, a.exact_math != 0);
             if (o.overflow) {
                 write_row = false;                        // a later pass with a longer list writes this row
                 o.has_power = 0;
@@ -251,12 +277,24 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         }
     }
     const unsigned long long tc1 = ph ? wall_clock64() : 0;
-    // ---- phase 3b: received power (per lane; s_ratio is dead after phase 3a and carries the work lists) ----
-    // (Packing the beams that reach this phase onto the first lanes of the block, so that whole waves skip it, was
-    // tried: three block barriers cost what the idle lanes did.)
     double best = 0.0;
     int k_best = 0;
-    constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together (register budget of the first tier: 128)
+    if constexpr (!LIST) {
+        // ---- direct mode: hand the beams that met a flake, with their occlusion dicts, to k_power ----------------
+        // Only a fraction of the beams gets here; walking phase 3 in place would keep most lanes of every wave idle.
+        // No queue counter: the beam is flagged (keep[g] = 16 + n_flakes), its dict goes to the slot of its own sorted
+        // position, and k_ovf_* build the list in sorted-row order -- no atomics, and the lanes of a k_power wave stay
+        // neighbours (one frame, one channel).
+        if (o.has_power) {
+            write_row = false;                                // k_power writes this row
+            a.keep[g] = (uint8_t)(16 + o.n_flakes);
+            double *dd = a.pq_dict + g * a.pq_stride;
+            for (int t = 0; t <= o.n_flakes; ++t) { dd[2 * t] = s_rho[t * BLOCK + tid]; dd[2 * t + 1] = s_ratio[t * BLOCK + tid]; }
+            o.has_power = 0;
+        }
+    } else {
+    // ---- phase 3b: received power (per lane; s_ratio is dead after phase 3a and carries the work lists) ----
+    constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together
     if (o.has_power) {
         int st[2] = {0, 0};
         if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
@@ -276,9 +314,10 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
             }
         }
     }
+    }
     if (ph && (tid & 63) == 0) {
         atomicAdd(&ph[0], tc0 - tcs);                  // frame lookup + row load
-        atomicAdd(&ph[4], wall_clock64() - tc1);       // phase 3b
+        atomicAdd(&ph[4], wall_clock64() - tc1);       // phase 3b (list mode) / queueing (direct mode)
         atomicAdd(&ph[5], 1ull);                       // waves
     }
     if (o.has_power) sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
@@ -294,28 +333,82 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         }
     }
     if (!write_row) continue;
-    // ---- frame-level epilogue (simulation.py:516-520) -------------------------------------------
-    T *orow = (T *)a.tmp_rows + g * 5;
-    T oi;
-    if constexpr (SgReal<T>::is_f32) {
-        orow[0] = (float)o.x; orow[1] = (float)o.y; orow[2] = (float)o.z;   // :178-180 store float64 -> float32
-        oi = rintf((float)o.intensity);                                     // :516 np.round (half to even)
-    } else {
-        orow[0] = o.x; orow[1] = o.y; orow[2] = o.z;
-        oi = rint(o.intensity);
-    }
-    orow[3] = oi;
-    orow[4] = (T)o.label;
-    // per-point threshold on the ORIGINAL range (:465, :469): p0 * d^2 + p1 * d + p2, d^2 in the row dtype
-    T dd;
-    if constexpr (SgReal<T>::is_f32) dd = sqrtf((px * px + py * py) + pz * pz);
-    else dd = sqrt((px * px + py * py) + pz * pz);
-    const T dd2 = dd * dd;
-    const double *p = a.thr_poly + (int64_t)f * 3;
-    const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
-    const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
-    a.keep[g] = keep ? 1 : 0;
+    sg_store_row<T>(a, g, f, px, py, pz, o);
     } while (LIST && (chunk += stride) < work_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Received power for the beams the direct-mode pass queued: one thread per queue slot, every lane busy.
+// Phase 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision), row epilogue.
+template <typename T, int LMAX, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_power(SgBeamArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *s_a1 = (double *)smem;
+    double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
+    double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
+    double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
+    const int tid = threadIdx.x;
+    int n = *a.pq_count;
+    if (n > a.pq_cap) n = a.pq_cap;
+    const int64_t slot = (int64_t)blockIdx.x * BLOCK + tid;
+    if ((int64_t)blockIdx.x * BLOCK >= n) return;     // surplus block (the grid covers every row)
+    const bool live = slot < n;
+    int64_t g = 0;
+    int f = 0, S = 0, ch = 0;
+    T px = 0, py = 0, pz = 0, pch = 0;
+    if (live) {
+        g = a.pq_list[slot];
+        S = (int)a.keep[g] - 16;
+        if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
+            const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
+            int fe = (int)((float)gu * a.inv_uniform_rows);
+            if (fe >= a.n_frames) fe = a.n_frames - 1;
+            while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
+            while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
+            f = fe;
+        } else f = sg_find_frame(a.frame_off, a.n_frames, g);
+        const int64_t src = a.frame_off[f] + a.perm[g];
+        const T *row = (const T *)a.rows + src * 5;
+        px = row[0]; py = row[1]; pz = row[2]; pch = row[4];
+        ch = (int)pch;
+        const double *dd = a.pq_dict + g * a.pq_stride;
+        for (int t = 0; t <= S; ++t) { s_rho[t * BLOCK + tid] = dd[2 * t]; s_ratio[t * BLOCK + tid] = dd[2 * t + 1]; }
+    }
+    SgBeamOut o;
+    o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = 0.0; o.label = 0.0;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S; o.k_min = 0; o.k_max = 0;
+    double best = 0.0;
+    int k_best = 0;
+    if (live) {
+        T d_t;
+        if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);    // simulation.py:89
+        else d_t = sqrt((px * px + py * py) + pz * pz);
+        sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, tid, o);
+        if (o.range_error) {
+            atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+            atomicCAS(&a.status[1], -1, (int32_t)g);
+        }
+        constexpr int NB = LMAX <= 4 ? 4 : 8;
+        if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
+        else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
+        sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
+    }
+    {   // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame (same-address atomics from every
+        // lane would serialise in L2); the list is in sorted-row order, so a wave rarely holds more than one frame
+        long long d2 = live ? (long long)o.diff2 : 0;
+        unsigned long long todo = __ballot(live && d2 != 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int fl = __shfl(f, leader);
+            const bool mine = live && f == fl;
+            long long part = mine ? d2 : 0;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+            if ((tid & 63) == leader && part != 0) atomicAdd(&a.diff2[fl], (unsigned long long)part);
+            todo &= ~__ballot(mine);
+        }
+    }
+    if (live) sg_store_row<T>(a, g, f, px, py, pz, o);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -389,17 +482,18 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered overflow list of the first pass: positions g with keep[g] == 2, ascending (count / scan / scatter
-// over tiles of SG_TILE positions).
-__global__ __launch_bounds__(SG_BLOCK) void k_ovf_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt)
+// Ordered lists of the first pass: positions g with lo <= keep[g] <= hi, ascending (count / scan / scatter over
+// tiles of SG_TILE positions).  keep[g] == 2: overflowed beams for the next capacity tier; 16 + n_flakes: beams with
+// an occlusion dict for k_power.
+__global__ __launch_bounds__(SG_BLOCK) void k_ovf_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt, int lo, int hi)
 {
     const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
     int c = 0;
     if (g0 + 3 < n_total) {
         const uint32_t v = *(const uint32_t *)(keep + g0);
-        c = ((v & 0xff) == 2) + (((v >> 8) & 0xff) == 2) + (((v >> 16) & 0xff) == 2) + ((v >> 24) == 2);
+        for (int q = 0; q < 4; ++q) { const int b = (int)((v >> (8 * q)) & 0xff); c += (b >= lo && b <= hi); }
     } else {
-        for (int q = 0; q < 4; ++q) if (g0 + q < n_total && keep[g0 + q] == 2) ++c;
+        for (int q = 0; q < 4; ++q) if (g0 + q < n_total) { const int b = keep[g0 + q]; c += (b >= lo && b <= hi); }
     }
     __shared__ int s[SG_BLOCK / 64];
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
@@ -430,12 +524,12 @@ __global__ __launch_bounds__(1024) void k_ovf_scan(const int32_t *__restrict__ t
 }
 
 __global__ __launch_bounds__(SG_BLOCK) void k_ovf_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
-                                                          int32_t *__restrict__ list, int32_t cap)
+                                                          int32_t *__restrict__ list, int32_t cap, int lo, int hi)
 {
     const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
     bool f[4];
     int c = 0;
-    for (int q = 0; q < 4; ++q) { f[q] = g0 + q < n_total && keep[g0 + q] == 2; c += f[q]; }
+    for (int q = 0; q < 4; ++q) { const int b = g0 + q < n_total ? (int)keep[g0 + q] : -1; f[q] = b >= lo && b <= hi; c += f[q]; }
     // exclusive prefix of c over the block: wave scan + wave totals
     int inc = c;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
@@ -632,6 +726,41 @@ static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st
 // lmax = per-beam list capacity of this pass: 4 (144 B of LDS per beam: 16 waves per CU), 16, 32 or 63 (the
 // hard cap).  Beams that exceed it are queued for the next pass.  With a->work_list set the grid covers
 // a->work_cap work items and idle blocks leave at once.
+template <typename T, int LMAX, int BLOCK>
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_power<T, LMAX, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    }
+    const unsigned blocks = (unsigned)((a->n_total + BLOCK - 1) / BLOCK);     // upper bound: surplus blocks leave at once
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL((k_power<T, LMAX, BLOCK>), dim3(blocks), dim3(BLOCK), lds, st, *a);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+// the received-power kernel for the queue a direct-mode pass of capacity lmax filled
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        if (lmax == 4) return launch_power_t<float, 4, 256>(a, st);
+        if (lmax == 8) return launch_power_t<float, 8, 64>(a, st);
+        if (lmax == 16) return launch_power_t<float, 16, 64>(a, st);
+        return launch_power_t<float, SG_LCAP, 64>(a, st);
+    }
+    if (lmax == 4) return launch_power_t<double, 4, 256>(a, st);
+    if (lmax == 8) return launch_power_t<double, 8, 64>(a, st);
+    if (lmax == 16) return launch_power_t<double, 16, 64>(a, st);
+    return launch_power_t<double, SG_LCAP, 64>(a, st);
+}
+
 // threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
 extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax == 32 ? 128 : 64); }
 
@@ -666,16 +795,16 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
 }
 
 extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                                  int32_t *count, int32_t cap, void *stream)
+                                  int32_t *count, int32_t cap, int lo, int hi, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_ovf_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt);
+    hipLaunchKernelGGL(k_ovf_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt, lo, hi);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ovf_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, tiles, count);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ovf_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap);
+    hipLaunchKernelGGL(k_ovf_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap, lo, hi);
     SG_CHECK_LAUNCH();
     return 0;
 }
