@@ -56,7 +56,6 @@ struct SgBeamArgs {
     const SgLasers *las;
     const double *rgrid;         // SG_RBINS
     double beam_div_deg;
-    const double *thr_poly;      // n_frames x 3
     void *tmp_rows;              // channel-sorted, un-compacted result rows
     uint8_t *keep;               // per sorted row
     int32_t *status;             // [0] error code, [1] first offending sorted row, [2] overflow beams
@@ -102,12 +101,12 @@ int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
-                       int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream);
+                       int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int64_t grid_blocks, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
                        int32_t *count, int32_t cap, int lo, int hi, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
-int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
+int sg_launch_compact(const void *tmp_rows, int dtype, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, int64_t max_tiles_per_frame,

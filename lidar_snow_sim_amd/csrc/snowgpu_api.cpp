@@ -46,6 +46,8 @@ template <typename T> struct DevBuf {
 struct snowgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux2 = nullptr;           // side stream of the noise-threshold prepass (only the compaction needs its result)
+    hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;
     hipStream_t aux = nullptr;            // side stream: launch-order bookkeeping that only needs the sort, next to the prepass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
@@ -141,6 +143,9 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork0, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join0, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming));
@@ -182,6 +187,9 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_fork2) (void)hipEventDestroy(ctx->ev_fork2);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->ev_fork0) (void)hipEventDestroy(ctx->ev_fork0);
+    if (ctx->ev_join0) (void)hipEventDestroy(ctx->ev_join0);
+    if (ctx->aux2) (void)hipStreamDestroy(ctx->aux2);
     if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -423,6 +431,27 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         HIPCHK(ctx, hipMemsetAsync(b.out_stats, 0, sizeof(int64_t) * 3 * (size_t)b.n_frames, st));
         return SNOWGPU_OK;
     }
+    // 0. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial.  Only the compaction
+    // (the noise-floor decision) needs its result, so it runs on its own stream next to the sort and the per-beam
+    // kernels: bandwidth-bound reductions beside latency-bound scans.
+    const double *thr = b.thr_poly;
+    bool pre_forked = false;
+    if (!thr) {
+        if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
+        ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux2, ctx->ev_fork0, 0));
+        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
+                               b.noise_floor, ctx->thr_poly.p, b.status, ctx->aux2);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+        thr = ctx->thr_poly.p;
+        if (b.out_thr_poly)
+            HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, ctx->aux2));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join0, ctx->aux2));
+        pre_forked = true;
+    } else if (b.out_thr_poly) {
+        HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
+    }
     // 1. channel sort (simulation.py:447)
     const int32_t *perm = b.perm;
     if (!perm) {
@@ -459,26 +488,17 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
         if (use_seg) {
             e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(), first_block,
-                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->seg_of_blk.p, ctx->aux);
+                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->seg_of_blk.p,
+                                   (b.n_total + first_block - 1) / first_block + (int64_t)b.n_frames * 256, ctx->aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
         }
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
-    // 2. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial
-    const double *thr = b.thr_poly;
-    if (!thr) {
-        if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
-        ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
-        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
-                               b.noise_floor, ctx->thr_poly.p, b.status, st);
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
-        thr = ctx->thr_poly.p;
-    }
-    if (b.out_thr_poly)
-        HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
     // 3. beams
     ENSURE(ctx, ctx->rows_tmp, n * 5 * esz);
     ENSURE(ctx, ctx->keep, n);
+    // flag bytes of the first pass (2: overflowed, 16 + n_flakes: queued for k_power): nothing stale may be left in them
+    HIPCHK(ctx, hipMemsetAsync(ctx->keep.p, 0, n, st));
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
     const int32_t ovf_cap = (int32_t)std::min<size_t>(n, (size_t)1 << 24);
     ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
@@ -490,7 +510,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
     a.frame_tables = ctx->frame_tables.p;
-    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.thr_poly = thr; a.tmp_rows = ctx->rows_tmp.p;
+    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.tmp_rows = ctx->rows_tmp.p;
     a.keep = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
@@ -546,7 +566,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     }
     int e = 0;
     // 4. round + noise-floor filter + compaction + stats (simulation.py:516-530)
-    e = sg_launch_compact(ctx->rows_tmp.p, b.dtype, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+    if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
+    e = sg_launch_compact(ctx->rows_tmp.p, b.dtype, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
                           ctx->diff2.p, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));

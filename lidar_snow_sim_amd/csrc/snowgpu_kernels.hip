@@ -128,7 +128,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
     }
 }
 
-// ---- frame-level epilogue of one row (simulation.py:516-520): rounded intensity, label, keep flag ----------------
+// ---- frame-level epilogue of one row (simulation.py:516): rounded intensity, label ------------------------------
 template <typename T>
 __device__ __forceinline__ void sg_store_row(const SgBeamArgs &a, int64_t g, int f, T px, T py, T pz, const SgBeamOut &o)
 {
@@ -143,15 +143,10 @@ __device__ __forceinline__ void sg_store_row(const SgBeamArgs &a, int64_t g, int
     }
     orow[3] = oi;
     orow[4] = (T)o.label;
-    // per-point threshold on the ORIGINAL range (:465, :469): p0 * d^2 + p1 * d + p2, d^2 in the row dtype
-    T dd;
-    if constexpr (SgReal<T>::is_f32) dd = sqrtf((px * px + py * py) + pz * pz);
-    else dd = sqrt((px * px + py * py) + pz * pz);
-    const T dd2 = dd * dd;
-    const double *p = a.thr_poly + (int64_t)f * 3;
-    const double thr = (p[0] * (double)dd2 + p[1] * (double)dd) + p[2];
-    const bool keep = (o.label == 2.0) || ((double)oi > thr);               // :518-520
-    a.keep[g] = keep ? 1 : 0;
+    (void)f; (void)px; (void)py; (void)pz;
+    // The noise-floor decision (:518-520) is taken by k_compact_count: rows that are not scattered keep their
+    // coordinates, so the original range is still in the row -- and the per-beam kernels do not have to wait for the
+    // threshold polynomial of the prepass.
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -421,8 +416,7 @@ __global__ __launch_bounds__(BLOCK) void k_power(SgBeamArgs a)
 __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
                                                     int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
                                                     int32_t *__restrict__ seg_pair, int32_t *__restrict__ seg_blk, int64_t *__restrict__ seg_start,
-                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n,
-                                                    int32_t *__restrict__ seg_of_blk)
+                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n)
 {
     __shared__ int hist[SG_SEG_MAXT + 1];
     __shared__ int sc[1024];
@@ -474,11 +468,23 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
         int64_t st;
         const int p = seg_pair[i], rows = pair_rows(p, st);
         seg_blk[i] = brun; seg_start[i] = st; seg_cnt[i] = rows; seg_frame[i] = p >> 8;
-        const int nb = (rows + blk - 1) / blk;
-        for (int q = 0; q < nb; ++q) seg_of_blk[brun + q] = i;
-        brun += nb;
+        brun += (rows + blk - 1) / blk;
     }
     if (t == 1023) { seg_blk[n_seg] = sc[1023]; seg_n[0] = n_seg; seg_n[1] = sc[1023]; }
+}
+
+// block -> segment table (one load per block in k_beams instead of a dependent binary search)
+__global__ __launch_bounds__(256) void k_seg_fill(const int32_t *__restrict__ seg_blk, const int32_t *__restrict__ seg_n, int32_t *__restrict__ seg_of_blk)
+{
+    const int n_seg = seg_n[0];
+    const int blk = blockIdx.x * 256 + threadIdx.x;
+    if (n_seg <= 0 || blk >= seg_blk[n_seg]) return;
+    int lo = 0, hi = n_seg - 1;                       // last segment whose first block is <= blk
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_blk[mid] <= blk) lo = mid; else hi = mid - 1;
+    }
+    seg_of_blk[blk] = lo;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,18 +551,32 @@ __global__ __launch_bounds__(SG_BLOCK) void k_ovf_scatter(const uint8_t *__restr
 
 // ------------------------------------------------------------------------------------------------
 // Stable compaction of kept rows, per frame.
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const uint8_t *__restrict__ keep,
-                                                            const int64_t *__restrict__ frame_off,
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ tmp_rows, const double *__restrict__ thr_poly,
+                                                            uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
                                                             int32_t *__restrict__ tile_cnt, int64_t max_tiles)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
+    const double p0 = thr_poly[(int64_t)f * 3], p1 = thr_poly[(int64_t)f * 3 + 1], p2 = thr_poly[(int64_t)f * 3 + 2];
     int c = 0;
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
-        if (r < n && keep[base + r]) ++c;
+        if (r >= n) continue;
+        // keep = (label == 2) | (intensity > p0 d^2 + p1 d + p2), d the ORIGINAL range, d^2 in the row dtype
+        // (simulation.py:465, :469, :518-520); rows with label != 2 still hold their original coordinates
+        const T *row = tmp_rows + (base + r) * 5;
+        const T x = row[0], y = row[1], z = row[2], oi = row[3], lab = row[4];
+        T dd;
+        if constexpr (sizeof(T) == 4) dd = sqrtf((x * x + y * y) + z * z);
+        else dd = sqrt((x * x + y * y) + z * z);
+        const T dd2 = dd * dd;
+        const double thr = (p0 * (double)dd2 + p1 * (double)dd) + p2;
+        const bool k = (lab == (T)2) || ((double)oi > thr);
+        keep[base + r] = k ? 1 : 0;
+        c += k;
     }
     __shared__ int s[4];
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
@@ -785,11 +805,14 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start,
-                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream)
+                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int64_t grid_blocks,
+                                  void *stream)
 {
     if (n_tables > SG_SEG_MAXT) return -1;
     hipLaunchKernelGGL(k_seg_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las,
-                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n, seg_of_blk);
+                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)((grid_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_blk, seg_n, seg_of_blk);
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -809,7 +832,7 @@ extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t 
     return 0;
 }
 
-extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t *keep, const int32_t *perm,
+extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                                  int64_t *out_stats, const unsigned long long *diff2, int64_t max_tiles, void *stream)
@@ -817,7 +840,8 @@ extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const uint8_t 
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
-    hipLaunchKernelGGL(k_compact_count, grid, dim3(SG_BLOCK), 0, st, keep, frame_off, tile_cnt, max_tiles);
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)tmp_rows, thr_poly, keep, frame_off, tile_cnt, max_tiles);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)tmp_rows, thr_poly, keep, frame_off, tile_cnt, max_tiles);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
