@@ -554,12 +554,15 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             // next to the (latency-bound, mostly empty) later capacity tiers
             HIPCHK(ctx, hipEventRecord(ctx->ev_fork2, st));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork2, 0));
-            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 6, (int32_t)n, 16, 255, ctx->aux);
+            // two runs of the list, each in sorted-row order: beams with one flake (most of them), then the rest -- the
+            // loops of k_power run S + 1 times, and a wave is as slow as its longest lane
+            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, nullptr, b.status + 7, (int32_t)n, 16, 17, ctx->aux);
+            if (!e) e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 7, b.status + 6, (int32_t)n, 18, 255, ctx->aux);
             if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], ctx->aux);
             HIPCHK(ctx, hipEventRecord(ctx->ev_join2, ctx->aux));
         }
         if (!e && t == 0 && n_tiers > 1)   // the first pass flags its overflowed beams; build the ordered list from the flags
-            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, 2, 2, st);
+            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], nullptr, b.status + 2, ovf_cap, 2, 2, st);
         if (t == n_tiers - 1) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
         if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));

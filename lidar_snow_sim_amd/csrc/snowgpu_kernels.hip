@@ -509,10 +509,11 @@ __global__ __launch_bounds__(SG_BLOCK) void k_ovf_count(const uint8_t *__restric
 }
 
 __global__ __launch_bounds__(1024) void k_ovf_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int64_t tiles,
-                                                   int32_t *__restrict__ count_out)
+                                                   const int32_t *__restrict__ base_in, int32_t *__restrict__ count_out)
 {
     __shared__ int s[1024];
     const int t = threadIdx.x;
+    const int first = base_in ? *base_in : 0;         // the list continues one that is already there
     const int64_t per = (tiles + 1023) / 1024, b0 = t * per, b1 = b0 + per < tiles ? b0 + per : tiles;
     int sum = 0;
     for (int64_t i = b0; i < b1; ++i) sum += tile_cnt[i];
@@ -524,9 +525,9 @@ __global__ __launch_bounds__(1024) void k_ovf_scan(const int32_t *__restrict__ t
         s[t] += add;
         __syncthreads();
     }
-    int run = s[t] - sum;
+    int run = first + s[t] - sum;
     for (int64_t i = b0; i < b1; ++i) { tile_base[i] = run; run += tile_cnt[i]; }
-    if (t == 1023) *count_out = s[t];
+    if (t == 1023) *count_out = first + s[t];
 }
 
 __global__ __launch_bounds__(SG_BLOCK) void k_ovf_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
@@ -818,14 +819,14 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
 }
 
 extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                                  int32_t *count, int32_t cap, int lo, int hi, void *stream)
+                                  const int32_t *base_in, int32_t *count, int32_t cap, int lo, int hi, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
     if (tiles == 0) return 0;
     hipLaunchKernelGGL(k_ovf_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt, lo, hi);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ovf_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, tiles, count);
+    hipLaunchKernelGGL(k_ovf_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, tiles, base_in, count);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_ovf_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap, lo, hi);
     SG_CHECK_LAUNCH();
