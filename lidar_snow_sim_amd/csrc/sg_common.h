@@ -103,8 +103,8 @@ int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *ti
                        int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
                        int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int64_t grid_blocks, void *stream);
 int sg_beams_block(int lmax);
-int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                       const int32_t *base_in, int32_t *count, int32_t cap, int lo, int hi, void *stream);
+int sg_launch_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *count, int32_t cap,
+                   int lo1, int hi1, int lo2, int hi2, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 int sg_launch_compact(const void *tmp_rows, int dtype, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,

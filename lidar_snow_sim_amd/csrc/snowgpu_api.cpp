@@ -515,8 +515,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
     a.phase_cycles = ctx->phase_cycles;
-    ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);     // also the tiles of the overflow list builder
-    ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
+    ENSURE(ctx, ctx->ctile_cnt, 2 * ((size_t)b.n_frames * (size_t)max_tiles + 1));     // also the tiles of the overflow list builder
+    ENSURE(ctx, ctx->ctile_base, 2 * ((size_t)b.n_frames * (size_t)max_tiles + 1));
     // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
     // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
     int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
@@ -532,8 +532,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the received-power queue of this table density: split it");
         if (b.n_frames >= (1 << 25)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");
         ENSURE(ctx, ctx->pq_list, n);
-        ENSURE(ctx, ctx->ptile_cnt, (n + SG_TILE - 1) / SG_TILE + 1);
-        ENSURE(ctx, ctx->ptile_base, (n + SG_TILE - 1) / SG_TILE + 1);
+        ENSURE(ctx, ctx->ptile_cnt, 2 * ((n + SG_TILE - 1) / SG_TILE + 1));
+        ENSURE(ctx, ctx->ptile_base, 2 * ((n + SG_TILE - 1) / SG_TILE + 1));
         ENSURE(ctx, ctx->pq_dict, n * stride);
         a.pq_list = ctx->pq_list.p; a.pq_dict = ctx->pq_dict.p; a.pq_count = b.status + 6; a.pq_cap = (int32_t)n; a.pq_stride = (int32_t)stride;
     }
@@ -556,13 +556,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork2, 0));
             // two runs of the list, each in sorted-row order: beams with one flake (most of them), then the rest -- the
             // loops of k_power run S + 1 times, and a wave is as slow as its longest lane
-            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, nullptr, b.status + 7, (int32_t)n, 16, 17, ctx->aux);
-            if (!e) e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 7, b.status + 6, (int32_t)n, 18, 255, ctx->aux);
+            e = sg_launch_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 6, (int32_t)n, 16, 17, 18, 255,
+                               ctx->aux);
             if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], ctx->aux);
             HIPCHK(ctx, hipEventRecord(ctx->ev_join2, ctx->aux));
         }
         if (!e && t == 0 && n_tiers > 1)   // the first pass flags its overflowed beams; build the ordered list from the flags
-            e = sg_launch_ovf_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], nullptr, b.status + 2, ovf_cap, 2, 2, st);
+            e = sg_launch_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, 2, 2, 1, 0, st);
         if (t == n_tiers - 1) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
         if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));

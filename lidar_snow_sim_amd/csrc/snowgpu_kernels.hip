@@ -488,66 +488,89 @@ __global__ __launch_bounds__(256) void k_seg_fill(const int32_t *__restrict__ se
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered lists of the first pass: positions g with lo <= keep[g] <= hi, ascending (count / scan / scatter over
-// tiles of SG_TILE positions).  keep[g] == 2: overflowed beams for the next capacity tier; 16 + n_flakes: beams with
-// an occlusion dict for k_power.
-__global__ __launch_bounds__(SG_BLOCK) void k_ovf_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt, int lo, int hi)
+// Ordered lists of the first pass, built from the flag bytes: positions g with keep[g] in class 1 = [lo1, hi1], ascending,
+// followed by those in class 2 = [lo2, hi2], ascending (lo2 > hi2: no second class).  keep[g] == 2: overflowed beams
+// for the next capacity tier; 16 + n_flakes: beams with an occlusion dict for k_power (one flake first, then the rest).
+// Three kernels over tiles of SG_TILE positions: count, one-block scan, scatter.  (Folding the scan into the last
+// block of the count kernel was tried: the device-scope fence it needs writes back the L2 of the block's XCD, and
+// 16 000 of those cost more than the launch they save.)
+__global__ __launch_bounds__(SG_BLOCK) void k_list_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt,
+                                                         int lo1, int hi1, int lo2, int hi2)
 {
-    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
-    int c = 0;
-    if (g0 + 3 < n_total) {
-        const uint32_t v = *(const uint32_t *)(keep + g0);
-        for (int q = 0; q < 4; ++q) { const int b = (int)((v >> (8 * q)) & 0xff); c += (b >= lo && b <= hi); }
-    } else {
-        for (int q = 0; q < 4; ++q) if (g0 + q < n_total) { const int b = keep[g0 + q]; c += (b >= lo && b <= hi); }
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
+    int c1 = 0, c2 = 0;
+    uint32_t v = 0;
+    if (g0 + 3 < n_total) v = *(const uint32_t *)(keep + g0);
+    else for (int q = 0; q < 4; ++q) if (g0 + q < n_total) v |= (uint32_t)keep[g0 + q] << (8 * q);
+    for (int q = 0; q < 4; ++q) {
+        const int b = g0 + q < n_total ? (int)((v >> (8 * q)) & 0xff) : -1;
+        c1 += (b >= lo1 && b <= hi1);
+        c2 += (b >= lo2 && b <= hi2);
     }
-    __shared__ int s[SG_BLOCK / 64];
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __shared__ int s1[SG_BLOCK / 64], s2[SG_BLOCK / 64];
+    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); }
+    if ((tid & 63) == 0) { s1[tid >> 6] = c1; s2[tid >> 6] = c2; }
     __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < SG_BLOCK / 64; ++w) t += s[w]; tile_cnt[blockIdx.x] = t; }
+    if (tid == 0) {
+        int t1 = 0, t2 = 0;
+        for (int w = 0; w < SG_BLOCK / 64; ++w) { t1 += s1[w]; t2 += s2[w]; }
+        tile_cnt[2 * blockIdx.x] = t1; tile_cnt[2 * blockIdx.x + 1] = t2;
+    }
 }
 
-__global__ __launch_bounds__(1024) void k_ovf_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int64_t tiles,
-                                                   const int32_t *__restrict__ base_in, int32_t *__restrict__ count_out)
+__global__ __launch_bounds__(1024) void k_list_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int tiles,
+                                                    int32_t *__restrict__ count_out)
 {
-    __shared__ int s[1024];
-    const int t = threadIdx.x;
-    const int first = base_in ? *base_in : 0;         // the list continues one that is already there
-    const int64_t per = (tiles + 1023) / 1024, b0 = t * per, b1 = b0 + per < tiles ? b0 + per : tiles;
-    int sum = 0;
-    for (int64_t i = b0; i < b1; ++i) sum += tile_cnt[i];
-    s[t] = sum;
+    __shared__ int s1[1024], s2[1024];
+    const int tid = threadIdx.x;
+    const int per = (tiles + 1023) / 1024, b0 = tid * per, b1 = b0 + per < tiles ? b0 + per : tiles;
+    int sum1 = 0, sum2 = 0;
+    for (int i = b0; i < b1; ++i) { sum1 += tile_cnt[2 * i]; sum2 += tile_cnt[2 * i + 1]; }
+    s1[tid] = sum1; s2[tid] = sum2;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        const int add = t >= d ? s[t - d] : 0;
+        const int a1 = tid >= d ? s1[tid - d] : 0, a2 = tid >= d ? s2[tid - d] : 0;
         __syncthreads();
-        s[t] += add;
+        s1[tid] += a1; s2[tid] += a2;
         __syncthreads();
     }
-    int run = first + s[t] - sum;
-    for (int64_t i = b0; i < b1; ++i) { tile_base[i] = run; run += tile_cnt[i]; }
-    if (t == 1023) *count_out = first + s[t];
+    const int total1 = s1[1023], total2 = s2[1023];
+    int run1 = s1[tid] - sum1, run2 = total1 + s2[tid] - sum2;      // class 2 follows class 1 in the list
+    for (int i = b0; i < b1; ++i) {
+        tile_base[2 * i] = run1; tile_base[2 * i + 1] = run2;
+        run1 += tile_cnt[2 * i]; run2 += tile_cnt[2 * i + 1];
+    }
+    if (tid == 0) *count_out = total1 + total2;
 }
 
-__global__ __launch_bounds__(SG_BLOCK) void k_ovf_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
-                                                          int32_t *__restrict__ list, int32_t cap, int lo, int hi)
+__global__ __launch_bounds__(SG_BLOCK) void k_list_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
+                                                           int32_t *__restrict__ list, int32_t cap, int lo1, int hi1, int lo2, int hi2)
 {
-    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)threadIdx.x * 4;
-    bool f[4];
-    int c = 0;
-    for (int q = 0; q < 4; ++q) { const int b = g0 + q < n_total ? (int)keep[g0 + q] : -1; f[q] = b >= lo && b <= hi; c += f[q]; }
-    // exclusive prefix of c over the block: wave scan + wave totals
-    int inc = c;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
-    __shared__ int s[SG_BLOCK / 64];
-    if ((threadIdx.x & 63) == 63) s[threadIdx.x >> 6] = inc;
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
+    int cls[4];
+    int c1 = 0, c2 = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int b = g0 + q < n_total ? (int)keep[g0 + q] : -1;
+        cls[q] = (b >= lo1 && b <= hi1) ? 1 : ((b >= lo2 && b <= hi2) ? 2 : 0);
+        c1 += cls[q] == 1; c2 += cls[q] == 2;
+    }
+    // exclusive prefixes of c1, c2 over the block: wave scan + wave totals
+    int i1 = c1, i2 = c2;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v1 = __shfl_up(i1, o), v2 = __shfl_up(i2, o);
+        if ((tid & 63) >= o) { i1 += v1; i2 += v2; }
+    }
+    __shared__ int s1[SG_BLOCK / 64], s2[SG_BLOCK / 64];
+    if ((tid & 63) == 63) { s1[tid >> 6] = i1; s2[tid >> 6] = i2; }
     __syncthreads();
-    int base = tile_base[blockIdx.x];
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s[w];
-    int slot = base + inc - c;
-    for (int q = 0; q < 4; ++q)
-        if (f[q]) { if (slot < cap) list[slot] = (int32_t)(g0 + q); ++slot; }
+    int slot1 = tile_base[2 * blockIdx.x] + i1 - c1, slot2 = tile_base[2 * blockIdx.x + 1] + i2 - c2;
+    for (int w = 0; w < (tid >> 6); ++w) { slot1 += s1[w]; slot2 += s2[w]; }
+    for (int q = 0; q < 4; ++q) {
+        if (cls[q] == 1) { if (slot1 < cap) list[slot1] = (int32_t)(g0 + q); ++slot1; }
+        else if (cls[q] == 2) { if (slot2 < cap) list[slot2] = (int32_t)(g0 + q); ++slot2; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -818,17 +841,17 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
     return 0;
 }
 
-extern "C" int sg_launch_ovf_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                                  const int32_t *base_in, int32_t *count, int32_t cap, int lo, int hi, void *stream)
+extern "C" int sg_launch_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *count,
+                              int32_t cap, int lo1, int hi1, int lo2, int hi2, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_ovf_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt, lo, hi);
+    hipLaunchKernelGGL(k_list_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt, lo1, hi1, lo2, hi2);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ovf_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, tiles, base_in, count);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, (int)tiles, count);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_ovf_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap, lo, hi);
+    hipLaunchKernelGGL(k_list_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap, lo1, hi1, lo2, hi2);
     SG_CHECK_LAUNCH();
     return 0;
 }
