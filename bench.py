@@ -190,7 +190,7 @@ def main():
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "kernel": "k_beams<float,LMAX,BLOCK> (capacity tiers 4/8/16/63, launched back to back)", "avg_launch_ms": avg_ms, "launches": n_launch,
+                         "kernel": "per-beam kernels of one step: k_beams<float,LMAX,BLOCK,LIST> (capacity tiers 4/8/16/63), k_power and the k_list_* builders between them, one HIP event pair around the region", "avg_launch_ms": avg_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "note": "40 B/point + 24 B per flake per channel per frame (tables counted, 251.3 B/point)"},
         }
