@@ -641,3 +641,36 @@ def test_full_size_batch_properties(eng, tables):
         assert np.all(np.abs(cosang) > 1 - 1e-6)
         assert np.all((cosang > 0) | (np.abs(d_out - 299792458.0 * 1e-8 / 2) < 1e-5))
     assert n_moved > 100
+
+
+@pytest.mark.parametrize("extra,first_tier", [(60000, 16), (110000, 63)])
+def test_dense_tables_start_at_a_higher_capacity_tier(so, tables, extra, first_tier):
+    """The first capacity tier follows the table size (choose_tiers): 16 entries above ~50 k flakes per line, the
+    63-entry tier above ~84 k.  Those direct-mode passes, their 64-thread blocks, segment order and k_power<16/63> are
+    exercised by padding a table with flakes beyond every target (they never intersect a beam, but they count)."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    rng = np.random.default_rng(extra)
+    base = tables["t"][0]
+    rho = rng.uniform(150.0, 200.0, extra)
+    phi = rng.uniform(0, 2 * np.pi, extra)
+    far = np.column_stack((rho * np.cos(phi), rho * np.sin(phi), np.full(extra, 1e-3)))
+    big = np.concatenate((base, far))
+    tl = [big if i % 2 == 0 else tables["t"][1] for i in range(64)]
+    full = synthetic_sweep(64, 2048, seed=1040, intensity="lambert").reshape(64, 2048, 5)
+    pc = full[:, ::24, :].reshape(-1, 5).copy()                 # 86 rows per channel: two 64-row blocks per segment
+    order = list(range(64))
+    bd = float(np.degrees(3e-3))
+    poly = [0.0, 0.01, 2.0]
+    eng2 = engine.Engine(0)                                     # own context: max table size drives the tier choice
+    try:
+        tids = eng2.table_ids_from_arrays(tl, order)
+        out, src, counts, stats, _ = eng2.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, thr_poly=[poly])
+    finally:
+        eng2.ctx.close()
+    s0, a0, src0 = so.augment(pc, tl, bd, order, thr_poly=np.array(poly), threads=8)
+    n = int(counts[0])
+    assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in s0)
+    assert np.array_equal(src[:n], src0) and np.array_equal(out[:n, 3:], a0[:, 3:])
+    np.testing.assert_allclose(out[:n, :3], a0[:, :3], rtol=1e-6, atol=0)
+    assert (a0[:, 4] == 1).sum() > 50
