@@ -150,9 +150,10 @@ __device__ __forceinline__ void sg_store_row(const SgBeamArgs &a, int64_t g, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// The per-beam kernel.  Dynamic LDS: range grid (1230 doubles) + four per-thread lists.
-// Second launch-bound argument = waves per SIMD the register allocator must leave room for: the 4-entry tier
-// keeps 16 waves per CU resident (its LDS footprint allows exactly that), later tiers are LDS-limited anyway.
+// The per-beam kernel.  Dynamic LDS: four per-thread lists of LMAX + 1 float64 entries, strided by the block size.
+//   LIST = false  direct mode, the first pass over all rows: phases 1-2 (scan, occlusion dict); beams that met a
+//                 flake are handed to k_power through their dict and a flag byte, overflowed beams are flagged
+//   LIST = true   a later capacity tier over a device-side list: phases 1-3 in place
 template <typename T, int LMAX, int BLOCK, bool LIST>
 __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
 {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         }
     }
     if (!LIST && LMAX < SG_LCAP) {
-        // Direct mode: an overflowed beam is only flagged (keep[g] = 2); k_ovf_* then build the next pass's list in
+        // Direct mode: an overflowed beam is only flagged (keep[g] = 2); k_list_* then build the next pass's list in
         // sorted-row order, so that the lanes of its waves stay neighbours in channel and azimuth -- one table, nearby
         // bins.  (An atomic queue hands a wave 64 beams of as many channels, i.e. tables: every load a miss.)
         if (o.overflow) a.keep[g] = 2;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
         // ---- direct mode: hand the beams that met a flake, with their occlusion dicts, to k_power ----------------
         // Only a fraction of the beams gets here; walking phase 3 in place would keep most lanes of every wave idle.
         // No queue counter: the beam is flagged (keep[g] = 16 + n_flakes), its dict goes to the slot of its own sorted
-        // position, and k_ovf_* build the list in sorted-row order -- no atomics, and the lanes of a k_power wave stay
+        // position, and k_list_* build the list in sorted-row order -- no atomics, and the lanes of a k_power wave stay
         // neighbours (one frame, one channel).
         if (o.has_power) {
             write_row = false;                                // k_power writes this row
@@ -767,9 +768,6 @@ static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st
                         : launch_beams_tl<T, LMAX, BLOCK, false>(a, n_threads, st);
 }
 
-// lmax = per-beam list capacity of this pass: 4 (144 B of LDS per beam: 16 waves per CU), 16, 32 or 63 (the
-// hard cap).  Beams that exceed it are queued for the next pass.  With a->work_list set the grid covers
-// a->work_cap work items and idle blocks leave at once.
 template <typename T, int LMAX, int BLOCK>
 static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
 {
@@ -808,6 +806,9 @@ extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *s
 // threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
 extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax == 32 ? 128 : 64); }
 
+// lmax = per-beam list capacity of this pass: 4 (160 B of LDS per beam: 16 waves per CU), 8, 16 or 63 (the hard
+// cap).  Beams that exceed it are flagged (direct mode) or queued (list mode) for the next pass.  With a->work_list
+// set, a chip-sized grid strides over the list, whose length is only known on the device.
 extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
