@@ -92,6 +92,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restric
     const int32_t *h = tile_hist + (int64_t)f * max_tiles * 256;
     int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
     int total = 0;
+#pragma unroll 8                                  // eight loads in flight: the loop is a chain of global-load latencies otherwise
     for (int64_t t = 0; t < tiles; ++t) total += h[t * 256 + v];
     __shared__ int s[256];
     s[v] = total;
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restric
         __syncthreads();
     }
     int run = s[v] - total;
+#pragma unroll 8
     for (int64_t t = 0; t < tiles; ++t) { b[t * 256 + v] = run; run += h[t * 256 + v]; }
 }
 
@@ -441,6 +443,7 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
     };
     for (int k = t; k <= NT; k += 1024) hist[k] = 0;
     __syncthreads();
+#pragma unroll 4                                  // several (tile_base, table id) loads in flight per thread
     for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) atomicAdd(&hist[pair_key(p)], 1); }
     __syncthreads();
     // exclusive scan of hist[0 .. NT]
@@ -454,6 +457,7 @@ __global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ 
     int run = sc[t] - sum;
     for (int k = t * per; k < (t + 1) * per && k <= NT; ++k) { const int h = hist[k]; hist[k] = run; run += h; }
     __syncthreads();
+#pragma unroll 4
     for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) seg_pair[atomicAdd(&hist[pair_key(p)], 1)] = p; }
     __threadfence_block();
     __syncthreads();
