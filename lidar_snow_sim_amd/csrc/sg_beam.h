@@ -32,7 +32,6 @@ struct SgBeamOut {
     double diff2;     // 2 * (0.9 * max_intensity - new_i) for label 1, else 0
     int has_power;    // >= 1 flake kept: the received-power phase has work for this beam
     int n_flakes;     // scatterers before the hard target (the target sits at index n_flakes)
-    int k_min, k_max; // union of the scatterers' bin windows
 };
 
 __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
@@ -69,7 +68,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     const unsigned long long ph0 = ph ? wall_clock64() : 0;
     unsigned long long ph_cand = 0;
     constexpr bool F32 = SgReal<T>::is_f32;
-    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.k_min = 0; out.k_max = 0;
+    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0;
     out.x = (double)px; out.y = (double)py; out.z = (double)pz; out.intensity = (double)pint; out.label = 0.0;
 
     // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
@@ -309,7 +308,6 @@ __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgL
     const double beta_0 = 1 * 1e-6 / SG_PI;                     // :108
     const double i_snow = 0.9 * max_i;                          // :140
     const double ca_p0 = i_snow / beta_0;                       // :141 (also used for the hard target, Q1)
-    int k_min = SG_RBINS, k_max = 0;
     for (int t = 0; t < n_dict; ++t) {
         int k0, k1;
         double amp;
@@ -333,12 +331,8 @@ __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgL
         if (k0 < 0) k0 = 0;
         SG_A1(t) = amp;
         SG_A2(t) = __hiloint2double(k1, k0);
-        if (k0 < k_min) k_min = k0;
-        if (k1 > k_max) k_max = k1;
     }
     out.n_flakes = S;
-    out.k_min = k_min;
-    out.k_max = k_max;
     out.has_power = 1;
 }
 

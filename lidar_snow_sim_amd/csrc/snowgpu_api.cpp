@@ -795,7 +795,6 @@ extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
     return SNOWGPU_OK;
 }
 
-extern "C" int sg_set_phase_dbg(unsigned long long *p);   // snowgpu_kernels.hip
 
 // Experiments only (not in snowgpu.h): per-phase cycle counters of the per-beam kernel.
 extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned long long *out8)
@@ -805,11 +804,9 @@ extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned
     if (enable) {
         if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 64 * sizeof(unsigned long long)));
         HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 64 * sizeof(unsigned long long)));
-        sg_set_phase_dbg(ctx->phase_cycles);
     } else if (ctx->phase_cycles) {
         HIPCHK(ctx, hipDeviceSynchronize());
         if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        sg_set_phase_dbg(nullptr);
         (void)hipFree(ctx->phase_cycles);
         ctx->phase_cycles = nullptr;
     }

@@ -1,8 +1,13 @@
 // snowgpu_kernels.hip -- gfx950 kernels of the snowfall-augmentation engine and their launch wrappers.
 //
-//   k_sort_*     stable counting sort of every frame's rows by channel         (simulation.py:447)
-//   k_beams      one thread per beam: occlusion + received power + decision    (simulation.py:50-424)
-//   k_compact_*  round, noise-floor filter, stable stream compaction, stats    (simulation.py:516-530)
+//   k_sort_*     stable counting sort of every frame's rows by channel                      (simulation.py:447)
+//   k_seg_*      launch order of the first pass: (table, frame, channel) segments
+//   k_beams      one thread per beam: candidate scan + occlusion dict; the first pass over all rows stops there and
+//                hands beams with flakes to k_power, the later capacity tiers run received power + decision in place
+//                                                                                           (simulation.py:50-424)
+//   k_list_*     ordered work lists from flag bytes (overflowed beams, beams for k_power)
+//   k_power      received power on the 10 cm grid, first maximum, attenuate-or-scatter        (simulation.py:135-188)
+//   k_compact_*  noise-floor filter, stable stream compaction, stats                         (simulation.py:516-530)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see lidar_snow_sim_amd/build.py).
 #include <hip/hip_runtime.h>
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     const unsigned long long tc0 = ph ? wall_clock64() : 0;
     SgBeamOut o;
     o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = (double)pint; o.label = (double)pch;
-    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.k_min = 0; o.k_max = 0;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0;
     bool write_row = live;
     if (simulated) {
         const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(BLOCK) void k_power(SgBeamArgs a)
     }
     SgBeamOut o;
     o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = 0.0; o.label = 0.0;
-    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S; o.k_min = 0; o.k_max = 0;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S;
     double best = 0.0;
     int k_best = 0;
     if (live) {
@@ -710,7 +715,6 @@ extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, con
     return (int)hipGetLastError();
 }
 
-extern "C" int sg_set_phase_dbg(unsigned long long *) { return 0; }
 
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (C linkage, called from snowgpu_api.cpp)
