@@ -290,3 +290,118 @@ def test_own_tangent_is_within_two_ulp_of_libm():
     ref = np.array([math.tan(t) for t in th])
     ulp = np.abs(sg_tan(th) - ref) / np.spacing(np.abs(ref))
     assert ulp.max() <= 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The pruning rules of the received-power phase (csrc/sg_beam.h: sg_lane_power), restated in NumPy
+# and checked against the full profile the reference computes: the first maximum must lie in a listed group.
+def _power_profile(r, ratio, ca_p0_beta0):
+    """simulation.py:135-149 for one beam: scatterers in dict order (range r, ratio), float64 throughout."""
+    c_tau = 299792458.0 * 1e-8
+    R = np.round(np.linspace(0, 120 + c_tau, 1230), 2)
+    prof = np.zeros(1230)
+    amps, wins = [], []
+    for rj, rt in zip(r, ratio):
+        xsi = 0.0 if rj <= 0.9 else (1.0 if rj >= 1.0 else (1 / (1.0 - 0.9)) * rj + (0 - (1 / (1.0 - 0.9)) * 0.9))
+        amp = ((ca_p0_beta0 * rt) * xsi) / (rj * rj)
+        k0, k1 = int(np.ceil(rj * 10)), int(np.floor((rj + c_tau) * 10) + 1)
+        for k in range(k0, min(k1, 1230)):
+            prof[k] += amp * np.sin((np.pi * (R[k] - rj)) / c_tau) ** 2
+        amps.append(amp)
+        wins.append((k0, min(k1, 1230)))
+    return prof, np.array(amps), wins, R
+
+
+def _listed_bins(r, amps, wins, nb):
+    """Stage A of sg_lane_power with best = 0: the bins it puts on the work list."""
+    c_tau = 299792458.0 * 1e-8
+    step = (120 + c_tau) / 1229
+    need = 0.9966 * amps.max()
+    listed = set()
+    n = len(r)
+    for t in range(n):
+        A = amps[t]
+        if not A > 0.0:
+            continue
+        k0, k1 = wins[t]
+        oth, lo_trim, hi_trim = 0.0, k0, k1
+
+        def visit(j):
+            nonlocal oth, lo_trim, hi_trim
+            q0, q1 = wins[j]
+            if amps[j] > A or (amps[j] == A and j < t):
+                if q0 <= k0:
+                    lo_trim = max(lo_trim, q1)
+                elif q1 >= k1:
+                    hi_trim = min(hi_trim, q0)
+            else:
+                oth += amps[j]
+        j = t - 1
+        while j >= 0 and wins[j][1] > k0:
+            visit(j)
+            j -= 1
+        j = t + 1
+        while j < n and wins[j][0] < k1:
+            visit(j)
+            j += 1
+        if (A + oth) * (1.0 + 1e-9) < need:
+            continue
+        q = (need * (1.0 - 1e-9) - oth * (1.0 + 1e-9)) / A
+        ka, kb = k0, k1 - 1
+        if q >= 0.5:
+            om = 1.0 - q if q < 1.0 else 0.0
+            delta = float(np.float32(np.sqrt(np.float32(1.26 * om)))) * (1.0 + 1e-6) + 1e-6
+            Rc = r[t] + c_tau / 2
+            D = delta * (c_tau / np.pi) + 0.006
+            ka = max(ka, int(np.floor((Rc - D) / step)))
+            kb = min(kb, int(np.ceil((Rc + D) / step)))
+        ka, kb = max(ka, lo_trim), min(kb, hi_trim - 1)
+        g = ka
+        while g <= kb:
+            listed.update(range(g, g + nb))
+            g += nb
+    return listed
+
+
+@pytest.mark.parametrize("nb", [4, 8])
+def test_power_phase_pruning_never_drops_the_first_maximum(nb):
+    rng = np.random.default_rng(2024 + nb)
+    ca = 0.9 * 255
+    cases = 0
+    for trial in range(4000):
+        s = int(rng.integers(1, 9))
+        d = float(rng.uniform(1.2, 115.0))
+        kind = trial % 5
+        if kind == 0:      # flakes anywhere in front of the target
+            r = np.sort(rng.uniform(0.5, d, s))
+        elif kind == 1:    # a cluster right in front of the target: overlapping windows
+            r = np.sort(d - rng.uniform(0.0, 2.9, s))
+        elif kind == 2:    # nested windows with nearly equal ranges
+            r = np.sort(rng.uniform(0.95, d, 1) + rng.uniform(0, 0.3, s))
+        elif kind == 3:    # near the sensor, around the xsi ramp
+            r = np.sort(rng.uniform(0.85, 1.6, s))
+        else:              # evenly spaced at about one window length
+            r = np.sort(rng.uniform(1.0, 3.0) + np.arange(s) * rng.uniform(2.5, 3.5))
+        r = r[(r > 0.3) & (r < d)]
+        if r.size == 0:
+            continue
+        ratio = rng.uniform(0.001, 0.4, r.size)
+        if trial % 7 == 0:
+            ratio[:] = ratio[0]                       # equal ratios: amplitudes differ only through 1 / r^2
+        tgt = float(np.clip(1.0 - ratio.sum(), 0.0, 1.0)) if trial % 3 else 0.0
+        rr = np.append(r, d)
+        rt = np.append(ratio, tgt)
+        if trial % 11 == 0 and rr.size >= 2:          # two scatterers with exactly the same amplitude
+            rt[1] = rt[0] * (rr[1] / rr[0]) ** 2
+        prof, amps, wins, R = _power_profile(rr, rt, ca)
+        if amps.max() <= 0:
+            continue
+        k_star = int(np.argmax(prof))                 # first maximum (simulation.py:151)
+        listed = _listed_bins(rr, amps, wins, nb)
+        assert k_star in listed, (trial, rr, rt, k_star)
+        # and nothing outside the listed bins ties with it
+        out = np.ones(1230, bool)
+        out[[k for k in listed if 0 <= k < 1230]] = False
+        assert not np.any(prof[out] >= prof[k_star]), (trial, rr, rt)
+        cases += 1
+    assert cases > 3200
