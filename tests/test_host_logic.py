@@ -405,3 +405,87 @@ def test_power_phase_pruning_never_drops_the_first_maximum(nb):
         assert not np.any(prof[out] >= prof[k_star]), (trial, rr, rt)
         cases += 1
     assert cases > 3200
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The single slot walk of phase 2 (csrc/sg_beam.h), restated in NumPy, against the oracle's compute_occlusion_dict
+# (itself pinned to the reference by the L2 golden vectors): same keys, bit-identical ratios.
+def _single_walk_dict(right, left, intervals, d, beam_div_deg):
+    a1 = intervals[:, 0].copy()
+    a2 = intervals[:, 1].copy()
+    rho = intervals[:, 2]
+    L = len(a1)
+    ra, la = right, left
+    if ra > la:                                                  # simulation.py:260-263
+        ra = ra - 2 * np.pi
+        sw = a1 > a2
+        a1[sw] = a1[sw] - 2 * np.pi
+    delta = np.radians(beam_div_deg)
+    pts = np.concatenate(([ra, la], a1, a2))
+    e, e_max = pts.min(), pts.max()
+    slots = [[] for _ in range(L)]                               # widths per owner, in walk order
+    free = []
+    while e < e_max:
+        own = -1
+        nxt = e_max
+        for q in range(L):
+            if own < 0 and a1[q] <= e < a2[q]:
+                own = q
+            for v in (a1[q], a2[q]):
+                if e < v < nxt:
+                    nxt = v
+        for v in (ra, la):
+            if e < v < nxt:
+                nxt = v
+        (free if own < 0 else slots[own]).append(nxt - e)
+        e = nxt
+    out = []
+    for j in range(L):
+        if not slots[j]:
+            continue
+        if len(slots[j]) < 8:                                    # a running sum is np.sum for fewer than 8 addends
+            acc = slots[j][0]
+            for w in slots[j][1:]:
+                acc = acc + w
+            total = 0.0 + acc
+        else:
+            total = np.sum(np.array(slots[j]))
+        out.append((j, float(rho[j]), float(np.clip(total / delta, 0, 1))))
+    out.append((-1, float(d), float(np.clip(np.sum(np.array(free)) / delta if free else 0.0, 0, 1))))
+    return out
+
+
+def test_single_slot_walk_equals_the_reference_assignment():
+    from oracle import snow_oracle as so
+    rng = np.random.default_rng(77)
+    bd = float(np.degrees(3e-3))
+    for trial in range(1500):
+        centre = rng.uniform(0, 2 * np.pi) if trial % 4 else rng.choice([1e-4, 2 * np.pi - 1e-4, 7e-4])   # also around the seam (Q9)
+        right, left = centre - 1.5e-3, centre + 1.5e-3
+        if right < 0:
+            right += 2 * np.pi
+        if left > 2 * np.pi:
+            left -= 2 * np.pi
+        L = int(rng.integers(1, 21))
+        c = centre + rng.uniform(-2.2e-3, 2.2e-3, L)
+        hw = rng.exponential(4e-4, L) + 1e-6
+        lo, hi = np.maximum(c - hw, centre - 1.5e-3), np.minimum(c + hw, centre + 1.5e-3)
+        ok = hi > lo
+        lo, hi = lo[ok], hi[ok]
+        if lo.size == 0:
+            continue
+        if trial % 5 == 0:                                       # shared endpoints: np.unique must not create empty slots
+            hi[: lo.size // 2] = np.resize(lo[lo.size // 2:], lo.size // 2) if lo.size > 1 else hi[:0]
+            ok = hi > lo
+            lo, hi = lo[ok], hi[ok]
+            if lo.size == 0:
+                continue
+        lo = np.where(lo < 0, lo + 2 * np.pi, np.where(lo > 2 * np.pi, lo - 2 * np.pi, lo))
+        hi = np.where(hi < 0, hi + 2 * np.pi, np.where(hi > 2 * np.pi, hi - 2 * np.pi, hi))
+        rho = np.sort(rng.uniform(1.0, 50.0, lo.size))
+        iv = np.column_stack((lo, hi, rho))
+        want = so.compute_occlusion_dict((right, left), iv, 60.0, bd)
+        got = _single_walk_dict(right, left, iv, 60.0, bd)
+        assert [k for k, _, _ in got] == [k for k, _, _ in want], (trial, iv)
+        for (k, r0, q0), (_, r1, q1) in zip(got, want):
+            assert r0 == r1 and q0 == q1, (trial, k, q0, q1)
