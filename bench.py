@@ -27,6 +27,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
+DEFAULT_FRAMES = 256       # sweeps per step and GPU (BASELINE.json's C3 streams 256-frame batches of the C2 sweep)
 BEAM_DIV = float(np.degrees(3e-3))
 SNOWFALL, VELOCITY = 2.5, 1.6
 
@@ -63,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=128, help="frames per batch (per GPU)")
+    ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 (default) is BASELINE.json's metric config")

@@ -72,11 +72,11 @@ struct SgBeamArgs {
     int32_t dbg_cap;
     // Segment-ordered direct mode (optional, first pass): blocks walk (table, frame, channel) segments of the sorted
     // rows, so that chip-wide one or two flake tables are in use at a time and stay in L2.  null = linear order.
-    const int32_t *seg_blk;      // n_seg + 1: first block of segment i
+    const int32_t *seg_blk;      // n_seg: first block of segment i
     const int64_t *seg_start;    // n_seg: global sorted position of the segment's first row
     const int32_t *seg_cnt;      // n_seg: rows
     const int32_t *seg_frame;    // n_seg
-    const int32_t *seg_n;        // [0] = n_seg
+    const int32_t *seg_n;        // [0] = n_seg, [1] = blocks in all segments
     const int32_t *seg_of_blk;   // grid_blocks: segment of block b (valid below seg_blk[n_seg])
     int64_t grid_blocks;         // host: blocks to launch in that mode (upper bound; surplus blocks leave at once)
     // First-pass split: the direct-mode pass stops at the occlusion dict and queues the beams that met a flake;
@@ -100,8 +100,8 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
-                       int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt,
-                       int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int64_t grid_blocks, void *stream);
+                       int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
+                       int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *count, int32_t cap,
                    int lo1, int hi1, int lo2, int hi2, void *stream);

@@ -62,7 +62,8 @@ struct snowgpu_ctx {
     int32_t *d_status = nullptr;      // 4 ints
     // scratch shared by every batch
     DevBuf<int32_t> tile_hist, tile_base, ovf_list, ovf_list2, perm, ctile_cnt, ctile_base, table_ids, out_src;
-    DevBuf<int32_t> seg_pair, seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk, pq_list, ptile_cnt, ptile_base;
+    DevBuf<unsigned long long> seg_tbl_cnt, seg_tbl_base;
+    DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk, pq_list, ptile_cnt, ptile_base;
     DevBuf<double> pq_dict;
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     DevBuf<int64_t> seg_start;
@@ -174,7 +175,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->ovf_list2.release(); ctx->perm.release();
-    ctx->seg_pair.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->pq_list.release(); ctx->ptile_cnt.release(); ctx->ptile_base.release(); ctx->pq_dict.release();
+    ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->pq_list.release(); ctx->ptile_cnt.release(); ctx->ptile_base.release(); ctx->pq_dict.release();
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
@@ -473,11 +474,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     int tiers[4], n_tiers = 0;
     choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
     const int first_block = sg_beams_block(tiers[0]);
-    const bool use_seg = !b.perm && !ctx->linear_order && ctx->tables.size() <= 4096 && b.n_frames <= (1 << 22)
+    const bool use_seg = !b.perm && !ctx->linear_order && ctx->tables.size() <= 65536 && b.n_frames <= (1 << 22)
                          && b.n_total < ((int64_t)1 << 31);
     if (use_seg) {
         const size_t P = (size_t)b.n_frames * 256;
-        ENSURE(ctx, ctx->seg_pair, P); ENSURE(ctx, ctx->seg_blk, P + 1); ENSURE(ctx, ctx->seg_cnt, P);
+        ENSURE(ctx, ctx->seg_tbl_cnt, ctx->tables.size() + 1); ENSURE(ctx, ctx->seg_tbl_base, ctx->tables.size() + 1);
+        ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
         ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
     }
@@ -488,9 +490,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
         if (use_seg) {
             e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(), first_block,
-                                   ctx->seg_pair.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->seg_of_blk.p,
-                                   (b.n_total + first_block - 1) / first_block + (int64_t)b.n_frames * 256, ctx->aux);
-            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "too many tables"));
+                                   ctx->seg_tbl_cnt.p, ctx->seg_tbl_base.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p,
+                                   ctx->seg_n.p, ctx->seg_of_blk.p, ctx->aux);
+            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));

@@ -183,9 +183,8 @@ __global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
     int seg_f = -1;                                   // segment-ordered direct mode: the block's frame
     int64_t seg_g = -1;
     if (!LIST && a.seg_blk) {
-        const int n_seg = a.seg_n[0];
         const int blk = (int)blockIdx.x;
-        if (blk >= a.seg_blk[n_seg]) return;          // surplus block (the grid is an upper bound)
+        if (blk >= a.seg_n[1]) return;                // surplus block (the grid is an upper bound)
         const int lo = a.seg_of_blk[blk];             // one load instead of a 13-step dependent search per block
         const int off = (blk - a.seg_blk[lo]) * BLOCK + tid;
         seg_f = a.seg_frame[lo];
@@ -418,83 +417,75 @@ __global__ __launch_bounds__(BLOCK) void k_power(SgBeamArgs a)
 // Segment order of the first pass.  A segment = the rows of one (frame, channel) pair in the channel-sorted order,
 // i.e. all beams of a frame that look up the same flake table.  Segments are ordered by table, so that the ~1000
 // blocks resident at any moment use one or two tables (2-3 MB each: L2-resident) instead of all 64 of a frame.
-// One block; n_frames * 256 pairs.  Order inside a table is whatever the LDS atomics give -- results do not depend
-// on the launch order.
-#define SG_SEG_MAXT 4096
-__global__ __launch_bounds__(1024) void k_seg_build(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
-                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
-                                                    int32_t *__restrict__ seg_pair, int32_t *__restrict__ seg_blk, int64_t *__restrict__ seg_start,
-                                                    int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame, int32_t *__restrict__ seg_n)
+// Three small kernels over the n_frames * 256 pairs: count segments and blocks per table (one packed 64-bit atomic
+// per pair: segments << 32 | blocks), exclusive scan over the tables, place every pair (a second packed atomic gives
+// its segment slot and its first block inside the table's range).  The order inside a table is whatever the atomics
+// give -- results do not depend on the launch order.
+struct SgPair { int64_t start; int rows; int key; };
+
+__device__ __forceinline__ SgPair sg_pair(int p, const int64_t *__restrict__ frame_off, const int32_t *__restrict__ tile_base, int64_t max_tiles,
+                                          const int32_t *__restrict__ table_ids, int n_las, int n_tables)
 {
-    __shared__ int hist[SG_SEG_MAXT + 1];
-    __shared__ int sc[1024];
-    const int t = threadIdx.x;
-    const int P = n_frames * 256, NT = n_tables;
-    auto pair_rows = [&](int p, int64_t &start) -> int {
-        const int f = p >> 8, c = p & 255;
-        const int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
-        const int64_t n = frame_off[f + 1] - frame_off[f];
-        start = frame_off[f];
-        if (n <= 0) return 0;                         // the sort wrote nothing for an empty frame
-        const int64_t s0 = b[c], s1 = c < 255 ? (int64_t)b[c + 1] : n;
-        start = frame_off[f] + s0;
-        return (int)(s1 - s0);
-    };
-    auto pair_key = [&](int p) -> int {
-        const int f = p >> 8, c = p & 255;
-        if (c >= n_las) return NT;
+    SgPair r;
+    const int f = p >> 8, c = p & 255;
+    const int64_t n = frame_off[f + 1] - frame_off[f];
+    r.start = frame_off[f]; r.rows = 0; r.key = n_tables;
+    if (n <= 0) return r;                             // the sort wrote nothing for an empty frame
+    const int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
+    const int64_t s0 = b[c], s1 = c < 255 ? (int64_t)b[c + 1] : n;
+    r.start += s0;
+    r.rows = (int)(s1 - s0);
+    if (c < n_las) {
         const int id = table_ids[(int64_t)f * n_las + c];
-        return (id >= 0 && id < NT) ? id : NT;
-    };
-    for (int k = t; k <= NT; k += 1024) hist[k] = 0;
-    __syncthreads();
-#pragma unroll 4                                  // several (tile_base, table id) loads in flight per thread
-    for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) atomicAdd(&hist[pair_key(p)], 1); }
-    __syncthreads();
-    // exclusive scan of hist[0 .. NT]
-    const int per = (NT + 1 + 1023) / 1024;
-    int sum = 0;
-    for (int k = t * per; k < (t + 1) * per && k <= NT; ++k) sum += hist[k];
-    sc[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { const int add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
-    const int n_seg = sc[1023];
-    int run = sc[t] - sum;
-    for (int k = t * per; k < (t + 1) * per && k <= NT; ++k) { const int h = hist[k]; hist[k] = run; run += h; }
-    __syncthreads();
-#pragma unroll 4
-    for (int p = t; p < P; p += 1024) { int64_t st; if (pair_rows(p, st) > 0) seg_pair[atomicAdd(&hist[pair_key(p)], 1)] = p; }
-    __threadfence_block();
-    __syncthreads();
-    // blocks per segment, exclusive prefix in segment order
-    const int per2 = (n_seg + 1023) / 1024;
-    int bsum = 0;
-    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) { int64_t st; bsum += (pair_rows(seg_pair[i], st) + blk - 1) / blk; }
-    sc[t] = bsum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { const int add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
-    int brun = sc[t] - bsum;
-    for (int i = t * per2; i < (t + 1) * per2 && i < n_seg; ++i) {
-        int64_t st;
-        const int p = seg_pair[i], rows = pair_rows(p, st);
-        seg_blk[i] = brun; seg_start[i] = st; seg_cnt[i] = rows; seg_frame[i] = p >> 8;
-        brun += (rows + blk - 1) / blk;
+        if (id >= 0 && id < n_tables) r.key = id;     // unknown ids and channels without a laser go last
     }
-    if (t == 1023) { seg_blk[n_seg] = sc[1023]; seg_n[0] = n_seg; seg_n[1] = sc[1023]; }
+    return r;
 }
 
-// block -> segment table (one load per block in k_beams instead of a dependent binary search)
-__global__ __launch_bounds__(256) void k_seg_fill(const int32_t *__restrict__ seg_blk, const int32_t *__restrict__ seg_n, int32_t *__restrict__ seg_of_blk)
+__global__ __launch_bounds__(256) void k_seg_count(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
+                                                   int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
+                                                   unsigned long long *__restrict__ tbl_cnt)
 {
-    const int n_seg = seg_n[0];
-    const int blk = blockIdx.x * 256 + threadIdx.x;
-    if (n_seg <= 0 || blk >= seg_blk[n_seg]) return;
-    int lo = 0, hi = n_seg - 1;                       // last segment whose first block is <= blk
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (seg_blk[mid] <= blk) lo = mid; else hi = mid - 1;
-    }
-    seg_of_blk[blk] = lo;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_frames * 256) return;
+    const SgPair r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
+    if (r.rows > 0) atomicAdd(&tbl_cnt[r.key], (1ull << 32) | (unsigned long long)((r.rows + blk - 1) / blk));
+}
+
+// exclusive scan of the packed per-table counts (both halves at once: neither overflows 32 bits); leaves the counts zero
+// so that k_seg_place can use them as cursors
+__global__ __launch_bounds__(1024) void k_seg_scan(unsigned long long *__restrict__ tbl_cnt, unsigned long long *__restrict__ tbl_base, int n,
+                                                   int32_t *__restrict__ seg_n)
+{
+    __shared__ unsigned long long sc[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024, b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    unsigned long long sum = 0;
+    for (int k = b0; k < b1; ++k) sum += tbl_cnt[k];
+    sc[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const unsigned long long add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
+    unsigned long long run = sc[t] - sum;
+    for (int k = b0; k < b1; ++k) { const unsigned long long c = tbl_cnt[k]; tbl_base[k] = run; run += c; tbl_cnt[k] = 0; }
+    if (t == 1023) { seg_n[0] = (int32_t)(sc[1023] >> 32); seg_n[1] = (int32_t)(sc[1023] & 0xffffffffull); }
+}
+
+__global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
+                                                   int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
+                                                   const unsigned long long *__restrict__ tbl_base, unsigned long long *__restrict__ tbl_cur,
+                                                   int64_t *__restrict__ seg_start, int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame,
+                                                   int32_t *__restrict__ seg_blk, int32_t *__restrict__ seg_of_blk)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_frames * 256) return;
+    const SgPair r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
+    if (r.rows <= 0) return;
+    const int nb = (r.rows + blk - 1) / blk;
+    const unsigned long long c = atomicAdd(&tbl_cur[r.key], (1ull << 32) | (unsigned long long)nb), base = tbl_base[r.key];
+    const int slot = (int)(base >> 32) + (int)(c >> 32);
+    const int b0 = (int)(base & 0xffffffffull) + (int)(c & 0xffffffffull);
+    seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = p >> 8; seg_blk[slot] = b0;
+    for (int q = 0; q < nb; ++q) seg_of_blk[b0 + q] = slot;      // block -> segment: one load per block in k_beams
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -837,15 +828,18 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *s
 }
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
-                                  int n_las, int n_tables, int block, int32_t *seg_pair, int32_t *seg_blk, int64_t *seg_start,
-                                  int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int64_t grid_blocks,
-                                  void *stream)
+                                  int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
+                                  int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream)
 {
-    if (n_tables > SG_SEG_MAXT) return -1;
-    hipLaunchKernelGGL(k_seg_build, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las,
-                       n_tables, block, seg_pair, seg_blk, seg_start, seg_cnt, seg_frame, seg_n);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)n_frames;         // 256 pairs per frame, one thread each
+    if (hipMemsetAsync(tbl_cnt, 0, sizeof(unsigned long long) * ((size_t)n_tables + 1), st) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(k_seg_count, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block, tbl_cnt);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)((grid_blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg_blk, seg_n, seg_of_blk);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, tbl_cnt, tbl_base, n_tables + 1, seg_n);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_seg_place, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block,
+                       tbl_base, tbl_cnt, seg_start, seg_cnt, seg_frame, seg_blk, seg_of_blk);
     SG_CHECK_LAUNCH();
     return 0;
 }

@@ -11,6 +11,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 tag = args[0] if args else "r01"
 traffic_only = "--traffic-only" in sys.argv      # on the GPU box, before the default bench run reads hbm_traffic.json
 prof = root / "profiles"
+sys.path.insert(0, str(root))
+from bench import DEFAULT_FRAMES as default_frames   # noqa: E402  (bench.py only parses arguments under __main__)
 
 
 def short(name):
@@ -33,7 +35,7 @@ steps = 3   # --steps 2 --warmup 1
 fetch = sum(sum(v["FETCH_SIZE"]) for k, v in per.items() if k.startswith(("k_beams", "k_power", "k_list"))) / steps
 write = sum(sum(v["WRITE_SIZE"]) for k, v in per.items() if k.startswith(("k_beams", "k_power", "k_list"))) / steps
 rec = {
-    "round": int(tag[1:]), "frames": 128,
+    "round": int(tag[1:]), "frames": default_frames,
     "kernel": "per-beam kernels of one step: k_beams (all capacity tiers), k_power, k_list_* (the region of roofline.avg_launch_ms)",
     "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "bytes_per_launch": (fetch + write) * 1024,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`, summed over the "
