@@ -489,3 +489,46 @@ def test_single_slot_walk_equals_the_reference_assignment():
         assert [k for k, _, _ in got] == [k for k, _, _ in want], (trial, iv)
         for (k, r0, q0), (_, r1, q1) in zip(got, want):
             assert r0 == r1 and q0 == q1, (trial, k, q0, q1)
+
+
+def test_result_buffer_pool_recycles_and_respects_its_limit():
+    """Engine.result_buffers hands out views of pooled page-locked buffers; they return to the pool when the caller
+    drops every view, and past PIN_LIMIT plain arrays are returned instead.  (No device: a fake context allocates
+    ordinary memory.)"""
+    import gc
+    import threading
+    from lidar_snow_sim_amd import engine
+
+    class FakeCtx:
+        def __init__(self):
+            self.allocs = 0
+
+        def pinned_empty(self, shape, dtype):
+            self.allocs += 1
+            return np.empty(shape, dtype)
+
+    e = engine.Engine.__new__(engine.Engine)
+    e.ctx = FakeCtx()
+    e._lock = threading.Lock()
+    e.batch_lock = threading.RLock()
+    rows, src = e.result_buffers(1000, np.float32)
+    assert rows.shape == (1000, 5) and rows.dtype == np.float32 and src.shape == (1000,) and src.dtype == np.int32
+    rows[:] = 7.0
+    src[:] = 3
+    assert np.all(rows == 7.0) and np.all(src == 3)                    # the two views do not overlap
+    view = rows[10:20]
+    del rows, src
+    gc.collect()
+    assert not e.__dict__.get("_pin_pool")                             # a live view keeps the lease out
+    del view
+    gc.collect()
+    assert len(e._pin_pool) == 1 and e._pin_out == 0
+    r2, s2 = e.result_buffers(500, np.float64)                         # fits the pooled buffer: no new allocation
+    assert e.ctx.allocs == 1 and r2.dtype == np.float64 and r2.shape == (500, 5)
+    e.PIN_LIMIT = 1                                                    # anything new is now over the limit
+    r3, s3 = e.result_buffers(10 ** 6, np.float32)
+    assert e.ctx.allocs == 1 and r3.shape == (10 ** 6, 5)              # pageable fallback
+    z, zs = e.result_buffers(0, np.float32)
+    assert z.shape == (0, 5) and zs.shape == (0,)
+    stage = e.staging_in(100, np.float32)
+    assert stage.shape == (100, 5) and e.staging_in(50, np.float32).ctypes.data == stage.ctypes.data
