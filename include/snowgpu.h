@@ -141,8 +141,12 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
  * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
  * the entry point bench.py times.  max_frame_rows = rows of the largest frame (sizes the per-frame grids;
- * 0 = unknown, n_total is used; when max_frame_rows * n_frames == n_total all frames are taken to be that size).  d_status (device int32[8]) receives {error code, first bad
- * global row, beams handed to the 2nd / 3rd / (unused) list capacity, reserved...}; check it after synchronising the stream.
+ * 0 = unknown, n_total is used; when max_frame_rows * n_frames == n_total all frames are taken to be that size).
+ * d_status (device int32[8]) receives {[0] error code, [1] first offending sorted row or -1, [2] [3] [4] beams handed
+ * to the 2nd / 3rd / 4th list capacity, [5] unused, [6] beams that met a flake in the first pass (the k_power list),
+ * [7] unused}; check it after synchronising the stream.  The call forks work onto the context's side streams and joins
+ * them back before the compaction kernels, so everything is ordered after earlier work and before later work on
+ * `stream`; one batch at a time per context (its scratch buffers are reused).
  */
 int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total,
                                  int64_t max_frame_rows, const int64_t *d_frame_offsets, const void *d_rows, int dtype,
