@@ -423,10 +423,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
     HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
-    {
-        const int32_t minus1 = -1;   // status[1] = first offending row, -1 = none
-        HIPCHK(ctx, hipMemcpyAsync(b.status + 1, &minus1, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
+    HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));   // status[1] = first offending row, -1 = none
     if (n == 0) {
         HIPCHK(ctx, hipMemsetAsync(b.out_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
         HIPCHK(ctx, hipMemsetAsync(b.out_stats, 0, sizeof(int64_t) * 3 * (size_t)b.n_frames, st));
