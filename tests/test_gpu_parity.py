@@ -1,6 +1,7 @@
 """-m gpu: the HIP path (through the C ABI) against the CPU oracle and the reference's golden vectors."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libsnowgpu.so is loaded: PyTorch bundles its own HIP runtime, and the process must end up with one
 
 from conftest import canonical
 
@@ -674,3 +675,44 @@ def test_dense_tables_start_at_a_higher_capacity_tier(so, tables, extra, first_t
     assert np.array_equal(src[:n], src0) and np.array_equal(out[:n, 3:], a0[:, 3:])
     np.testing.assert_allclose(out[:n, :3], a0[:, :3], rtol=1e-6, atol=0)
     assert (a0[:, 4] == 1).sum() > 50
+
+
+def test_device_entry_can_be_captured_into_a_hip_graph(eng, tables):
+    """snowgpu_augment_batch_device neither allocates (after the first call of a given size), nor synchronises, nor copies
+    from host memory: with its side streams forking from and joining back into the caller's stream, the whole launch
+    sequence is capturable and a replay gives the same rows."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    dev = torch.device("cuda:0")
+    F, n = 2, 64 * 256
+    frames = [synthetic_sweep(64, 256, seed=1050 + f, intensity="lambert") for f in range(F)]
+    rows = torch.from_numpy(np.concatenate(frames)).to(dev)
+    off = torch.arange(F + 1, dtype=torch.int64, device=dev) * n
+    tids = torch.tensor([eng.table_ids_from_arrays(_tables64(tables), list(range(64))) for _ in range(F)], dtype=torch.int32, device=dev)
+    plane = torch.tensor([[0.0, 0.0, -1.0, -1.7]] * F, dtype=torch.float64, device=dev)
+    out = torch.empty_like(rows)
+    src = torch.empty(F * n, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(F, dtype=torch.int64, device=dev)
+    st = torch.zeros(F, 3, dtype=torch.int64, device=dev)
+    status = torch.zeros(8, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+
+    def call():
+        eng.ctx.augment_batch_device(F, F * n, n, off.data_ptr(), rows.data_ptr(), 0, tids.data_ptr(), float(np.degrees(3e-3)), 0,
+                                     plane.data_ptr(), 0.7, 0, out.data_ptr(), src.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0,
+                                     status.data_ptr(), s.cuda_stream)
+
+    with torch.cuda.stream(s):
+        call()
+        call()
+        s.synchronize()
+        want = (out.clone(), src.clone(), cnt.clone(), st.clone())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            call()
+        out.zero_(); src.zero_(); cnt.zero_(); st.zero_()
+        g.replay()
+        s.synchronize()
+    assert int(status[0]) == 0 and torch.equal(cnt, want[2]) and torch.equal(st, want[3])
+    for f in range(F):
+        m = int(cnt[f])
+        assert m > 0 and torch.equal(out[f * n:f * n + m], want[0][f * n:f * n + m]) and torch.equal(src[f * n:f * n + m], want[1][f * n:f * n + m])
