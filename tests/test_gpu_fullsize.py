@@ -1,0 +1,215 @@
+"""-m gpu: FULL-SIZE frames of every BASELINE.json config through the HIP path against the threaded C oracle,
+with mismatch COUNTS (kept rows, labels, intensities) asserted to be zero and printed.
+
+  C2     64 x 2048 sweeps, 2.5 mm/h @ 1.6 m/s (18 k flakes per line)            -- the headline workload
+  C2far  the same sweeps with every range stretched x1.8 (long scatterer lists: capacity tiers 8 / 16 / 63 busy)
+  C1     64 x 2048 sweeps, 0.5 mm/h @ 2.0 m/s (40 k flakes per line: the first tier is 8)
+  C4     128 x 4096 sweeps, 10 mm/h @ 1.6 m/s, 128-entry laser table (the 64-entry one tiled)
+  C3     snowfall + wet ground fused (pointcloud_viewer.py:2807-2821) on C2 sweeps
+
+Both sides run end to end from the same frames, tables, channel permutations and ground plane: the HIP path with
+its device prepass, the oracle with its NumPy/SciPy prepass (simulation.py:449-467).  Frames and tables are the ones
+bench.py uses (SURVEY 8 d generator).  The counts also go to gpurun_out/fullsize_parity.jsonl.
+"""
+import json
+import os
+import random
+import time
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  -- before libsnowgpu.so is loaded (one HIP runtime per process)
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+BD = float(np.degrees(3e-3))
+PLANE = ([0.0, 0.0, -1.0], -1.7)
+N_FRAMES = int(os.environ.get("SNOWGPU_FULLSIZE_FRAMES", "8"))
+_TABLE_CACHE = {}
+
+
+def _tables(workload):
+    """bench.py's tables for the workload (dart_throwing(..., default_rng(42 + line)), R0 = 80 m); C1's 40 k-flake
+    tables take 0.4 s each on the host, so 16 distinct ones are tiled over the 64 lines."""
+    import bench
+    layers, _, snowfall, velocity, _ = bench.WORKLOADS[workload]
+    key = (snowfall, velocity, layers)
+    if key not in _TABLE_CACHE:
+        distinct = 16 if workload == "C1" else min(layers, 64)
+        _TABLE_CACHE[key] = bench.make_tables(layers, snowfall, velocity, distinct=distinct)
+    return _TABLE_CACHE[key]
+
+
+def _frames(workload, dtype, n):
+    import bench
+    layers, azimuths, _, _, scale = bench.WORKLOADS[workload]
+    out, orders = [], []
+    for f in range(n):
+        seed = 1000 + f
+        pc = bench.make_frame(layers, azimuths, seed, scale)
+        random.seed(seed)                                   # SURVEY 8 d: random.seed(f); random.shuffle(order)
+        order = list(range(layers))
+        random.shuffle(order)
+        out.append(pc.astype(dtype))
+        orders.append(order)
+    return out, orders
+
+
+def _report(capsys, rec):
+    line = json.dumps(rec)
+    with capsys.disabled():
+        print("\n[fullsize-parity] " + line, flush=True)
+    try:
+        d = ROOT / "gpurun_out"
+        d.mkdir(exist_ok=True)
+        with open(d / "fullsize_parity.jsonl", "a") as fh:
+            fh.write(line + "\n")
+    except OSError:
+        pass
+
+
+def _count_mismatches(got_rows, got_src, ref_rows, ref_src, rtol):
+    """Mismatch counts between two augment() results of one frame (rows in channel-sorted, stable order)."""
+    rec = {"rows_gpu": int(got_rows.shape[0]), "rows_ref": int(ref_rows.shape[0])}
+    rec["mismatched_src"] = int(np.setxor1d(got_src, ref_src).size)
+    rec["same_order"] = bool(np.array_equal(got_src, ref_src))
+    common, ig, ir = np.intersect1d(got_src, ref_src, return_indices=True)
+    g, r = got_rows[ig], ref_rows[ir]
+    rec["mismatched_labels"] = int((g[:, 4] != r[:, 4]).sum())
+    rec["mismatched_intensity"] = int((g[:, 3] != r[:, 3]).sum())
+    den = np.maximum(np.abs(r[:, :3].astype(np.float64)), 1e-30)
+    rel = np.abs(g[:, :3].astype(np.float64) - r[:, :3].astype(np.float64)) / den
+    rec["xyz_max_rel"] = float(rel.max()) if rel.size else 0.0
+    rec["xyz_over_tol"] = int((rel > rtol).any(axis=1).sum()) if rel.size else 0
+    return rec
+
+
+def _sum_counts(recs):
+    keys = ("mismatched_src", "mismatched_labels", "mismatched_intensity", "xyz_over_tol")
+    tot = {k: int(sum(r[k] for r in recs)) for k in keys}
+    tot["same_order"] = bool(all(r["same_order"] for r in recs))
+    tot["xyz_max_rel"] = float(max(r["xyz_max_rel"] for r in recs))
+    tot["rows_gpu"] = int(sum(r["rows_gpu"] for r in recs))
+    tot["rows_ref"] = int(sum(r["rows_ref"] for r in recs))
+    return tot
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["float32", "float64"])
+@pytest.mark.parametrize("workload", ["C2", "C2far", "C1", "C4"])
+def test_fullsize_parity(workload, dtype, capsys):
+    """Every row of N_FRAMES full-size frames: kept-row indices, labels and intensities bit-exact, xyz within 1e-6
+    (float32 rows) / 1e-12 (float64 rows) relative, statistics equal."""
+    import bench
+    from lidar_snow_sim_amd import engine
+    from oracle import snow_oracle as so
+    layers = bench.WORKLOADS[workload][0]
+    n_frames = N_FRAMES if layers == 64 else max(2, N_FRAMES // 2)      # C4 frames hold 4 x the points
+    tables = _tables(workload)
+    frames, orders = _frames(workload, dtype, n_frames)
+    lasers = engine.load_lasers() * (layers // 64)
+    rtol = 1e-6 if dtype == np.float32 else 1e-12
+    eng = engine.Engine(0, lasers=lasers)          # own context: the largest table drives the capacity-tier choice
+    try:
+        tids = [eng.table_ids_from_arrays(tables, o) for o in orders]
+        rows = np.concatenate(frames)
+        off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+        t0 = time.perf_counter()
+        out, src, counts, stats, thr = eng.ctx.augment_batch(rows, off, tids, BD, plane=[[*PLANE[0], PLANE[1]]] * n_frames,
+                                                             want_thr=True)
+        t_gpu = time.perf_counter() - t0
+    finally:
+        eng.ctx.close()
+    las_o = so.load_lasers() * (layers // 64)
+    threads = max(1, min(os.cpu_count() or 1, layers))
+    recs, stat_bad, t_cpu, thr_dev = [], 0, 0.0, 0.0
+    for f in range(n_frames):
+        t0 = time.perf_counter()
+        s0, a0, src0, extra = so.augment(frames[f], tables, BD, orders[f], plane=PLANE, lasers=las_o, threads=threads,
+                                         return_full=True)
+        t_cpu += time.perf_counter() - t0
+        n = int(counts[f])
+        a = int(off[f])
+        recs.append(_count_mismatches(out[a:a + n], src[a:a + n], a0, src0, rtol))
+        stat_bad += tuple(int(v) for v in stats[f]) != tuple(int(v) for v in s0)
+        dist = np.linspace(3.0, 119.0, 59)
+        thr_dev = max(thr_dev, float(np.abs(np.polyval(thr[f], dist) - np.polyval(extra["thr_poly"], dist)).max()))
+    tot = _sum_counts(recs)
+    tot.update(workload=workload, dtype=np.dtype(dtype).name, frames=n_frames, points=int(off[-1]), mismatched_stats=int(stat_bad),
+               max_threshold_deviation=thr_dev, gpu_call_s=round(t_gpu, 3), oracle_s=round(t_cpu, 2), oracle_threads=threads)
+    _report(capsys, tot)
+    assert tot["mismatched_src"] == 0 and tot["same_order"]
+    assert tot["mismatched_labels"] == 0 and tot["mismatched_intensity"] == 0
+    assert tot["xyz_over_tol"] == 0
+    assert stat_bad == 0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["float32", "float64"])
+def test_fullsize_parity_C3_snow_and_wet_fused(dtype, capsys):
+    """C3: full-size C2 sweeps through the fused snowfall + wet-ground entry (snow rows never leave the device) against
+    oracle augment() followed by oracle ground_water_augmentation() with the kwargs of pointcloud_viewer.py:2814-2821."""
+    from lidar_snow_sim_amd import engine
+    from oracle import snow_oracle as so
+    tables = _tables("C2")
+    frames, orders = _frames("C2", dtype, N_FRAMES)
+    n_frames = len(frames)
+    wet = dict(water_height=0.0008, pavement_depth=0.001, power_factor=15, flat_earth=False, delta=0.5, replace=False)
+    eng = engine.Engine(0)
+    try:
+        tids = [eng.table_ids_from_arrays(tables, o) for o in orders]
+        rows = np.concatenate(frames)
+        off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+        pl = [[*PLANE[0], PLANE[1]]] * n_frames
+        out, src, counts, stats, flags = eng.ctx.augment_wet_batch(rows, off, tids, BD, wet_plane=pl, plane=pl, wet_noise_floor=0.7, **wet)
+    finally:
+        eng.ctx.close()
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    recs, stat_bad, int_bad, int_max = [], 0, 0, 0.0
+    for f in range(n_frames):
+        s0, a0, src0 = so.augment(frames[f], tables, BD, orders[f], plane=PLANE, threads=threads)
+        o0, wsrc0 = so.ground_water_augmentation(a0, noise_floor=0.7, plane=PLANE, return_src=True, **wet)
+        n, a = int(counts[f]), int(off[f])
+        got, gsrc, rsrc = out[a:a + n], src[a:a + n], src0[wsrc0]
+        rec = _count_mismatches(got, gsrc, o0, rsrc, 1e-6 if dtype == np.float32 else 1e-12)
+        # wet-ground intensities are float64 values of a float chain, not integers: relative tolerance
+        # (1e-7 on float32 frames, where the laser-power line amplifies float32 rounding; 1e-9 on float64 frames)
+        common, ig, ir = np.intersect1d(gsrc, rsrc, return_indices=True)
+        tol = 1e-6 if dtype == np.float32 else 1e-9
+        rel = np.abs(got[ig, 3] - o0[ir, 3]) / np.maximum(np.abs(o0[ir, 3]), 1e-30)
+        int_bad += int((rel > tol).sum())
+        int_max = max(int_max, float(rel.max()) if rel.size else 0.0)
+        rec["mismatched_intensity"] = int((rel > tol).sum())
+        recs.append(rec)
+        stat_bad += tuple(int(v) for v in stats[f]) != tuple(int(v) for v in s0)
+        assert int(flags[f]) == 0
+    tot = _sum_counts(recs)
+    tot.update(workload="C3 (snow + wet fused)", dtype=np.dtype(dtype).name, frames=n_frames, points=int(off[-1]),
+               mismatched_stats=int(stat_bad), wet_intensity_max_rel=int_max)
+    _report(capsys, tot)
+    assert tot["mismatched_src"] == 0 and tot["same_order"] and tot["mismatched_labels"] == 0
+    assert tot["mismatched_intensity"] == 0 and tot["xyz_over_tol"] == 0 and stat_bad == 0
+
+
+def test_L5_counts_against_the_native_numpy_flavour(golden, tables, capsys):
+    """The reference's own numbers depend on NumPy's SIMD dispatch: the product pins the portable
+    flavour.  This test REPORTS (does not assert) how far the HIP path is from the AVX-512 flavour of the same
+    reference on the L5 fixtures -- the distance between the reference and itself on another CPU."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    dn = golden("L5_augment", "native")
+    dp = golden("L5_augment", "portable")
+    tl = [tables["t"][i % 4] for i in range(64)]
+    for case in range(8):
+        pc = dp[f"c{case}_pc"]
+        plane = (dp[f"c{case}_plane_w"], float(dp[f"c{case}_plane_h"]))
+        stats, aug, src = augment(pc, "unused", float(dp["bd"]), only_camera_fov=False, plane=plane,
+                                  order=list(dp[f"c{case}_order"]), particles=tl, return_src=True)
+        rec = {"fixture": f"L5 case {case}", "dtype": pc.dtype.name}
+        for name, d in (("vs_portable", dp), ("vs_native", dn)):
+            o = np.argsort(d[f"c{case}_src"], kind="stable")
+            g = np.argsort(src, kind="stable")
+            c = _count_mismatches(aug[g], src[g], d[f"c{case}_aug"][o], d[f"c{case}_src"][o], 1e-6)
+            rec[name] = {k: c[k] for k in ("mismatched_src", "mismatched_labels", "mismatched_intensity")}
+            rec[name]["stats_equal"] = tuple(int(v) for v in stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+        _report(capsys, rec)
+        assert rec["vs_portable"]["mismatched_src"] == 0 and rec["vs_portable"]["stats_equal"]
