@@ -54,13 +54,15 @@ enum {
                                    IndexError there (simulation.py:146-149, quirk Q6) */
     SNOWGPU_E_CHANNELS = 5,     /* channel column holds values other than integers in [0, 255]
                                    and no explicit permutation was supplied */
-    SNOWGPU_E_OVERFLOW = 6,     /* more than SNOWGPU_MAX_FLAKES_PER_BEAM flakes intersect one beam */
+    SNOWGPU_E_OVERFLOW = 6,     /* more than SNOWGPU_MAX_FLAKES_GLOBAL flakes intersect one beam */
     SNOWGPU_E_GROUND = 7,       /* fewer than 3 ground points: the reference raises TypeError
                                    (simulation.py:462 on None, quirk Q7) */
     SNOWGPU_E_NO_DEVICE = 8     /* no HIP device / device index out of range */
 };
 
-#define SNOWGPU_MAX_FLAKES_PER_BEAM 63
+#define SNOWGPU_MAX_FLAKES_PER_BEAM 63   /* largest per-beam list kept in LDS; beams beyond it take the global-list tier */
+#define SNOWGPU_MAX_FLAKES_GLOBAL 8192  /* capacity of that tier (or the largest uploaded table, if smaller); the
+                                           reference's lists are unbounded (simulation.py:413-419) */
 #define SNOWGPU_MAX_LASERS 256
 #define SNOWGPU_RANGE_BINS 1230  /* M_extended, simulation.py:113 */
 
@@ -104,6 +106,10 @@ int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio,
  * evaluates.  Both modes give the same labels / intensities (tests/test_gpu_parity.py); mode 1 is ~3x slower. */
 int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
 
+/* Status words (int32[8], layout under snowgpu_augment_batch_device) of the last batch that went through a host-pointer
+ * entry of this context: e.g. out8[2..5] = beams each later list capacity took. */
+int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8);
+
 /* The 1230-entry range grid of simulation.py:106-116 as the library computes it (for tests). */
 int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
 
@@ -142,9 +148,9 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is
  * the entry point bench.py times.  max_frame_rows = rows of the largest frame (sizes the per-frame grids;
  * 0 = unknown, n_total is used; when max_frame_rows * n_frames == n_total all frames are taken to be that size).
- * d_status (device int32[8]) receives {[0] error code, [1] first offending sorted row or -1, [2] [3] [4] beams handed
- * to the 2nd / 3rd / 4th list capacity, [5] unused, [6] beams that met a flake in the first pass (the k_power list),
- * [7] unused}; check it after synchronising the stream.  The call forks work onto the context's side streams and joins
+ * d_status (device int32[8]) receives {[0] error code, [1] first offending sorted row or -1, [2] [3] [4] [5] beams handed
+ * to the 2nd / 3rd / 4th / 5th list capacity (the last one in use is the global-list tier), [6] [7] unused}; check it
+ * after synchronising the stream.  The call forks work onto the context's side streams and joins
  * them back before the compaction kernels, so everything is ordered after earlier work and before later work on
  * `stream`; one batch at a time per context (its scratch buffers are reused).
  */
@@ -164,6 +170,16 @@ int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total
 int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows, int dtype,
                              const int32_t *table_ids, double beam_divergence_deg, int cap,
                              int32_t *count, double *rj, double *ratio, int32_t *sorted_src);
+
+/*
+ * Camera-FOV crop of augment(only_camera_fov=True) (simulation.py:39-47, :532-540; get_fov_flag(lidar_to_rect(xyz),
+ * (img_h, img_w))) inside the compaction kernels of every later batch of this context: v2c = Tr_velo_to_cam (3 x 4,
+ * row-major), r0 = R0_rect (3 x 3), p2 = P2 (3 x 4); (1024, 1920) is the reference's image.  Cropped rows count in
+ * num_removed (:538); num_attenuated / avg_intensity_diff are taken before the crop (:525-530).  enabled = 0 switches it
+ * off (the matrices may then be NULL).  The reference's projection lives in an un-vendored module: textbook KITTI,
+ * float64 -- parity unpinned.
+ */
+int snowgpu_set_fov(snowgpu_ctx *ctx, int enabled, const double *v2c, const double *r0, const double *p2, int img_h, int img_w);
 
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 
@@ -204,8 +220,8 @@ int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *fram
 
 /*
  * augment() followed by ground_water_augmentation() on its output, as pointcloud_viewer.py:2807-2821 chains them
- * (snow first, then wet with replace=False), without the intermediate cloud leaving the device.  Arguments are
- * those of snowgpu_augment_batch followed by those of snowgpu_wet_ground_batch (wet_plane: n_frames x 4).
+ * (snow first, then wet with replace=False), as ONE launch sequence: the intermediate cloud never leaves the device.
+ * Arguments are those of snowgpu_augment_batch followed by those of snowgpu_wet_ground_batch (wet_plane: n_frames x 4).
  * out_stats are the snowfall statistics; out_rows (float64) / out_counts / out_flags the wet-ground result;
  * out_src maps every final row to its row in the original input frame.
  */
@@ -216,6 +232,20 @@ int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *fra
                               double pavement_depth, double wet_noise_floor, double power_factor,
                               int flat_earth, double delta, int replace, double *out_rows, int32_t *out_src,
                               int64_t *out_counts, int64_t *out_stats, int32_t *out_flags);
+
+/*
+ * The same chain with every array in DEVICE memory, asynchronous on the caller's stream (semantics of
+ * snowgpu_augment_batch_device: no host copy, no synchronisation, no allocation after the first call of a given size --
+ * capturable into a HIP graph).  d_out_rows: n_total x 5 float64; the snowfall stage's rows stay in context scratch.
+ */
+int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
+                                     const int64_t *d_frame_offsets, const void *d_rows, int dtype,
+                                     const int32_t *d_table_ids, double beam_divergence_deg, const double *d_thr_poly,
+                                     const double *d_plane, double noise_floor, const int32_t *d_perm,
+                                     const double *d_wet_plane, double water_height, double pavement_depth,
+                                     double wet_noise_floor, double power_factor, int flat_earth, double delta, int replace,
+                                     double *d_out_rows, int32_t *d_out_src, int64_t *d_out_counts, int64_t *d_out_stats,
+                                     int32_t *d_out_flags, int32_t *d_status, void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,8 @@ EXPORTS = [
     "snowgpu_upload_table", "snowgpu_table_count", "snowgpu_range_grid", "snowgpu_augment_batch",
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
-    "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free",
+    "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
+    "snowgpu_augment_wet_batch_device", "snowgpu_last_status",
 ]
 
 
@@ -74,6 +75,14 @@ def lib():
             L.snowgpu_augment_wet_batch.restype = ctypes.c_int
             L.snowgpu_augment_wet_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp, vp,
                                                     dbl, dbl, dbl, dbl, ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp, vp]
+            L.snowgpu_augment_wet_batch_device.restype = ctypes.c_int
+            L.snowgpu_augment_wet_batch_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp,
+                                                           vp, dbl, dbl, dbl, dbl, ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp, vp,
+                                                           vp, vp]
+            L.snowgpu_last_status.restype = ctypes.c_int
+            L.snowgpu_last_status.argtypes = [vp, vp]
+            L.snowgpu_set_fov.restype = ctypes.c_int
+            L.snowgpu_set_fov.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
             L.snowgpu_sample_table.restype = ctypes.c_int
             L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
@@ -159,7 +168,8 @@ class Context:
         t = np.ascontiguousarray(xyr, np.float64)
         if t.ndim != 2 or t.shape[1] != 3:
             raise ValueError("a particle table is K x 3 (x, y, disk radius)")
-        self._check(self._L.snowgpu_upload_table(self._h, int(table_id), _p(t), t.shape[0]))
+        with self._call_lock:             # never while a batch of this context is in flight (it reads the table list)
+            self._check(self._L.snowgpu_upload_table(self._h, int(table_id), _p(t), t.shape[0]))
 
     def pinned_empty(self, shape, dtype):
         """An uninitialised NumPy array in page-locked host memory (snowgpu_host_alloc); freed with the array."""
@@ -171,8 +181,8 @@ class Context:
         self._check(self._L.snowgpu_host_alloc(self._h, ctypes.c_size_t(nbytes), ctypes.byref(ptr)))
         buf = (ctypes.c_char * max(nbytes, 1)).from_address(ptr.value)
         arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
-        L, h, addr = self._L, self._h, ptr.value
-        weakref.finalize(buf, lambda: L.snowgpu_host_free(h, ctypes.c_void_p(addr)))
+        L, addr = self._L, ptr.value       # page-locked memory is not tied to the context: the array may outlive it
+        weakref.finalize(buf, lambda: L.snowgpu_host_free(None, ctypes.c_void_p(addr)))
         return arr
 
     def augment_batch(self, rows, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None,
@@ -225,6 +235,32 @@ class Context:
                                                   vp(d_out_stats), vp(d_out_thr or None), vp(d_status), vp(stream or None))
         self._check(rc)
 
+    def augment_wet_batch_device(self, n_frames, n_total, max_frame_rows, d_frame_off, d_rows, dtype_code, d_table_ids,
+                                 beam_divergence, d_thr_poly, d_plane, noise_floor, d_perm, d_wet_plane, water_height,
+                                 pavement_depth, wet_noise_floor, power_factor, flat_earth, delta, replace, d_out_rows, d_out_src,
+                                 d_out_counts, d_out_stats, d_out_flags, d_status, stream=0):
+        """Raw device-pointer entry of the fused snowfall + wet-ground chain; asynchronous on `stream`."""
+        vp = ctypes.c_void_p
+        rc = self._L.snowgpu_augment_wet_batch_device(
+            self._h, int(n_frames), int(n_total), int(max_frame_rows), vp(d_frame_off), vp(d_rows), int(dtype_code),
+            vp(d_table_ids), float(beam_divergence), vp(d_thr_poly or None), vp(d_plane or None), float(noise_floor),
+            vp(d_perm or None), vp(d_wet_plane), float(water_height), float(pavement_depth), float(wet_noise_floor),
+            float(power_factor), int(bool(flat_earth)), float(delta), int(bool(replace)), vp(d_out_rows), vp(d_out_src),
+            vp(d_out_counts), vp(d_out_stats), vp(d_out_flags), vp(d_status), vp(stream or None))
+        self._check(rc)
+
+    def set_fov(self, calib=None, img_shape=(1024, 1920)):
+        """Camera-FOV crop inside the compaction of every later batch (None switches it off).  `calib` carries V2C (3 x 4),
+        R0 (3 x 3) and P2 (3 x 4), as lidar_snow_sim_amd.calibration.Calibration does."""
+        with self._call_lock:
+            if calib is None:
+                self._check(self._L.snowgpu_set_fov(self._h, 0, None, None, None, 0, 0))
+                return
+            v2c = np.ascontiguousarray(calib.V2C, np.float64).reshape(3, 4)
+            r0 = np.ascontiguousarray(calib.R0, np.float64).reshape(3, 3)
+            p2 = np.ascontiguousarray(calib.P2, np.float64).reshape(3, 4)
+            self._check(self._L.snowgpu_set_fov(self._h, 1, _p(v2c), _p(r0), _p(p2), int(img_shape[0]), int(img_shape[1])))
+
     def sample_table(self, table_id, occupancy_ratio, diameter_scale_mm, r_0, seed, want_rows=True):
         """Sample a snowflake table on the device; returns the K x 3 rows (or K when want_rows is False)."""
         n = ctypes.c_int64(0)
@@ -236,6 +272,12 @@ class Context:
         # same seed -> same table: the second call only fetches the rows
         self._check(self._L.snowgpu_sample_table(self._h, -1, float(occupancy_ratio), float(diameter_scale_mm), float(r_0),
                                                  ctypes.c_uint64(int(seed)), _p(out), n.value, ctypes.byref(n)))
+        return out
+
+    def last_status(self):
+        """int32[8] status words of the last host-entry batch ([2..5]: beams per later capacity tier)."""
+        out = np.zeros(8, np.int32)
+        self._check(self._L.snowgpu_last_status(self._h, _p(out)))
         return out
 
     def set_exact_math(self, on: bool):

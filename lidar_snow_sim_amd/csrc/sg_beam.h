@@ -24,14 +24,15 @@ template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
 template <> struct SgReal<double> { static constexpr bool is_f32 = false; };
 
 struct SgBeamOut {
-    double x, y, z;   // possibly moved point (label 2)
-    double intensity; // un-rounded output intensity
-    double label;     // 0 / 1 / 2
-    int overflow;     // list capacity exceeded: nothing else is valid
+    int overflow;     // more flakes than the list holds: n_hits is still exact, nothing else is valid
     int range_error;  // window beyond the 1230-bin grid (reference: IndexError)
-    double diff2;     // 2 * (0.9 * max_intensity - new_i) for label 1, else 0
     int has_power;    // >= 1 flake kept: the received-power phase has work for this beam
     int n_flakes;     // scatterers before the hard target (the target sits at index n_flakes)
+    int n_hits;       // flakes intersecting the beam (counted on after the list is full)
+    int label;        // 0 / 1 / 2                                   (set by sg_beam_decide)
+    int new_i;        // output intensity, labels 1 / 2
+    int k_best;       // argmax bin of the power profile
+    double diff2;     // 2 * (0.9 * max_intensity - new_i) for label 1, else 0
 };
 
 __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
@@ -45,31 +46,36 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
     return b;
 }
 
-// LDS views: element j of this thread's private array lives at base[j * STRIDE + tid].
-#define SG_A1(j) s_a1[(j) * STRIDE + tid]
-#define SG_A2(j) s_a2[(j) * STRIDE + tid]
-#define SG_RHO(j) s_rho[(j) * STRIDE + tid]
-#define SG_RATIO(j) s_ratio[(j) * STRIDE + tid]
+// List views: element j of this thread's private array lives at base[j * stride + tid] -- LDS, strided by the block
+// size (STRIDE > 0, a compile-time constant), or global memory strided by the lane count of the global-list tier
+// (STRIDE == 0: run-time stride `rstride`).
+#define SG_IDX(j) ((STRIDE) ? ((j) * (STRIDE) + tid) : (int)((long long)(j) * rstride + tid))
+#define SG_A1(j) s_a1[SG_IDX(j)]
+#define SG_A2(j) s_a2[SG_IDX(j)]
+#define SG_RHO(j) s_rho[SG_IDX(j)]
+#define SG_RATIO(j) s_ratio[SG_IDX(j)]
 
-// Phases 1-2 and 3a for one beam (per lane).  Leaves the scatterer list in this lane's LDS column:
+// Phases 1-2 and 3a for one beam (per lane).  Leaves the scatterer list in this lane's list column:
 // s_a1[t] amplitude, s_a2[t] packed (k1, k0), s_rho[t] range, t = 0 .. n_flakes (hard target last).
-template <typename T, int LMAX, int STRIDE> __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2, double *s_rho, double *s_ratio, int tid, SgBeamOut &out);
+template <typename T, int LMAX, int STRIDE> __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2, double *s_rho, double *s_ratio, int tid, SgBeamOut &out, int rstride = 0);
 
-// DICT_ONLY: stop after phase 2 and leave the occlusion dict (s_rho[t], s_ratio[t], t = 0 .. n_flakes) in LDS --
-// the direct-mode pass then queues the beam for k_power instead of walking phase 3 with most lanes idle.
+// LMAX > 0: list capacity, a compile-time constant (lists in LDS).  LMAX == 0: the global-list tier, capacity `rcap`
+// and stride `rstride` at run time.  The scan keeps counting after the list is full: out.n_hits is exact either way.
+// DICT_ONLY: stop after phase 2 and leave the occlusion dict (s_rho[t], s_ratio[t], t = 0 .. n_flakes) in the list
+// columns -- the beam is then handed to k_power instead of walking phase 3 with most lanes idle.
 template <typename T, int LMAX, int STRIDE, bool DICT_ONLY = false>
-__device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, const SgTable tab,
-                                        const SgLasers *__restrict__ las, const double *__restrict__ s_rgrid,
+__device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgTable tab,
+                                        const SgLasers *__restrict__ las,
                                         double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
                                         double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
                                         int32_t *dbg_count, double *dbg_rj, double *dbg_ratio,
-                                        unsigned long long *ph = nullptr, bool EXACT_TAN = false)
+                                        bool EXACT_TAN = false, int rstride = 0, int rcap = 0)
 {
-    const unsigned long long ph0 = ph ? wall_clock64() : 0;
-    unsigned long long ph_cand = 0;
     constexpr bool F32 = SgReal<T>::is_f32;
-    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0;
-    out.x = (double)px; out.y = (double)py; out.z = (double)pz; out.intensity = (double)pint; out.label = 0.0;
+    constexpr bool HUGE_TIER = LMAX == 0;
+    const int lcap = HUGE_TIER ? rcap : LMAX;
+    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.n_hits = 0;
+    out.label = 0; out.new_i = 0; out.k_best = 0;
 
     // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
     T d_t;
@@ -117,10 +123,10 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
     // (A split scan -- cheap angular prefilter first, the exact predicates on the survivors only -- was tried and
     // made no difference: the scan is bound by its dependent record gathers, not by arithmetic.)
-    int L = 0;
+    int L = 0, hits = 0;
     {
         int b = b_lo;
-        for (int s = 0; s <= span && !out.overflow; ++s) {
+        for (int s = 0; s <= span; ++s) {
             uint32_t e0, e1;
             if (s == 0) { e0 = st0; e1 = st1; }
             else if (s == 1) { e0 = st2; e1 = st3; }
@@ -132,7 +138,6 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             for (uint32_t e = e0; e < e1; ++e) {
                 const SgEntry f = nxt;
                 nxt = tab.entries[e + 1];
-                ++ph_cand;
                 const double rho = f.rho;
                 if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
                 if (s > 0 && !(f.flags & 1u)) continue;         // already met in an earlier bin
@@ -151,7 +156,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
                 const bool hit_r = near_r && sg_forward(theta_r, phi);            // :379-384
                 const bool hit_l = near_l && sg_forward(theta_l, phi);            // :379-385
                 if (!(centre || hit_r || hit_l)) continue;      // :389
-                if (L == LMAX) { out.overflow = 1; break; }
+                ++hits;
+                if (L == lcap) continue;                        // list full: keep counting (the count picks the tier)
                 const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26
                 const double na2 = hit_l ? theta_l : f.t1;      // geometry.py:27
                 int p = L;                                      // insertion sort by rho (:413-417)
@@ -165,8 +171,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             if (++b == nb) b = 0;
         }
     }
-    if (out.overflow) return;
-    const unsigned long long ph1 = ph ? wall_clock64() : 0;
+    out.n_hits = hits;
+    if (hits > lcap) { out.overflow = 1; return; }
 
     // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------
     // The reference sorts the unique endpoints, gives every elementary slot to the nearest flake
@@ -218,7 +224,10 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     // column; the slots of one owner arrive in the order of diffs[assignment == j]) or to the hard target.
     // A running sum is NumPy's sum for fewer than 8 addends; an owner with more is redone by owner_walk.
     double tgt_sum;
-    unsigned long long cnt = 0;      // LMAX <= 16: 4 bits per owner, saturating at 8; else: one "owns a slot" bit per owner
+    // "has this owner got a slot yet, and how many": LMAX <= 16: 4 bits per owner in cnt, saturating at 8; LMAX <= 64: one
+    // bit per owner; global-list tier: the ratio column itself, -1 = no slot yet (slot widths are positive)
+    unsigned long long cnt = 0;
+    if constexpr (HUGE_TIER) for (int j = 0; j < L; ++j) SG_RATIO(j) = -1.0;
     acc.reset();
     {
         double e = e_min;
@@ -235,7 +244,10 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
             if (la > e && la < nxt) nxt = la;
             const double w = nxt - e;
             if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)
-            else if constexpr (LMAX <= 16) {
+            else if constexpr (HUGE_TIER) {
+                const double have = SG_RATIO(own);
+                SG_RATIO(own) = have < 0 ? w : have + w;
+            } else if constexpr (LMAX <= 16) {
                 const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
                 SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
                 if (c < 8) cnt += 1ull << (4 * own);
@@ -250,12 +262,13 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     tgt_sum = acc.result();
     for (int j = 0; j < L; ++j) {
         bool redo;
-        if constexpr (LMAX <= 16) {
+        if constexpr (!HUGE_TIER && LMAX <= 16) {
             const unsigned c = (unsigned)(cnt >> (4 * j)) & 15u;
             if (c == 0) continue;                               // every slot already owned by nearer flakes
             redo = c >= 8;
         } else {
-            if (!((cnt >> j) & 1ull)) continue;
+            if constexpr (HUGE_TIER) { if (SG_RATIO(j) < 0) continue; }
+            else { if (!((cnt >> j) & 1ull)) continue; }
             // fewer than 7 endpoints strictly inside the interval -> fewer than 8 slots
             const double lo = SG_A1(j), hi = SG_A2(j);
             int inside = (ra > lo && ra < hi) + (la > lo && la < hi);
@@ -275,22 +288,17 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
     SG_RHO(S) = d;
     SG_RATIO(S) = sg_clip01(tgt_sum / delta);
     const int n_dict = S + 1;
-    const unsigned long long ph2 = ph ? wall_clock64() : 0;
     if (dbg_count) {
         *dbg_count = n_dict;
         for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
     }
     if (n_dict == 1) return;                                    // :133 no snowflake in this beam -> label 0
-    if (ph && (tid & 63) == 0) {
-        atomicAdd(&ph[1], ph1 - ph0); atomicAdd(&ph[2], ph2 - ph1);
-        atomicAdd(&ph[6], (unsigned long long)L); atomicAdd(&ph[7], ph_cand);
-    }
     if constexpr (DICT_ONLY) {
         out.n_flakes = S;
         out.has_power = 1;
         return;
     } else {
-        sg_beam_amp<T, LMAX, STRIDE>(d_t, S, channel, las, s_a1, s_a2, s_rho, s_ratio, tid, out);
+        sg_beam_amp<T, LMAX, STRIDE>(d_t, S, channel, las, s_a1, s_a2, s_rho, s_ratio, tid, out, rstride);
     }
 }
 
@@ -298,7 +306,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, T pint, int channel, c
 // In: s_rho[t], s_ratio[t] for t = 0 .. S (the hard target last, range d).  Out: s_a1[t] amplitude, s_a2[t] packed (k1, k0).
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2,
-                                            double *s_rho, double *s_ratio, int tid, SgBeamOut &out)
+                                            double *s_rho, double *s_ratio, int tid, SgBeamOut &out, int rstride)
 {
     constexpr bool F32 = SgReal<T>::is_f32;
     const int n_dict = S + 1;
@@ -396,7 +404,7 @@ __device__ __forceinline__ double sg_range_bin(int k)
 template <int STRIDE, bool EXACT, int NB>
 __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const double *__restrict__ rgrid, const double *s_a1,
                                               const double *s_a2, const double *s_rho, int tid, int tk0, int tk1, double tamp,
-                                              double td, double &best, int &k_best)
+                                              double td, double &best, int &k_best, int rstride)
 {
     double R[NB], sm[NB];
 #pragma unroll
@@ -406,11 +414,11 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
         sm[i] = 0.0;                                         // :135 np.zeros
     }
     for (int t = t_from; t < S; ++t) {
-        const double pk = s_a2[t * STRIDE + tid];
+        const double pk = s_a2[SG_IDX(t)];
         const int q0 = __double2loint(pk), q1 = __double2hiint(pk);
         if (q0 >= k + NB) break;                             // flake windows start in range order
         if (q1 <= k) continue;
-        const double amp = s_a1[t * STRIDE + tid], r = s_rho[t * STRIDE + tid];
+        const double amp = s_a1[SG_IDX(t)], r = s_rho[SG_IDX(t)];
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             if (k + i >= q0 && k + i < q1) sm[i] += sg_power_term<EXACT>(amp, R[i], r);   // :149
@@ -438,37 +446,35 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
 //           |u_t - pi/2| <= sqrt(1.26 (1 - q_t)) for q_t >= 1/2: a zone of a few bins around the peak of t.
 //           Applied to the strongest scatterer covering the bin (the others then being the weaker overlapping
 //           windows only), every bin that matters lies in such a zone; q_t < 1/2 keeps the whole window.
+// WCAP: slots of the per-lane work list (0: run-time capacity `rwcap`, the global-list tier)
 template <int STRIDE, bool EXACT, int NB, int WCAP>
 __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
                                               const double *s_rho, double *s_work, int tid, double &best, int &k_best,
-                                              int *stat = nullptr)
+                                              int rstride = 0, int rwcap = 0)
 {
     best = 0.0;
     k_best = 0;
-    int n_iter = 0, n_eval = 0;                   // experiment counters (scripts/gpu_phases.py)
+    const int wcap = WCAP ? WCAP : rwcap;
     const double c_tau = 299792458.0 * 1e-8;
     const double step = (120 + c_tau) / (SG_RBINS - 1);
-    const double tpk = s_a2[S * STRIDE + tid];
+    const double tpk = s_a2[SG_IDX(S)];
     const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
-    const double tamp = s_a1[S * STRIDE + tid], td = s_rho[S * STRIDE + tid];
+    const double tamp = s_a1[SG_IDX(S)], td = s_rho[SG_IDX(S)];
     double amax = tamp;
-    for (int t = 0; t < S; ++t) amax = fmax(amax, s_a1[t * STRIDE + tid]);
+    for (int t = 0; t < S; ++t) amax = fmax(amax, s_a1[SG_IDX(t)]);
     const double floor_ = 0.9966 * amax;
     int nw = 0;
     auto flush = [&]() {
-        for (int w = 0; w < nw; ++w) {
-            ++n_eval;
-            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[w * STRIDE + tid]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
-                                             tk1, tamp, td, best, k_best);
-        }
+        for (int w = 0; w < nw; ++w)
+            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
+                                             tk1, tamp, td, best, k_best, rstride);
         nw = 0;
     };
     // ---- stage A ----
     for (int t = 0; t <= S; ++t) {                // the hard target is scatterer S
-        ++n_iter;
-        const double A = s_a1[t * STRIDE + tid];
+        const double A = s_a1[SG_IDX(t)];
         if (!(A > 0.0)) continue;                 // adds nothing anywhere; the bins it covers belong to others' zones
-        const double pk = s_a2[t * STRIDE + tid];
+        const double pk = s_a2[SG_IDX(t)];
         const int k0 = __double2loint(pk), k1 = __double2hiint(pk);
         // Each bin is the business of the strongest scatterer covering it (ties: the nearer one).  So this window
         // answers only for its bins outside stronger overlapping windows -- those trim it from the left (lo_trim) or
@@ -477,19 +483,19 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
         double oth = 0.0;
         int lo_trim = k0, hi_trim = k1;
         auto visit = [&](int j, int q0, int q1) {
-            const double Aj = s_a1[j * STRIDE + tid];
+            const double Aj = s_a1[SG_IDX(j)];
             if (Aj > A || (Aj == A && j < t)) {
                 if (q0 <= k0) { if (q1 > lo_trim) lo_trim = q1; }
                 else if (q1 >= k1) { if (q0 < hi_trim) hi_trim = q0; }
             } else oth += Aj;
         };
         for (int j = t - 1; j >= 0; --j) {
-            const double pj = s_a2[j * STRIDE + tid];
+            const double pj = s_a2[SG_IDX(j)];
             if (__double2hiint(pj) <= k0) break;
             visit(j, __double2loint(pj), __double2hiint(pj));
         }
         for (int j = t + 1; j <= S; ++j) {
-            const double pj = s_a2[j * STRIDE + tid];
+            const double pj = s_a2[SG_IDX(j)];
             if (__double2loint(pj) >= k1) break;
             visit(j, __double2loint(pj), __double2hiint(pj));
         }
@@ -500,7 +506,7 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
         if (q >= 0.5) {
             const double om = q < 1.0 ? 1.0 - q : 0.0;
             const double delta = (double)sqrtf((float)(1.26 * om)) * (1.0 + 1e-6) + 1e-6;
-            const double Rc = s_rho[t * STRIDE + tid] + c_tau / 2;
+            const double Rc = s_rho[SG_IDX(t)] + c_tau / 2;
             const double D = delta * (c_tau / SG_PI) + 0.006;      // + half a centimetre of grid rounding
             const int za = (int)floor((Rc - D) * (1.0 / step)), zb = (int)ceil((Rc + D) * (1.0 / step));
             if (za > ka) ka = za;
@@ -509,25 +515,21 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
         if (lo_trim > ka) ka = lo_trim;
         if (hi_trim - 1 < kb) kb = hi_trim - 1;
         for (int g = ka; g <= kb; g += NB) {
-            if (nw == WCAP) flush();
-            s_work[nw * STRIDE + tid] = __hiloint2double(0, g);
+            if (nw == wcap) flush();
+            s_work[SG_IDX(nw)] = __hiloint2double(0, g);
             ++nw;
         }
     }
     // ---- stage B ----
     flush();
-    if (stat) { stat[0] = n_iter; stat[1] = n_eval; }
 }
 
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------
-template <typename T>
-__device__ __forceinline__ void sg_beam_decide(T px, T py, T pz, int channel, const SgLasers *__restrict__ las, double best,
-                                               int k_best, SgBeamOut &out)
+// d = the beam's range as float64 (the value of the row dtype).  A scattered point (label 2) moves to
+// d_max = k_best / 10 - c tau / 2 on its ray; the row is rebuilt from the record by sg_scatter_scale below.
+__device__ __forceinline__ void sg_beam_decide(double d, int channel, const SgLasers *__restrict__ las, double best, int k_best,
+                                               SgBeamOut &out)
 {
-    T d_t;
-    if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);
-    else d_t = sqrt((px * px + py * py) + pz * pz);
-    const double d = (double)d_t;
     const int max_i = las->max_i[channel], min_i = las->min_i[channel];
     const double c_tau = 299792458.0 * 1e-8;
     const double i_snow = 0.9 * max_i;
@@ -539,16 +541,27 @@ __device__ __forceinline__ void sg_beam_decide(T px, T py, T pz, int channel, co
     if (i_max > max_i) i_max = max_i;
     long long new_i = (long long)i_max;                         // :162 / :182
     if (fabs(d_max - d) < 2 * (1.0 / 10)) {                     // :158
-        out.label = 1.0;                                        // :160
+        out.label = 1;                                          // :160
         out.diff2 = 2.0 * (i_snow - (double)new_i);             // :170 (Q2)
     } else {
-        out.label = 2.0;                                        // :174
-        const double scale = d_max / d;                         // :176
-        out.x = (double)px * scale;                             // :178-180
-        out.y = (double)py * scale;
-        out.z = (double)pz * scale;
+        out.label = 2;                                          // :174
     }
     if (new_i < min_i) new_i = min_i;                           // :186
     if (new_i > max_i) new_i = max_i;
-    out.intensity = (double)new_i;                              // :188
+    out.new_i = (int)new_i;                                     // :188
+    out.k_best = k_best;
+}
+
+// scale = d_max / d of a scattered point (simulation.py:153, :176); the moved coordinates are (T)((double)p * scale)
+// (:178-180: a float32 column times a float64 scalar, stored back into the row dtype)
+__device__ __forceinline__ double sg_scatter_scale(int k_best, double d)
+{
+    const double c_tau = 299792458.0 * 1e-8;
+    const double d_max = ((double)k_best / 10) - (c_tau / 2);
+    return d_max / d;
+}
+
+__device__ __forceinline__ uint32_t sg_pack_record(const SgBeamOut &o)
+{
+    return (uint32_t)(o.new_i & 255) | ((uint32_t)o.label << 8) | ((uint32_t)o.k_best << 12);
 }

@@ -41,6 +41,23 @@ struct SgLasers {
     int32_t n;
 };
 
+// Result record of one beam, one uint32 per channel-sorted position (the per-beam kernels write 4 bytes per row; the
+// compaction kernels rebuild the output row from the ORIGINAL row and this record -- no un-compacted copy of the cloud):
+//   bits 0..7   new intensity (simulation.py:188, an integer in [min_i, max_i] <= 255), labels 1 / 2 only
+//   bits 8..9   label: 0 unchanged, 1 attenuated, 2 scattered (simulation.py:160, :174)
+//   bit  10     copy-through row: its channel has no laser (Q5), column 4 keeps the channel value
+//   bits 12..22 argmax bin of the power profile (simulation.py:151), label 2: the point moves to k / 10 - c tau / 2
+#define SG_REC_LABEL_SHIFT 8
+#define SG_REC_COPY (1u << 10)
+#define SG_REC_K_SHIFT 12
+#define SG_MAX_CLASSES 4        /* later capacity tiers incl. the global-list tier */
+
+#if defined(__HIPCC__) || defined(__HIP__)
+typedef int2 int2_t;
+#else
+struct int2_t { int32_t x, y; };
+#endif
+
 struct SgBeamArgs {
     const void *rows;            // AoS rows, all frames
     const int64_t *frame_off;    // n_frames + 1
@@ -49,45 +66,75 @@ struct SgBeamArgs {
     int64_t uniform_rows;        // > 0: every frame has this many rows (frame = position / uniform_rows)
     float inv_uniform_rows;
     const int32_t *perm;         // channel-sorted position (global) -> frame-local source row
-    const SgTable *tables;
-    int32_t n_tables;
-    const int32_t *table_ids;    // n_frames x n_lasers
     const SgTable *frame_tables; // n_frames x n_lasers resolved descriptors (entries == nullptr: unknown table id)
     const SgLasers *las;
     const double *rgrid;         // SG_RBINS
     double beam_div_deg;
-    void *tmp_rows;              // channel-sorted, un-compacted result rows
-    uint8_t *keep;               // per sorted row
-    int32_t *status;             // [0] error code, [1] first offending sorted row, [2] overflow beams
-    int32_t *ovf_list;           // sorted positions that overflowed this pass's list capacity
-    int32_t *ovf_count;          // counter to bump for them (status[2] or status[3])
-    int32_t ovf_cap;
-    const int32_t *work_list;    // non-null: process these sorted positions (overflow pass)
-    const int32_t *work_count;
-    int32_t work_cap;            // entries of work_list that may be read
+    uint32_t *rec;               // per sorted position: result record (SG_REC_*)
+    uint8_t *flag;               // per sorted position: 0, or 3 + k for a beam that needs later capacity tier k
+    int32_t *status;             // [0] error code, [1] first offending sorted row
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
-    int32_t *dbg_count;          // optional occlusion-dict tap
-    double *dbg_rj;
-    double *dbg_ratio;
-    int32_t dbg_cap;
-    // Segment-ordered direct mode (optional, first pass): blocks walk (table, frame, channel) segments of the sorted
-    // rows, so that chip-wide one or two flake tables are in use at a time and stay in L2.  null = linear order.
+    int32_t exact_math;          // 1: libm sin / tan + true division (validation mode)
+    // tier classes: a beam of the first pass that met more flakes than its list holds is flagged with the first later
+    // tier whose capacity takes all of them (the scan keeps COUNTING after the list is full, so the count is exact)
+    int32_t n_cls;               // later tiers (the last one is the global-list tier, capacity = table size)
+    int32_t cls_cap[SG_MAX_CLASSES];
+    // direct mode: blocks walk (table, frame, channel) segments of the sorted rows (seg_blk != null) or plain chunks of
+    // q_chunk sorted positions.  Either way a block lies in ONE region, and the region is also its slice of the dict queue.
     const int32_t *seg_blk;      // n_seg: first block of segment i
     const int64_t *seg_start;    // n_seg: global sorted position of the segment's first row
     const int32_t *seg_cnt;      // n_seg: rows
-    const int32_t *seg_frame;    // n_seg
+    const int32_t *seg_frame;    // n_seg: frame | channel << 22
     const int32_t *seg_n;        // [0] = n_seg, [1] = blocks in all segments
     const int32_t *seg_of_blk;   // grid_blocks: segment of block b (valid below seg_blk[n_seg])
-    int64_t grid_blocks;         // host: blocks to launch in that mode (upper bound; surplus blocks leave at once)
-    // First-pass split: the direct-mode pass stops at the occlusion dict and queues the beams that met a flake;
-    // k_power runs the received-power phase over the queue with every lane busy.
-    const int32_t *pq_list;      // sorted positions of the queued beams, ascending (built from the keep flags 16 + n_flakes)
-    double *pq_dict;             // pq_stride doubles per sorted position: (range, ratio) x (n_flakes + 1), the hard target last
-    int32_t *pq_count;
-    int32_t pq_cap;
-    int32_t pq_stride;           // 2 * (first-pass capacity + 1)
-    int32_t exact_math;          // 1: libm sin + true division in the power term (validation mode)
-    unsigned long long *phase_cycles;   // optional [8]: per-wave cycle totals per phase (profiling builds of the call)
+    int64_t grid_blocks;         // host: blocks of this launch (upper bound; surplus blocks leave at once)
+    int32_t q_chunk;             // linear mode: sorted positions per region (a multiple of the block size)
+    // The pass runs as a few launches over consecutive block ranges, so that k_power of one range runs next to the scan
+    // of the next: blocks [blk_lo, blk_hi) (linear order), or chunk `chunk` of chunk_blk (segment order: device-built
+    // boundaries, cut at segment starts).
+    int64_t blk_lo, blk_hi;
+    const int32_t *chunk_blk;
+    int32_t chunk;
+    // Dict queue of the direct-mode pass: a beam that met flakes hands its occlusion dict to k_power.  Blocked SoA (groups
+    // of 64 slots): plane 2 t = range of scatterer t, plane 2 t + 1 = its ratio (the hard target is entry n_flakes).
+    // A region's beams with ONE flake fill its slice from the front, the others from the back (waves of uniform loop
+    // length in k_power); qn[region] = front count | back count << 32, bumped once per wave.
+    double *dq;
+    int32_t *dq_g;               // per slot: sorted position of the beam
+    uint16_t *dq_sc;             // per slot: n_flakes | channel << 8
+    unsigned long long *qn;      // per region
+    int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 7}
+    int32_t *pw_count;           // items planned (reset per chunk)
+    int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
+    int32_t blk_rows;            // rows per block of the direct-mode pass
+    int64_t dq_n;                // plane stride (= n_total)
+    // list mode: this launch handles entries [work_lo, min(work_hi, count)) of class `cls` of the tier lists
+    const int32_t *tier_list;    // the class lists, concatenated
+    const int32_t *tier_info;    // [0..3] entries per class, [4..7] start of each class in tier_list
+    int32_t cls;
+    int32_t work_lo, work_hi;
+    // dict hand-over of a list-mode pass: entry i of the class -> slot i (planes of tq_cap entries)
+    double *tq;
+    uint16_t *tq_sc;
+    int32_t tq_cap;
+    // global-list tier: per-lane lists in global memory, h_cap entries each, h_lanes lanes
+    double *h_lists;
+    int32_t h_cap, h_lanes;
+    // optional occlusion-dict tap (snowgpu_debug_occlusions)
+    int32_t *dbg_count;
+    double *dbg_rj;
+    double *dbg_ratio;
+    int32_t dbg_cap;
+};
+
+// Camera-FOV crop of augment() (simulation.py:39-47, :532-540) as the compaction applies it: M = V2C^T R0^T (4 x 3,
+// lidar_to_rect) and P2 (3 x 4) in float64, image h x w.  enabled = 0: no crop.
+struct SgFov {
+    int32_t enabled;
+    int32_t pre;                 // 1: crop on the ORIGINAL coordinates before anything else (precompute.py:96-99)
+    double m[12];                // lidar_to_rect: rect = [x y z 1] . m   (row-major 4 x 3)
+    double p[12];                // P2 (row-major 3 x 4)
+    double img_h, img_w;
 };
 
 // Launch wrappers implemented in snowgpu_kernels.hip (hipStream_t passed as void*).
@@ -95,21 +142,26 @@ struct SgBeamArgs {
 extern "C" {
 #endif
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
-                   int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
+                   int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, void *stream);
-int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+// direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
+// dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
+int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
-                       int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream);
+                       int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
+                       int32_t *chunk_blk, void *stream);
 int sg_beams_block(int lmax);
-int sg_launch_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *count, int32_t cap,
-                   int lo1, int hi1, int lo2, int hi2, void *stream);
+int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *tier_info,
+                         int32_t *status_counts, int32_t cap, int n_cls, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
-int sg_launch_compact(const void *tmp_rows, int dtype, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
-                      int64_t *out_stats, const unsigned long long *diff2, int64_t max_tiles_per_frame,
+                      int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,
                       void *stream);
 #ifdef __cplusplus
 }

@@ -23,6 +23,9 @@ int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64
 int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
                const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
                int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream);
+// out[off[f] + i] = first[off[f] + second[off[f] + i]] for i < counts[f] (device arrays)
+int sg_launch_compose_src(const int64_t *frame_off, const int64_t *counts, int n_frames, int64_t max_frame,
+                          const int32_t *second, const int32_t *first, int32_t *out, void *stream);
 void sg_prepass_release(SgPrepassScratch *s);
 #ifdef __cplusplus
 }

@@ -15,6 +15,8 @@
 #include "sg_common.h"
 #include "sg_prepass.h"
 
+#define SG_MAX_CHUNKS 16
+
 namespace {
 
 struct DeviceTable {
@@ -46,30 +48,50 @@ template <typename T> struct DevBuf {
 struct snowgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux2 = nullptr;           // side stream of the noise-threshold prepass (only the compaction needs its result)
-    hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;
-    hipStream_t aux = nullptr;            // side stream: launch-order bookkeeping that only needs the sort, next to the prepass
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // side streams of one batch; each forks from the caller's stream and joins back before the compaction
+    hipStream_t aux = nullptr;            // table resolve + segment order (next to the prepass), later k_power of the first pass
+    hipStream_t aux2 = nullptr;           // noise-threshold prepass (only the compaction needs its result)
+    hipStream_t aux3 = nullptr;           // later capacity tiers beyond the first of them
+    hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;   // prepass
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // resolve / segments
+    hipEvent_t ev_fp[SG_MAX_CHUNKS] = {}, ev_join2 = nullptr;   // chunk of the first pass done -> its k_power
+    hipEvent_t ev_lists = nullptr, ev_join3 = nullptr;   // tier lists built -> later tiers
     std::string err;
     std::vector<DeviceTable> tables;
     SgTable *d_tables = nullptr;      // device mirror of the descriptors
     size_t d_tables_cap = 0;
     bool tables_dirty = true;
-    uint32_t max_flakes = 0;          // largest uploaded table (drives the LMAX choice)
+    uint32_t max_flakes = 0;          // largest uploaded table (drives the capacity-tier choice)
     SgLasers h_las{};
     SgLasers *d_las = nullptr;
     double *d_rgrid = nullptr;
-    int32_t *d_status = nullptr;      // 4 ints
+    int32_t *d_status = nullptr;      // 8 ints
+    SgFov fov{};                      // camera-FOV crop applied by the compaction (snowgpu_set_fov)
     // scratch shared by every batch
-    DevBuf<int32_t> tile_hist, tile_base, ovf_list, ovf_list2, perm, ctile_cnt, ctile_base, table_ids, out_src;
+    DevBuf<int32_t> tile_hist, tile_base, perm, ctile_cnt, ctile_base, table_ids, out_src;
     DevBuf<unsigned long long> seg_tbl_cnt, seg_tbl_base;
-    DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk, pq_list, ptile_cnt, ptile_base;
-    DevBuf<double> pq_dict;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk;
     DevBuf<int64_t> seg_start;
+    DevBuf<uint32_t> rec;             // result records, one per sorted position
+    DevBuf<double> dq;                // dict queue of the first pass (SoA planes)
+    DevBuf<int32_t> dq_g;
+    DevBuf<uint16_t> dq_sc;
+    DevBuf<unsigned long long> qn;    // per region: front | back << 32
+    DevBuf<int2_t> pw_items;          // work items of k_power
+    DevBuf<int32_t> pw_count;
+    DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base;
+    DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
+    DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
+    DevBuf<double> h_lists;           // global-list tier: per-lane lists
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
+    int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
+    int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
+    int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
+    bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
+    bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
+    DevBuf<int32_t> chunk_blk;
     DevBuf<uint16_t> rank;
-    DevBuf<uint8_t> keep, rows_in, rows_tmp, rows_out;
+    DevBuf<uint8_t> keep, rows_in, rows_out;
     DevBuf<int64_t> frame_off, out_counts, out_stats;
     DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio, user_thr, out_thr;
     DevBuf<int32_t> user_perm;
@@ -77,13 +99,17 @@ struct snowgpu_ctx {
     DevBuf<unsigned long long> diff2;
     DevBuf<SgTable> frame_tables;
     SgPrepassScratch prepass{};
+    // fused snow + wet (snowgpu_augment_wet_batch*): the snowfall result stays here
+    DevBuf<uint8_t> snow_rows;
+    DevBuf<int32_t> snow_src, wet_src, wet_flags;
+    DevBuf<int64_t> snow_counts, wet_counts;
+    DevBuf<double> wet_rows, wet_plane;
     // measurement hooks (snowgpu_profile_begin / _end)
     std::vector<hipEvent_t> ev_start, ev_stop;
     int ev_used = 0;
     bool prof = false;
     hipStream_t prof_stream = nullptr;
     int exact_math = 0;
-    unsigned long long *phase_cycles = nullptr;   // device [8], experiments only
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -142,15 +168,16 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *lo = std::getenv("SNOWGPU_LINEAR_ORDER"); ctx->linear_order = lo && lo[0] == '1'; }
     *out = ctx;   // hand the context back even on failure so that last_error is readable
     HIPCHK(ctx, hipSetDevice(device));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->aux2, hipStreamNonBlocking));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork0, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join0, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming));
+    { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
+    for (hipStream_t *sp : {&ctx->stream, &ctx->aux, &ctx->aux2, &ctx->aux3})
+        HIPCHK(ctx, hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
+        HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
+    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 8));
@@ -174,25 +201,27 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_las) (void)hipFree(ctx->d_las);
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->ovf_list.release(); ctx->ovf_list2.release(); ctx->perm.release();
-    ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release(); ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->pq_list.release(); ctx->ptile_cnt.release(); ctx->ptile_base.release(); ctx->pq_dict.release();
+    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
+    ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
+    ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
+    ctx->rec.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
+    ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
-    ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_tmp.release(); ctx->rows_out.release();
+    ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
     ctx->dbg_count.release(); ctx->diff2.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
+    ctx->snow_rows.release(); ctx->snow_src.release(); ctx->wet_src.release(); ctx->wet_flags.release(); ctx->snow_counts.release();
+    ctx->wet_counts.release(); ctx->wet_rows.release(); ctx->wet_plane.release();
     sg_prepass_release(&ctx->prepass);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_fork2) (void)hipEventDestroy(ctx->ev_fork2);
-    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
-    if (ctx->ev_fork0) (void)hipEventDestroy(ctx->ev_fork0);
-    if (ctx->ev_join0) (void)hipEventDestroy(ctx->ev_join0);
-    if (ctx->aux2) (void)hipStreamDestroy(ctx->aux2);
-    if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3})
+        if (e) (void)hipEventDestroy(e);
+    for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_fp[c]) (void)hipEventDestroy(ctx->ev_fp[c]);
+    for (hipStream_t st : {ctx->aux3, ctx->aux2, ctx->aux, ctx->stream})
+        if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -374,12 +403,23 @@ static int sync_tables(snowgpu_ctx *ctx)
 static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[4], int *n_tiers)
 {
     const double expect = (double)ctx->max_flakes * (beam_div_deg * (SG_PI / 180.0)) / SG_TWO_PI;
+    int first = expect <= 12.0 ? 4 : (expect <= 24.0 ? 8 : (expect <= 40.0 ? 16 : SG_LCAP));
+    if (ctx->first_tier_override == 4 || ctx->first_tier_override == 8 || ctx->first_tier_override == 16 ||
+        ctx->first_tier_override == SG_LCAP)
+        first = ctx->first_tier_override;
     int n = 0;
-    if (expect <= 12.0) tiers[n++] = 4;
-    if (expect <= 24.0) tiers[n++] = 8;
-    if (expect <= 40.0) tiers[n++] = 16;
-    tiers[n++] = SG_LCAP;
+    for (int c : {4, 8, 16, SG_LCAP})
+        if (c >= first) tiers[n++] = c;
     *n_tiers = n;
+}
+
+// dict hand-over buffer of a list-mode tier: entries it holds for a batch of n rows (the rest of the class, if any,
+// runs the received-power phase in place)
+static int64_t tier_queue_cap(const snowgpu_ctx *ctx, int lmax, int64_t n)
+{
+    if (ctx->tier_cap_override > 0) return std::min<int64_t>(ctx->tier_cap_override, std::max<int64_t>(n, 1));
+    const int64_t div = lmax <= 8 ? 4 : (lmax <= 16 ? 16 : 64);
+    return std::min<int64_t>(std::max<int64_t>(n, 1), std::max<int64_t>(n / div, 4096));
 }
 
 // ---- the batch launch sequence (everything on device pointers) --------------------------------------
@@ -409,6 +449,7 @@ struct BatchDev {
     double *dbg_rj = nullptr, *dbg_ratio = nullptr;
     int dbg_cap = 0;
     int32_t *perm_out = nullptr;   // where the permutation actually used lives (device)
+    bool no_fov = false;           // debug tap: never crop
 };
 
 static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
@@ -418,10 +459,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         return fail(ctx, SNOWGPU_E_INVALID, "beam divergence must be in (0, 45) degrees");
     int rc = sync_tables(ctx);
     if (rc) return rc;
-    const size_t esz = b.dtype == 0 ? 4 : 8;
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
+    hipStream_t s_aux = ctx->serial ? st : ctx->aux, s_aux2 = ctx->serial ? st : ctx->aux2, s_aux3 = ctx->serial ? st : ctx->aux3;
     HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
     HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));   // status[1] = first offending row, -1 = none
     if (n == 0) {
@@ -434,19 +475,23 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // kernels: bandwidth-bound reductions beside latency-bound scans.
     const double *thr = b.thr_poly;
     bool pre_forked = false;
+    auto launch_prepass = [&]() -> int {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
+        HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
+        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
+                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+        if (b.out_thr_poly)
+            HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, ctx->thr_poly.p, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, s_aux2));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join0, s_aux2));
+        pre_forked = true;
+        return SNOWGPU_OK;
+    };
     if (!thr) {
         if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
-        HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->aux2, ctx->ev_fork0, 0));
-        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
-                               b.noise_floor, ctx->thr_poly.p, b.status, ctx->aux2);
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         thr = ctx->thr_poly.p;
-        if (b.out_thr_poly)
-            HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, ctx->aux2));
-        HIPCHK(ctx, hipEventRecord(ctx->ev_join0, ctx->aux2));
-        pre_forked = true;
+        if (ctx->prepass_early) { int prc = launch_prepass(); if (prc) return prc; }
     } else if (b.out_thr_poly) {
         HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
     }
@@ -457,8 +502,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->tile_base, (size_t)b.n_frames * (size_t)max_tiles * 256);
         ENSURE(ctx, ctx->rank, n);
         ENSURE(ctx, ctx->perm, n);
+        ENSURE(ctx, ctx->keep, n);                // channel bytes between the two sort passes; flag / keep bytes afterwards
         int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
-                               ctx->rank.p, ctx->perm.p, b.status, max_tiles, st);
+                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;
     }
@@ -479,99 +525,159 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
         ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
+        ENSURE(ctx, ctx->chunk_blk, SG_MAX_CHUNKS + 1);
     }
+    // The first pass runs as n_chunks launches over consecutive block ranges; k_power of one range runs beside the scan of
+    // the next (the scan is latency-bound, the received-power phase ALU-bound), and only the last k_power is a tail.
+    const int64_t total_blocks_ub = (b.n_total + first_block - 1) / first_block + (use_seg ? (int64_t)b.n_frames * 256 : 0);
+    int n_chunks = total_blocks_ub >= 16384 ? 8 : (total_blocks_ub >= 2048 ? 2 : 1);
+    if (ctx->chunks_override > 0) n_chunks = std::min(ctx->chunks_override, SG_MAX_CHUNKS);
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
     {
-        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, ctx->aux);
+        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
         if (use_seg) {
             e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(), first_block,
                                    ctx->seg_tbl_cnt.p, ctx->seg_tbl_base.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p,
-                                   ctx->seg_n.p, ctx->seg_of_blk.p, ctx->aux);
+                                   ctx->seg_n.p, ctx->seg_of_blk.p, n_chunks, ctx->chunk_blk.p, s_aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->aux));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, s_aux));
     // 3. beams
-    ENSURE(ctx, ctx->rows_tmp, n * 5 * esz);
+    ENSURE(ctx, ctx->rec, n);
     ENSURE(ctx, ctx->keep, n);
-    // flag bytes of the first pass (2: overflowed, 16 + n_flakes: queued for k_power): nothing stale may be left in them
-    HIPCHK(ctx, hipMemsetAsync(ctx->keep.p, 0, n, st));
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
-    const int32_t ovf_cap = (int32_t)std::min<size_t>(n, (size_t)1 << 24);
-    ENSURE(ctx, ctx->ovf_list, (size_t)ovf_cap);
-    ENSURE(ctx, ctx->ovf_list2, (size_t)ovf_cap);
+    ENSURE(ctx, ctx->tier_list, n);
+    ENSURE(ctx, ctx->tier_info, 2 * SG_MAX_CLASSES);
+    const size_t ttiles = (n + SG_TILE - 1) / SG_TILE + 1;
+    ENSURE(ctx, ctx->ttile_cnt, SG_MAX_CLASSES * ttiles);
+    ENSURE(ctx, ctx->ttile_base, SG_MAX_CLASSES * ttiles);
+    ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);
+    ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
+    // flag bytes of the first pass (3 + k: the beam needs later capacity tier k): nothing stale may be left in them
+    HIPCHK(ctx, hipMemsetAsync(ctx->keep.p, 0, n, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->tier_info.p, 0, sizeof(int32_t) * 2 * SG_MAX_CLASSES, st));
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
-    a.tables = ctx->d_tables; a.n_tables = (int32_t)ctx->tables.size(); a.table_ids = b.table_ids; a.las = ctx->d_las;
-    a.frame_tables = ctx->frame_tables.p;
-    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.tmp_rows = ctx->rows_tmp.p;
-    a.keep = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
+    a.las = ctx->d_las; a.frame_tables = ctx->frame_tables.p;
+    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p;
+    a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
-    a.phase_cycles = ctx->phase_cycles;
-    ENSURE(ctx, ctx->ctile_cnt, 2 * ((size_t)b.n_frames * (size_t)max_tiles + 1));     // also the tiles of the overflow list builder
-    ENSURE(ctx, ctx->ctile_base, 2 * ((size_t)b.n_frames * (size_t)max_tiles + 1));
-    // pass t reads the overflow list of pass t-1 (counter status[1 + t]) and fills its own (status[2 + t]);
-    // the counts live on the device, grids are sized for the worst case and idle blocks leave at once.
-    int32_t *lists[2] = {ctx->ovf_list.p, ctx->ovf_list2.p};
+    // Later capacity tiers = classes of the tier lists; the last class is the global-list tier, whose lists hold a whole
+    // table if need be (capped at 8192 flakes in one beam).
+    const int n_cls = n_tiers;
+    const int h_lanes = 256;
+    const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(ctx->max_flakes, 64u), 8192u);
+    a.n_cls = n_cls;
+    for (int k = 0; k + 1 < n_cls; ++k) a.cls_cap[k] = tiers[k + 1];
+    a.cls_cap[n_cls - 1] = h_cap;
+    ENSURE(ctx, ctx->h_lists, (size_t)4 * (size_t)(h_cap + 1) * (size_t)h_lanes);
+    a.h_lists = ctx->h_lists.p; a.h_cap = h_cap; a.h_lanes = h_lanes;
+    a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p;
+    int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
+    for (int k = 0; k + 1 < n_cls; ++k) {
+        tq_caps[k] = tier_queue_cap(ctx, tiers[k + 1], b.n_total);
+        ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * 2 * ((size_t)tiers[k + 1] + 1));
+        ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
+    }
+    // Regions of the first pass = slices of its dict queue: the segments, or plain chunks of 8 blocks in linear order.
+    a.q_chunk = 8 * first_block;
+    {
+        const size_t planes = 2 * ((size_t)tiers[0] + 1);
+        if (n * planes * sizeof(double) > ((size_t)64 << 30))
+            return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the dict queue of this table density: split it");
+        if (b.n_frames >= (1 << 22)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");
+        const size_t regions = std::max<size_t>((size_t)b.n_frames * 256, n / (size_t)a.q_chunk + 2);
+        ENSURE(ctx, ctx->dq, (n + 64) * planes);          // blocked SoA: groups of 64 slots
+        ENSURE(ctx, ctx->dq_g, n);
+        ENSURE(ctx, ctx->dq_sc, n);
+        ENSURE(ctx, ctx->qn, regions);
+        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * regions, st));
+        a.dq = ctx->dq.p; a.dq_g = ctx->dq_g.p; a.dq_sc = ctx->dq_sc.p; a.qn = ctx->qn.p; a.dq_n = b.n_total;
+        const int lanes = first_block < 64 ? first_block : 64;
+        a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
+        a.blk_rows = first_block;
+        ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
+        ENSURE(ctx, ctx->pw_count, 4);
+        a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
+    }
     if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
-        a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p;
-        a.grid_blocks = (b.n_total + first_block - 1) / first_block + (int64_t)b.n_frames * 256;   // every non-empty pair wastes less than one block
+        a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-    {   // queue of the first pass: one slot per row would always do; slots carry (range, ratio) x (capacity + 1)
-        const size_t stride = 2 * ((size_t)tiers[0] + 1);
-        if (n * stride * sizeof(double) > ((size_t)32 << 30))
-            return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the received-power queue of this table density: split it");
-        if (b.n_frames >= (1 << 25)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");
-        ENSURE(ctx, ctx->pq_list, n);
-        ENSURE(ctx, ctx->ptile_cnt, 2 * ((n + SG_TILE - 1) / SG_TILE + 1));
-        ENSURE(ctx, ctx->ptile_base, 2 * ((n + SG_TILE - 1) / SG_TILE + 1));
-        ENSURE(ctx, ctx->pq_dict, n * stride);
-        a.pq_list = ctx->pq_list.p; a.pq_dict = ctx->pq_dict.p; a.pq_count = b.status + 6; a.pq_cap = (int32_t)n; a.pq_stride = (int32_t)stride;
-    }
-    for (int t = 0; t < n_tiers; ++t) {
-        if (t > 0) a.seg_blk = nullptr;
-        a.work_list = t == 0 ? nullptr : lists[(t - 1) & 1];
-        a.work_count = t == 0 ? nullptr : b.status + 1 + t;
-        a.work_cap = ovf_cap;
-        a.ovf_list = lists[t & 1];
-        a.ovf_count = b.status + 2 + t;
-        a.ovf_cap = ovf_cap;
-        // measurement hooks: one event pair around ALL capacity tiers of the per-beam kernel
-        const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
-        if (timed && t == 0) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
-        int e = sg_launch_beams(&a, b.dtype, tiers[t], st);
-        if (!e && t == 0) {
-            // the first pass queued the beams that met a flake: their received-power phase runs on the side stream,
-            // next to the (latency-bound, mostly empty) later capacity tiers
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fork2, st));
-            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork2, 0));
-            // two runs of the list, each in sorted-row order: beams with one flake (most of them), then the rest -- the
-            // loops of k_power run S + 1 times, and a wave is as slow as its longest lane
-            e = sg_launch_list(ctx->keep.p, b.n_total, ctx->ptile_cnt.p, ctx->ptile_base.p, ctx->pq_list.p, b.status + 6, (int32_t)n, 16, 17, 18, 255,
-                               ctx->aux);
-            if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], ctx->aux);
-            HIPCHK(ctx, hipEventRecord(ctx->ev_join2, ctx->aux));
-        }
-        if (!e && t == 0 && n_tiers > 1)   // the first pass flags its overflowed beams; build the ordered list from the flags
-            e = sg_launch_list(ctx->keep.p, b.n_total, ctx->ctile_cnt.p, ctx->ctile_base.p, lists[0], b.status + 2, ovf_cap, 2, 2, 1, 0, st);
-        if (t == n_tiers - 1) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
-        if (timed && t == n_tiers - 1) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
-        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
-    }
+    // measurement hooks: one event pair around the whole per-beam region
+    const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
+    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = 0;
-    // 4. round + noise-floor filter + compaction + stats (simulation.py:516-530)
+    {
+        // linear order: regions are runs of 8 blocks, chunk boundaries fall on them
+        const int64_t lin_blocks = (b.n_total + first_block - 1) / first_block;
+        const int64_t lin_step = ((lin_blocks + n_chunks - 1) / n_chunks + 7) / 8 * 8;
+        for (int c = 0; c < n_chunks && !e; ++c) {
+            if (use_seg) {
+                a.chunk = c;                                 // every non-empty pair wastes less than one block; a chunk is cut at a segment start
+                a.grid_blocks = total_blocks_ub / n_chunks + b.max_frame / first_block + 2;
+            } else {
+                a.blk_lo = std::min<int64_t>((int64_t)c * lin_step, lin_blocks); a.blk_hi = std::min<int64_t>(a.blk_lo + lin_step, lin_blocks);
+                a.grid_blocks = a.blk_hi - a.blk_lo;
+            }
+            e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
+            if (e) break;
+            // The pass queued the beams that met a flake: their received-power phase runs on a side stream, next to the
+            // following chunks and to the (latency-bound, mostly empty) later capacity tiers.
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
+            HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp[c], 0));
+            HIPCHK(ctx, hipMemsetAsync(ctx->pw_count.p, 0, sizeof(int32_t), s_aux));
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux);
+        }
+    }
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join2, s_aux));
+    // The noise-threshold prepass streams the rows (bandwidth-bound, no LDS): it runs beside the received-power phase and
+    // the later tiers (latency-bound, LDS-bound) rather than beside the sort and the scan, which it would slow down.
+    if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
+    // Tier lists from the flag bytes (the scan counted on past a full list, so every flagged beam knows its tier), then
+    // the tiers side by side: class 0 on the caller's stream, the others on two side streams.
+    e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
+                             b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier list launch: ") + hipGetErrorString((hipError_t)e));
+    const bool side3 = n_cls >= 2;
+    if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
+    for (int k = 0; k < n_cls && !e; ++k) {
+        hipStream_t sk = k == 0 ? st : s_aux3;
+        a.seg_blk = nullptr;
+        a.cls = k;
+        if (k == n_cls - 1) {                            // the global-list tier
+            e = sg_launch_huge(&a, b.dtype, sk);
+            break;
+        }
+        const int lmax = tiers[k + 1];
+        a.tq = ctx->tq[k].p; a.tq_sc = ctx->tq_sc[k].p; a.tq_cap = (int32_t)tq_caps[k];
+        a.work_lo = 0; a.work_hi = (int32_t)tq_caps[k];
+        e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);                       // scan + dict, hand-over
+        if (!e) e = sg_launch_power_list(&a, b.dtype, lmax, sk);
+        if (!e && tq_caps[k] < b.n_total) {              // entries beyond the hand-over buffer: received power in place
+            a.work_lo = (int32_t)tq_caps[k]; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
+            e = sg_launch_beams(&a, b.dtype, lmax, 0, 0, sk);
+        }
+    }
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier launch: ") + hipGetErrorString((hipError_t)e));
+    if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_join3, s_aux3)); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0)); }
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
+    if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
+    // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats
+    // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
-    e = sg_launch_compact(ctx->rows_tmp.p, b.dtype, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          ctx->diff2.p, max_tiles, st);
+                          ctx->diff2.p, b.no_fov ? nullptr : &ctx->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
 }
@@ -688,6 +794,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     b.plane = (!thr_poly && plane) ? ctx->plane.p : nullptr; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
     b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = ctx->out_counts.p; b.out_stats = ctx->out_stats.p;
     b.out_thr_poly = out_thr_poly ? d_out_thr.p : nullptr; b.status = ctx->d_status; b.stream = st;
+    b.no_fov = dbg_count != nullptr;
     if (dbg_count) {
         ENSURE(ctx, ctx->dbg_count, std::max<size_t>(n, 1));
         ENSURE(ctx, ctx->dbg_rj, std::max<size_t>(n * (size_t)dbg_cap, 1));
@@ -787,6 +894,17 @@ extern "C" int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occup
     return SNOWGPU_OK;
 }
 
+// The status words of the last batch that went through a host-pointer entry of this context (layout: see
+// snowgpu_augment_batch_device): how many beams each later capacity tier took.
+extern "C" int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8)
+{
+    if (!ctx || !out8) return SNOWGPU_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out8, ctx->d_status, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
@@ -794,23 +912,6 @@ extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
     return SNOWGPU_OK;
 }
 
-
-// Experiments only (not in snowgpu.h): per-phase cycle counters of the per-beam kernel.
-extern "C" int snowgpu_debug_phase_cycles(snowgpu_ctx *ctx, int enable, unsigned long long *out8)
-{
-    if (!ctx) return SNOWGPU_E_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (enable) {
-        if (!ctx->phase_cycles) HIPCHK(ctx, hipMalloc((void **)&ctx->phase_cycles, 64 * sizeof(unsigned long long)));
-        HIPCHK(ctx, hipMemset(ctx->phase_cycles, 0, 64 * sizeof(unsigned long long)));
-    } else if (ctx->phase_cycles) {
-        HIPCHK(ctx, hipDeviceSynchronize());
-        if (out8) HIPCHK(ctx, hipMemcpy(out8, ctx->phase_cycles, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        (void)hipFree(ctx->phase_cycles);
-        ctx->phase_cycles = nullptr;
-    }
-    return SNOWGPU_OK;
-}
 
 extern "C" int snowgpu_host_alloc(snowgpu_ctx *ctx, size_t bytes, void **ptr)
 {
@@ -821,13 +922,13 @@ extern "C" int snowgpu_host_alloc(snowgpu_ctx *ctx, size_t bytes, void **ptr)
     return SNOWGPU_OK;
 }
 
+// ctx may be NULL (or already destroyed by the caller): page-locked memory is not tied to a context, and a buffer handed
+// to a caller may outlive the context that allocated it.
 extern "C" int snowgpu_host_free(snowgpu_ctx *ctx, void *ptr)
 {
-    if (!ctx) return SNOWGPU_E_INVALID;
+    (void)ctx;
     if (!ptr) return SNOWGPU_OK;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipHostFree(ptr));
-    return SNOWGPU_OK;
+    return hipHostFree(ptr) == hipSuccess ? SNOWGPU_OK : SNOWGPU_E_HIP;
 }
 
 extern "C" int snowgpu_profile_begin(snowgpu_ctx *ctx, int max_launches)
@@ -864,8 +965,56 @@ extern "C" int snowgpu_profile_end(snowgpu_ctx *ctx, double *beam_kernel_ms, int
     return SNOWGPU_OK;
 }
 
-// augment() followed by ground_water_augmentation() on its output (pointcloud_viewer.py:2807-2821), with the
-// intermediate cloud staying on the device.
+// augment() followed by ground_water_augmentation() on its output (pointcloud_viewer.py:2807-2821) as ONE launch
+// sequence on the caller's stream: the snowfall rows are compacted into context scratch, the wet-ground kernels read
+// them there (rows of frame f: [off[f], off[f] + snowfall count[f])), and a last kernel composes the source indices.
+// No host copy, no synchronisation, no allocation after the first call of a given size.
+extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
+                                                const int64_t *d_frame_offsets, const void *d_rows, int dtype,
+                                                const int32_t *d_table_ids, double beam_divergence_deg, const double *d_thr_poly,
+                                                const double *d_plane, double noise_floor, const int32_t *d_perm,
+                                                const double *d_wet_plane, double water_height, double pavement_depth,
+                                                double wet_noise_floor, double power_factor, int flat_earth, double delta, int replace,
+                                                double *d_out_rows, int32_t *d_out_src, int64_t *d_out_counts, int64_t *d_out_stats,
+                                                int32_t *d_out_flags, int32_t *d_status, void *stream)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || n_total < 0 || !d_frame_offsets || (n_total > 0 && !d_rows) || !d_table_ids || !d_wet_plane || !d_out_rows ||
+        !d_out_src || !d_out_counts || !d_out_stats || !d_out_flags || !d_status || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch_device: null pointer or bad dtype");
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total;
+    ENSURE(ctx, ctx->snow_rows, std::max<size_t>(n * 5 * esz, 8));
+    ENSURE(ctx, ctx->snow_src, std::max<size_t>(n, 1));
+    ENSURE(ctx, ctx->wet_src, std::max<size_t>(n, 1));
+    ENSURE(ctx, ctx->snow_counts, (size_t)n_frames);
+    BatchDev b{};
+    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = (max_frame_rows > 0 && max_frame_rows <= n_total) ? max_frame_rows : n_total;
+    b.frame_off = d_frame_offsets;
+    b.uniform_rows = (max_frame_rows > 0 && max_frame_rows * (int64_t)n_frames == n_total) ? max_frame_rows : 0; b.rows = d_rows;
+    b.dtype = dtype; b.table_ids = d_table_ids; b.beam_div_deg = beam_divergence_deg; b.thr_poly = d_thr_poly;
+    b.plane = d_plane; b.noise_floor = noise_floor; b.perm = d_perm; b.out_rows = ctx->snow_rows.p; b.out_src = ctx->snow_src.p;
+    b.out_counts = ctx->snow_counts.p; b.out_stats = d_out_stats; b.out_thr_poly = nullptr; b.status = d_status;
+    b.stream = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = run_batch(ctx, b);
+    if (rc) return rc;
+    if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(d_out_counts, 0, sizeof(int64_t) * (size_t)n_frames, b.stream));
+        HIPCHK(ctx, hipMemsetAsync(d_out_flags, 0, sizeof(int32_t) * (size_t)n_frames, b.stream));
+        return SNOWGPU_OK;
+    }
+    SgWetParams wp{};
+    wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = wet_noise_floor;
+    wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    int e = sg_wet_run(&ctx->prepass, ctx->snow_rows.p, dtype, d_frame_offsets, ctx->snow_counts.p, n_frames, n_total, b.max_frame,
+                       d_wet_plane, &wp, d_out_rows, ctx->wet_src.p, d_out_counts, d_out_flags, d_status, b.stream);
+    if (!e) e = sg_launch_compose_src(d_frame_offsets, d_out_counts, n_frames, b.max_frame, ctx->wet_src.p, ctx->snow_src.p, d_out_src, b.stream);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    return SNOWGPU_OK;
+}
+
+// The same chain for frames in HOST memory: copies in, the device entry above, copies out -- one synchronisation.
 extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                                          const int32_t *table_ids, double beam_divergence_deg, const double *thr_poly,
                                          const double *plane, double noise_floor, const int32_t *perm, const double *wet_plane,
@@ -874,51 +1023,92 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
                                          int64_t *out_counts, int64_t *out_stats, int32_t *out_flags)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
-    if (n_frames <= 0 || !frame_offsets || !wet_plane || !out_counts || !out_stats || !out_flags)
-        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch: null pointer");
-    const int64_t n_total = frame_offsets[n_frames];
-    const size_t n = (size_t)std::max<int64_t>(n_total, 0), esz = dtype == 0 ? 4 : 8;
+    if (n_frames <= 0 || !frame_offsets || !table_ids || !wet_plane || !out_counts || !out_stats || !out_flags || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch: null pointer or bad dtype");
+    if (frame_offsets[0] != 0) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets[0] must be 0");
+    if (!thr_poly && !plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
+    if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     int64_t max_frame = 0;
-    for (int f = 0; f < n_frames; ++f) max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
-    // stage 1: snowfall, results left on the device (ctx->rows_out / out_src / out_counts)
-    std::vector<unsigned char> tmp_rows(n * 5 * esz + 8);
-    std::vector<int32_t> snow_src(n + 1);
-    std::vector<int64_t> snow_counts((size_t)n_frames);
-    int rc = host_batch(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_divergence_deg, thr_poly, plane, noise_floor, perm,
-                        tmp_rows.data(), snow_src.data(), snow_counts.data(), out_stats, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    // stage 2: wet ground on the compacted rows still resident in ctx->rows_out (frame f: rows [off[f], off[f] + count[f]))
+    bool uni = true;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets must be non-decreasing");
+        max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    }
+    for (int f = 0; f < n_frames; ++f) uni = uni && (frame_offsets[f + 1] - frame_offsets[f]) == max_frame;
+    const int64_t n_total = frame_offsets[n_frames];
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    if (n_total > 0 && (!rows || !out_rows || !out_src)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total, nf = (size_t)n_frames, nl = (size_t)ctx->h_las.n;
     hipStream_t st = ctx->stream;
-    DevBuf<double> wet_out;
-    DevBuf<int32_t> wet_src, wet_flags;
-    DevBuf<int64_t> wet_counts;
-    DevBuf<double> d_plane;
-    if (wet_out.ensure(std::max<size_t>(n * 5, 1)) || wet_src.ensure(std::max<size_t>(n, 1)) || wet_flags.ensure((size_t)n_frames) ||
-        wet_counts.ensure((size_t)n_frames) || d_plane.ensure((size_t)n_frames * 4))
-        return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed (wet stage)");
-    HIPCHK(ctx, hipMemcpyAsync(d_plane.p, wet_plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
-    SgWetParams wp{};
-    wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = wet_noise_floor;
-    wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
-    int e = sg_wet_run(&ctx->prepass, ctx->rows_out.p, dtype, ctx->frame_off.p, ctx->out_counts.p, n_frames, n_total, max_frame,
-                       d_plane.p, &wp, wet_out.p, wet_src.p, wet_counts.p, wet_flags.p, ctx->d_status, st);
-    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
-    HIPCHK(ctx, hipMemcpyAsync(out_counts, wet_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(out_flags, wet_flags.p, sizeof(int32_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
-    std::vector<int32_t> wsrc(n + 1);
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(out_rows, wet_out.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(wsrc.data(), wet_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    ENSURE(ctx, ctx->rows_in, std::max<size_t>(n * 5 * esz, 8));
+    ENSURE(ctx, ctx->wet_rows, std::max<size_t>(n * 5, 1));
+    ENSURE(ctx, ctx->out_src, std::max<size_t>(n, 1));
+    ENSURE(ctx, ctx->frame_off, nf + 1);
+    ENSURE(ctx, ctx->wet_counts, nf);
+    ENSURE(ctx, ctx->wet_flags, nf);
+    ENSURE(ctx, ctx->out_stats, nf * 3);
+    ENSURE(ctx, ctx->table_ids, nf * nl);
+    ENSURE(ctx, ctx->plane, nf * 4);
+    ENSURE(ctx, ctx->wet_plane, nf * 4);
+    if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->wet_plane.p, wet_plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+    const double *d_thr = nullptr;
+    if (thr_poly) {
+        ENSURE(ctx, ctx->user_thr, nf * 3);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, thr_poly, sizeof(double) * 3 * nf, hipMemcpyHostToDevice, st));
+        d_thr = ctx->user_thr.p;
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+    }
+    if (perm) {
+        ENSURE(ctx, ctx->user_perm, std::max<size_t>(n, 1));
+        if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    }
+    int rc = snowgpu_augment_wet_batch_device(ctx, n_frames, n_total, uni ? max_frame : std::max<int64_t>(max_frame, 1) , ctx->frame_off.p,
+                                              ctx->rows_in.p, dtype, ctx->table_ids.p, beam_divergence_deg, d_thr, d_thr ? nullptr : ctx->plane.p,
+                                              noise_floor, perm ? ctx->user_perm.p : nullptr, ctx->wet_plane.p, water_height,
+                                              pavement_depth, wet_noise_floor, power_factor, flat_earth, delta, replace, ctx->wet_rows.p,
+                                              ctx->out_src.p, ctx->wet_counts.p, ctx->out_stats.p, ctx->wet_flags.p, ctx->d_status, st);
+    int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
+    if (rc == SNOWGPU_OK) {
+        HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->wet_counts.p, sizeof(int64_t) * nf, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_flags, ctx->wet_flags.p, sizeof(int32_t) * nf, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * nf, hipMemcpyDeviceToHost, st));
+        if (n) {
+            HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->wet_rows.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        }
     }
     hipError_t se = hipStreamSynchronize(st);
-    wet_out.release(); wet_src.release(); wet_flags.release(); wet_counts.release(); d_plane.release();
+    if (rc != SNOWGPU_OK) return rc;
     if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
-    // compose the source indices: wet row -> snow row -> input row
-    if (out_src)
-        for (int f = 0; f < n_frames; ++f) {
-            const int64_t b = frame_offsets[f];
-            for (int64_t i = 0; i < out_counts[f]; ++i) out_src[b + i] = snow_src[(size_t)(b + wsrc[(size_t)(b + i)])];
+    return status_to_error(ctx, status);
+}
+
+// Camera-FOV crop of augment(only_camera_fov=True) (simulation.py:39-47, :532-540): lidar_to_rect with
+// Tr_velo_to_cam (3 x 4) and R0_rect (3 x 3), rect_to_img with P2 (3 x 4), image img_h x img_w ((1024, 1920) in the
+// reference).  The crop is applied by the compaction of every later batch of this context (and num_removed counts it,
+// :538) until it is switched off again.  The reference's own projection code is un-vendored: textbook KITTI, float64.
+extern "C" int snowgpu_set_fov(snowgpu_ctx *ctx, int enabled, const double *v2c, const double *r0, const double *p2, int img_h, int img_w)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (!enabled) { ctx->fov.enabled = 0; return SNOWGPU_OK; }
+    if (!v2c || !r0 || !p2 || img_h <= 0 || img_w <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_fov: need V2C, R0, P2 and an image size");
+    SgFov f{};
+    f.enabled = 1;
+    for (int i = 0; i < 4; ++i)                      // M = V2C^T . R0^T  (4 x 3)
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; ++k) acc = acc + v2c[4 * k + i] * r0[3 * j + k];
+            f.m[3 * i + j] = acc;
         }
+    for (int i = 0; i < 12; ++i) f.p[i] = p2[i];
+    f.img_h = img_h; f.img_w = img_w;
+    ctx->fov = f;
     return SNOWGPU_OK;
 }
 

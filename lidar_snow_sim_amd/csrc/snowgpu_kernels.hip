@@ -2,12 +2,14 @@
 //
 //   k_sort_*     stable counting sort of every frame's rows by channel                      (simulation.py:447)
 //   k_seg_*      launch order of the first pass: (table, frame, channel) segments
-//   k_beams      one thread per beam: candidate scan + occlusion dict; the first pass over all rows stops there and
-//                hands beams with flakes to k_power, the later capacity tiers run received power + decision in place
-//                                                                                           (simulation.py:50-424)
-//   k_list_*     ordered work lists from flag bytes (overflowed beams, beams for k_power)
+//   k_beams      one thread per beam: candidate scan + occlusion dict; beams with flakes hand their dict to k_power
+//                through a compact queue, beams with more flakes than the list holds are flagged with the capacity
+//                tier that takes them                                                       (simulation.py:50-424)
+//   k_tier_*     ordered tier lists from the flag bytes
 //   k_power      received power on the 10 cm grid, first maximum, attenuate-or-scatter        (simulation.py:135-188)
-//   k_compact_*  noise-floor filter, stable stream compaction, stats                         (simulation.py:516-530)
+//   k_beams_huge the global-list tier (more than 63 flakes in one beam)
+//   k_compact_*  output rows from original rows + 4-byte result records, noise-floor filter, camera-FOV crop, stable
+//                stream compaction, stats                                                   (simulation.py:516-540)
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see lidar_snow_sim_amd/build.py).
 #include <hip/hip_runtime.h>
@@ -38,7 +40,7 @@ __device__ __forceinline__ unsigned long long sg_lanemask_lt()
 template <typename T>
 __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
                                                         int32_t *__restrict__ tile_hist, uint16_t *__restrict__ rank,
-                                                        int32_t *__restrict__ status, int64_t max_tiles)
+                                                        uint8_t *__restrict__ ch8, int32_t *__restrict__ status, int64_t max_tiles)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
         }
         my_bucket[q] = bucket;
         my_rank[q] = 0;
+        if (valid) ch8[base + r] = (uint8_t)bucket;     // the scatter pass reads 1 byte per row instead of the row again
         unsigned long long todo = __ballot(valid);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
@@ -113,8 +116,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restric
     for (int64_t t = 0; t < tiles; ++t) { b[t * 256 + v] = run; run += h[t * 256 + v]; }
 }
 
-template <typename T>
-__global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
+__global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const uint8_t *__restrict__ ch8, const int64_t *__restrict__ frame_off,
                                                            const int32_t *__restrict__ tile_base,
                                                            const uint16_t *__restrict__ rank, int32_t *__restrict__ perm,
                                                            int64_t max_tiles)
@@ -126,291 +128,427 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
     const int32_t *b = tile_base + ((int64_t)f * max_tiles + blockIdx.x) * 256;
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
-        if (r < n) {
-            const T c = rows[(base + r) * 5 + 4];
-            int ci = (int)c;
-            if (!((T)ci == c && ci >= 0 && ci < 256)) ci = 255;
-            perm[base + b[ci] + rank[base + r]] = (int32_t)r;
-        }
+        if (r < n) perm[base + b[ch8[base + r]] + rank[base + r]] = (int32_t)r;
     }
 }
 
-// ---- frame-level epilogue of one row (simulation.py:516): rounded intensity, label ------------------------------
-template <typename T>
-__device__ __forceinline__ void sg_store_row(const SgBeamArgs &a, int64_t g, int f, T px, T py, T pz, const SgBeamOut &o)
+// ------------------------------------------------------------------------------------------------
+// Dict queues are "blocked SoA": 64 consecutive slots form a group, a group holds its P planes back to back (plane 2 t =
+// range of scatterer t, plane 2 t + 1 = its ratio; P = 2 (capacity + 1)).  A wave reads / writes 512 contiguous bytes per
+// plane (coalesced like plain SoA), and everything one beam needs sits within P x 512 bytes -- plain SoA planes lie
+// hundreds of MB apart, and a wave touching ten of them misses the TLB ten times.
+template <int P>
+__device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 {
-    T *orow = (T *)a.tmp_rows + g * 5;
-    T oi;
-    if constexpr (SgReal<T>::is_f32) {
-        orow[0] = (float)o.x; orow[1] = (float)o.y; orow[2] = (float)o.z;   // :178-180 store float64 -> float32
-        oi = rintf((float)o.intensity);                                     // :516 np.round (half to even)
-    } else {
-        orow[0] = o.x; orow[1] = o.y; orow[2] = o.z;
-        oi = rint(o.intensity);
+    return (slot >> 6) * (int64_t)(P * 64) + (int64_t)plane * 64 + (slot & 63);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Frame of a sorted position.
+__device__ __forceinline__ int sg_frame_of(const SgBeamArgs &a, int64_t g)
+{
+    if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
+        const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
+        int fe = (int)((float)gu * a.inv_uniform_rows);
+        if (fe >= a.n_frames) fe = a.n_frames - 1;
+        while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
+        while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
+        return fe;
     }
-    orow[3] = oi;
-    orow[4] = (T)o.label;
-    (void)f; (void)px; (void)py; (void)pz;
-    // The noise-floor decision (:518-520) is taken by k_compact_count: rows that are not scattered keep their
-    // coordinates, so the original range is still in the row -- and the per-beam kernels do not have to wait for the
-    // threshold polynomial of the prepass.
+    return sg_find_frame(a.frame_off, a.n_frames, g);
+}
+
+// intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam (same-address atomics
+// from every lane serialise in L2).  Every lane of the wave must call this.
+__device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool live, int f, long long d2)
+{
+    unsigned long long todo = __ballot(live && d2 != 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int fl = __shfl(f, leader);
+        const bool mine = live && f == fl;
+        long long part = mine ? d2 : 0;
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        if ((int)(threadIdx.x & 63) == leader && part != 0) atomicAdd(&diff2[fl], (unsigned long long)part);
+        todo &= ~__ballot(mine);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // The per-beam kernel.  Dynamic LDS: four per-thread lists of LMAX + 1 float64 entries, strided by the block size.
-//   LIST = false  direct mode, the first pass over all rows: phases 1-2 (scan, occlusion dict); beams that met a
-//                 flake are handed to k_power through their dict and a flag byte, overflowed beams are flagged
-//   LIST = true   a later capacity tier over a device-side list: phases 1-3 in place
-template <typename T, int LMAX, int BLOCK, bool LIST>
-__global__ __launch_bounds__(BLOCK) void k_beams(SgBeamArgs a)
+//   LIST = false  direct mode, the pass over all rows: phases 1-2 (scan, occlusion dict).  A beam without flakes is
+//                 finished (record written); a beam with flakes hands its dict to k_power through its region's slice
+//                 of the dict queue; a beam with more flakes than the list holds is flagged with the capacity tier that
+//                 takes all of them (the scan counts on, so the count is exact).
+//   LIST = true   a later capacity tier over its class of the tier lists; DICT = true: dict hand-over to
+//                 k_power<.., LISTQ> (entry i of the class -> slot i), DICT = false: phases 1-3 in place (the entries
+//                 beyond the hand-over buffer).  A fixed grid strides over the list, whose length only the device knows.
+//   BLOCK         beams per block = stride of the LDS lists.  BLOCK = 16 (the 63-entry tier) still launches one wave: 16
+//                 live lanes, 32 KB of LDS per block instead of 131 KB -- a block that needs most of a CU's LDS waits until
+//                 one has drained, and meanwhile holds up everything queued behind it.
+template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const double *s_rgrid = a.rgrid;                  // 9.8 KB, read with consecutive bins per lane: L1-resident
     double *s_a1 = (double *)smem;                    // LMAX + 1 rows each: the hard target is entry n_flakes <= LMAX
     double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
     double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
     double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
     const int tid = threadIdx.x;
-    // Direct mode: one block per 256 consecutive channel-sorted rows.  List mode (a later capacity tier): the
-    // number of queued beams is only known on the device, so a small fixed grid strides over the queue -- a block
-    // with this much LDS cannot share its CU, and thousands of empty ones would each cost a dispatch slot.
-    int64_t work_n = a.n_total;
+    const int n_las = a.las->n;
+    int64_t work_n = 0, work_off = 0;
     if (LIST) {
-        work_n = *a.work_count;
-        if (work_n > a.work_cap) work_n = a.work_cap;
+        work_n = a.tier_info[a.cls];
+        if (work_n > a.work_hi) work_n = a.work_hi;
+        work_off = a.tier_info[4 + a.cls];
     }
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
-    int seg_f = -1;                                   // segment-ordered direct mode: the block's frame
-    int64_t seg_g = -1;
-    if (!LIST && a.seg_blk) {
-        const int blk = (int)blockIdx.x;
-        if (blk >= a.seg_n[1]) return;                // surplus block (the grid is an upper bound)
-        const int lo = a.seg_of_blk[blk];             // one load instead of a 13-step dependent search per block
-        const int off = (blk - a.seg_blk[lo]) * BLOCK + tid;
-        seg_f = a.seg_frame[lo];
-        if (off < a.seg_cnt[lo]) seg_g = a.seg_start[lo] + off;
+    int seg_f = -1, seg_ch = -1;                      // segment-ordered direct mode: the block's frame and channel
+    int64_t seg_g = -1, q_base = 0;
+    int q_size = 0, region = 0;
+    int64_t blk = blockIdx.x;                         // direct mode: this launch walks blocks [lo, hi) of the pass
+    if (!LIST) {
+        const int64_t lo = a.chunk_blk ? a.chunk_blk[a.chunk] : a.blk_lo, hi = a.chunk_blk ? a.chunk_blk[a.chunk + 1] : a.blk_hi;
+        blk += lo;
+        if (blk >= hi) return;                        // surplus block (the grid is an upper bound)
+        if (a.seg_blk) {
+            const int sg = a.seg_of_blk[blk];         // one load instead of a dependent search per block
+            const int off = (int)(blk - a.seg_blk[sg]) * BLOCK + tid;
+            const int fc = a.seg_frame[sg];
+            seg_f = fc & 0x3fffff; seg_ch = (int)((unsigned)fc >> 22);
+            q_base = a.seg_start[sg]; q_size = a.seg_cnt[sg]; region = sg;
+            if (tid < BLOCK && off < q_size) seg_g = q_base + off;
+        } else {
+            region = (int)((blk * BLOCK) / a.q_chunk);
+            q_base = (int64_t)region * a.q_chunk;
+            q_size = (int)(a.n_total - q_base < a.q_chunk ? a.n_total - q_base : a.q_chunk);
+        }
     }
-    int64_t chunk = (int64_t)blockIdx.x * BLOCK;
+    int64_t chunk = LIST ? (int64_t)a.work_lo + (int64_t)blockIdx.x * BLOCK : blk * BLOCK;
     if (LIST && chunk >= work_n) return;
     do {                                              // direct mode: exactly one trip, and the compiler must see that
     int64_t g = -1;
     if (LIST) {
-        if (chunk + tid < work_n) g = a.work_list[chunk + tid];
+        if (tid < BLOCK && chunk + tid < work_n) g = a.tier_list[work_off + chunk + tid];
     } else if (seg_f >= 0) {
         g = seg_g;
     } else {
         g = chunk + tid;
-        if (g >= a.n_total) g = -1;
+        if (tid >= BLOCK || g >= a.n_total) g = -1;
     }
-    unsigned long long *ph = a.phase_cycles ? a.phase_cycles + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3) : nullptr;
-    const unsigned long long tcs = ph ? wall_clock64() : 0;
-    // No early return from here on: wave-wide ballots / shuffles follow (overflow queue, per-frame sums).
+    // No early return from here on: wave-wide ballots / shuffles follow (queue slots, per-frame sums).
     const bool live = g >= 0;
-    int f = 0;
-    T px = 0, py = 0, pz = 0, pint = 0, pch = 0;
-    int ch = 0;
+    int f = 0, ch = 0;
+    T px = 0, py = 0, pz = 0;
     bool simulated = false;
-    const int n_las = a.las->n;
     if (live) {
-        if (!LIST && seg_f >= 0) f = seg_f;
-        else if (a.uniform_rows > 0) {               // equal-sized frames: no search (float estimate, integer fix-up)
-            const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
-            int fe = (int)((float)gu * a.inv_uniform_rows);
-            if (fe >= a.n_frames) fe = a.n_frames - 1;
-            while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
-            while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
-            f = fe;
-        } else f = sg_find_frame(a.frame_off, a.n_frames, g);
+        f = (!LIST && seg_f >= 0) ? seg_f : sg_frame_of(a, g);
         const int64_t src = a.frame_off[f] + a.perm[g];
         const T *row = (const T *)a.rows + src * 5;
-        px = row[0]; py = row[1]; pz = row[2]; pint = row[3]; pch = row[4];
-        ch = (int)pch;
-        simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;            // simulation.py:80, :482 (Q5)
+        px = row[0]; py = row[1]; pz = row[2];
+        if (!LIST && seg_f >= 0) {                    // the device sort only builds segments of integer channels
+            ch = seg_ch;
+            simulated = ch < n_las;
+        } else {
+            const T pch = row[4];
+            ch = (int)pch;
+            simulated = ((T)ch == pch) && ch >= 0 && ch < n_las;            // simulation.py:80, :482 (Q5)
+        }
     }
-    const unsigned long long tc0 = ph ? wall_clock64() : 0;
     SgBeamOut o;
-    o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = (double)pint; o.label = (double)pch;
-    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0;
-    bool write_row = live;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+    uint32_t rec = (live && !simulated) ? SG_REC_COPY : 0u;
+    bool pending = false;                             // another kernel writes this row's record
     if (simulated) {
         const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
         if (tab.entries == nullptr) {
             atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
-            write_row = false;
         } else {
             int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
             double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
             double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-            sg_beam<T, LMAX, BLOCK, !LIST>(px, py, pz, pint, ch, tab, a.las, s_rgrid, a.beam_div_deg, s_a1, s_a2, s_rho,
-                                           s_ratio, tid, o, a.dbg_cap, dc, drj, dra, ph, a.exact_math != 0);
+            sg_beam<T, LMAX, BLOCK, DICT>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o,
+                                          a.dbg_cap, dc, drj, dra, a.exact_math != 0);
             if (o.overflow) {
-                write_row = false;                        // a later pass with a longer list writes this row
                 o.has_power = 0;
+                int k = 0;                            // the first later tier that holds every flake of this beam
+                while (k < a.n_cls && o.n_hits > a.cls_cap[k]) ++k;
+                if (LIST || k >= a.n_cls) {           // a listed beam fits its tier by construction
+                    atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+                    atomicCAS(&a.status[1], -1, (int32_t)g);
+                } else {
+                    a.flag[g] = (uint8_t)(3 + k);     // k_tier_* build the tier lists from the flags, in sorted-row order
+                    pending = true;
+                }
             } else if (o.range_error) {
                 atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
                 atomicCAS(&a.status[1], -1, (int32_t)g);
             }
         }
     }
-    if (!LIST && LMAX < SG_LCAP) {
-        // Direct mode: an overflowed beam is only flagged (keep[g] = 2); k_list_* then build the next pass's list in
-        // sorted-row order, so that the lanes of its waves stay neighbours in channel and azimuth -- one table, nearby
-        // bins.  (An atomic queue hands a wave 64 beams of as many channels, i.e. tables: every load a miss.)
-        if (o.overflow) a.keep[g] = 2;
-    } else {   // queue the overflowed beams of this wave with ONE atomic (a per-lane atomic on a single counter
-        // serialises in L2 and stalls every other memory request behind it)
-        const unsigned long long om = __ballot(o.overflow != 0);
-        if (om) {
-            if (LMAX >= SG_LCAP) {
-                if (o.overflow) {
-                    atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
-                    atomicCAS(&a.status[1], -1, (int32_t)g);
-                }
-            } else {
-                int base = 0;
-                const int leader = __ffsll((long long)om) - 1;
-                if ((tid & 63) == leader) base = atomicAdd(a.ovf_count, (int)__popcll(om));
-                base = __shfl(base, leader);
-                if (o.overflow) {
-                    const int slot = base + (int)__popcll(om & sg_lanemask_lt());
-                    if (slot < a.ovf_cap) a.ovf_list[slot] = (int32_t)g;
+    if constexpr (DICT) {
+        // ---- hand the beams that met a flake, with their occlusion dicts, to k_power -------------------------------
+        // Only a fraction of the beams gets here; walking phase 3 in place would keep most lanes of every wave idle.
+        const int S = o.n_flakes;
+        if constexpr (!LIST) {
+            // The region's slice of the queue: beams with one flake from the front, the others from the back -- one
+            // packed 64-bit atomic per wave on the region's counter (thousands of distinct addresses: no serialisation).
+            const bool front = o.has_power && S == 1, back = o.has_power && S > 1;
+            const unsigned long long mf = __ballot(front), mb = __ballot(back);
+            if (mf | mb) {
+                const int leader = __ffsll((long long)(mf | mb)) - 1;
+                unsigned long long base = 0;
+                if ((tid & 63) == leader)
+                    base = atomicAdd(&a.qn[region], (unsigned long long)__popcll(mf) | ((unsigned long long)__popcll(mb) << 32));
+                const unsigned blo = __shfl((unsigned)(base & 0xffffffffull), leader), bhi = __shfl((unsigned)(base >> 32), leader);
+                if (o.has_power) {
+                    const int64_t slot = front ? q_base + (int)blo + (int)__popcll(mf & sg_lanemask_lt())
+                                               : q_base + q_size - 1 - ((int)bhi + (int)__popcll(mb & sg_lanemask_lt()));
+                    for (int t = 0; t <= S; ++t) {
+                        a.dq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t)] = s_rho[t * BLOCK + tid];
+                        a.dq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t + 1)] = s_ratio[t * BLOCK + tid];
+                    }
+                    a.dq_g[slot] = (int32_t)g;
+                    a.dq_sc[slot] = (uint16_t)(S | (ch << 8));
+                    pending = true;
                 }
             }
-        }
-    }
-    const unsigned long long tc1 = ph ? wall_clock64() : 0;
-    double best = 0.0;
-    int k_best = 0;
-    if constexpr (!LIST) {
-        // ---- direct mode: hand the beams that met a flake, with their occlusion dicts, to k_power ----------------
-        // Only a fraction of the beams gets here; walking phase 3 in place would keep most lanes of every wave idle.
-        // No queue counter: the beam is flagged (keep[g] = 16 + n_flakes), its dict goes to the slot of its own sorted
-        // position, and k_list_* build the list in sorted-row order -- no atomics, and the lanes of a k_power wave stay
-        // neighbours (one frame, one channel).
-        if (o.has_power) {
-            write_row = false;                                // k_power writes this row
-            a.keep[g] = (uint8_t)(16 + o.n_flakes);
-            double *dd = a.pq_dict + g * a.pq_stride;
-            for (int t = 0; t <= o.n_flakes; ++t) { dd[2 * t] = s_rho[t * BLOCK + tid]; dd[2 * t + 1] = s_ratio[t * BLOCK + tid]; }
-            o.has_power = 0;
+        } else if (live) {
+            const int64_t slot = chunk + tid;         // entry i of the class -> slot i
+            uint16_t sc = 0xffff;                     // no dict: the record below is final
+            if (o.has_power) {
+                for (int t = 0; t <= S; ++t) {
+                    a.tq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t)] = s_rho[t * BLOCK + tid];
+                    a.tq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t + 1)] = s_ratio[t * BLOCK + tid];
+                }
+                sc = (uint16_t)(S | (ch << 8));
+                pending = true;
+            }
+            a.tq_sc[slot] = sc;
         }
     } else {
-    // ---- phase 3b: received power (per lane; s_ratio is dead after phase 3a and carries the work lists) ----
-    constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together
-    if (o.has_power) {
-        int st[2] = {0, 0};
-        if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
-        else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, s_rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best, ph ? st : nullptr);
-        if (ph) {                                         // experiment: trip counts of the two stages, per wave
-            int mx[2], sm[2];
-            for (int q = 0; q < 2; ++q) {
-                mx[q] = st[q]; sm[q] = st[q];
-                for (int off = 32; off > 0; off >>= 1) { mx[q] = max(mx[q], __shfl_xor(mx[q], off)); sm[q] += __shfl_xor(sm[q], off); }
-            }
-            const unsigned long long am = __ballot(1);
-            if ((tid & 63) == __ffsll((long long)am) - 1) {
-                unsigned long long *p2 = a.phase_cycles + 32 + 8 * (LMAX == 4 ? 0 : LMAX == 8 ? 1 : LMAX == 16 ? 2 : 3);
-                atomicAdd(&p2[0], 1ull); atomicAdd(&p2[1], (unsigned long long)__popcll(am));
-                atomicAdd(&p2[2], (unsigned long long)mx[0]); atomicAdd(&p2[3], (unsigned long long)mx[1]);
-                atomicAdd(&p2[4], (unsigned long long)sm[0]); atomicAdd(&p2[5], (unsigned long long)sm[1]);
-            }
+        // ---- phases 3b / 3c in place (s_ratio is dead after phase 3a and carries the work lists) -----------------
+        constexpr int NB = LMAX <= 4 ? 4 : 8;    // bins carried together
+        if (o.has_power) {
+            double best = 0.0;
+            int k_best = 0;
+            if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
+            else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
+            T d_t;
+            if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);
+            else d_t = sqrt((px * px + py * py) + pz * pz);
+            sg_beam_decide((double)d_t, ch, a.las, best, k_best, o);
+            rec = sg_pack_record(o);
         }
+        sg_add_diff2(a.diff2, live, f, (long long)o.diff2);
     }
-    }
-    if (ph && (tid & 63) == 0) {
-        atomicAdd(&ph[0], tc0 - tcs);                  // frame lookup + row load
-        atomicAdd(&ph[4], wall_clock64() - tc1);       // phase 3b (list mode) / queueing (direct mode)
-        atomicAdd(&ph[5], 1ull);                       // waves
-    }
-    if (o.has_power) sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
-    {   // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam
-        long long d2 = write_row ? (long long)o.diff2 : 0;
-        const int f0 = __shfl(f, 0);
-        const bool same = __all(!live || f == f0);
-        if (same) {
-            for (int off = 32; off > 0; off >>= 1) d2 += __shfl_down(d2, off);
-            if ((tid & 63) == 0 && d2 != 0) atomicAdd(&a.diff2[f0], (unsigned long long)d2);
-        } else if (d2 != 0) {
-            atomicAdd(&a.diff2[f], (unsigned long long)d2);      // wave straddling two frames
-        }
-    }
-    if (!write_row) continue;
-    sg_store_row<T>(a, g, f, px, py, pz, o);
+    if (live && !pending) a.rec[g] = rec;
     } while (LIST && (chunk += stride) < work_n);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Received power for the beams the direct-mode pass queued: one thread per queue slot, every lane busy.
-// Phase 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision), row epilogue.
-template <typename T, int LMAX, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_power(SgBeamArgs a)
+// Work items of k_power for the queue of a direct-mode pass: one item = up to `lanes` consecutive live slots of one
+// region (its front run, then its back run).  One thread per region; items are appended with one atomic per wave.
+// item = {first slot, count | (frame + 1) << 7}.
+__global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int n_regions_ub)
 {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int n_items = 0, nf = 0, nb = 0, q_size = 0, f1 = 0;
+    int64_t q_base = 0;
+    const int64_t lo = a.chunk_blk ? a.chunk_blk[a.chunk] : a.blk_lo, hi = a.chunk_blk ? a.chunk_blk[a.chunk + 1] : a.blk_hi;
+    bool mine = false;
+    if (a.seg_blk) {
+        if (r < a.seg_n[0]) {
+            const int64_t b0 = a.seg_blk[r];
+            mine = b0 >= lo && b0 < hi;               // chunks are cut at segment starts
+            if (mine) { q_base = a.seg_start[r]; q_size = a.seg_cnt[r]; f1 = (a.seg_frame[r] & 0x3fffff) + 1; }
+        }
+    } else if (r < n_regions_ub) {
+        q_base = (int64_t)r * a.q_chunk;
+        const int64_t b0 = q_base / a.blk_rows;
+        mine = q_base < a.n_total && b0 >= lo && b0 < hi;
+        if (mine) q_size = (int)(a.n_total - q_base < a.q_chunk ? a.n_total - q_base : a.q_chunk);
+    }
+    if (mine) {
+        const unsigned long long c = a.qn[r];
+        nf = (int)(c & 0xffffffffull); nb = (int)(c >> 32);
+        n_items = (nf + lanes - 1) / lanes + (nb + lanes - 1) / lanes;
+    }
+    int inc = n_items;                                // inclusive scan over the wave, one atomic for its total
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+    const int total = __shfl(inc, 63);
+    int base = 0;
+    if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(a.pw_count, total);
+    base = __shfl(base, 63) + inc - n_items;
+    for (int k = 0; k < nf; k += lanes)
+        a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 7));
+    for (int k = 0; k < nb; k += lanes)
+        a.pw_items[base++] = make_int2((int)(q_base + q_size - nb + k), (nb - k < lanes ? nb - k : lanes) | (f1 << 7));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Received power for the beams a dict-only pass handed over: one lane per queue slot, every lane busy.
+// Phase 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision), result record.
+// Nothing is read but the queue: the beam's range is the last range of its dict, its channel rides in the slot.
+//   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots)
+//   LISTQ = true   a list-mode pass's hand-over buffer: item i = slots [i LANES, (i + 1) LANES) of the class
+// PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
+// barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
+// that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
+// then bound by the latency of its first loads.  Here a wave requests the slot data of its NEXT item before it computes
+// the current one.
+template <typename T, int LMAX, int BLOCK, bool LISTQ>
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? 4 : 1) void k_power(SgBeamArgs a)
+{
+    constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
+    constexpr int P = 2 * (LMAX + 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_a1 = (double *)smem;
     double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
     double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
     double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
-    const int tid = threadIdx.x;
-    int n = *a.pq_count;
-    if (n > a.pq_cap) n = a.pq_cap;
-    const int64_t slot = (int64_t)blockIdx.x * BLOCK + tid;
-    if ((int64_t)blockIdx.x * BLOCK >= n) return;     // surplus block (the grid covers every row)
-    const bool live = slot < n;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ltid = BLOCK < 64 ? lane : tid;          // column of the LDS lists
+    int64_t work_n = 0, work_off = 0;
+    int n_items;
+    if (LISTQ) {
+        work_n = a.tier_info[a.cls];
+        if (work_n > a.work_hi) work_n = a.work_hi;
+        work_off = a.tier_info[4 + a.cls];
+        n_items = (int)((work_n + LANES - 1) / LANES);
+    } else {
+        n_items = *a.pw_count;
+    }
+    const int step = (int)gridDim.x * WAVES;
+    int i = (int)blockIdx.x * WAVES + (tid >> 6);
+    if (i >= n_items) return;
+    const double *planes = LISTQ ? a.tq : a.dq;
+    const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
+    // slot data of one item, as far as every beam has it: flag word, sorted position, scatterer 0 and scatterer 1
+    // (a queued beam met at least one flake; with exactly one, scatterer 1 is the hard target)
+    struct Item { int64_t slot; int f; bool live; unsigned sc; int32_t g; double r0, q0, r1, q1; };
+    auto fetch = [&](int it) -> Item {
+        Item m;
+        int start, cnt;
+        m.f = -1;
+        if (LISTQ) {
+            start = it * LANES;
+            cnt = (int)(work_n - start < LANES ? work_n - start : LANES);
+        } else {
+            const int2 d = a.pw_items[it];
+            start = d.x; cnt = d.y & 127; m.f = (d.y >> 7) - 1;
+        }
+        m.live = lane < cnt;
+        m.slot = (int64_t)start + lane;
+        m.sc = 0xffffu; m.g = 0; m.r0 = m.q0 = m.r1 = m.q1 = 0.0;
+        if (m.live) {
+            m.sc = scs[m.slot];
+            m.g = LISTQ ? a.tier_list[work_off + m.slot] : a.dq_g[m.slot];
+            m.r0 = planes[sg_qaddr<P>(m.slot, 0)]; m.q0 = planes[sg_qaddr<P>(m.slot, 1)];
+            m.r1 = planes[sg_qaddr<P>(m.slot, 2)]; m.q1 = planes[sg_qaddr<P>(m.slot, 3)];
+        }
+        return m;
+    };
+    Item cur = fetch(i);
+    for (;;) {
+        const int nxt_i = i + step;
+        const bool more = nxt_i < n_items;             // wave-uniform
+        Item nxt = cur;
+        if (more) nxt = fetch(nxt_i);                  // in flight while the current item is computed
+        const bool live = cur.live && cur.sc != 0xffffu;   // 0xffff: a listed beam without a dict (its record is final)
+        const int S = (int)(cur.sc & 255u), ch = (int)(cur.sc >> 8);
+        int f = 0;
+        SgBeamOut o;
+        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+        if (live) {
+            f = cur.f >= 0 ? cur.f : sg_frame_of(a, cur.g);
+            s_rho[0 * BLOCK + ltid] = cur.r0; s_ratio[0 * BLOCK + ltid] = cur.q0;
+            s_rho[1 * BLOCK + ltid] = cur.r1; s_ratio[1 * BLOCK + ltid] = cur.q1;
+            for (int t = 2; t <= S; ++t) {
+                s_rho[t * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 * t)];
+                s_ratio[t * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 * t + 1)];
+            }
+            const double d = s_rho[S * BLOCK + ltid];   // the hard target's range: the beam's own (simulation.py:89)
+            const T d_t = (T)d;                         // exact: d was widened from the row dtype
+            sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
+            if (o.range_error) {
+                atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+                atomicCAS(&a.status[1], -1, cur.g);
+            }
+            constexpr int NB = LMAX <= 4 ? 4 : 8;
+            double best = 0.0;
+            int k_best = 0;
+            if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+            else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+            sg_beam_decide(d, ch, a.las, best, k_best, o);
+            a.rec[cur.g] = sg_pack_record(o);
+        }
+        sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+        if (!more) break;
+        cur = nxt;
+        i = nxt_i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The global-list tier: beams that met more flakes than the largest LDS list holds (SNOWGPU_MAX_FLAKES_PER_BEAM).  The
+// reference's lists are unbounded (simulation.py:413-419); here each lane keeps its lists in global memory, h_cap + 1
+// entries per column, strided by the lane count -- the same code as the LDS tiers, slower, and only ever run for the
+// handful of beams that need it.  h_lanes lanes stride over the class.
+template <typename T>
+__global__ __launch_bounds__(64) void k_beams_huge(SgBeamArgs a)
+{
+    const int tid = (int)(blockIdx.x * 64 + threadIdx.x);             // lane of the tier = column of the lists
+    const int rstride = a.h_lanes;
+    const size_t col = (size_t)(a.h_cap + 1) * (size_t)a.h_lanes;
+    double *s_a1 = a.h_lists, *s_a2 = s_a1 + col, *s_rho = s_a2 + col, *s_ratio = s_rho + col;
+    const int n_las = a.las->n;
+    int64_t work_n = a.tier_info[a.cls];
+    const int64_t work_off = a.tier_info[4 + a.cls];
+    int64_t chunk = (int64_t)blockIdx.x * 64;
+    if (chunk >= work_n) return;
+    do {
+    const bool live = chunk + threadIdx.x < work_n;
     int64_t g = 0;
-    int f = 0, S = 0, ch = 0;
-    T px = 0, py = 0, pz = 0, pch = 0;
+    int f = 0;
+    SgBeamOut o;
+    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
     if (live) {
-        g = a.pq_list[slot];
-        S = (int)a.keep[g] - 16;
-        if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
-            const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
-            int fe = (int)((float)gu * a.inv_uniform_rows);
-            if (fe >= a.n_frames) fe = a.n_frames - 1;
-            while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
-            while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
-            f = fe;
-        } else f = sg_find_frame(a.frame_off, a.n_frames, g);
+        g = a.tier_list[work_off + chunk + threadIdx.x];
+        f = sg_frame_of(a, g);
         const int64_t src = a.frame_off[f] + a.perm[g];
         const T *row = (const T *)a.rows + src * 5;
-        px = row[0]; py = row[1]; pz = row[2]; pch = row[4];
-        ch = (int)pch;
-        const double *dd = a.pq_dict + g * a.pq_stride;
-        for (int t = 0; t <= S; ++t) { s_rho[t * BLOCK + tid] = dd[2 * t]; s_ratio[t * BLOCK + tid] = dd[2 * t + 1]; }
-    }
-    SgBeamOut o;
-    o.x = (double)px; o.y = (double)py; o.z = (double)pz; o.intensity = 0.0; o.label = 0.0;
-    o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S;
-    double best = 0.0;
-    int k_best = 0;
-    if (live) {
-        T d_t;
-        if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);    // simulation.py:89
-        else d_t = sqrt((px * px + py * py) + pz * pz);
-        sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, tid, o);
-        if (o.range_error) {
+        const T px = row[0], py = row[1], pz = row[2];
+        const int ch = (int)row[4];                                    // a flagged beam was simulated: valid channel
+        const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];
+        int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+        double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
+        double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
+        sg_beam<T, 0, 0, false>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
+                                dra, a.exact_math != 0, rstride, a.h_cap);
+        uint32_t rec = 0;
+        if (o.overflow) {
+            atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+            atomicCAS(&a.status[1], -1, (int32_t)g);
+        } else if (o.range_error) {
             atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
             atomicCAS(&a.status[1], -1, (int32_t)g);
         }
-        constexpr int NB = LMAX <= 4 ? 4 : 8;
-        if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
-        else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
-        sg_beam_decide<T>(px, py, pz, ch, a.las, best, k_best, o);
-    }
-    {   // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame (same-address atomics from every
-        // lane would serialise in L2); the list is in sorted-row order, so a wave rarely holds more than one frame
-        long long d2 = live ? (long long)o.diff2 : 0;
-        unsigned long long todo = __ballot(live && d2 != 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int fl = __shfl(f, leader);
-            const bool mine = live && f == fl;
-            long long part = mine ? d2 : 0;
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-            if ((tid & 63) == leader && part != 0) atomicAdd(&a.diff2[fl], (unsigned long long)part);
-            todo &= ~__ballot(mine);
+        if (o.has_power) {
+            double best = 0.0;
+            int k_best = 0;
+            if (a.exact_math) sg_lane_power<0, true, 8, 0>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best, rstride, a.h_cap);
+            else sg_lane_power<0, false, 8, 0>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best, rstride, a.h_cap);
+            T d_t;
+            if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);
+            else d_t = sqrt((px * px + py * py) + pz * pz);
+            sg_beam_decide((double)d_t, ch, a.las, best, k_best, o);
+            rec = sg_pack_record(o);
         }
+        a.rec[g] = rec;
     }
-    if (live) sg_store_row<T>(a, g, f, px, py, pz, o);
+    sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+    } while ((chunk += (int64_t)gridDim.x * 64) < work_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,102 +622,158 @@ __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ f
     const unsigned long long c = atomicAdd(&tbl_cur[r.key], (1ull << 32) | (unsigned long long)nb), base = tbl_base[r.key];
     const int slot = (int)(base >> 32) + (int)(c >> 32);
     const int b0 = (int)(base & 0xffffffffull) + (int)(c & 0xffffffffull);
-    seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = p >> 8; seg_blk[slot] = b0;
+    seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = b0;
     for (int q = 0; q < nb; ++q) seg_of_blk[b0 + q] = slot;      // block -> segment: one load per block in k_beams
 }
 
 // ------------------------------------------------------------------------------------------------
-// Ordered lists of the first pass, built from the flag bytes: positions g with keep[g] in class 1 = [lo1, hi1], ascending,
-// followed by those in class 2 = [lo2, hi2], ascending (lo2 > hi2: no second class).  keep[g] == 2: overflowed beams
-// for the next capacity tier; 16 + n_flakes: beams with an occlusion dict for k_power (one flake first, then the rest).
-// Three kernels over tiles of SG_TILE positions: count, one-block scan, scatter.  (Folding the scan into the last
-// block of the count kernel was tried: the device-scope fence it needs writes back the L2 of the block's XCD, and
-// 16 000 of those cost more than the launch they save.)
-__global__ __launch_bounds__(SG_BLOCK) void k_list_count(const uint8_t *__restrict__ keep, int64_t n_total, int32_t *__restrict__ tile_cnt,
-                                                         int lo1, int hi1, int lo2, int hi2)
+// Tier lists, built from the flag bytes of the direct-mode pass: class k = positions g with flag[g] == 3 + k, ascending
+// (sorted-row order keeps the lanes of a tier's waves neighbours in channel and azimuth -- one table, nearby bins; an
+// atomic queue would hand a wave 64 beams of as many channels, i.e. tables: every load a miss).  The classes are
+// concatenated in one list; tier_info = {entries per class [4], start of each class [4]}.  Three kernels over tiles
+// of SG_TILE positions: count, one-block scan, scatter.  (Folding the scan into the last block of the count kernel was
+// tried: the device-scope fence it needs writes back the L2 of the block's XCD, and 16 000 of those cost more than the
+// launch they save.)
+__global__ __launch_bounds__(SG_BLOCK) void k_tier_count(const uint8_t *__restrict__ flag, int64_t n_total, int32_t *__restrict__ tile_cnt)
 {
     const int tid = threadIdx.x;
     const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
-    int c1 = 0, c2 = 0;
     uint32_t v = 0;
-    if (g0 + 3 < n_total) v = *(const uint32_t *)(keep + g0);
-    else for (int q = 0; q < 4; ++q) if (g0 + q < n_total) v |= (uint32_t)keep[g0 + q] << (8 * q);
-    for (int q = 0; q < 4; ++q) {
-        const int b = g0 + q < n_total ? (int)((v >> (8 * q)) & 0xff) : -1;
-        c1 += (b >= lo1 && b <= hi1);
-        c2 += (b >= lo2 && b <= hi2);
+    if (g0 + 3 < n_total) v = *(const uint32_t *)(flag + g0);
+    else for (int q = 0; q < 4; ++q) if (g0 + q < n_total) v |= (uint32_t)flag[g0 + q] << (8 * q);
+    int c[SG_MAX_CLASSES] = {0, 0, 0, 0};
+    if (v) {                                                        // most words carry no flag at all
+        for (int q = 0; q < 4; ++q) {
+            const int b = (int)((v >> (8 * q)) & 0xff) - 3;
+            for (int k = 0; k < SG_MAX_CLASSES; ++k) c[k] += (b == k);
+        }
     }
-    __shared__ int s1[SG_BLOCK / 64], s2[SG_BLOCK / 64];
-    for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); }
-    if ((tid & 63) == 0) { s1[tid >> 6] = c1; s2[tid >> 6] = c2; }
+    __shared__ int sm[SG_BLOCK / 64][SG_MAX_CLASSES];
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) {
+        int x = c[k];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        if ((tid & 63) == 0) sm[tid >> 6][k] = x;
+    }
     __syncthreads();
-    if (tid == 0) {
-        int t1 = 0, t2 = 0;
-        for (int w = 0; w < SG_BLOCK / 64; ++w) { t1 += s1[w]; t2 += s2[w]; }
-        tile_cnt[2 * blockIdx.x] = t1; tile_cnt[2 * blockIdx.x + 1] = t2;
+    if (tid < SG_MAX_CLASSES) {
+        int t = 0;
+        for (int w = 0; w < SG_BLOCK / 64; ++w) t += sm[w][tid];
+        tile_cnt[SG_MAX_CLASSES * (int64_t)blockIdx.x + tid] = t;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_list_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int tiles,
-                                                    int32_t *__restrict__ count_out)
+__global__ __launch_bounds__(1024) void k_tier_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int tiles,
+                                                    int32_t *__restrict__ tier_info, int32_t *__restrict__ status_counts)
 {
-    __shared__ int s1[1024], s2[1024];
+    __shared__ int s[SG_MAX_CLASSES][1024];
     const int tid = threadIdx.x;
     const int per = (tiles + 1023) / 1024, b0 = tid * per, b1 = b0 + per < tiles ? b0 + per : tiles;
-    int sum1 = 0, sum2 = 0;
-    for (int i = b0; i < b1; ++i) { sum1 += tile_cnt[2 * i]; sum2 += tile_cnt[2 * i + 1]; }
-    s1[tid] = sum1; s2[tid] = sum2;
+    int sum[SG_MAX_CLASSES] = {0, 0, 0, 0};
+    for (int i = b0; i < b1; ++i)
+        for (int k = 0; k < SG_MAX_CLASSES; ++k) sum[k] += tile_cnt[SG_MAX_CLASSES * i + k];
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) s[k][tid] = sum[k];
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        const int a1 = tid >= d ? s1[tid - d] : 0, a2 = tid >= d ? s2[tid - d] : 0;
+        int add[SG_MAX_CLASSES];
+        for (int k = 0; k < SG_MAX_CLASSES; ++k) add[k] = tid >= d ? s[k][tid - d] : 0;
         __syncthreads();
-        s1[tid] += a1; s2[tid] += a2;
+        for (int k = 0; k < SG_MAX_CLASSES; ++k) s[k][tid] += add[k];
         __syncthreads();
     }
-    const int total1 = s1[1023], total2 = s2[1023];
-    int run1 = s1[tid] - sum1, run2 = total1 + s2[tid] - sum2;      // class 2 follows class 1 in the list
-    for (int i = b0; i < b1; ++i) {
-        tile_base[2 * i] = run1; tile_base[2 * i + 1] = run2;
-        run1 += tile_cnt[2 * i]; run2 += tile_cnt[2 * i + 1];
+    int run[SG_MAX_CLASSES], start = 0;
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) {                      // class k follows class k - 1 in the list
+        run[k] = start + s[k][tid] - sum[k];
+        if (tid == 0) { tier_info[k] = s[k][1023]; tier_info[SG_MAX_CLASSES + k] = start; status_counts[k] = s[k][1023]; }
+        start += s[k][1023];
     }
-    if (tid == 0) *count_out = total1 + total2;
+    for (int i = b0; i < b1; ++i)
+        for (int k = 0; k < SG_MAX_CLASSES; ++k) {
+            tile_base[SG_MAX_CLASSES * i + k] = run[k];
+            run[k] += tile_cnt[SG_MAX_CLASSES * i + k];
+        }
 }
 
-__global__ __launch_bounds__(SG_BLOCK) void k_list_scatter(const uint8_t *__restrict__ keep, int64_t n_total, const int32_t *__restrict__ tile_base,
-                                                           int32_t *__restrict__ list, int32_t cap, int lo1, int hi1, int lo2, int hi2)
+__global__ __launch_bounds__(SG_BLOCK) void k_tier_scatter(const uint8_t *__restrict__ flag, int64_t n_total, const int32_t *__restrict__ tile_cnt,
+                                                           const int32_t *__restrict__ tile_base, int32_t *__restrict__ list, int32_t cap)
 {
     const int tid = threadIdx.x;
+    const int32_t *tc = tile_cnt + SG_MAX_CLASSES * (int64_t)blockIdx.x;
+    if ((tc[0] | tc[1] | tc[2] | tc[3]) == 0) return;               // most tiles hold no flagged beam
     const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
     int cls[4];
-    int c1 = 0, c2 = 0;
+    int c[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int q = 0; q < 4; ++q) {
-        const int b = g0 + q < n_total ? (int)keep[g0 + q] : -1;
-        cls[q] = (b >= lo1 && b <= hi1) ? 1 : ((b >= lo2 && b <= hi2) ? 2 : 0);
-        c1 += cls[q] == 1; c2 += cls[q] == 2;
+        const int b = g0 + q < n_total ? (int)flag[g0 + q] - 3 : -1;
+        cls[q] = (b >= 0 && b < SG_MAX_CLASSES) ? b : -1;
+        for (int k = 0; k < SG_MAX_CLASSES; ++k) c[k] += (cls[q] == k);
     }
-    // exclusive prefixes of c1, c2 over the block: wave scan + wave totals
-    int i1 = c1, i2 = c2;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int v1 = __shfl_up(i1, o), v2 = __shfl_up(i2, o);
-        if ((tid & 63) >= o) { i1 += v1; i2 += v2; }
+    __shared__ int sm[SG_BLOCK / 64][SG_MAX_CLASSES];
+    int slot[SG_MAX_CLASSES];
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) {                      // exclusive prefix of c[k] over the block
+        int inc = c[k];
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((tid & 63) >= o) inc += v; }
+        if ((tid & 63) == 63) sm[tid >> 6][k] = inc;
+        slot[k] = inc - c[k];
     }
-    __shared__ int s1[SG_BLOCK / 64], s2[SG_BLOCK / 64];
-    if ((tid & 63) == 63) { s1[tid >> 6] = i1; s2[tid >> 6] = i2; }
     __syncthreads();
-    int slot1 = tile_base[2 * blockIdx.x] + i1 - c1, slot2 = tile_base[2 * blockIdx.x + 1] + i2 - c2;
-    for (int w = 0; w < (tid >> 6); ++w) { slot1 += s1[w]; slot2 += s2[w]; }
-    for (int q = 0; q < 4; ++q) {
-        if (cls[q] == 1) { if (slot1 < cap) list[slot1] = (int32_t)(g0 + q); ++slot1; }
-        else if (cls[q] == 2) { if (slot2 < cap) list[slot2] = (int32_t)(g0 + q); ++slot2; }
+    for (int k = 0; k < SG_MAX_CLASSES; ++k) {
+        slot[k] += tile_base[SG_MAX_CLASSES * (int64_t)blockIdx.x + k];
+        for (int w = 0; w < (tid >> 6); ++w) slot[k] += sm[w][k];
     }
+    for (int q = 0; q < 4; ++q)
+        if (cls[q] >= 0) { const int sl = slot[cls[q]]++; if (sl < cap) list[sl] = (int32_t)(g0 + q); }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stable compaction of kept rows, per frame.
+// Output row of a sorted position, rebuilt from its ORIGINAL row and its result record (simulation.py:160-192, :516):
+// unchanged rows keep their coordinates and get np.round(intensity); attenuated rows (label 1) the new intensity; scattered
+// rows (label 2) move to d_max on their ray; rows of channels without a laser keep their channel value in column 4 (Q5).
+// dd = the ORIGINAL range in the row dtype (simulation.py:465).
+template <typename T> struct SgRow { T x, y, z, i, lab, dd; };
+
 template <typename T>
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ tmp_rows, const double *__restrict__ thr_poly,
+__device__ __forceinline__ SgRow<T> sg_rebuild_row(const T *__restrict__ row, uint32_t rec)
+{
+    SgRow<T> r;
+    const T px = row[0], py = row[1], pz = row[2], pint = row[3], pch = row[4];
+    if constexpr (sizeof(T) == 4) r.dd = sqrtf((px * px + py * py) + pz * pz);
+    else r.dd = sqrt((px * px + py * py) + pz * pz);
+    r.x = px; r.y = py; r.z = pz;
+    const int label = (int)((rec >> SG_REC_LABEL_SHIFT) & 3u);
+    if (label == 0) {
+        if constexpr (sizeof(T) == 4) r.i = rintf(pint); else r.i = rint(pint);      // :516 np.round (half to even)
+        r.lab = (rec & SG_REC_COPY) ? pch : (T)0;
+    } else {
+        r.i = (T)(int)(rec & 255u);
+        r.lab = (T)label;
+        if (label == 2) {
+            const double scale = sg_scatter_scale((int)((rec >> SG_REC_K_SHIFT) & 2047u), (double)r.dd);   // :176
+            r.x = (T)((double)px * scale); r.y = (T)((double)py * scale); r.z = (T)((double)pz * scale);   // :178-180
+        }
+    }
+    return r;
+}
+
+// get_fov_flag(calib.lidar_to_rect(xyz), (h, w), calib) (simulation.py:39-47, :535-536) in float64, fixed operation order
+// (the reference's own arithmetic lives in an un-vendored module: parity unpinned, SURVEY 8 c)
+__device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, double z)
+{
+    double r[3];
+    for (int j = 0; j < 3; ++j) r[j] = ((x * v.m[j] + y * v.m[3 + j]) + z * v.m[6 + j]) + v.m[9 + j];
+    double h[3];
+    for (int j = 0; j < 3; ++j) h[j] = ((r[0] * v.p[4 * j] + r[1] * v.p[4 * j + 1]) + r[2] * v.p[4 * j + 2]) + v.p[4 * j + 3];
+    const double u = h[0] / h[2], w = h[1] / h[2];
+    const double depth = h[2] - v.p[11];
+    return u >= 0 && u < v.img_w && w >= 0 && w < v.img_h && depth >= 0;
+}
+
+// Stable compaction of kept rows, per frame.  keep byte: bit 0 = row is in the output, bit 1 = row passed the noise filter
+// (num_attenuated counts those, before the camera crop: simulation.py:525 precedes :532-540).
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
+                                                            const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
-                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles)
+                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
@@ -591,16 +785,14 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
         if (r >= n) continue;
         // keep = (label == 2) | (intensity > p0 d^2 + p1 d + p2), d the ORIGINAL range, d^2 in the row dtype
-        // (simulation.py:465, :469, :518-520); rows with label != 2 still hold their original coordinates
-        const T *row = tmp_rows + (base + r) * 5;
-        const T x = row[0], y = row[1], z = row[2], oi = row[3], lab = row[4];
-        T dd;
-        if constexpr (sizeof(T) == 4) dd = sqrtf((x * x + y * y) + z * z);
-        else dd = sqrt((x * x + y * y) + z * z);
-        const T dd2 = dd * dd;
-        const double thr = (p0 * (double)dd2 + p1 * (double)dd) + p2;
-        const bool k = (lab == (T)2) || ((double)oi > thr);
-        keep[base + r] = k ? 1 : 0;
+        // (simulation.py:465, :469, :518-520)
+        const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rec[base + r]);
+        const T dd2 = o.dd * o.dd;
+        const double thr = (p0 * (double)dd2 + p1 * (double)o.dd) + p2;
+        const bool noise_ok = (o.lab == (T)2) || ((double)o.i > thr);
+        bool k = noise_ok;
+        if (fov.enabled && k) k = sg_in_fov(fov, (double)o.x, (double)o.y, (double)o.z);   // :532-540
+        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0));
         c += k;
     }
     __shared__ int s[4];
@@ -626,14 +818,14 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__rest
         }
         out_counts[f] = run;
         out_stats[f * 3 + 0] = 0;                // num_attenuated: filled by k_compact_scatter
-        out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522)
+        out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522, + the camera crop :538)
         out_stats[f * 3 + 2] = 0;
     }
 }
 
 template <typename T>
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ tmp_rows, const uint8_t *__restrict__ keep,
-                                                              const int32_t *__restrict__ perm,
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
+                                                              const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
                                                               const int64_t *__restrict__ frame_off,
                                                               const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
                                                               int32_t *__restrict__ out_src, int64_t *__restrict__ out_stats,
@@ -646,29 +838,29 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     __shared__ int wave_cnt[4][4];               // [round][wave]
     const int tid = threadIdx.x, w = tid >> 6;
     bool k[4];
-    int pre[4];
+    int pre[4], att = 0;
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + tid;
-        k[q] = (r < n) && keep[base + r];
+        const int kb = r < n ? (int)keep[base + r] : 0;
+        k[q] = kb & 1;
+        if ((kb & 2) && ((rec[base + r] >> SG_REC_LABEL_SHIFT) & 3u) == 1u) ++att;   // simulation.py:525
         const unsigned long long m = __ballot(k[q]);
         pre[q] = __popcll(m & sg_lanemask_lt());
         if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
     }
     __syncthreads();
     int run = tile_base[(int64_t)f * max_tiles + blockIdx.x];
-    int att = 0;
     for (int q = 0; q < 4; ++q) {
         int off = run;
         for (int ww = 0; ww < w; ++ww) off += wave_cnt[q][ww];
         if (k[q]) {
             const int64_t r = base + tile0 + q * SG_BLOCK + tid;
             const int64_t dst = base + off + pre[q];
-            const T *s = tmp_rows + r * 5;
+            const int32_t src = perm[r];
+            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + src) * 5, rec[r]);
             T *d = out_rows + dst * 5;
-            const T lab = s[4];
-            d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; d[4] = lab;
-            out_src[dst] = perm[r];
-            if (lab == (T)1) ++att;              // simulation.py:525
+            d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
+            out_src[dst] = src;
         }
         run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
     }
@@ -685,6 +877,24 @@ __global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, con
     out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // simulation.py:527-530 int()
 }
 
+// Chunk boundaries of the segment order: chunk c of n_chunks = blocks [chunk_blk[c], chunk_blk[c + 1]), cut at segment
+// starts (a segment's slice of the dict queue is complete only when all of its blocks have run), as even as that allows.
+__global__ void k_seg_chunks(const int32_t *__restrict__ seg_n, const int32_t *__restrict__ seg_blk, int n_chunks,
+                             int32_t *__restrict__ chunk_blk)
+{
+    const int c = threadIdx.x;
+    if (c > n_chunks) return;
+    const int n_seg = seg_n[0], total = seg_n[1];
+    if (c == n_chunks) { chunk_blk[c] = total; return; }
+    const int target = (int)(((int64_t)total * c) / n_chunks);
+    int lo = 0, hi = n_seg;                          // first segment whose first block is >= target (seg_blk ascends with the slot)
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_blk[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    chunk_blk[c] = lo < n_seg ? seg_blk[lo] : total;
+}
+
 // table_ids[frame][channel] -> the table descriptor itself, so that a beam needs one load instead of two dependent ones
 __global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_tables, const int32_t *__restrict__ table_ids,
                                  int64_t n, SgTable *__restrict__ out)
@@ -697,16 +907,6 @@ __global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_table
     out[i] = d;
 }
 
-extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out,
-                                        void *stream)
-{
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_resolve_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tables, n_tables,
-                       table_ids, n, out);
-    return (int)hipGetLastError();
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // launch wrappers (C linkage, called from snowgpu_api.cpp)
 
@@ -716,74 +916,128 @@ extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, con
         if (e__ != hipSuccess) return (int)e__;            \
     } while (0)
 
+extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out,
+                                        void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_resolve_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tables, n_tables,
+                       table_ids, n, out);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
-                              int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, int32_t *perm, int32_t *status,
+                              int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                               int64_t max_tiles, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
-    if (dtype == 0) hipLaunchKernelGGL(k_sort_hist<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, status, max_tiles);
-    else hipLaunchKernelGGL(k_sort_hist<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, status, max_tiles);
+    if (dtype == 0) hipLaunchKernelGGL(k_sort_hist<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles);
+    else hipLaunchKernelGGL(k_sort_hist<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sort_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_hist, tile_base, max_tiles);
     SG_CHECK_LAUNCH();
-    if (dtype == 0) hipLaunchKernelGGL(k_sort_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_base, rank, perm, max_tiles);
-    else hipLaunchKernelGGL(k_sort_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_base, rank, perm, max_tiles);
+    hipLaunchKernelGGL(k_sort_scatter, grid, dim3(SG_BLOCK), 0, st, ch8, frame_off, tile_base, rank, perm, max_tiles);
     SG_CHECK_LAUNCH();
     return 0;
 }
 
-template <typename T, int LMAX, int BLOCK, bool LIST>
-static int launch_beams_tl(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
+static int sg_cu_count(int dev_id)
 {
-    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
-    static bool attr_set[64] = {};                       // per device: several contexts may live in one process
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
+    return cus > 0 ? cus : 256;
+}
+
+template <typename K>
+static int sg_set_lds(K kernel, size_t lds, bool *attr_set)
+{
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_beams<T, LMAX, BLOCK, LIST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {          // per device: several contexts may live in one process
+        hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    unsigned blocks = (unsigned)((n_threads + BLOCK - 1) / BLOCK);
-    if (!LIST && a->seg_blk) blocks = (unsigned)a->grid_blocks;
-    if (blocks == 0) return 0;
+    return 0;
+}
+
+template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
+static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
+{
+    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
+    static bool attr_set[64] = {};
+    if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
+    constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK;
+    unsigned blocks;
     if (LIST) {                                          // list mode: at most what the chip can hold at once
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-        const unsigned per_cu = (unsigned)std::max<size_t>(1, (size_t)(160 * 1024) / lds);
-        blocks = std::min(blocks, (unsigned)cus * per_cu);
+        const int64_t n = (int64_t)a->work_hi - a->work_lo;
+        if (n <= 0) return 0;
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        const unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
+        blocks = (unsigned)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)sg_cu_count(dev_id) * per_cu);
+    } else {
+        blocks = (unsigned)a->grid_blocks;               // blocks [blk_lo, blk_hi) or chunk a->chunk of the segment order
     }
-    hipLaunchKernelGGL((k_beams<T, LMAX, BLOCK, LIST>), dim3(blocks), dim3(BLOCK), lds, st, *a);
+    if (blocks == 0) return 0;
+    hipLaunchKernelGGL((k_beams<T, LMAX, BLOCK, LIST, DICT>), dim3(blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
     return 0;
 }
 
 template <typename T, int LMAX, int BLOCK>
-static int launch_beams_t(const SgBeamArgs *a, int64_t n_threads, hipStream_t st)
+static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStream_t st)
 {
-    return a->work_list ? launch_beams_tl<T, LMAX, BLOCK, true>(a, n_threads, st)
-                        : launch_beams_tl<T, LMAX, BLOCK, false>(a, n_threads, st);
+    if (direct) return launch_beams_t<T, LMAX, BLOCK, false, true>(a, st);
+    return dict_only ? launch_beams_t<T, LMAX, BLOCK, true, true>(a, st) : launch_beams_t<T, LMAX, BLOCK, true, false>(a, st);
 }
 
-template <typename T, int LMAX, int BLOCK>
+template <typename T, int LMAX, int BLOCK, bool LISTQ>
 static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
     static bool attr_set[64] = {};
+    if (int e = sg_set_lds(k_power<T, LMAX, BLOCK, LISTQ>, lds, attr_set)) return e;
+    constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, LANES = BLOCK < 64 ? BLOCK : 64;
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_power<T, LMAX, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    // persistent waves: what the chip holds at once (LDS and the 32-waves-per-CU limit), fewer if the queue cannot be longer
+    const unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
+    int64_t blocks = (int64_t)sg_cu_count(dev_id) * per_cu;
+    const int64_t items_ub = LISTQ ? ((int64_t)a->work_hi + LANES - 1) / LANES : (a->n_total + LANES - 1) / LANES + 2 * a->n_regions_ub;
+    blocks = std::min<int64_t>(blocks, (items_ub + THREADS / 64 - 1) / (THREADS / 64));
+    if (blocks <= 0) return 0;
+    if (!LISTQ) {
+        const unsigned pg = (unsigned)((a->n_regions_ub + 255) / 256);
+        if (pg == 0) return 0;
+        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, (int)a->n_regions_ub);
+        SG_CHECK_LAUNCH();
     }
-    const unsigned blocks = (unsigned)((a->n_total + BLOCK - 1) / BLOCK);     // upper bound: surplus blocks leave at once
-    if (blocks == 0) return 0;
-    hipLaunchKernelGGL((k_power<T, LMAX, BLOCK>), dim3(blocks), dim3(BLOCK), lds, st, *a);
+    hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
     return 0;
+}
+
+// threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
+extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax >= SG_LCAP ? 16 : 64); }
+
+// lmax = per-beam list capacity of this pass: 4 (160 B of LDS per beam: 16 waves per CU), 8, 16 or 63 (the largest
+// LDS list).  direct: the pass over all rows, dict hand-over to sg_launch_power; else list mode over class a->cls.
+extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int direct, int dict_only, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == 0) {
+        if (lmax == 4) return launch_beams_m<float, 4, 256>(a, direct, dict_only, st);
+        if (lmax == 8) return launch_beams_m<float, 8, 64>(a, direct, dict_only, st);
+        if (lmax == 16) return launch_beams_m<float, 16, 64>(a, direct, dict_only, st);
+        return launch_beams_m<float, SG_LCAP, 16>(a, direct, dict_only, st);
+    }
+    if (lmax == 4) return launch_beams_m<double, 4, 256>(a, direct, dict_only, st);
+    if (lmax == 8) return launch_beams_m<double, 8, 64>(a, direct, dict_only, st);
+    if (lmax == 16) return launch_beams_m<double, 16, 64>(a, direct, dict_only, st);
+    return launch_beams_m<double, SG_LCAP, 16>(a, direct, dict_only, st);
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
@@ -791,45 +1045,46 @@ extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *s
 {
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256>(a, st);
-        if (lmax == 8) return launch_power_t<float, 8, 64>(a, st);
-        if (lmax == 16) return launch_power_t<float, 16, 64>(a, st);
-        return launch_power_t<float, SG_LCAP, 64>(a, st);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st);
+        if (lmax == 8) return launch_power_t<float, 8, 64, false>(a, st);
+        if (lmax == 16) return launch_power_t<float, 16, 64, false>(a, st);
+        return launch_power_t<float, SG_LCAP, 16, false>(a, st);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256>(a, st);
-    if (lmax == 8) return launch_power_t<double, 8, 64>(a, st);
-    if (lmax == 16) return launch_power_t<double, 16, 64>(a, st);
-    return launch_power_t<double, SG_LCAP, 64>(a, st);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st);
+    if (lmax == 8) return launch_power_t<double, 8, 64, false>(a, st);
+    if (lmax == 16) return launch_power_t<double, 16, 64, false>(a, st);
+    return launch_power_t<double, SG_LCAP, 16, false>(a, st);
 }
 
-// threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
-extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax == 32 ? 128 : 64); }
-
-// lmax = per-beam list capacity of this pass: 4 (160 B of LDS per beam: 16 waves per CU), 8, 16 or 63 (the hard
-// cap).  Beams that exceed it are flagged (direct mode) or queued (list mode) for the next pass.  With a->work_list
-// set, a chip-sized grid strides over the list, whose length is only known on the device.
-extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, void *stream)
+// ... and for the hand-over buffer of a list-mode pass
+extern "C" int sg_launch_power_list(const SgBeamArgs *a, int dtype, int lmax, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
-    const int64_t n = a->work_list ? (int64_t)a->work_cap : a->n_total;
     if (dtype == 0) {
-        if (lmax == 4) return launch_beams_t<float, 4, 256>(a, n, st);
-        if (lmax == 8) return launch_beams_t<float, 8, 64>(a, n, st);
-        if (lmax == 16) return launch_beams_t<float, 16, 64>(a, n, st);
-        if (lmax == 32) return launch_beams_t<float, 32, 128>(a, n, st);
-        return launch_beams_t<float, SG_LCAP, 64>(a, n, st);
-    } else {
-        if (lmax == 4) return launch_beams_t<double, 4, 256>(a, n, st);
-        if (lmax == 8) return launch_beams_t<double, 8, 64>(a, n, st);
-        if (lmax == 16) return launch_beams_t<double, 16, 64>(a, n, st);
-        if (lmax == 32) return launch_beams_t<double, 32, 128>(a, n, st);
-        return launch_beams_t<double, SG_LCAP, 64>(a, n, st);
+        if (lmax == 8) return launch_power_t<float, 8, 64, true>(a, st);
+        if (lmax == 16) return launch_power_t<float, 16, 64, true>(a, st);
+        return launch_power_t<float, SG_LCAP, 16, true>(a, st);
     }
+    if (lmax == 8) return launch_power_t<double, 8, 64, true>(a, st);
+    if (lmax == 16) return launch_power_t<double, 16, 64, true>(a, st);
+    return launch_power_t<double, SG_LCAP, 16, true>(a, st);
+}
+
+extern "C" int sg_launch_huge(const SgBeamArgs *a, int dtype, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(a->h_lanes / 64);
+    if (blocks == 0) return 0;
+    if (dtype == 0) hipLaunchKernelGGL(k_beams_huge<float>, dim3(blocks), dim3(64), 0, st, *a);
+    else hipLaunchKernelGGL(k_beams_huge<double>, dim3(blocks), dim3(64), 0, st, *a);
+    SG_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
-                                  int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, void *stream)
+                                  int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
+                                  int32_t *chunk_blk, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)n_frames;         // 256 pairs per frame, one thread each
@@ -841,41 +1096,46 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
     hipLaunchKernelGGL(k_seg_place, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block,
                        tbl_base, tbl_cnt, seg_start, seg_cnt, seg_frame, seg_blk, seg_of_blk);
     SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_seg_chunks, dim3(1), dim3(64), 0, st, seg_n, seg_blk, n_chunks, chunk_blk);
+    SG_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sg_launch_list(const uint8_t *keep, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *count,
-                              int32_t cap, int lo1, int hi1, int lo2, int hi2, void *stream)
+extern "C" int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
+                                    int32_t *tier_info, int32_t *status_counts, int32_t cap, int n_cls, void *stream)
 {
+    (void)n_cls;
     hipStream_t st = (hipStream_t)stream;
     const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
     if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_list_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_cnt, lo1, hi1, lo2, hi2);
+    hipLaunchKernelGGL(k_tier_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, flag, n_total, tile_cnt);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, (int)tiles, count);
+    hipLaunchKernelGGL(k_tier_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, (int)tiles, tier_info, status_counts);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_list_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, keep, n_total, tile_base, list, cap, lo1, hi1, lo2, hi2);
+    hipLaunchKernelGGL(k_tier_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, flag, n_total, tile_cnt, tile_base, list, cap);
     SG_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int sg_launch_compact(const void *tmp_rows, int dtype, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
-                                 int64_t *out_stats, const unsigned long long *diff2, int64_t max_tiles, void *stream)
+                                 int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)tmp_rows, thr_poly, keep, frame_off, tile_cnt, max_tiles);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)tmp_rows, thr_poly, keep, frame_off, tile_cnt, max_tiles);
+    SgFov fv{};
+    if (fov) fv = *fov;
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     if (dtype == 0)
-        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)tmp_rows, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
     else
-        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)tmp_rows, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_stats_final, dim3((n_frames + 63) / 64), dim3(64), 0, st, n_frames, out_stats, diff2);
     SG_CHECK_LAUNCH();

@@ -12,6 +12,7 @@
 // bit for bit (NumPy's own summation order depends on its build) -- see DESIGN.md "prepass tolerance".
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include "sg_common.h"
 #include "sg_prepass.h"
 
@@ -685,6 +686,17 @@ __global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
     }
 }
 
+// Source rows of a chained result (snowfall, then wet ground): final row -> snowfall row -> input row.
+__global__ __launch_bounds__(PB) void k_compose_src(const int64_t *__restrict__ frame_off, const int64_t *__restrict__ counts,
+                                                   const int32_t *__restrict__ second, const int32_t *__restrict__ first,
+                                                   int32_t *__restrict__ out)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = counts[f];
+    for (int64_t i = (int64_t)blockIdx.x * PB + threadIdx.x; i < n; i += (int64_t)gridDim.x * PB)
+        out[base + i] = first[base + second[base + i]];
+}
+
 // ================================================================================================================
 // host side
 
@@ -796,6 +808,16 @@ extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, cons
     LCHK();
     if (dtype == 0) hipLaunchKernelGGL(k_wet_scatter<float>, grid, dim3(PB), 0, st, w);
     else hipLaunchKernelGGL(k_wet_scatter<double>, grid, dim3(PB), 0, st, w);
+    LCHK();
+    return 0;
+}
+
+extern "C" int sg_launch_compose_src(const int64_t *frame_off, const int64_t *counts, int n_frames, int64_t max_frame,
+                                     const int32_t *second, const int32_t *first, int32_t *out, void *stream)
+{
+    if (n_frames <= 0 || max_frame <= 0) return 0;
+    const unsigned gx = (unsigned)std::min<int64_t>((max_frame + PB - 1) / PB, 64);
+    hipLaunchKernelGGL(k_compose_src, dim3(gx, (unsigned)n_frames), dim3(PB), 0, (hipStream_t)stream, frame_off, counts, second, first, out);
     LCHK();
     return 0;
 }

@@ -9,9 +9,9 @@ replaces ``from tools.snowfall.simulation import augment`` at the reference's ca
 (pointcloud_viewer.py:2807-2810, :2865-2868; tools/snowfall/precompute.py:103-104).
 
 This module is host logic only: argument handling, the channel permutation drawn from Python's global
-``random`` exactly as the reference does (:482-486), particle-table lookup (:78, :324-329) and the
-optional camera-FOV crop.  The simulation itself -- channel sort, noise-threshold prepass, per-beam
-occlusion and received-power integration, noise-floor filter, compaction, statistics -- runs in
+``random`` exactly as the reference does (:482-486) and particle-table lookup (:78, :324-329).  The
+simulation itself -- channel sort, noise-threshold prepass, per-beam occlusion and received-power
+integration, noise-floor filter, camera-FOV crop, compaction, statistics -- runs in
 libsnowgpu.so (hand-written HIP for gfx950).  There is no CPU fallback.
 """
 from __future__ import annotations
@@ -51,7 +51,8 @@ def _raise_like_reference(err: _native.SnowGPUError):
 
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
-                  thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0):
+                  thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0,
+                  calib=None):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch)
@@ -60,6 +61,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 `random` module when shuffle=True, one draw per frame in frame order
     particles   optional sequence of K x 3 tables (index = line - 1) instead of <prefix>_<line>.npy files
     thr_polys   optional per-frame (p0, p1, p2) noise-threshold polynomials (skips the prepass)
+    calib       optional calibration (V2C, R0, P2): the camera-FOV crop of simulation.py:532-540 is then applied inside the
+                compaction kernels, (1024, 1920) image; num_removed counts the cropped rows (:538)
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
     """
     eng = _engine.get_engine(device, slot)
@@ -102,18 +105,24 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         # The device counting sort handles integer channel values 0..255 and reports anything else
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
         perm = None
-        for attempt in (0, 1):
-            try:
-                out, src, counts, stats, _ = eng.ctx.augment_batch(
-                    flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
-                    plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
-                    out_rows=out_rows, out_src=out_src)
-                break
-            except _native.SnowGPUError as err:
-                if attempt == 0 and err.code == _native.E_CHANNELS:
-                    perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
-                    continue
-                _raise_like_reference(err)
+        if calib is not None:
+            eng.ctx.set_fov(calib, (1024, 1920))                                 # simulation.py:536
+        try:
+            for attempt in (0, 1):
+                try:
+                    out, src, counts, stats, _ = eng.ctx.augment_batch(
+                        flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
+                        plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
+                        out_rows=out_rows, out_src=out_src)
+                    break
+                except _native.SnowGPUError as err:
+                    if attempt == 0 and err.code == _native.E_CHANNELS:
+                        perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
+                        continue
+                    _raise_like_reference(err)
+        finally:
+            if calib is not None:
+                eng.ctx.set_fov(None)
     results = []
     for i in range(len(rows)):
         a, n = int(offsets[i]), int(counts[i])
@@ -143,19 +152,14 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
     Keyword-only extras: plane=(w, h), order=<permutation>, particles=<tables>, thr_poly, calib, device,
     return_src (append the source-row index of every output row to the result).
     """
+    cal = None
+    if only_camera_fov:                                                     # simulation.py:532-533
+        from ...calibration import get_calib
+        cal = get_calib() if calib is None else calib                       # AssertionError if the file is missing (:35)
     res = augment_batch([pc], particle_file_prefix, beam_divergence, shuffle=shuffle, noise_floor=noise_floor,
                         root_path=root_path, planes=None if plane is None else [plane],
                         orders=None if order is None else [order], particles=particles,
                         thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=True,
-                        device_prepass=device_prepass)[0]
-    (num_att, num_removed, avg), aug_pc, src = res
-    if only_camera_fov:                                                     # simulation.py:532-540
-        from ...calibration import get_calib, get_fov_flag
-        cal = get_calib() if calib is None else calib
-        pts_rect = cal.lidar_to_rect(aug_pc[:, 0:3])
-        fov_flag = get_fov_flag(pts_rect, (1024, 1920), cal)
-        num_removed = num_removed + np.logical_not(fov_flag).sum()
-        aug_pc = aug_pc[fov_flag]
-        src = src[fov_flag]
-    stats = num_att, num_removed, avg
+                        device_prepass=device_prepass, calib=cal)[0]
+    stats, aug_pc, src = res
     return (stats, aug_pc, src) if return_src else (stats, aug_pc)

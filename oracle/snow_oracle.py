@@ -329,6 +329,31 @@ def augment(pc, tables, beam_divergence, order, noise_floor=0.7, plane=None, las
 
 
 # ---------------------------------------------------------------------------------------------------
+# camera-FOV crop (sim:39-47, :532-540).  PARITY UNPINNED: the reference projects with pcdet's calibration_kitti from
+# an un-vendored submodule and a calibration file that is not in its tree (SURVEY 8 c); this is the textbook KITTI
+# projection (Tr_velo_to_cam, R0_rect, P2) in float64 with a fixed operation order, which the HIP path restates.
+
+def fov_flag(xyz, v2c, r0, p2, img_shape=(1024, 1920)):
+    """get_fov_flag(calib.lidar_to_rect(xyz), img_shape, calib): bool mask of points whose image lies inside the picture
+    and in front of the camera.  v2c 3 x 4, r0 3 x 3, p2 3 x 4."""
+    v2c, r0, p2 = (np.asarray(m, np.float64) for m in (v2c, r0, p2))
+    m = np.zeros((4, 3))                                                # lidar_to_rect: [x y z 1] . (V2C^T . R0^T)
+    for i in range(4):
+        for j in range(3):
+            acc = 0.0
+            for k in range(3):
+                acc = acc + v2c[k, i] * r0[j, k]
+            m[i, j] = acc
+    x, y, z = (np.asarray(xyz[:, c], np.float64) for c in range(3))
+    rect = [((x * m[0, j] + y * m[1, j]) + z * m[2, j]) + m[3, j] for j in range(3)]
+    hom = [((rect[0] * p2[j, 0] + rect[1] * p2[j, 1]) + rect[2] * p2[j, 2]) + p2[j, 3] for j in range(3)]   # rect_to_img
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u, w = hom[0] / hom[2], hom[1] / hom[2]
+    depth = hom[2] - p2[2, 3]
+    return (u >= 0) & (u < img_shape[1]) & (w >= 0) & (w < img_shape[0]) & (depth >= 0)        # sim:42-45
+
+
+# ---------------------------------------------------------------------------------------------------
 # wet ground (wet:25-161; wet_ground/phy_equations.py:35-108)
 
 def fresnel_power(ain, n_in, n_out):
