@@ -87,6 +87,14 @@ int snowgpu_set_lasers(snowgpu_ctx *ctx, int n_lasers, const double *focal_slope
  * out of the frame loop: rows are (x, y, disk radius) float64.  table_id is a small non-negative
  * integer chosen by the caller; uploading again under the same id replaces the table. */
 int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t n_flakes);
+/* snowgpu_upload_table for rows that are already in DEVICE memory (K x 3 float64): derived, binned and sorted by kernels.
+ * Per-flake quantities come from the device math library (atan / atan2 / asin may differ from glibc's in the last bit);
+ * for the reference's .npy tables, whose results are pinned bit for bit, use snowgpu_upload_table. */
+int snowgpu_file_table_device(snowgpu_ctx *ctx, int table_id, const double *d_xyr, int64_t n_flakes);
+
+/* Drops a table and its device memory; the id may be uploaded again.  Batches that name a dropped id fail with
+ * SNOWGPU_E_INVALID. */
+int snowgpu_free_table(snowgpu_ctx *ctx, int table_id);
 int snowgpu_table_count(const snowgpu_ctx *ctx);
 
 /* dart_throwing (tools/snowfall/sampling.py:90-194) on the device: same process (uniform-area centres, Exp(scale)
@@ -97,6 +105,9 @@ int snowgpu_table_count(const snowgpu_ctx *ctx);
  *                        (sampling.py:108-115, :154)
  *   table_id >= 0      file the table under that id (as snowgpu_upload_table does); -1: only return the rows
  *   xyr_out / cap      optional host buffer for the K x 3 rows; *n_out = K */
+/*   The rows never visit the host unless xyr_out asks for them: with table_id >= 0 the table is filed by kernels on the
+ *   sampler's output (same per-flake quantities and bin order as snowgpu_upload_table, with the device math library's
+ *   atan / atan2 / asin, which may differ from glibc's in the last bit). */
 int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm,
                          double r_0, uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out);
 
@@ -105,6 +116,10 @@ int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio,
  * 1 / (c tau_h); 1: the device math library's sin and a true division, operation for operation what NumPy
  * evaluates.  Both modes give the same labels / intensities (tests/test_gpu_parity.py); mode 1 is ~3x slower. */
 int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
+
+/* Debug / parity tap: per-flake quantities of a filed table, by table row: range (simulation.py:332), azimuth in
+ * [0, 2 pi] (:351-352) and the two tangent angles ordered (right, left) (geometry.py:138-190, :32-80).  out: K x 4 doubles. */
+int snowgpu_debug_table(snowgpu_ctx *ctx, int table_id, double *out, int64_t cap_rows);
 
 /* Status words (int32[8], layout under snowgpu_augment_batch_device) of the last batch that went through a host-pointer
  * entry of this context: e.g. out8[2..5] = beams each later list capacity took. */
@@ -180,6 +195,11 @@ int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows,
  * float64 -- parity unpinned.
  */
 int snowgpu_set_fov(snowgpu_ctx *ctx, int enabled, const double *v2c, const double *r0, const double *p2, int img_h, int img_w);
+/* precompute.py:96-99 crops every frame to the camera's view BEFORE augment() is called.  on = 1 (with a crop set by
+ * snowgpu_set_fov): snowgpu_augment_batch compacts the uploaded frames on the device first -- num_removed etc. then
+ * count against the cropped frame, as in the reference's loop, and out_src still indexes the ORIGINAL frame's rows.
+ * Host-pointer entry only (the per-frame counts of the cropped batch are read back to lay the batch out). */
+int snowgpu_set_fov_precrop(snowgpu_ctx *ctx, int on);
 
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 

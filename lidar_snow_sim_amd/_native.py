@@ -24,7 +24,7 @@ EXPORTS = [
     "snowgpu_augment_batch_device", "snowgpu_debug_occlusions", "snowgpu_wet_ground_batch",
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
-    "snowgpu_augment_wet_batch_device", "snowgpu_last_status",
+    "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
 ]
 
 
@@ -57,6 +57,12 @@ def lib():
             L.snowgpu_set_lasers.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp]
             L.snowgpu_upload_table.restype = ctypes.c_int
             L.snowgpu_upload_table.argtypes = [vp, ctypes.c_int, vp, i64]
+            L.snowgpu_file_table_device.restype = ctypes.c_int
+            L.snowgpu_file_table_device.argtypes = [vp, ctypes.c_int, vp, i64]
+            L.snowgpu_debug_table.restype = ctypes.c_int
+            L.snowgpu_debug_table.argtypes = [vp, ctypes.c_int, vp, i64]
+            L.snowgpu_free_table.restype = ctypes.c_int
+            L.snowgpu_free_table.argtypes = [vp, ctypes.c_int]
             L.snowgpu_table_count.restype = ctypes.c_int
             L.snowgpu_table_count.argtypes = [vp]
             L.snowgpu_range_grid.restype = ctypes.c_int
@@ -79,6 +85,8 @@ def lib():
             L.snowgpu_augment_wet_batch_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp,
                                                            vp, dbl, dbl, dbl, dbl, ctypes.c_int, dbl, ctypes.c_int, vp, vp, vp, vp, vp,
                                                            vp, vp]
+            L.snowgpu_set_fov_precrop.restype = ctypes.c_int
+            L.snowgpu_set_fov_precrop.argtypes = [vp, ctypes.c_int]
             L.snowgpu_last_status.restype = ctypes.c_int
             L.snowgpu_last_status.argtypes = [vp, vp]
             L.snowgpu_set_fov.restype = ctypes.c_int
@@ -171,6 +179,15 @@ class Context:
         with self._call_lock:             # never while a batch of this context is in flight (it reads the table list)
             self._check(self._L.snowgpu_upload_table(self._h, int(table_id), _p(t), t.shape[0]))
 
+    def file_table_device(self, table_id: int, d_xyr: int, n_flakes: int):
+        """File a K x 3 float64 table that already lives in device memory (d_xyr: device pointer as int)."""
+        with self._call_lock:
+            self._check(self._L.snowgpu_file_table_device(self._h, int(table_id), ctypes.c_void_p(d_xyr), int(n_flakes)))
+
+    def free_table(self, table_id: int):
+        with self._call_lock:
+            self._check(self._L.snowgpu_free_table(self._h, int(table_id)))
+
     def pinned_empty(self, shape, dtype):
         """An uninitialised NumPy array in page-locked host memory (snowgpu_host_alloc); freed with the array."""
         import weakref
@@ -249,10 +266,12 @@ class Context:
             vp(d_out_counts), vp(d_out_stats), vp(d_out_flags), vp(d_status), vp(stream or None))
         self._check(rc)
 
-    def set_fov(self, calib=None, img_shape=(1024, 1920)):
+    def set_fov(self, calib=None, img_shape=(1024, 1920), pre_crop=False):
         """Camera-FOV crop inside the compaction of every later batch (None switches it off).  `calib` carries V2C (3 x 4),
-        R0 (3 x 3) and P2 (3 x 4), as lidar_snow_sim_amd.calibration.Calibration does."""
+        R0 (3 x 3) and P2 (3 x 4), as lidar_snow_sim_amd.calibration.Calibration does.  pre_crop: also crop the input frames
+        before the augmentation (precompute.py:96-99)."""
         with self._call_lock:
+            self._check(self._L.snowgpu_set_fov_precrop(self._h, int(bool(pre_crop and calib is not None))))
             if calib is None:
                 self._check(self._L.snowgpu_set_fov(self._h, 0, None, None, None, 0, 0))
                 return
@@ -262,16 +281,30 @@ class Context:
             self._check(self._L.snowgpu_set_fov(self._h, 1, _p(v2c), _p(r0), _p(p2), int(img_shape[0]), int(img_shape[1])))
 
     def sample_table(self, table_id, occupancy_ratio, diameter_scale_mm, r_0, seed, want_rows=True):
-        """Sample a snowflake table on the device; returns the K x 3 rows (or K when want_rows is False)."""
+        """Sample a snowflake table on the device (and file it there under table_id >= 0).  Returns the K x 3 rows, or K
+        when want_rows is False (the rows then never leave the device)."""
         n = ctypes.c_int64(0)
-        self._check(self._L.snowgpu_sample_table(self._h, int(table_id), float(occupancy_ratio), float(diameter_scale_mm),
-                                                 float(r_0), ctypes.c_uint64(int(seed)), None, 0, ctypes.byref(n)))
-        if not want_rows:
-            return n.value
-        out = np.empty((n.value, 3), np.float64)
-        # same seed -> same table: the second call only fetches the rows
-        self._check(self._L.snowgpu_sample_table(self._h, -1, float(occupancy_ratio), float(diameter_scale_mm), float(r_0),
-                                                 ctypes.c_uint64(int(seed)), _p(out), n.value, ctypes.byref(n)))
+        args = (float(occupancy_ratio), float(diameter_scale_mm), float(r_0), ctypes.c_uint64(int(seed)))
+        with self._call_lock:
+            if not want_rows:
+                self._check(self._L.snowgpu_sample_table(self._h, int(table_id), *args, None, 0, ctypes.byref(n)))
+                return n.value
+            # one run: a buffer for twice the expected flake count (E[disk area] = pi s^2 / 3 for Exp(s) sphere diameters)
+            s_m = float(diameter_scale_mm) / 1000.0
+            cap = int(2.0 * occupancy_ratio * r_0 * r_0 / (s_m * s_m / 3.0)) + 4096
+            out = np.empty((cap, 3), np.float64)
+            rc = self._L.snowgpu_sample_table(self._h, int(table_id), *args, _p(out), cap, ctypes.byref(n))
+            if rc == E_INVALID and n.value > cap:            # buffer too small after all: fetch with the exact size
+                out = np.empty((n.value, 3), np.float64)
+                rc = self._L.snowgpu_sample_table(self._h, int(table_id), *args, _p(out), n.value, ctypes.byref(n))
+            self._check(rc)
+        return np.ascontiguousarray(out[:n.value])
+
+    def debug_table(self, table_id, n_flakes):
+        """K x 4 per-flake quantities of a filed table by table row: range, azimuth, right and left tangent angle."""
+        out = np.zeros((int(n_flakes), 4), np.float64)
+        with self._call_lock:
+            self._check(self._L.snowgpu_debug_table(self._h, int(table_id), _p(out), int(n_flakes)))
         return out
 
     def last_status(self):

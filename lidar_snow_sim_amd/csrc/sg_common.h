@@ -163,6 +163,10 @@ int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const do
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,
                       void *stream);
+int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
+                         int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles, void *stream);
+int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,
+                           int n_frames, const int32_t *tile_base, void *out_rows, int32_t *crop_src, int64_t max_tiles, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,10 @@ struct snowgpu_ctx {
     double *d_rgrid = nullptr;
     int32_t *d_status = nullptr;      // 8 ints
     SgFov fov{};                      // camera-FOV crop applied by the compaction (snowgpu_set_fov)
+    int fov_pre = 0;                  // also crop the INPUT rows before anything else (host entries; precompute.py:96-99)
+    DevBuf<uint8_t> rows_crop;
+    DevBuf<int32_t> crop_src, crop_out_src;
+    DevBuf<int64_t> crop_counts, crop_off, crop_stats;
     // scratch shared by every batch
     DevBuf<int32_t> tile_hist, tile_base, perm, ctile_cnt, ctile_base, table_ids, out_src;
     DevBuf<unsigned long long> seg_tbl_cnt, seg_tbl_base;
@@ -214,6 +218,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->dbg_count.release(); ctx->diff2.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
     ctx->snow_rows.release(); ctx->snow_src.release(); ctx->wet_src.release(); ctx->wet_flags.release(); ctx->snow_counts.release();
     ctx->wet_counts.release(); ctx->wet_rows.release(); ctx->wet_plane.release();
+    ctx->rows_crop.release(); ctx->crop_src.release(); ctx->crop_out_src.release(); ctx->crop_counts.release(); ctx->crop_off.release(); ctx->crop_stats.release();
     sg_prepass_release(&ctx->prepass);
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
@@ -296,6 +301,113 @@ static int bin_of(double theta, double inv_w, int nb)
     return b;
 }
 
+// hand a filed table (device arrays, owned by the context from here on) to the table list under table_id
+static int register_table(snowgpu_ctx *ctx, int table_id, SgEntry *entries, uint32_t *bin_start, uint32_t n_entries, uint32_t k,
+                          uint32_t max_bin)
+{
+    if ((size_t)table_id >= ctx->tables.size()) ctx->tables.resize((size_t)table_id + 1);
+    DeviceTable &dt = ctx->tables[(size_t)table_id];
+    if (dt.entries || dt.bin_start) (void)hipStreamSynchronize(ctx->stream);     // no batch may still read the old table
+    if (dt.entries) (void)hipFree(dt.entries);
+    if (dt.bin_start) (void)hipFree(dt.bin_start);
+    dt.entries = entries; dt.bin_start = bin_start;
+    dt.desc.entries = entries;
+    dt.desc.bin_start = bin_start;
+    dt.desc.n_bins = (uint32_t)SG_NBINS;
+    dt.desc.n_entries = n_entries;
+    dt.desc.inv_bin_w = SG_NBINS / SG_TWO_PI;
+    dt.desc.n_flakes = k;
+    dt.desc.max_bin = max_bin;
+    ctx->tables_dirty = true;
+    ctx->max_flakes = std::max(ctx->max_flakes, k);
+    return SNOWGPU_OK;
+}
+
+extern "C" int sg_file_table_stage_a(const double *d_xyr, int64_t k, SgEntry *fl, int32_t *b0, int32_t *span, uint32_t *count,
+                                     uint32_t *start, uint32_t *fill, int32_t *misc, void *stream);   // snowgpu_tables.hip
+extern "C" int sg_file_table_stage_b(int64_t k, const SgEntry *fl, const int32_t *b0, const int32_t *span, const uint32_t *start,
+                                     uint32_t *fill, SgEntry *tmp, SgEntry *entries, void *stream);
+extern "C" int sg_table_dump(const SgEntry *entries, uint32_t n_entries, double *d_out, void *stream);
+
+// File a table whose rows are in DEVICE memory (a table sampled there): derive, bin, sort on the device; only the record
+// count comes back to size the allocation.
+static int file_table_device(snowgpu_ctx *ctx, int table_id, const double *d_xyr, int64_t k)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nb = SG_NBINS;
+    DevBuf<SgEntry> fl, tmp;
+    DevBuf<int32_t> b0, span, misc;
+    DevBuf<uint32_t> count, start, fill;
+    auto cleanup = [&]() { fl.release(); tmp.release(); b0.release(); span.release(); misc.release(); count.release(); start.release(); fill.release(); };
+    if (fl.ensure((size_t)std::max<int64_t>(k, 1)) || b0.ensure((size_t)std::max<int64_t>(k, 1)) || span.ensure((size_t)std::max<int64_t>(k, 1)) ||
+        misc.ensure(2) || count.ensure(nb + 1) || start.ensure(nb + 1) || fill.ensure(nb + 1)) {
+        cleanup();
+        return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed while filing a table");
+    }
+    int e = sg_file_table_stage_a(d_xyr, k, fl.p, b0.p, span.p, count.p, start.p, fill.p, misc.p, st);
+    uint32_t n_entries = 0;
+    int32_t h_misc[2] = {0, 0};
+    if (!e) e = (int)hipMemcpyAsync(&n_entries, start.p + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+    if (!e) e = (int)hipMemcpyAsync(h_misc, misc.p, sizeof h_misc, hipMemcpyDeviceToHost, st);
+    if (!e) e = (int)hipStreamSynchronize(st);
+    if (e) { cleanup(); return fail(ctx, SNOWGPU_E_HIP, std::string("table filing: ") + hipGetErrorString((hipError_t)e)); }
+    if (h_misc[0] > 0) {
+        cleanup();
+        char buf[128];
+        snprintf(buf, sizeof buf, "table row %d is not a disk clear of the origin", 0x7fffffff - h_misc[0]);
+        return fail(ctx, SNOWGPU_E_TABLE, buf);
+    }
+    if ((size_t)n_entries > (size_t)64 * (size_t)std::max<int64_t>(k, 1) + 4096) {
+        cleanup();
+        return fail(ctx, SNOWGPU_E_TABLE, "flakes so close to the sensor that they cover most azimuths");
+    }
+    SgEntry *d_entries = nullptr;
+    uint32_t *d_start = nullptr;
+    if (tmp.ensure((size_t)n_entries + 1) || hipMalloc((void **)&d_entries, ((size_t)n_entries + 1) * sizeof(SgEntry)) != hipSuccess ||
+        hipMalloc((void **)&d_start, (nb + 1) * sizeof(uint32_t)) != hipSuccess) {
+        if (d_entries) (void)hipFree(d_entries);
+        cleanup();
+        return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed while filing a table");
+    }
+    e = sg_file_table_stage_b(k, fl.p, b0.p, span.p, start.p, fill.p, tmp.p, d_entries, st);
+    if (!e) e = (int)hipMemcpyAsync(d_start, start.p, (nb + 1) * sizeof(uint32_t), hipMemcpyDeviceToDevice, st);
+    if (!e) e = (int)hipStreamSynchronize(st);
+    cleanup();
+    if (e) { (void)hipFree(d_entries); (void)hipFree(d_start); return fail(ctx, SNOWGPU_E_HIP, std::string("table filing: ") + hipGetErrorString((hipError_t)e)); }
+    return register_table(ctx, table_id, d_entries, d_start, n_entries, (uint32_t)k, (uint32_t)h_misc[1]);
+}
+
+// snowgpu_upload_table for rows that already live in DEVICE memory (K x 3 float64): filed by kernels, no host copy.
+extern "C" int snowgpu_file_table_device(snowgpu_ctx *ctx, int table_id, const double *d_xyr, int64_t n_flakes)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (table_id < 0 || table_id > (1 << 20) || n_flakes < 0 || (n_flakes > 0 && !d_xyr))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_file_table_device: bad table id or size");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return file_table_device(ctx, table_id, d_xyr, n_flakes);
+}
+
+// Debug / parity tap: the per-flake quantities of a filed table by table row -- range (simulation.py:332), azimuth
+// (:351-352) and the two tangent angles ordered (right, left) (geometry.py:138-190, :32-80).  out: K x 4 doubles (host).
+extern "C" int snowgpu_debug_table(snowgpu_ctx *ctx, int table_id, double *out, int64_t cap_rows)
+{
+    if (!ctx || !out) return SNOWGPU_E_INVALID;
+    if (table_id < 0 || (size_t)table_id >= ctx->tables.size() || !ctx->tables[(size_t)table_id].entries)
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_debug_table: unknown table id");
+    const DeviceTable &dt = ctx->tables[(size_t)table_id];
+    const size_t k = dt.desc.n_flakes;
+    if ((int64_t)k > cap_rows) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_debug_table: buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> d;
+    if (d.ensure(std::max<size_t>(k * 4, 1))) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
+    int e = sg_table_dump(dt.entries, dt.desc.n_entries, d.p, ctx->stream);
+    if (!e && k) e = (int)hipMemcpyAsync(out, d.p, sizeof(double) * 4 * k, hipMemcpyDeviceToHost, ctx->stream);
+    if (!e) e = (int)hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table dump: ") + hipGetErrorString((hipError_t)e));
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double *xyr, int64_t k)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
@@ -352,23 +464,26 @@ extern "C" int snowgpu_upload_table(snowgpu_ctx *ctx, int table_id, const double
                   [](const SgEntry &p, const SgEntry &q) { return p.rho < q.rho || (p.rho == q.rho && p.src < q.src); });
         max_bin = std::max(max_bin, start[(size_t)b + 1] - start[(size_t)b]);
     }
-    if ((size_t)table_id >= ctx->tables.size()) ctx->tables.resize((size_t)table_id + 1);
+    SgEntry *d_entries = nullptr;
+    uint32_t *d_start = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_entries, (n_entries + 1) * sizeof(SgEntry)));
+    if (hipMalloc((void **)&d_start, ((size_t)nb + 1) * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_entries); return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for bin offsets"); }
+    HIPCHK(ctx, hipMemcpy(d_entries, entries.data(), (n_entries + 1) * sizeof(SgEntry), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(d_start, start.data(), ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return register_table(ctx, table_id, d_entries, d_start, (uint32_t)n_entries, (uint32_t)k, max_bin);
+}
+
+extern "C" int snowgpu_free_table(snowgpu_ctx *ctx, int table_id)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (table_id < 0 || (size_t)table_id >= ctx->tables.size()) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_free_table: unknown table id");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     DeviceTable &dt = ctx->tables[(size_t)table_id];
-    if (dt.entries) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(dt.entries); dt.entries = nullptr; }
+    if (dt.entries || dt.bin_start) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dt.entries) { (void)hipFree(dt.entries); dt.entries = nullptr; }
     if (dt.bin_start) { (void)hipFree(dt.bin_start); dt.bin_start = nullptr; }
-    HIPCHK(ctx, hipMalloc((void **)&dt.entries, (n_entries + 1) * sizeof(SgEntry)));
-    HIPCHK(ctx, hipMalloc((void **)&dt.bin_start, ((size_t)nb + 1) * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMemcpy(dt.entries, entries.data(), (n_entries + 1) * sizeof(SgEntry), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(dt.bin_start, start.data(), ((size_t)nb + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    dt.desc.entries = dt.entries;
-    dt.desc.bin_start = dt.bin_start;
-    dt.desc.n_bins = (uint32_t)nb;
-    dt.desc.n_entries = (uint32_t)n_entries;
-    dt.desc.inv_bin_w = inv_w;
-    dt.desc.n_flakes = (uint32_t)k;
-    dt.desc.max_bin = max_bin;
+    dt.desc = SgTable{};
     ctx->tables_dirty = true;
-    ctx->max_flakes = std::max(ctx->max_flakes, (uint32_t)k);
     return SNOWGPU_OK;
 }
 
@@ -783,12 +898,51 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     }
     DevBuf<double> &d_out_thr = ctx->out_thr;
     if (out_thr_poly && d_out_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
+    // Pre-augment camera crop (precompute.py:96-99): the frames are compacted on the device before anything else sees
+    // them; only the per-frame counts visit the host (the frame offsets of the cropped batch are made there).
+    const bool precrop = ctx->fov.enabled && ctx->fov_pre && !dbg_count && n > 0;
+    std::vector<int64_t> crop_off;
+    const void *d_rows_used = ctx->rows_in.p;
+    const int64_t *d_off_used = ctx->frame_off.p;
+    int64_t n_used = n_total, max_frame_used = max_frame;
+    if (precrop) {
+        if (perm) return fail(ctx, SNOWGPU_E_INVALID, "a caller-supplied permutation cannot be combined with the pre-augment crop");
+        const int64_t max_tiles = std::max<int64_t>(1, (max_frame + SG_TILE - 1) / SG_TILE);
+        ENSURE(ctx, ctx->keep, n);
+        ENSURE(ctx, ctx->ctile_cnt, (size_t)n_frames * (size_t)max_tiles + 1);
+        ENSURE(ctx, ctx->ctile_base, (size_t)n_frames * (size_t)max_tiles + 1);
+        ENSURE(ctx, ctx->crop_counts, (size_t)n_frames);
+        ENSURE(ctx, ctx->crop_stats, (size_t)n_frames * 3);
+        ENSURE(ctx, ctx->crop_off, (size_t)n_frames + 1);
+        ENSURE(ctx, ctx->rows_crop, row_bytes);
+        ENSURE(ctx, ctx->crop_src, n);
+        ENSURE(ctx, ctx->crop_out_src, n);
+        int e = sg_launch_crop_count(ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, ctx->keep.p, ctx->ctile_cnt.p, ctx->ctile_base.p,
+                                     ctx->crop_counts.p, ctx->crop_stats.p, &ctx->fov, max_tiles, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("crop launch: ") + hipGetErrorString((hipError_t)e));
+        std::vector<int64_t> cnt((size_t)n_frames);
+        HIPCHK(ctx, hipMemcpyAsync(cnt.data(), ctx->crop_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        crop_off.assign((size_t)n_frames + 1, 0);
+        max_frame_used = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            crop_off[(size_t)f + 1] = crop_off[(size_t)f] + cnt[(size_t)f];
+            max_frame_used = std::max(max_frame_used, cnt[(size_t)f]);
+        }
+        n_used = crop_off[(size_t)n_frames];
+        HIPCHK(ctx, hipMemcpyAsync(ctx->crop_off.p, crop_off.data(), sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
+        e = sg_launch_crop_scatter(ctx->rows_in.p, dtype, ctx->keep.p, ctx->frame_off.p, ctx->crop_off.p, n_frames, ctx->ctile_base.p,
+                                   ctx->rows_crop.p, ctx->crop_src.p, max_tiles, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("crop launch: ") + hipGetErrorString((hipError_t)e));
+        d_rows_used = ctx->rows_crop.p; d_off_used = ctx->crop_off.p;
+    }
     BatchDev b{};
-    b.n_frames = n_frames; b.n_total = n_total; b.max_frame = max_frame; b.frame_off = ctx->frame_off.p; b.rows = ctx->rows_in.p;
+    b.n_frames = n_frames; b.n_total = n_used; b.max_frame = max_frame_used; b.frame_off = d_off_used; b.rows = d_rows_used;
     {
-        bool uni = max_frame > 0;
-        for (int f = 0; f < n_frames && uni; ++f) uni = (frame_offsets[f + 1] - frame_offsets[f]) == max_frame;
-        b.uniform_rows = uni ? max_frame : 0;
+        bool uni = max_frame_used > 0;
+        const int64_t *ho = precrop ? crop_off.data() : frame_offsets;
+        for (int f = 0; f < n_frames && uni; ++f) uni = (ho[f + 1] - ho[f]) == max_frame_used;
+        b.uniform_rows = uni ? max_frame_used : 0;
     }
     b.dtype = dtype; b.table_ids = ctx->table_ids.p; b.beam_div_deg = beam_div_deg; b.thr_poly = d_thr;
     b.plane = (!thr_poly && plane) ? ctx->plane.p : nullptr; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
@@ -808,9 +962,21 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
-        if (row_bytes) {
+        if (row_bytes && !precrop) {
             HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, row_bytes, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        } else if (precrop && n_used > 0) {
+            // source rows in the ORIGINAL frame: output row -> cropped row -> original row; every frame goes back to its own slot
+            int e = sg_launch_compose_src(ctx->crop_off.p, ctx->out_counts.p, n_frames, max_frame_used, ctx->out_src.p, ctx->crop_src.p,
+                                          ctx->crop_out_src.p, st);
+            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compose launch: ") + hipGetErrorString((hipError_t)e));
+            for (int f = 0; f < n_frames; ++f) {
+                const size_t m = (size_t)(crop_off[(size_t)f + 1] - crop_off[(size_t)f]);
+                if (!m) continue;
+                HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)frame_offsets[f] * 5 * esz, (const char *)ctx->rows_out.p + (size_t)crop_off[(size_t)f] * 5 * esz,
+                                           m * 5 * esz, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(out_src + frame_offsets[f], ctx->crop_out_src.p + crop_off[(size_t)f], sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
+            }
         }
         if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, d_out_thr.p, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
         if (dbg_count && n) {
@@ -865,11 +1031,10 @@ extern "C" int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occup
     const double s_m = diameter_scale_mm / 1000.0;
     const double mean_area = SG_PI * s_m * s_m / 3.0;         // E[pi r^2], r^2 = d^2/4 - h^2, h ~ U(-d/2, d/2), d ~ Exp(s)
     int64_t n_cand = (int64_t)(1.3 * target / mean_area) + 4096;
-    std::vector<double> host;
     int64_t rows = 0;
+    DevBuf<double> d_xyr;
     for (int attempt = 0;; ++attempt) {
         if (n_cand > ((int64_t)1 << 27)) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: table would exceed 2^27 candidates");
-        DevBuf<double> d_xyr;
         if (d_xyr.ensure((size_t)n_cand * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for the sampled table");
         int rc = sg_sample_table(occupancy_ratio, diameter_scale_mm, r_0, seed, n_cand, d_xyr.p, n_cand, &rows, ctx->stream);
         if (rc == -2 && attempt < 4) { d_xyr.release(); n_cand *= 2; continue; }     // not enough darts: throw more
@@ -879,19 +1044,19 @@ extern "C" int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occup
             return fail(ctx, SNOWGPU_E_TABLE, rc == -3 ? "sampler: a dart overlaps more than 4 earlier darts (occupancy too high for this sampler)"
                                                        : "sampler: acceptance did not settle / target area not reached");
         }
-        host.resize((size_t)rows * 3);
-        hipError_t e = rows ? hipMemcpy(host.data(), d_xyr.p, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost) : hipSuccess;
-        d_xyr.release();
-        if (e != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("sampler copy: ") + hipGetErrorString(e));
         break;
     }
     *n_out = rows;
+    int rc = SNOWGPU_OK;
     if (xyr_out) {
-        if (cap < rows) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: output buffer too small (see *n_out)");
-        std::memcpy(xyr_out, host.data(), sizeof(double) * 3 * (size_t)rows);
+        if (cap < rows) rc = fail(ctx, SNOWGPU_E_INVALID, "snowgpu_sample_table: output buffer too small (see *n_out)");
+        else if (rows && hipMemcpy(xyr_out, d_xyr.p, sizeof(double) * 3 * (size_t)rows, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(ctx, SNOWGPU_E_HIP, "sampler copy failed");
     }
-    if (table_id >= 0) return snowgpu_upload_table(ctx, table_id, host.data(), rows);
-    return SNOWGPU_OK;
+    // the table is filed where it was made: derive / bin / sort kernels on the sampler's output, no host round trip
+    if (rc == SNOWGPU_OK && table_id >= 0) rc = file_table_device(ctx, table_id, d_xyr.p, rows);
+    d_xyr.release();
+    return rc;
 }
 
 // The status words of the last batch that went through a host-pointer entry of this context (layout: see
@@ -1093,6 +1258,16 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
 // Tr_velo_to_cam (3 x 4) and R0_rect (3 x 3), rect_to_img with P2 (3 x 4), image img_h x img_w ((1024, 1920) in the
 // reference).  The crop is applied by the compaction of every later batch of this context (and num_removed counts it,
 // :538) until it is switched off again.  The reference's own projection code is un-vendored: textbook KITTI, float64.
+// precompute.py:96-99 crops every frame to the camera's view BEFORE augment() sees it.  With this switch on (and a crop set
+// by snowgpu_set_fov) the host-pointer entry snowgpu_augment_batch does the same on the device, right after the upload;
+// statistics and out_src then refer to what augment() would have been given / to rows of the original frame.
+extern "C" int snowgpu_set_fov_precrop(snowgpu_ctx *ctx, int on)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    ctx->fov_pre = on ? 1 : 0;
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_set_fov(snowgpu_ctx *ctx, int enabled, const double *v2c, const double *r0, const double *p2, int img_h, int img_w)
 {
     if (!ctx) return SNOWGPU_E_INVALID;

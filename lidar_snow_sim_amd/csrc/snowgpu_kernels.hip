@@ -868,6 +868,71 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     if ((tid & 63) == 0 && att) atomicAdd((unsigned long long *)&out_stats[f * 3 + 0], (unsigned long long)att);
 }
 
+// ---- pre-augment camera crop (precompute.py:96-99): pc = pc[get_fov_flag(lidar_to_rect(pc[:, 0:3]), (1024, 1920))] -----
+// Stable compaction of the INPUT rows of every frame by the FOV test on their original coordinates: flag + tile counts,
+// per-frame scan (k_compact_scan), then scatter to the frame's new offset.
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_crop_flag(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
+                                                        uint8_t *__restrict__ keep, int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    int c = 0;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
+        if (r >= n) continue;
+        const T *row = rows + (base + r) * 5;
+        const bool k = sg_in_fov(fov, (double)row[0], (double)row[1], (double)row[2]);
+        keep[base + r] = k ? 1 : 0;
+        c += k;
+    }
+    __shared__ int s[4];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_crop_scatter(const T *__restrict__ rows, const uint8_t *__restrict__ keep,
+                                                           const int64_t *__restrict__ frame_off, const int64_t *__restrict__ new_off,
+                                                           const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
+                                                           int32_t *__restrict__ crop_src, int64_t max_tiles)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    __shared__ int wave_cnt[4][4];
+    const int tid = threadIdx.x, w = tid >> 6;
+    bool k[4];
+    int pre[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + tid;
+        k[q] = r < n && keep[base + r];
+        const unsigned long long m = __ballot(k[q]);
+        pre[q] = __popcll(m & sg_lanemask_lt());
+        if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
+    }
+    __syncthreads();
+    int run = tile_base[(int64_t)f * max_tiles + blockIdx.x];
+    const int64_t nbase = new_off[f];
+    for (int q = 0; q < 4; ++q) {
+        int off = run;
+        for (int ww = 0; ww < w; ++ww) off += wave_cnt[q][ww];
+        if (k[q]) {
+            const int64_t r = tile0 + q * SG_BLOCK + tid;
+            const T *sr = rows + (base + r) * 5;
+            T *d = out_rows + (nbase + off + pre[q]) * 5;
+            d[0] = sr[0]; d[1] = sr[1]; d[2] = sr[2]; d[3] = sr[3]; d[4] = sr[4];
+            crop_src[nbase + off + pre[q]] = (int32_t)r;
+        }
+        run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+    }
+}
+
 __global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1138,6 +1203,33 @@ extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *re
         hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_stats_final, dim3((n_frames + 63) / 64), dim3(64), 0, st, n_frames, out_stats, diff2);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+// pre-augment crop, stage 1: flags + per-frame counts (out_counts[f] = rows of frame f inside the camera's view)
+extern "C" int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
+                                    int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles,
+                                    void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_crop_flag<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
+    else hipLaunchKernelGGL(k_crop_flag<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
+    SG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, max_tiles);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+// stage 2: rows of frame f to new_off[f] .. (stable), crop_src = their rows in the original frame
+extern "C" int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,
+                                      int n_frames, const int32_t *tile_base, void *out_rows, int32_t *crop_src, int64_t max_tiles, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_crop_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, keep, frame_off, new_off, tile_base, (float *)out_rows, crop_src, max_tiles);
+    else hipLaunchKernelGGL(k_crop_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, keep, frame_off, new_off, tile_base, (double *)out_rows, crop_src, max_tiles);
     SG_CHECK_LAUNCH();
     return 0;
 }

@@ -43,7 +43,9 @@ class Engine:
         self.device = device
         self.lasers = load_lasers() if lasers is None else lasers
         self.ctx.set_lasers(*laser_constants(self.lasers))
-        self._tables = {}          # key -> table id
+        self._tables = {}          # key -> table id (file tables: kept for the life of the engine)
+        self._arrays = {}          # id(array) -> (array, table id), least recently used first (array-backed tables)
+        self._free_ids = []
         self._next_id = 0
         self._lock = threading.Lock()
         self.batch_lock = threading.RLock()   # one batch at a time per engine: the input staging buffer is reused
@@ -108,16 +110,49 @@ class Engine:
         self.lasers = lasers
         self.ctx.set_lasers(*laser_constants(lasers))
 
+    ARRAY_TABLES = 1024          # array-backed tables kept on the device; the least recently used one goes first
+
+    def _new_id(self):
+        if self._free_ids:
+            return self._free_ids.pop()
+        self._next_id += 1
+        return self._next_id - 1
+
     def table_id(self, key, loader):
         """Device table id for `key`, uploading `loader()` (K x 3 float64) the first time."""
         with self._lock:
             tid = self._tables.get(key)
             if tid is None:
-                tid = self._next_id
-                self.ctx.upload_table(tid, loader())
+                table = loader()                                         # may raise (missing file): no id is spent then
+                tid = self._new_id()
+                self.ctx.upload_table(tid, table)
                 self._tables[key] = tid
-                self._next_id += 1
             return tid
+
+    def array_table_id(self, arr):
+        """Device table id of a caller-owned K x 3 array.  The cache holds a reference to the array, so its identity cannot
+        be recycled for another array while the entry lives (a table is looked up by `is`, never by address alone); the
+        contents are taken as they are at the first use.  Beyond ARRAY_TABLES entries the least recently used table is
+        dropped from the device."""
+        with self._lock:
+            hit = self._arrays.get(id(arr))
+            if hit is not None and hit[0] is arr:
+                self._arrays[id(arr)] = self._arrays.pop(id(arr))        # most recently used last
+                return hit[1]
+            tid = self._new_id()
+            self.ctx.upload_table(tid, arr)
+            self._arrays[id(arr)] = (arr, tid)
+            while len(self._arrays) > self.ARRAY_TABLES:
+                old_key = next(iter(self._arrays))
+                _, old_tid = self._arrays.pop(old_key)
+                self.ctx.free_table(old_tid)
+                self._free_ids.append(old_tid)
+            return tid
+
+    def user_table_id(self):
+        """A fresh table id for a table the caller files itself (e.g. sampled on the device): never one of the cache's."""
+        with self._lock:
+            return self._new_id()
 
     def table_ids_from_files(self, particle_file_prefix, order, root_path=None):
         """The reference's lookup (simulation.py:78, :324-329): channel c reads <prefix>_<order[c]+1>.npy."""
@@ -135,8 +170,7 @@ class Engine:
         """particles: sequence (index = line - 1) of K x 3 arrays; channel c uses particles[order[c]]."""
         ids = []
         for ch in range(self.n_lasers):
-            arr = particles[order[ch]]
-            ids.append(self.table_id(("array", id(arr), arr.shape[0]), lambda a=arr: a))
+            ids.append(self.array_table_id(particles[order[ch]]))
         return ids
 
 

@@ -1,18 +1,35 @@
-"""Frame-stream driver: the reference's batch pre-computation loop on top of augment_batch.
+"""Frame-stream driver: the reference's batch pre-computation loop as a reader / augment / writer pipeline.
 
 Counterpart of tools/snowfall/precompute.py::__main__ (:47-106): for every frame id of a split and every
-(snowfall rate, terminal velocity) pair, read the float32 N x 5 STF `.bin` (:78), optionally crop to the camera
-field of view (:96-99), augment with the reference's defaults (:103-104: beam_divergence = degrees(3e-3),
-shuffle=True) and write float32 rows to
+(snowfall rate, terminal velocity) pair, read the float32 N x 5 STF `.bin` (:78), crop to the camera field of view
+(:96-99), augment with the reference's defaults (:103-104: beam_divergence = degrees(3e-3), shuffle=True,
+only_camera_fov=True) and write float32 rows to
     <lidar>/../snowfall_simulation/<mode>/<lidar_folder>_rainrate_<int(rain_rate)>/<id>.bin   (:85-89, :106)
-skipping outputs that already exist (:91-92).  Frames are independent, so a multi-GPU run shards the frame
-list round-robin over ranks (lidar_snow_sim_amd.dist) and batches frames per launch.
+skipping outputs that already exist (:91-92).
+
+The reference walks mode -> frame -> combo one augment() at a time.  Here the same work items are grouped into batches
+per (mode, combo) -- one flake-table set per batch -- and flow through three stages joined by bounded queues:
+
+    reader threads  np.fromfile of the batch's frames, `depth` batches ahead
+    GPU workers     one host thread + engine context (stream, scratch, page-locked staging) each: upload, crop on the device,
+                    augment, crop again (augment's only_camera_fov), download; the copies of one context overlap the
+                    kernels of the other
+    writer threads  float32 `.bin` files
+
+The channel permutations are drawn from the global `random` in the reference's nesting order -- per mode, per frame, per
+combo, one shuffle per output that does not exist yet -- BEFORE the items are regrouped, so a seeded run gives every
+(frame, combo) the permutation the reference's sequential loop gives it.  Frames are independent, so a multi-GPU run
+shards the frame list round-robin over ranks (lidar_snow_sim_amd.dist).
 
     python -m lidar_snow_sim_amd.stream --lidar <dir> --split <file> --particles <npy dir> [--batch 32]
 """
 from __future__ import annotations
 
 import argparse
+import queue
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Iterable, List, Sequence
 
@@ -45,63 +62,128 @@ def output_path(lidar_folder: Path, mode: str, rainfall_rate: float, sample_id: 
             f'{lidar_folder.name}_rainrate_{int(rainfall_rate)}' / f'{sample_id}.bin')
 
 
+def plan(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
+    """The work items in the reference's order (precompute.py:70-92: mode -> frame -> combo, existing outputs skipped), one
+    `random.shuffle` per item in that order (simulation.py:483-486), regrouped into batches of one (mode, combo)."""
+    import random
+    groups = {}
+    for mode in modes:
+        for s in mine:
+            for ci, (rainfall_rate, _occ) in enumerate(combos):
+                if output_path(lidar_folder, mode, rainfall_rate, s).is_file():          # :91-92
+                    continue
+                order = list(range(n_lasers))
+                random.shuffle(order)
+                groups.setdefault((mode, ci), []).append((s, order))
+    jobs = []
+    for (mode, ci), items in groups.items():
+        rainfall_rate, occupancy = combos[ci]
+        prefix = f'{mode}_{rainfall_rate}_{occupancy}'                                   # precompute.py:101
+        for b0 in range(0, len(items), batch):
+            chunk = items[b0:b0 + batch]
+            jobs.append((mode, rainfall_rate, prefix, [c[0] for c in chunk], [c[1] for c in chunk]))
+    return jobs
+
+
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
         batch: int = 32, calib=None, device: int = 0, rank: int = 0, world: int = 1, particles_by_prefix=None,
-        planes=None, workers: int = 1) -> int:
+        planes=None, workers: int = 2, readers: int = 4, writers: int = 4, depth: int = 4, keep_outputs: bool = True,
+        report: dict = None) -> int:
     """Process this rank's share of `sample_ids`; returns the number of files written.
 
-    workers > 1: that many host threads, each with its own engine context (stream + scratch) on `device`, take
-    batches in turn -- file reads, H2D/D2H copies and file writes of one batch overlap the kernels of another.
-    The channel permutations are drawn from the global `random` in the main thread, frame by frame in processing
-    order (as the reference's sequential loop would), so the output does not depend on `workers`."""
-    import random
-    from concurrent.futures import ThreadPoolExecutor
+    workers   GPU worker threads, each with its own engine context on `device`
+    readers / writers   file I/O threads; depth: batches the readers may run ahead, results the writers may lag behind
+    planes    None (calculate_plane per frame, as the reference) or one (w, h) used for every frame
+    keep_outputs=False  unlink every output right after it has been written (throughput dry runs on a small disk)
+    report    optional dict that receives wall time, files, points in / out and the per-stage busy times"""
     lidar_folder = Path(lidar_folder)
     combos = rate_combos() if combos is None else combos
     ids = list(sample_ids)
     mine = [ids[i] for i in sdist.shard_indices(len(ids), rank, world)]
-    n_lasers = 64
+    jobs = plan(lidar_folder, mine, modes, combos, batch)
+    t_start = time.perf_counter()
+    tally = {'files': 0, 'points_in': 0, 'points_out': 0, 'read_s': 0.0, 'gpu_s': 0.0, 'write_s': 0.0}
+    tally_lock = threading.Lock()
+    errors = []
 
-    def do_chunk(job):
-        slot, mode, rainfall_rate, prefix, chunk, orders = job
-        frames = []
-        for s in chunk:
-            pts = np.fromfile(str(lidar_folder / f'{s}.bin'), dtype=np.float32).reshape(-1, 5)       # :78
-            if calib is not None:                                                                    # :96-99
-                from .calibration import get_fov_flag
-                pts = pts[get_fov_flag(calib.lidar_to_rect(pts[:, 0:3]), (1024, 1920), calib)]
-            frames.append(pts)
-        results = augment_batch(frames, prefix, float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
-                                particles=None if particles_by_prefix is None else particles_by_prefix[prefix],
-                                planes=planes, orders=orders, device=device, slot=slot)
-        for s, (stats, aug) in zip(chunk, results):
-            if calib is not None:                                        # augment()'s only_camera_fov default
-                from .calibration import get_fov_flag
-                aug = aug[get_fov_flag(calib.lidar_to_rect(aug[:, 0:3]), (1024, 1920), calib)]
+    def read_job(job):
+        t0 = time.perf_counter()
+        frames = [np.fromfile(str(lidar_folder / f'{s}.bin'), dtype=np.float32).reshape(-1, 5) for s in job[3]]   # :78
+        with tally_lock:
+            tally['read_s'] += time.perf_counter() - t0
+        return frames
+
+    def write_job(job, results):
+        t0 = time.perf_counter()
+        mode, rainfall_rate = job[0], job[1]
+        n_out = 0
+        for s, (stats, aug) in zip(job[3], results):
             out = output_path(lidar_folder, mode, rainfall_rate, s)
             out.parent.mkdir(parents=True, exist_ok=True)
-            aug.astype(np.float32).tofile(out)                           # :106
-        return len(chunk)
+            aug.astype(np.float32, copy=False).tofile(out)                               # :106
+            n_out += aug.shape[0]
+            if not keep_outputs:
+                out.unlink()
+        with tally_lock:
+            tally['files'] += len(results)
+            tally['points_out'] += n_out
+            tally['write_s'] += time.perf_counter() - t0
 
-    jobs = []
-    for mode in modes:
-        for rainfall_rate, occupancy in combos:
-            prefix = f'{mode}_{rainfall_rate}_{occupancy}'                      # precompute.py:101
-            todo = [s for s in mine if not output_path(lidar_folder, mode, rainfall_rate, s).is_file()]   # :91-92
-            for b0 in range(0, len(todo), batch):
-                chunk = todo[b0:b0 + batch]
-                orders = []
-                for _ in chunk:                                          # simulation.py:483-486, one draw per frame
-                    order = list(range(n_lasers))
-                    random.shuffle(order)
-                    orders.append(order)
-                jobs.append((len(jobs) % max(workers, 1), mode, rainfall_rate, prefix, chunk, orders))
-    if workers <= 1:
-        return sum(do_chunk(j) for j in jobs)
-    # one thread per slot so that a context is never used by two threads at once
-    per_slot = [[j for j in jobs if j[0] == w] for w in range(workers)]
-    with ThreadPoolExecutor(max_workers=workers) as pool:
-        return sum(pool.map(lambda js: sum(do_chunk(j) for j in js), per_slot))
+    q_read = queue.Queue(maxsize=max(depth, 1))        # (job, future of its frames): the readers' lead
+    q_write = queue.Queue(maxsize=max(depth, 1))       # write futures: the writers' lag
+    with ThreadPoolExecutor(max_workers=max(readers, 1)) as read_pool, ThreadPoolExecutor(max_workers=max(writers, 1)) as write_pool:
+
+        def feeder():
+            for job in jobs:
+                q_read.put((job, read_pool.submit(read_job, job)))
+            for _ in range(max(workers, 1)):
+                q_read.put(None)
+
+        def gpu_worker(slot):
+            while True:
+                item = q_read.get()
+                if item is None:
+                    return
+                job, fut = item
+                try:
+                    frames = fut.result()
+                    t0 = time.perf_counter()
+                    results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
+                                            particles=None if particles_by_prefix is None else particles_by_prefix[job[2]],
+                                            planes=None if planes is None else [planes] * len(frames),
+                                            orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None)
+                    with tally_lock:
+                        tally['gpu_s'] += time.perf_counter() - t0
+                        tally['points_in'] += sum(f.shape[0] for f in frames)
+                    q_write.put(write_pool.submit(write_job, job, results))
+                except BaseException as e:                                               # noqa: BLE001 -- reported after the drain
+                    errors.append(e)
+
+        def drainer():
+            while True:
+                fut = q_write.get()
+                if fut is None:
+                    return
+                try:
+                    fut.result()
+                except BaseException as e:                                               # noqa: BLE001
+                    errors.append(e)
+
+        threads = [threading.Thread(target=feeder, daemon=True), threading.Thread(target=drainer, daemon=True)]
+        gpu_threads = [threading.Thread(target=gpu_worker, args=(w,), daemon=True) for w in range(max(workers, 1))]
+        for t in threads + gpu_threads:
+            t.start()
+        for t in gpu_threads:
+            t.join()
+        q_write.put(None)
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    if report is not None:
+        report.update(tally, wall_s=time.perf_counter() - t_start, batches=len(jobs), workers=workers, readers=readers,
+                      writers=writers, batch=batch)
+    return tally['files']
 
 
 def main(argv=None):
@@ -111,16 +193,19 @@ def main(argv=None):
     ap.add_argument('--particles', default=None, help='root_path holding training/snowflakes/npy/<prefix>_<line>.npy')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--calib', default=None, help='KITTI-style calibration file for the camera-FOV crop')
-    ap.add_argument('--workers', type=int, default=2, help='host threads (engine contexts) per GPU')
+    ap.add_argument('--workers', type=int, default=2, help='GPU worker threads (engine contexts) per GPU')
+    ap.add_argument('--readers', type=int, default=4)
+    ap.add_argument('--writers', type=int, default=4)
     args = ap.parse_args(argv)
     rank, local_rank, world = sdist.env_rank_world()
     calib = None
     if args.calib:
         from .calibration import Calibration
         calib = Calibration(args.calib)
+    rep = {}
     n = run(args.lidar, read_split(args.split), particle_root=args.particles, batch=args.batch, calib=calib,
-            device=local_rank, rank=rank, world=world, workers=args.workers)
-    print(f'rank {rank}/{world}: wrote {n} files')
+            device=local_rank, rank=rank, world=world, workers=args.workers, readers=args.readers, writers=args.writers, report=rep)
+    print(f'rank {rank}/{world}: wrote {n} files in {rep.get("wall_s", 0.0):.1f} s')
 
 
 if __name__ == '__main__':

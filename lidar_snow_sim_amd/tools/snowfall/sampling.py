@@ -94,10 +94,14 @@ def dart_throwing(occupancy_ratio: float, precipitation_rate: float, R_0: float,
 
 
 def dart_throwing_device(occupancy_ratio: float, precipitation_rate: float, R_0: float, seed: int,
-                         distribution: str = 'gunn', device: int = 0, table_id: int = -1) -> np.ndarray:
+                         distribution: str = 'gunn', device: int = 0, file_table: bool = False, want_rows: bool = True):
     """dart_throwing on the GPU (libsnowgpu `snowgpu_sample_table`): the same sampling process driven by a
     counter-based Philox stream instead of a sequential NumPy Generator, so tables are statistically -- not bit for
-    bit -- those of `dart_throwing`.  With table_id >= 0 the table is also filed on the device under that id."""
+    bit -- those of `dart_throwing`.
+
+    Returns the K x 3 rows.  With file_table=True the table is also filed on the device (derived, binned and sorted by
+    kernels: it never visits the host) under a fresh engine table id, and (rows, table_id) is returned -- rows is None
+    with want_rows=False.  Such ids go into the `table_ids` rows of the C ABI / `Context.augment_batch`."""
     if distribution == 'sekhon':
         rate_parameter = sekhon_srivastava(precipitation_rate)
     elif distribution == 'gunn':
@@ -106,4 +110,9 @@ def dart_throwing_device(occupancy_ratio: float, precipitation_rate: float, R_0:
         raise NotImplementedError('Distribution model unknown.')
     from ... import engine
     eng = engine.get_engine(device)
-    return eng.ctx.sample_table(table_id, occupancy_ratio, (1 / rate_parameter) * 10, R_0, seed)
+    scale_mm = (1 / rate_parameter) * 10
+    if not file_table:
+        return eng.ctx.sample_table(-1, occupancy_ratio, scale_mm, R_0, seed)
+    tid = eng.user_table_id()                       # never an id of the engine's own file / array caches
+    res = eng.ctx.sample_table(tid, occupancy_ratio, scale_mm, R_0, seed, want_rows=want_rows)
+    return (res if want_rows else None), tid

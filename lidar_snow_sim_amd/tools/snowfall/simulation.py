@@ -52,7 +52,7 @@ def _raise_like_reference(err: _native.SnowGPUError):
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
                   thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0,
-                  calib=None):
+                  calib=None, pre_crop: bool = False):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch)
@@ -63,6 +63,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     thr_polys   optional per-frame (p0, p1, p2) noise-threshold polynomials (skips the prepass)
     calib       optional calibration (V2C, R0, P2): the camera-FOV crop of simulation.py:532-540 is then applied inside the
                 compaction kernels, (1024, 1920) image; num_removed counts the cropped rows (:538)
+    pre_crop    with calib: also crop every frame to the camera's view BEFORE it is augmented, on the device, as
+                tools/snowfall/precompute.py:96-99 does on the host
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
     """
     eng = _engine.get_engine(device, slot)
@@ -106,7 +108,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
         perm = None
         if calib is not None:
-            eng.ctx.set_fov(calib, (1024, 1920))                                 # simulation.py:536
+            eng.ctx.set_fov(calib, (1024, 1920), pre_crop=pre_crop)              # simulation.py:536
         try:
             for attempt in (0, 1):
                 try:

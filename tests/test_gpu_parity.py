@@ -104,7 +104,7 @@ def test_L4_special_channels(eng, so, golden, tables, tag):
     else:
         pc, ch, bd, ref = d[f"{tag}_pc"], int(d[f"{tag}_ch"]), float(d[f"{tag}_bd"]), d[f"{tag}_out"]
         tab = {"dense": tables["dense"], "nearflakes": d["nearflakes_xyr"]}.get(str(d[f"{tag}_table"]), tables["t"][0])
-    tids = [eng.table_id(("array", id(tab), tab.shape[0]), lambda: tab)] * 64
+    tids = [eng.array_table_id(tab)] * 64
     off = np.array([0, pc.shape[0]])
     out, src, counts, stats, _ = eng.ctx.augment_batch(pc, off, [tids], bd, thr_poly=[[0.0, 0.0, -1.0]])
     assert counts[0] == pc.shape[0]                            # threshold -1: nothing is filtered
@@ -877,3 +877,31 @@ def test_fused_snow_and_wet_device_entry_is_capturable(eng, so, tables):
         assert np.array_equal(src[f * n:f * n + m].cpu().numpy(), src0[wsrc0])
         np.testing.assert_allclose(got[:, :3], o0[:, :3], rtol=1e-6, atol=0)
         np.testing.assert_allclose(got[:, 3], o0[:, 3], rtol=1e-6, atol=0)
+
+
+def test_pre_augment_crop_on_device_matches_crop_then_augment(eng, so, tables):
+    """tools/snowfall/precompute.py:96-104: crop the frame to the camera's view, THEN augment (whose only_camera_fov default
+    crops the result again).  pre_crop=True does the first crop on the device right after the upload; checked against the
+    oracle chain crop -> augment -> crop, batch of two ragged frames (projection parity unpinned: SURVEY 8 c)."""
+    from lidar_snow_sim_amd.calibration import Calibration
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    cal = Calibration(P2=np.array([[700.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
+                      V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
+    full = synthetic_sweep(64, 2048, seed=23, intensity="lambert").reshape(64, 2048, 5)
+    frames = [np.ascontiguousarray(full[:, ::4, :].reshape(-1, 5)), np.ascontiguousarray(full[:, 1::8, :].reshape(-1, 5))]
+    bd = float(np.degrees(3e-3))
+    tl = _tables64(tables)
+    orders = [list(range(64)), list(range(63, -1, -1))]
+    res = augment_batch(frames, "unused", bd, particles=tl, orders=orders, planes=[PLANE, PLANE], return_src=True, calib=cal,
+                        pre_crop=True)
+    for pc, order, (st, aug, src) in zip(frames, orders, res):
+        flag1 = so.fov_flag(pc[:, :3], cal.V2C, cal.R0, cal.P2, (1024, 1920))
+        kept1 = np.where(flag1)[0]
+        assert 0 < kept1.size < pc.shape[0]
+        s0, a0, src0 = so.augment(pc[flag1], tl, bd, order, plane=PLANE)
+        flag2 = so.fov_flag(a0[:, :3], cal.V2C, cal.R0, cal.P2, (1024, 1920))
+        assert np.array_equal(src, kept1[src0][flag2])                       # rows of the ORIGINAL frame
+        assert np.array_equal(aug[:, 3:], a0[flag2][:, 3:])
+        np.testing.assert_allclose(aug[:, :3], a0[flag2][:, :3], rtol=1e-6, atol=0)
+        assert (int(st[0]), int(st[1]), int(st[2])) == (int(s0[0]), int(s0[1]) + int((~flag2).sum()), int(s0[2]))

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+import torch  # noqa: F401  -- before libsnowgpu.so is loaded (one HIP runtime per process)
+
 pytestmark = pytest.mark.gpu
 
 
@@ -63,21 +65,60 @@ def test_device_sampler_is_deterministic_per_seed_and_mode(smp):
 
 
 def test_sampled_tables_feed_the_simulation(smp):
-    """Tables made on the device, filed on the device, used by augment -- and the CPU oracle agrees on those tables."""
+    """Tables made on the device and FILED on the device (no host round trip) feed augment -- and the CPU oracle, given the
+    same rows, agrees row for row."""
     from lidar_snow_sim_amd import engine
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     from oracle import snow_oracle as so
     occ, rate = _params(smp, 2.5, 1.6)
     eng = engine.get_engine(0)
-    tabs = [smp.dart_throwing_device(occ, rate, 40.0, seed=900 + i) for i in range(2)]
+    made = [smp.dart_throwing_device(occ, rate, 40.0, seed=900 + i, file_table=True) for i in range(2)]
+    tabs, ids = [m[0] for m in made], [m[1] for m in made]
+    assert ids[0] != ids[1] and all(t.shape[0] > 1000 for t in tabs)
     tl = [tabs[i % 2] for i in range(64)]
     full = synthetic_sweep(64, 2048, seed=31, intensity="lambert").reshape(64, 2048, 5)
     pc = np.ascontiguousarray(full[:, ::32, :].reshape(-1, 5))
     order = list(range(64))
     bd = float(np.degrees(3e-3))
-    tids = eng.table_ids_from_arrays(tl, order)
+    tids = [ids[order[c] % 2] for c in range(64)]
     out, src, counts, stats, _ = eng.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, plane=[[0, 0, -1.0, -1.7]])
     s0, a0, src0 = so.augment(pc, tl, bd, order, plane=([0.0, 0.0, -1.0], -1.7))
     n = int(counts[0])
     assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in s0)
     assert np.array_equal(src[:n], src0) and np.array_equal(out[:n, 3:], a0[:, 3:])
+    # rows that never left the device: only the count comes back
+    none_rows, tid3 = smp.dart_throwing_device(occ, rate, 40.0, seed=900, file_table=True, want_rows=False)
+    assert none_rows is None and tid3 not in ids
+    q3, q0 = eng.ctx.debug_table(tid3, tabs[0].shape[0]), eng.ctx.debug_table(ids[0], tabs[0].shape[0])
+    assert np.array_equal(q3, q0)                                   # same seed -> same table, filed the same way
+
+
+def test_filed_per_flake_quantities_match_the_reference_geometry(golden):
+    """The per-flake quantities hoisted out of get_occlusions' beam loop -- range, azimuth, tangent angles (geometry.py:138-190,
+    :32-80) -- read back through the debug tap against the reference's own L1 outputs: bit for bit when the table is filed on
+    the host (snowgpu_upload_table, glibc libm), to the last bits when it is filed by the device kernels (OCML atan / atan2)."""
+    import torch
+    from lidar_snow_sim_amd import engine
+    d = golden("L1_geometry")
+    disks = np.ascontiguousarray(d["disks"])
+    k = disks.shape[0]
+    eng = engine.get_engine(0)
+    t_host, t_dev = eng.user_table_id(), eng.user_table_id()
+    eng.ctx.upload_table(t_host, disks)
+    dd = torch.from_numpy(disks).to("cuda:0")
+    eng.ctx.file_table_device(t_dev, dd.data_ptr(), k)
+    qh, qd = eng.ctx.debug_table(t_host, k), eng.ctx.debug_table(t_dev, k)
+    want = np.column_stack((d["rho"], d["phi"], d["tangent_angles"]))
+    assert np.array_equal(qh, want)                                  # host filing: the reference's numbers exactly
+    np.testing.assert_allclose(qd, want, rtol=4e-16, atol=0)         # device filing: within 2 ulp
+    assert (qd != want).mean() < 0.5
+    # both filings put every flake into the same bins in the same order: a sweep over either gives the same rows
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    full = synthetic_sweep(64, 2048, seed=77, intensity="lambert").reshape(64, 2048, 5)
+    pc = np.ascontiguousarray(full[:, ::64, :].reshape(-1, 5))
+    res = [eng.ctx.augment_batch(pc, [0, pc.shape[0]], [[t] * 64], float(np.degrees(3e-2)), thr_poly=[[0.0, 0.0, -1.0]]) for t in (t_host, t_dev)]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][0][:, 3:], res[1][0][:, 3:])
+    assert (res[0][0][:, 4] > 0).sum() > 5
+    with pytest.raises(Exception):                                   # a disk over the origin is refused by the device path too
+        bad = torch.tensor([[0.001, 0.001, 0.01]], dtype=torch.float64, device="cuda:0")
+        eng.ctx.file_table_device(eng.user_table_id(), bad.data_ptr(), 1)

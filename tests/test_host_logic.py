@@ -179,7 +179,7 @@ def test_missing_particle_file_raises_file_not_found(tmp_path):
     class Stub(engine.Engine):
         def __init__(self):                                      # no device needed for the lookup rule itself
             self.lasers = engine.load_lasers()
-            self._tables, self._next_id = {}, 0
+            self._tables, self._arrays, self._free_ids, self._next_id = {}, {}, [], 0
             import threading
             self._lock = threading.Lock()
 
@@ -532,3 +532,81 @@ def test_result_buffer_pool_recycles_and_respects_its_limit():
     assert z.shape == (0, 5) and zs.shape == (0,)
     stage = e.staging_in(100, np.float32)
     assert stage.shape == (100, 5) and e.staging_in(50, np.float32).ctypes.data == stage.ctypes.data
+
+
+def test_array_table_cache_holds_its_arrays_and_evicts_least_recently_used():
+    """Engine.array_table_id: a table is found again by identity (`is`), never by a recycled address -- the cache keeps a
+    reference to the array, so CPython cannot hand its id to another array while the entry lives; past ARRAY_TABLES entries
+    the least recently used table is dropped from the device and its id is reused.  (No device: a fake context.)"""
+    import gc
+    import threading
+    from lidar_snow_sim_amd import engine
+
+    class FakeCtx:
+        def __init__(self):
+            self.up, self.freed = [], []
+
+        def upload_table(self, tid, arr):
+            self.up.append((tid, float(arr[0, 0])))
+
+        def free_table(self, tid):
+            self.freed.append(tid)
+
+    e = engine.Engine.__new__(engine.Engine)
+    e.ctx = FakeCtx()
+    e._lock = threading.Lock()
+    e._tables, e._arrays, e._free_ids, e._next_id = {}, {}, [], 0
+    e.ARRAY_TABLES = 3
+    a = np.full((4, 3), 1.0)
+    ta = e.array_table_id(a)
+    assert e.array_table_id(a) == ta and len(e.ctx.up) == 1
+    addr = id(a)
+    del a
+    gc.collect()
+    # an array of the same shape allocated now may or may not land on the old address: either way it is a NEW table,
+    # because the cached entry still owns the old array
+    b = np.full((4, 3), 2.0)
+    tb = e.array_table_id(b)
+    assert tb != ta and e.ctx.up[-1] == (tb, 2.0)
+    assert addr in e._arrays and e._arrays[addr][0][0, 0] == 1.0
+    c, d = np.full((4, 3), 3.0), np.full((4, 3), 4.0)
+    tc = e.array_table_id(c)
+    assert e.array_table_id(b) == tb                              # touch b: a is now the least recently used
+    td = e.array_table_id(d)                                      # fourth table: a goes
+    assert e.ctx.freed == [ta] and addr not in e._arrays
+    assert len({tb, tc, td}) == 3
+    f = np.full((4, 3), 5.0)
+    tf = e.array_table_id(f)                                      # evicts c (least recently used), reuses a freed id
+    assert e.ctx.freed == [ta, tc] and tf in (ta, tc)
+    assert e.user_table_id() not in (tb, td, tf)
+
+
+def test_stream_plan_draws_permutations_in_the_reference_order(tmp_path):
+    """precompute.py:70-92 walks mode -> frame -> combo and augment() shuffles once per output it actually computes
+    (simulation.py:483-486).  stream.plan regroups the items into (mode, combo) batches but draws in THAT order, so a
+    seeded run hands every (frame, combo) the permutation the reference's loop hands it; existing outputs draw nothing."""
+    import random
+    from lidar_snow_sim_amd import stream
+    lidar = tmp_path / "lidar_hdl64_strongest"
+    lidar.mkdir()
+    ids = ["a_1", "a_2", "b_1"]
+    combos = [(10.5, 1e-6), (20.5, 2e-6)]
+    done = stream.output_path(lidar, "gunn", 20.5, "a_2")
+    done.parent.mkdir(parents=True)
+    done.write_bytes(b"")
+    random.seed(11)
+    want = {}
+    for mode in ("gunn", "sekhon"):
+        for s in ids:
+            for rr, _ in combos:
+                if stream.output_path(lidar, mode, rr, s).is_file():
+                    continue
+                order = list(range(64))
+                random.shuffle(order)
+                want[(mode, rr, s)] = order
+    random.seed(11)
+    jobs = stream.plan(lidar, ids, ("gunn", "sekhon"), combos, batch=2)
+    got = {(mode, rr, s): o for mode, rr, prefix, ss, orders in jobs for s, o in zip(ss, orders)}
+    assert got == want and len(got) == 11
+    assert all(len(j[3]) <= 2 for j in jobs)
+    assert {j[2] for j in jobs} == {f"{m}_{rr}_{occ}" for m in ("gunn", "sekhon") for rr, occ in combos}
