@@ -642,10 +642,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
         ENSURE(ctx, ctx->chunk_blk, SG_MAX_CHUNKS + 1);
     }
-    // The first pass runs as n_chunks launches over consecutive block ranges; k_power of one range runs beside the scan of
-    // the next (the scan is latency-bound, the received-power phase ALU-bound), and only the last k_power is a tail.
+    // The first pass can run as n_chunks launches over consecutive block ranges, k_power of one range beside the scan of the
+    // next.  Measured: no gain -- both kernels are bound by the LDS their lists need (four 256-thread blocks per CU between
+    // them), so sharing a CU only trades waves -- hence one launch by default; SNOWGPU_CHUNKS keeps the experiment at hand.
     const int64_t total_blocks_ub = (b.n_total + first_block - 1) / first_block + (use_seg ? (int64_t)b.n_frames * 256 : 0);
-    int n_chunks = total_blocks_ub >= 16384 ? 8 : (total_blocks_ub >= 2048 ? 2 : 1);
+    int n_chunks = 1;
     if (ctx->chunks_override > 0) n_chunks = std::min(ctx->chunks_override, SG_MAX_CHUNKS);
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
     HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));

@@ -17,6 +17,20 @@
 #include "sg_beam.h"
 
 #define SG_BLOCK 256
+// Beams per wave of the per-beam kernels by list capacity (the LDS lists are strided by it).  The first capacity fills
+// whole 256-thread blocks; 8 and 16 entries run full 64-lane waves; the 63-entry tier runs 16 live lanes per wave (32 KB of
+// LDS per block instead of 131 KB: a block that needs most of a CU's LDS waits until one has drained and holds up what is
+// queued behind it).  Narrower waves for the 8- / 16-entry tiers (32 / 16 lanes: more waves per SIMD, a wave waits for its
+// slowest lane among fewer) were measured: no gain on the long-list workload, a loss where such a tier runs over all rows.
+#ifndef SG_LANES_8
+#define SG_LANES_8 64
+#endif
+#ifndef SG_LANES_16
+#define SG_LANES_16 64
+#endif
+#ifndef SG_LANES_63
+#define SG_LANES_63 16
+#endif
 
 __device__ __forceinline__ int sg_find_frame(const int64_t *__restrict__ off, int n_frames, int64_t g)
 {
@@ -1086,7 +1100,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
 }
 
 // threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)
-extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax >= SG_LCAP ? 16 : 64); }
+extern "C" int sg_beams_block(int lmax) { return lmax == 4 ? 256 : (lmax == 8 ? SG_LANES_8 : (lmax == 16 ? SG_LANES_16 : SG_LANES_63)); }
 
 // lmax = per-beam list capacity of this pass: 4 (160 B of LDS per beam: 16 waves per CU), 8, 16 or 63 (the largest
 // LDS list).  direct: the pass over all rows, dict hand-over to sg_launch_power; else list mode over class a->cls.
@@ -1095,14 +1109,14 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         if (lmax == 4) return launch_beams_m<float, 4, 256>(a, direct, dict_only, st);
-        if (lmax == 8) return launch_beams_m<float, 8, 64>(a, direct, dict_only, st);
-        if (lmax == 16) return launch_beams_m<float, 16, 64>(a, direct, dict_only, st);
-        return launch_beams_m<float, SG_LCAP, 16>(a, direct, dict_only, st);
+        if (lmax == 8) return launch_beams_m<float, 8, SG_LANES_8>(a, direct, dict_only, st);
+        if (lmax == 16) return launch_beams_m<float, 16, SG_LANES_16>(a, direct, dict_only, st);
+        return launch_beams_m<float, SG_LCAP, SG_LANES_63>(a, direct, dict_only, st);
     }
     if (lmax == 4) return launch_beams_m<double, 4, 256>(a, direct, dict_only, st);
-    if (lmax == 8) return launch_beams_m<double, 8, 64>(a, direct, dict_only, st);
-    if (lmax == 16) return launch_beams_m<double, 16, 64>(a, direct, dict_only, st);
-    return launch_beams_m<double, SG_LCAP, 16>(a, direct, dict_only, st);
+    if (lmax == 8) return launch_beams_m<double, 8, SG_LANES_8>(a, direct, dict_only, st);
+    if (lmax == 16) return launch_beams_m<double, 16, SG_LANES_16>(a, direct, dict_only, st);
+    return launch_beams_m<double, SG_LCAP, SG_LANES_63>(a, direct, dict_only, st);
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
@@ -1111,14 +1125,14 @@ extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *s
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
         if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st);
-        if (lmax == 8) return launch_power_t<float, 8, 64, false>(a, st);
-        if (lmax == 16) return launch_power_t<float, 16, 64, false>(a, st);
-        return launch_power_t<float, SG_LCAP, 16, false>(a, st);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st);
     }
     if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st);
-    if (lmax == 8) return launch_power_t<double, 8, 64, false>(a, st);
-    if (lmax == 16) return launch_power_t<double, 16, 64, false>(a, st);
-    return launch_power_t<double, SG_LCAP, 16, false>(a, st);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st);
 }
 
 // ... and for the hand-over buffer of a list-mode pass
@@ -1126,13 +1140,13 @@ extern "C" int sg_launch_power_list(const SgBeamArgs *a, int dtype, int lmax, vo
 {
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0) {
-        if (lmax == 8) return launch_power_t<float, 8, 64, true>(a, st);
-        if (lmax == 16) return launch_power_t<float, 16, 64, true>(a, st);
-        return launch_power_t<float, SG_LCAP, 16, true>(a, st);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, true>(a, st);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, true>(a, st);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, true>(a, st);
     }
-    if (lmax == 8) return launch_power_t<double, 8, 64, true>(a, st);
-    if (lmax == 16) return launch_power_t<double, 16, 64, true>(a, st);
-    return launch_power_t<double, SG_LCAP, 16, true>(a, st);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, true>(a, st);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, true>(a, st);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, true>(a, st);
 }
 
 extern "C" int sg_launch_huge(const SgBeamArgs *a, int dtype, void *stream)
