@@ -59,17 +59,39 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 // s_a1[t] amplitude, s_a2[t] packed (k1, k0), s_rho[t] range, t = 0 .. n_flakes (hard target last).
 template <typename T, int LMAX, int STRIDE> __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2, double *s_rho, double *s_ratio, int tid, SgBeamOut &out, int rstride = 0);
 
+// Beam limits of a beam from its azimuth (simulation.py:96-101): theta_r = right, theta_l = left, each in [0, 2 pi].
+__device__ __forceinline__ void sg_beam_limits(double theta_c, double beam_div_deg, double &theta_r, double &theta_l)
+{
+    const double half = (beam_div_deg / 2) * (SG_PI / 180.0);   // np.radians(beam_divergence / 2)
+    theta_r = theta_c - half;                                   // :96
+    theta_l = theta_c + half;                                   // :97
+    if (theta_r < 0) theta_r = theta_r + SG_TWO_PI;             // :100
+    if (theta_l < 0) theta_l = theta_l + SG_TWO_PI;
+    if (theta_r > SG_TWO_PI) theta_r = theta_r - SG_TWO_PI;     // :101
+    if (theta_l > SG_TWO_PI) theta_l = theta_l - SG_TWO_PI;
+}
+
+// Unoccluded ratio of a beam that met no flake (debug tap): compute_occlusion_dict's single slot over the whole wedge
+// (simulation.py:260-293 with no intervals) -- (left - right) / beam divergence, not exactly 1 in floating point.
+__device__ __forceinline__ double sg_clear_beam_ratio(double theta_c, double beam_div_deg)
+{
+    double ra, la;
+    sg_beam_limits(theta_c, beam_div_deg, ra, la);
+    if (ra > la) ra = ra - SG_TWO_PI;                           // :260-263
+    const double e_min = ra < la ? ra : la, e_max = ra < la ? la : ra;
+    const double w = e_min < e_max ? 0.0 + (-0.0 + (e_max - e_min)) : 0.0;      // np.sum of one addend
+    return sg_clip01(w / (beam_div_deg * (SG_PI / 180.0)));
+}
+
+// ---- beam geometry + phase 1 (candidate scan) for one beam (per lane) -----------------------------------------------
 // LMAX > 0: list capacity, a compile-time constant (lists in LDS).  LMAX == 0: the global-list tier, capacity `rcap`
 // and stride `rstride` at run time.  The scan keeps counting after the list is full: out.n_hits is exact either way.
-// DICT_ONLY: stop after phase 2 and leave the occlusion dict (s_rho[t], s_ratio[t], t = 0 .. n_flakes) in the list
-// columns -- the beam is then handed to k_power instead of walking phase 3 with most lanes idle.
-template <typename T, int LMAX, int STRIDE, bool DICT_ONLY = false>
-__device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgTable tab,
-                                        const SgLasers *__restrict__ las,
-                                        double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
-                                        double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
-                                        int32_t *dbg_count, double *dbg_rj, double *dbg_ratio,
-                                        bool EXACT_TAN = false, int rstride = 0, int rcap = 0)
+// Leaves the intersecting flakes, near -> far, in the list columns: s_a1[j], s_a2[j] interval angles (geometry.py:14-29),
+// s_rho[j] range, j < min(n_hits, capacity); returns that length.  d_t / theta_c: the beam's range (row dtype) and azimuth.
+template <typename T, int LMAX, int STRIDE>
+__device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
+                                            double *s_rho, int tid, SgBeamOut &out, T &d_t, double &theta_c,
+                                            bool EXACT_TAN = false, int rstride = 0, int rcap = 0)
 {
     constexpr bool F32 = SgReal<T>::is_f32;
     constexpr bool HUGE_TIER = LMAX == 0;
@@ -78,8 +100,6 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgT
     out.label = 0; out.new_i = 0; out.k_best = 0;
 
     // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
-    T d_t;
-    double theta_c;
     if constexpr (F32) {
         d_t = sqrtf((px * px + py * py) + pz * pz);             // :89 np.linalg.norm in float32
         float tc = sg_atan2f(py, px);                           // :91
@@ -91,13 +111,8 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgT
         if (theta_c < 0) theta_c = theta_c + SG_TWO_PI;
     }
     const double d = (double)d_t;
-    const double half = (beam_div_deg / 2) * (SG_PI / 180.0);   // np.radians(beam_divergence / 2)
-    double theta_r = theta_c - half;                            // :96
-    double theta_l = theta_c + half;                            // :97
-    if (theta_r < 0) theta_r = theta_r + SG_TWO_PI;             // :100
-    if (theta_l < 0) theta_l = theta_l + SG_TWO_PI;
-    if (theta_r > SG_TWO_PI) theta_r = theta_r - SG_TWO_PI;     // :101
-    if (theta_l > SG_TWO_PI) theta_l = theta_l - SG_TWO_PI;
+    double theta_r, theta_l;
+    sg_beam_limits(theta_c, beam_div_deg, theta_r, theta_l);
 
     // Azimuth bins the wedge touches.  Their offsets are requested now so that the loads fly while the two
     // tangents below are evaluated (the compiler waits at first use, not here).
@@ -106,6 +121,7 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgT
     const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
     int span = b_hi - b_lo;
     if (span < 0) span += nb;
+
     const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
     const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
     const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
@@ -172,13 +188,25 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgT
         }
     }
     out.n_hits = hits;
-    if (hits > lcap) { out.overflow = 1; return; }
+    if (hits > lcap) out.overflow = 1;
+    return L;
+}
 
-    // ---- phase 2: compute_occlusion_dict (simulation.py:252-295) ------------------------------
-    // The reference sorts the unique endpoints, gives every elementary slot to the nearest flake
-    // covering it and sums the slot widths per owner.  Owner of the slot starting at endpoint e is
-    // the first (nearest) j with a1_j <= e < a2_j, so each owner's sum can be produced by walking
-    // the endpoints inside its own interval -- no sorted endpoint array, no assignment array.
+// ---- phase 2: compute_occlusion_dict (simulation.py:252-295) for one beam (per lane) ------------------------------
+// In: the L intersecting flakes of sg_beam_scan in the list columns, the beam's azimuth and range.  Out: the occlusion dict
+// in s_rho[t], s_ratio[t], t = 0 .. S (scatterers near -> far, the hard target last at range d); returns S.
+// The reference sorts the unique endpoints, gives every elementary slot to the nearest flake covering it and sums the slot
+// widths per owner.  Owner of the slot starting at endpoint e is the first (nearest) j with a1_j <= e < a2_j, so each
+// owner's sum can be produced by walking the endpoints inside its own interval -- no sorted endpoint array, no assignment
+// array.
+template <int LMAX, int STRIDE>
+__device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, double beam_div_deg, double *s_a1, double *s_a2,
+                                            double *s_rho, double *s_ratio, int tid, int dbg_cap, int32_t *dbg_count,
+                                            double *dbg_rj, double *dbg_ratio, int rstride = 0)
+{
+    constexpr bool HUGE_TIER = LMAX == 0;
+    double theta_r, theta_l;
+    sg_beam_limits(theta_c, beam_div_deg, theta_r, theta_l);
     double ra = theta_r, la = theta_l;
     if (ra > la) {                                              // :260-263
         ra = ra - SG_TWO_PI;
@@ -292,14 +320,27 @@ __device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgT
         *dbg_count = n_dict;
         for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
     }
-    if (n_dict == 1) return;                                    // :133 no snowflake in this beam -> label 0
-    if constexpr (DICT_ONLY) {
-        out.n_flakes = S;
-        out.has_power = 1;
-        return;
-    } else {
-        sg_beam_amp<T, LMAX, STRIDE>(d_t, S, channel, las, s_a1, s_a2, s_rho, s_ratio, tid, out, rstride);
-    }
+    return S;
+}
+
+// Phases 1, 2 and 3a in place (the tiers that do not hand their beams over): scan, dict, amplitudes.
+template <typename T, int LMAX, int STRIDE>
+__device__ __forceinline__ void sg_beam(T px, T py, T pz, int channel, const SgTable tab,
+                                        const SgLasers *__restrict__ las,
+                                        double beam_div_deg, double *s_a1, double *s_a2, double *s_rho,
+                                        double *s_ratio, int tid, SgBeamOut &out, int dbg_cap,
+                                        int32_t *dbg_count, double *dbg_rj, double *dbg_ratio,
+                                        bool EXACT_TAN = false, int rstride = 0, int rcap = 0)
+{
+    T d_t;
+    double theta_c;
+    const int L = sg_beam_scan<T, LMAX, STRIDE>(px, py, pz, tab, beam_div_deg, s_a1, s_a2, s_rho, tid, out, d_t, theta_c, EXACT_TAN,
+                                                rstride, rcap);
+    if (out.overflow) return;
+    const int S = sg_beam_dict<LMAX, STRIDE>(L, theta_c, (double)d_t, beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, dbg_cap, dbg_count,
+                                             dbg_rj, dbg_ratio, rstride);
+    if (S == 0) return;                                         // :133 no snowflake in this beam -> label 0
+    sg_beam_amp<T, LMAX, STRIDE>(d_t, S, channel, las, s_a1, s_a2, s_rho, s_ratio, tid, out, rstride);
 }
 
 // ---- phase 3a (per lane): amplitude and bin window of every scatterer (simulation.py:137-146) --------

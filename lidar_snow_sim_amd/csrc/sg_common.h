@@ -95,13 +95,13 @@ struct SgBeamArgs {
     int64_t blk_lo, blk_hi;
     const int32_t *chunk_blk;
     int32_t chunk;
-    // Dict queue of the direct-mode pass: a beam that met flakes hands its occlusion dict to k_power.  Blocked SoA (groups
-    // of 64 slots): plane 2 t = range of scatterer t, plane 2 t + 1 = its ratio (the hard target is entry n_flakes).
+    // Hand-over queue of the direct-mode pass: a beam that met flakes hands its range, azimuth and flake list to k_power,
+    // which builds the occlusion dict and everything after it.  Blocked SoA (groups of 64 slots, snowgpu_kernels.hip).
     // A region's beams with ONE flake fill its slice from the front, the others from the back (waves of uniform loop
     // length in k_power); qn[region] = front count | back count << 32, bumped once per wave.
     double *dq;
     int32_t *dq_g;               // per slot: sorted position of the beam
-    uint16_t *dq_sc;             // per slot: n_flakes | channel << 8
+    uint16_t *dq_sc;             // per slot: flakes in the list | channel << 8
     unsigned long long *qn;      // per region
     int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 7}
     int32_t *pw_count;           // items planned (reset per chunk)

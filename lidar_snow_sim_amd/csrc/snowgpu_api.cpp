@@ -699,13 +699,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int k = 0; k + 1 < n_cls; ++k) {
         tq_caps[k] = tier_queue_cap(ctx, tiers[k + 1], b.n_total);
-        ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * 2 * ((size_t)tiers[k + 1] + 1));
+        ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * (3 * (size_t)tiers[k + 1] + 2));
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
     }
     // Regions of the first pass = slices of its dict queue: the segments, or plain chunks of 8 blocks in linear order.
     a.q_chunk = 8 * first_block;
     {
-        const size_t planes = 2 * ((size_t)tiers[0] + 1);
+        const size_t planes = 3 * (size_t)tiers[0] + 2;        // range, azimuth, three values per flake
         if (n * planes * sizeof(double) > ((size_t)64 << 30))
             return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the dict queue of this table density: split it");
         if (b.n_frames >= (1 << 22)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");

@@ -17,6 +17,12 @@
 #include "sg_beam.h"
 
 #define SG_BLOCK 256
+#ifndef SG_NB4
+#define SG_NB4 4
+#endif
+#ifndef SG_KP_WAVES
+#define SG_KP_WAVES 4     /* waves per SIMD k_power<4> is compiled for */
+#endif
 // Beams per wave of the per-beam kernels by list capacity (the LDS lists are strided by it).  The first capacity fills
 // whole 256-thread blocks; 8 and 16 entries run full 64-lane waves; the 63-entry tier runs 16 live lanes per wave (32 KB of
 // LDS per block instead of 131 KB: a block that needs most of a CU's LDS waits until one has drained and holds up what is
@@ -147,10 +153,11 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const uint8_t *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// Dict queues are "blocked SoA": 64 consecutive slots form a group, a group holds its P planes back to back (plane 2 t =
-// range of scatterer t, plane 2 t + 1 = its ratio; P = 2 (capacity + 1)).  A wave reads / writes 512 contiguous bytes per
-// plane (coalesced like plain SoA), and everything one beam needs sits within P x 512 bytes -- plain SoA planes lie
-// hundreds of MB apart, and a wave touching ten of them misses the TLB ten times.
+// Hand-over queues (scan -> k_power) are "blocked SoA": 64 consecutive slots form a group, a group holds its P planes back to
+// back.  A beam hands over what phase 2 needs: plane 0 = its range, plane 1 = its azimuth, planes 2 + 3 j .. 4 + 3 j = the
+// interval angles and the range of its j-th intersecting flake (near -> far); P = 3 capacity + 2.  A wave reads / writes 512
+// contiguous bytes per plane (coalesced like plain SoA), and everything one beam needs sits within P x 512 bytes.
+#define SG_QPLANES(LMAX) (3 * (LMAX) + 2)
 template <int P>
 __device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 {
@@ -204,10 +211,13 @@ template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
 __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *s_a1 = (double *)smem;                    // LMAX + 1 rows each: the hard target is entry n_flakes <= LMAX
-    double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
-    double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
-    double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
+    // hand-over passes keep three LMAX-entry lists (interval angles, range); the in-place passes four of LMAX + 1 entries
+    // (the dict and the scatterer list of phase 3 carry the hard target as entry n_flakes <= LMAX)
+    constexpr int ROWS = DICT ? LMAX : LMAX + 1;
+    double *s_a1 = (double *)smem;
+    double *s_a2 = s_a1 + ROWS * BLOCK;
+    double *s_rho = s_a2 + ROWS * BLOCK;
+    double *s_ratio = DICT ? nullptr : s_rho + ROWS * BLOCK;
     const int tid = threadIdx.x;
     const int n_las = a.las->n;
     int64_t work_n = 0, work_off = 0;
@@ -273,16 +283,29 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
     o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
     uint32_t rec = (live && !simulated) ? SG_REC_COPY : 0u;
     bool pending = false;                             // another kernel writes this row's record
+    int L = 0;                                        // hand-over passes: flakes in the list
+    T d_t = 0;
+    double theta_c = 0.0;
     if (simulated) {
         const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
         if (tab.entries == nullptr) {
             atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
         } else {
-            int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
-            double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
-            double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-            sg_beam<T, LMAX, BLOCK, DICT>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o,
-                                          a.dbg_cap, dc, drj, dra, a.exact_math != 0);
+            if constexpr (DICT) {
+                L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
+                o.has_power = !o.overflow && L > 0;       // k_power builds the dict (phase 2) and everything after it
+                if (!o.overflow && L == 0 && a.dbg_count) {   // debug tap: the dict of a clear beam is its hard target alone
+                    a.dbg_count[g] = 1;
+                    a.dbg_rj[g * a.dbg_cap] = (double)d_t;
+                    a.dbg_ratio[g * a.dbg_cap] = sg_clear_beam_ratio(theta_c, a.beam_div_deg);
+                }
+            } else {
+                int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+                double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
+                double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
+                sg_beam<T, LMAX, BLOCK>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
+                                        dra, a.exact_math != 0);
+            }
             if (o.overflow) {
                 o.has_power = 0;
                 int k = 0;                            // the first later tier that holds every flake of this beam
@@ -301,13 +324,23 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
         }
     }
     if constexpr (DICT) {
-        // ---- hand the beams that met a flake, with their occlusion dicts, to k_power -------------------------------
-        // Only a fraction of the beams gets here; walking phase 3 in place would keep most lanes of every wave idle.
-        const int S = o.n_flakes;
+        // ---- hand the beams that met a flake, with their flake lists, to k_power ------------------------------------
+        // Only a fraction of the beams gets here; walking phases 2-3 in place would keep most lanes of every wave idle
+        // (measured: phase 2 alone was 30 % of this pass at 28 % of the lanes).
+        constexpr int P = SG_QPLANES(LMAX);
+        auto hand_over = [&](double *q, int64_t slot) {
+            q[sg_qaddr<P>(slot, 0)] = (double)d_t;
+            q[sg_qaddr<P>(slot, 1)] = theta_c;
+            for (int j = 0; j < L; ++j) {
+                q[sg_qaddr<P>(slot, 2 + 3 * j)] = s_a1[j * BLOCK + tid];
+                q[sg_qaddr<P>(slot, 3 + 3 * j)] = s_a2[j * BLOCK + tid];
+                q[sg_qaddr<P>(slot, 4 + 3 * j)] = s_rho[j * BLOCK + tid];
+            }
+        };
         if constexpr (!LIST) {
             // The region's slice of the queue: beams with one flake from the front, the others from the back -- one
             // packed 64-bit atomic per wave on the region's counter (thousands of distinct addresses: no serialisation).
-            const bool front = o.has_power && S == 1, back = o.has_power && S > 1;
+            const bool front = o.has_power && L == 1, back = o.has_power && L > 1;
             const unsigned long long mf = __ballot(front), mb = __ballot(back);
             if (mf | mb) {
                 const int leader = __ffsll((long long)(mf | mb)) - 1;
@@ -318,24 +351,18 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
                 if (o.has_power) {
                     const int64_t slot = front ? q_base + (int)blo + (int)__popcll(mf & sg_lanemask_lt())
                                                : q_base + q_size - 1 - ((int)bhi + (int)__popcll(mb & sg_lanemask_lt()));
-                    for (int t = 0; t <= S; ++t) {
-                        a.dq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t)] = s_rho[t * BLOCK + tid];
-                        a.dq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t + 1)] = s_ratio[t * BLOCK + tid];
-                    }
+                    hand_over(a.dq, slot);
                     a.dq_g[slot] = (int32_t)g;
-                    a.dq_sc[slot] = (uint16_t)(S | (ch << 8));
+                    a.dq_sc[slot] = (uint16_t)(L | (ch << 8));
                     pending = true;
                 }
             }
         } else if (live) {
             const int64_t slot = chunk + tid;         // entry i of the class -> slot i
-            uint16_t sc = 0xffff;                     // no dict: the record below is final
+            uint16_t sc = 0xffff;                     // no flake list: the record below is final
             if (o.has_power) {
-                for (int t = 0; t <= S; ++t) {
-                    a.tq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t)] = s_rho[t * BLOCK + tid];
-                    a.tq[sg_qaddr<2 * (LMAX + 1)>(slot, 2 * t + 1)] = s_ratio[t * BLOCK + tid];
-                }
-                sc = (uint16_t)(S | (ch << 8));
+                hand_over(a.tq, slot);
+                sc = (uint16_t)(L | (ch << 8));
                 pending = true;
             }
             a.tq_sc[slot] = sc;
@@ -348,7 +375,6 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
             int k_best = 0;
             if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
             else sg_lane_power<BLOCK, false, NB, LMAX>(o.n_flakes, a.rgrid, s_a1, s_a2, s_rho, s_ratio, tid, best, k_best);
-            T d_t;
             if constexpr (SgReal<T>::is_f32) d_t = sqrtf((px * px + py * py) + pz * pz);
             else d_t = sqrt((px * px + py * py) + pz * pz);
             sg_beam_decide((double)d_t, ch, a.las, best, k_best, o);
@@ -401,9 +427,9 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// Received power for the beams a dict-only pass handed over: one lane per queue slot, every lane busy.
-// Phase 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision), result record.
-// Nothing is read but the queue: the beam's range is the last range of its dict, its channel rides in the slot.
+// Everything after the scan for the beams a hand-over pass queued: one lane per queue slot, every lane busy.
+// Phase 2 (occlusion dict), 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision),
+// result record.  Nothing is read but the queue: range, azimuth and flake list of the beam; its channel rides in the slot.
 //   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots)
 //   LISTQ = true   a list-mode pass's hand-over buffer: item i = slots [i LANES, (i + 1) LANES) of the class
 // PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
@@ -412,10 +438,10 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
 // then bound by the latency of its first loads.  Here a wave requests the slot data of its NEXT item before it computes
 // the current one.
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? 4 : 1) void k_power(SgBeamArgs a)
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 1) void k_power(SgBeamArgs a)
 {
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
-    constexpr int P = 2 * (LMAX + 1);
+    constexpr int P = SG_QPLANES(LMAX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_a1 = (double *)smem;
     double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
@@ -438,9 +464,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? 4 : 1) void k_
     if (i >= n_items) return;
     const double *planes = LISTQ ? a.tq : a.dq;
     const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
-    // slot data of one item, as far as every beam has it: flag word, sorted position, scatterer 0 and scatterer 1
-    // (a queued beam met at least one flake; with exactly one, scatterer 1 is the hard target)
-    struct Item { int64_t slot; int f; bool live; unsigned sc; int32_t g; double r0, q0, r1, q1; };
+    // slot data of one item, as far as every beam has it: flag word, sorted position, range, azimuth and the first flake
+    struct Item { int64_t slot; int f; bool live; unsigned sc; int32_t g; double d, tc, a1, a2, rho; };
     auto fetch = [&](int it) -> Item {
         Item m;
         int start, cnt;
@@ -454,12 +479,12 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? 4 : 1) void k_
         }
         m.live = lane < cnt;
         m.slot = (int64_t)start + lane;
-        m.sc = 0xffffu; m.g = 0; m.r0 = m.q0 = m.r1 = m.q1 = 0.0;
+        m.sc = 0xffffu; m.g = 0; m.d = m.tc = m.a1 = m.a2 = m.rho = 0.0;
         if (m.live) {
             m.sc = scs[m.slot];
             m.g = LISTQ ? a.tier_list[work_off + m.slot] : a.dq_g[m.slot];
-            m.r0 = planes[sg_qaddr<P>(m.slot, 0)]; m.q0 = planes[sg_qaddr<P>(m.slot, 1)];
-            m.r1 = planes[sg_qaddr<P>(m.slot, 2)]; m.q1 = planes[sg_qaddr<P>(m.slot, 3)];
+            m.d = planes[sg_qaddr<P>(m.slot, 0)]; m.tc = planes[sg_qaddr<P>(m.slot, 1)];
+            m.a1 = planes[sg_qaddr<P>(m.slot, 2)]; m.a2 = planes[sg_qaddr<P>(m.slot, 3)]; m.rho = planes[sg_qaddr<P>(m.slot, 4)];
         }
         return m;
     };
@@ -469,33 +494,41 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? 4 : 1) void k_
         const bool more = nxt_i < n_items;             // wave-uniform
         Item nxt = cur;
         if (more) nxt = fetch(nxt_i);                  // in flight while the current item is computed
-        const bool live = cur.live && cur.sc != 0xffffu;   // 0xffff: a listed beam without a dict (its record is final)
-        const int S = (int)(cur.sc & 255u), ch = (int)(cur.sc >> 8);
+        const bool live = cur.live && cur.sc != 0xffffu;   // 0xffff: a listed beam without a flake (its record is final)
+        const int L = (int)(cur.sc & 255u), ch = (int)(cur.sc >> 8);
         int f = 0;
         SgBeamOut o;
-        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = S; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
         if (live) {
             f = cur.f >= 0 ? cur.f : sg_frame_of(a, cur.g);
-            s_rho[0 * BLOCK + ltid] = cur.r0; s_ratio[0 * BLOCK + ltid] = cur.q0;
-            s_rho[1 * BLOCK + ltid] = cur.r1; s_ratio[1 * BLOCK + ltid] = cur.q1;
-            for (int t = 2; t <= S; ++t) {
-                s_rho[t * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 * t)];
-                s_ratio[t * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 * t + 1)];
+            s_a1[0 * BLOCK + ltid] = cur.a1; s_a2[0 * BLOCK + ltid] = cur.a2; s_rho[0 * BLOCK + ltid] = cur.rho;
+            for (int j = 1; j < L; ++j) {
+                s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 + 3 * j)];
+                s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 3 + 3 * j)];
+                s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 4 + 3 * j)];
             }
-            const double d = s_rho[S * BLOCK + ltid];   // the hard target's range: the beam's own (simulation.py:89)
-            const T d_t = (T)d;                         // exact: d was widened from the row dtype
-            sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
-            if (o.range_error) {
-                atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
-                atomicCAS(&a.status[1], -1, cur.g);
+            const double d = cur.d;                     // the beam's range (simulation.py:89), widened from the row dtype
+            int32_t *dc = a.dbg_count ? a.dbg_count + cur.g : nullptr;
+            double *drj = a.dbg_count ? a.dbg_rj + (int64_t)cur.g * a.dbg_cap : nullptr;
+            double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)cur.g * a.dbg_cap : nullptr;
+            const int S = sg_beam_dict<LMAX, BLOCK>(L, cur.tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+            uint32_t rec = 0;                           // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
+            if (S > 0) {
+                const T d_t = (T)d;                     // exact
+                sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
+                if (o.range_error) {
+                    atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+                    atomicCAS(&a.status[1], -1, cur.g);
+                }
+                constexpr int NB = LMAX <= 4 ? SG_NB4 : 8;
+                double best = 0.0;
+                int k_best = 0;
+                if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                sg_beam_decide(d, ch, a.las, best, k_best, o);
+                rec = sg_pack_record(o);
             }
-            constexpr int NB = LMAX <= 4 ? 4 : 8;
-            double best = 0.0;
-            int k_best = 0;
-            if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-            else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-            sg_beam_decide(d, ch, a.las, best, k_best, o);
-            a.rec[cur.g] = sg_pack_record(o);
+            a.rec[cur.g] = rec;
         }
         sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
         if (!more) break;
@@ -538,7 +571,7 @@ __global__ __launch_bounds__(64) void k_beams_huge(SgBeamArgs a)
         int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
         double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
         double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-        sg_beam<T, 0, 0, false>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
+        sg_beam<T, 0, 0>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
                                 dra, a.exact_math != 0, rstride, a.h_cap);
         uint32_t rec = 0;
         if (o.overflow) {
@@ -1045,7 +1078,7 @@ static int sg_set_lds(K kernel, size_t lds, bool *attr_set)
 template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
 static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
+    const size_t lds = sizeof(double) * (size_t)BLOCK * (DICT ? 3 * (size_t)LMAX : 4 * ((size_t)LMAX + 1));
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK;
