@@ -107,6 +107,7 @@ struct SgBeamArgs {
     int32_t *pw_count;           // items planned (reset per chunk)
     int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
     int32_t blk_rows;            // rows per block of the direct-mode pass
+    int32_t kp_blocks_per_cu;    // host: k_power blocks per CU (0 = all that fit): the later tiers need LDS beside it
     int64_t dq_n;                // plane stride (= n_total)
     // list mode: this launch handles entries [work_lo, min(work_hi, count)) of class `cls` of the tier lists
     const int32_t *tier_list;    // the class lists, concatenated

@@ -90,6 +90,8 @@ struct snowgpu_ctx {
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
+    int kp_per_cu = 2;                // k_power blocks per CU (SNOWGPU_KP_PER_CU; 0 = all that fit): its persistent blocks would
+                                      // otherwise hold every CU's LDS until they are done, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
@@ -174,11 +176,19 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_KP_PER_CU"); ctx->kp_per_cu = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
-    for (hipStream_t *sp : {&ctx->stream, &ctx->aux, &ctx->aux2, &ctx->aux3})
+    for (hipStream_t *sp : {&ctx->stream, &ctx->aux, &ctx->aux3})
         HIPCHK(ctx, hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
+        // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
+        // else.  It gets the highest stream priority.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, greatest));
+    }
     for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
     for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
@@ -719,6 +729,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
         a.blk_rows = first_block;
+        a.kp_blocks_per_cu = ctx->kp_per_cu;
         ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;

@@ -20,6 +20,9 @@
 #ifndef SG_NB4
 #define SG_NB4 4
 #endif
+#ifndef SG_KP_PREFETCH
+#define SG_KP_PREFETCH 0     /* 1: k_power requests the slot data of its next item before computing the current one */
+#endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 4     /* waves per SIMD k_power<4> is compiled for */
 #endif
@@ -493,7 +496,9 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
         const int nxt_i = i + step;
         const bool more = nxt_i < n_items;             // wave-uniform
         Item nxt = cur;
+#if SG_KP_PREFETCH
         if (more) nxt = fetch(nxt_i);                  // in flight while the current item is computed
+#endif
         const bool live = cur.live && cur.sc != 0xffffu;   // 0xffff: a listed beam without a flake (its record is final)
         const int L = (int)(cur.sc & 255u), ch = (int)(cur.sc >> 8);
         int f = 0;
@@ -532,6 +537,9 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
         }
         sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
         if (!more) break;
+#if !SG_KP_PREFETCH
+        nxt = fetch(nxt_i);
+#endif
         cur = nxt;
         i = nxt_i;
     }
@@ -1090,6 +1098,9 @@ static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
         (void)hipGetDevice(&dev_id);
         const unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
         blocks = (unsigned)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)sg_cu_count(dev_id) * per_cu);
+        // the in-place pass only sees the entries beyond the hand-over buffer, i.e. normally none: a small grid (its LDS-heavy
+        // blocks would otherwise queue for CU space just to find that out)
+        if (!DICT) blocks = std::min(blocks, 128u);
     } else {
         blocks = (unsigned)a->grid_blocks;               // blocks [blk_lo, blk_hi) or chunk a->chunk of the segment order
     }
@@ -1116,7 +1127,8 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     // persistent waves: what the chip holds at once (LDS and the 32-waves-per-CU limit), fewer if the queue cannot be longer
-    const unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
+    unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
+    if (!LISTQ && a->kp_blocks_per_cu > 0) per_cu = std::min<unsigned>(per_cu, (unsigned)a->kp_blocks_per_cu);
     int64_t blocks = (int64_t)sg_cu_count(dev_id) * per_cu;
     const int64_t items_ub = LISTQ ? ((int64_t)a->work_hi + LANES - 1) / LANES : (a->n_total + LANES - 1) / LANES + 2 * a->n_regions_ub;
     blocks = std::min<int64_t>(blocks, (items_ub + THREADS / 64 - 1) / (THREADS / 64));
