@@ -47,8 +47,10 @@ struct SgLasers {
 //   bits 8..9   label: 0 unchanged, 1 attenuated, 2 scattered (simulation.py:160, :174)
 //   bit  10     copy-through row: its channel has no laser (Q5), column 4 keeps the channel value
 //   bits 12..22 argmax bin of the power profile (simulation.py:151), label 2: the point moves to k / 10 - c tau / 2
+//   bit  31     reference: the record is rec_q[bits 0..30] (written by k_power, densely, in queue order)
 #define SG_REC_LABEL_SHIFT 8
 #define SG_REC_COPY (1u << 10)
+#define SG_REC_SLOT (1u << 31)  /* the record proper is rec_q[low 31 bits]: the row's slot in the hand-over queue */
 #define SG_REC_K_SHIFT 12
 #define SG_MAX_CLASSES 4        /* later capacity tiers incl. the global-list tier */
 
@@ -71,6 +73,7 @@ struct SgBeamArgs {
     const double *rgrid;         // SG_RBINS
     double beam_div_deg;
     uint32_t *rec;               // per sorted position: result record (SG_REC_*)
+    uint32_t *rec_q;             // per queue slot of the direct-mode pass: result record of the beam queued there
     uint8_t *flag;               // per sorted position: 0, or 3 + k for a beam that needs later capacity tier k
     int32_t *status;             // [0] error code, [1] first offending sorted row
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
@@ -107,7 +110,7 @@ struct SgBeamArgs {
     int32_t *pw_count;           // items planned (reset per chunk)
     int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
     int32_t blk_rows;            // rows per block of the direct-mode pass
-    int32_t kp_blocks_per_cu;    // host: k_power blocks per CU (0 = all that fit): the later tiers need LDS beside it
+    int32_t kp_lds_quarters;     // host: share of a CU's capacity k_power takes for the main queue (1..4 quarters; 0 = all)
     int64_t dq_n;                // plane stride (= n_total)
     // list mode: this launch handles entries [work_lo, min(work_hi, count)) of class `cls` of the tier lists
     const int32_t *tier_list;    // the class lists, concatenated
@@ -159,7 +162,7 @@ int sg_beams_block(int lmax);
 int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *tier_info,
                          int32_t *status_counts, int32_t cap, int n_cls, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
-int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,

@@ -76,7 +76,7 @@ struct snowgpu_ctx {
     DevBuf<unsigned long long> seg_tbl_cnt, seg_tbl_base;
     DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk;
     DevBuf<int64_t> seg_start;
-    DevBuf<uint32_t> rec;             // result records, one per sorted position
+    DevBuf<uint32_t> rec, rec_q;      // result records: one per sorted position / per queue slot
     DevBuf<double> dq;                // dict queue of the first pass (SoA planes)
     DevBuf<int32_t> dq_g;
     DevBuf<uint16_t> dq_sc;
@@ -90,8 +90,8 @@ struct snowgpu_ctx {
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
-    int kp_per_cu = 2;                // k_power blocks per CU (SNOWGPU_KP_PER_CU; 0 = all that fit): its persistent blocks would
-                                      // otherwise hold every CU's LDS until they are done, and the later tiers + prepass run beside it
+    int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
+                                      // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
@@ -176,7 +176,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_KP_PER_CU"); ctx->kp_per_cu = v ? std::atoi(v) : 2; }
+    { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
@@ -218,7 +218,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -673,6 +673,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     HIPCHK(ctx, hipEventRecord(ctx->ev_join, s_aux));
     // 3. beams
     ENSURE(ctx, ctx->rec, n);
+    ENSURE(ctx, ctx->rec_q, n);
     ENSURE(ctx, ctx->keep, n);
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
     ENSURE(ctx, ctx->tier_list, n);
@@ -691,7 +692,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.las = ctx->d_las; a.frame_tables = ctx->frame_tables.p;
-    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p;
+    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
     a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
@@ -729,7 +730,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
         a.blk_rows = first_block;
-        a.kp_blocks_per_cu = ctx->kp_per_cu;
+        a.kp_lds_quarters = ctx->kp_quarters;
         ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
@@ -802,7 +803,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats
     // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
-    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
                           ctx->diff2.p, b.no_fov ? nullptr : &ctx->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));

@@ -357,7 +357,9 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
                     hand_over(a.dq, slot);
                     a.dq_g[slot] = (int32_t)g;
                     a.dq_sc[slot] = (uint16_t)(L | (ch << 8));
-                    pending = true;
+                    // this row's record is a reference to its queue slot: k_power writes its result there, slot after slot
+                    // (a 4-byte store per beam scattered over the sorted positions costs a whole memory sector each)
+                    rec = SG_REC_SLOT | (uint32_t)slot;
                 }
             }
         } else if (live) {
@@ -533,7 +535,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                 sg_beam_decide(d, ch, a.las, best, k_best, o);
                 rec = sg_pack_record(o);
             }
-            a.rec[cur.g] = rec;
+            if (LISTQ) a.rec[cur.g] = rec;
+            else a.rec_q[cur.slot] = rec;               // the row's record points here (SG_REC_SLOT)
         }
         sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
         if (!more) break;
@@ -826,7 +829,7 @@ __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, do
 // (num_attenuated counts those, before the camera crop: simulation.py:525 precedes :532-540).
 template <typename T>
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
-                                                            const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
+                                                            const uint32_t *__restrict__ rec_q, const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
                                                             int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
 {
@@ -841,13 +844,15 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         if (r >= n) continue;
         // keep = (label == 2) | (intensity > p0 d^2 + p1 d + p2), d the ORIGINAL range, d^2 in the row dtype
         // (simulation.py:465, :469, :518-520)
-        const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rec[base + r]);
+        uint32_t rc = rec[base + r];
+        if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
+        const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rc);
         const T dd2 = o.dd * o.dd;
         const double thr = (p0 * (double)dd2 + p1 * (double)o.dd) + p2;
         const bool noise_ok = (o.lab == (T)2) || ((double)o.i > thr);
         bool k = noise_ok;
         if (fov.enabled && k) k = sg_in_fov(fov, (double)o.x, (double)o.y, (double)o.z);   // :532-540
-        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0));
+        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0) | ((noise_ok && o.lab == (T)1) ? 4 : 0));   // bit 2: counts in num_attenuated
         c += k;
     }
     __shared__ int s[4];
@@ -880,7 +885,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__rest
 
 template <typename T>
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
-                                                              const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
+                                                              const uint32_t *__restrict__ rec_q, const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
                                                               const int64_t *__restrict__ frame_off,
                                                               const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
                                                               int32_t *__restrict__ out_src, int64_t *__restrict__ out_stats,
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
         const int64_t r = tile0 + q * SG_BLOCK + tid;
         const int kb = r < n ? (int)keep[base + r] : 0;
         k[q] = kb & 1;
-        if ((kb & 2) && ((rec[base + r] >> SG_REC_LABEL_SHIFT) & 3u) == 1u) ++att;   // simulation.py:525
+        if (kb & 4) ++att;                                                         // simulation.py:525
         const unsigned long long m = __ballot(k[q]);
         pre[q] = __popcll(m & sg_lanemask_lt());
         if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
@@ -912,7 +917,9 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
             const int64_t r = base + tile0 + q * SG_BLOCK + tid;
             const int64_t dst = base + off + pre[q];
             const int32_t src = perm[r];
-            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + src) * 5, rec[r]);
+            uint32_t rc = rec[r];
+            if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
+            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + src) * 5, rc);
             T *d = out_rows + dst * 5;
             d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
             out_src[dst] = src;
@@ -1128,7 +1135,9 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
     (void)hipGetDevice(&dev_id);
     // persistent waves: what the chip holds at once (LDS and the 32-waves-per-CU limit), fewer if the queue cannot be longer
     unsigned per_cu = (unsigned)std::min<size_t>(32 * 64 / THREADS, std::max<size_t>(1, (size_t)(160 * 1024) / lds));
-    if (!LISTQ && a->kp_blocks_per_cu > 0) per_cu = std::min<unsigned>(per_cu, (unsigned)a->kp_blocks_per_cu);
+    // the queue of the pass over all rows: its persistent blocks would hold every CU's LDS until they are done, while the
+    // later tiers and the prepass run beside it -- it takes a share (in quarters) of what fits
+    if (!LISTQ && a->kp_lds_quarters > 0 && a->kp_lds_quarters < 4) per_cu = std::max(1u, per_cu * (unsigned)a->kp_lds_quarters / 4u);
     int64_t blocks = (int64_t)sg_cu_count(dev_id) * per_cu;
     const int64_t items_ub = LISTQ ? ((int64_t)a->work_hi + LANES - 1) / LANES : (a->n_total + LANES - 1) / LANES + 2 * a->n_regions_ub;
     blocks = std::min<int64_t>(blocks, (items_ub + THREADS / 64 - 1) / (THREADS / 64));
@@ -1241,7 +1250,7 @@ extern "C" int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_
     return 0;
 }
 
-extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                                  int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, void *stream)
@@ -1251,15 +1260,15 @@ extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *re
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     SgFov fv{};
     if (fov) fv = *fov;
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     if (dtype == 0)
-        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
     else
-        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_stats_final, dim3((n_frames + 63) / 64), dim3(64), 0, st, n_frames, out_stats, diff2);
     SG_CHECK_LAUNCH();
