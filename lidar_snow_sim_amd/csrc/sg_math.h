@@ -10,6 +10,18 @@
 // and one float32 ULP of beam azimuth (2.4e-7 rad) is enough to move occlusion ratios by 1e-4 of
 // a beam -- so this is restated operation by operation instead of calling OCML's atan2f.
 // Verified against glibc on 6e7 inputs (0 mismatches) in the build container.
+//
+// The constants and the branch structure of sg_atanf / sg_atan2f, and the __kernel_sin / __kernel_cos polynomials used by
+// sg_tan_0_2pi below, are fdlibm's (a third-party algorithm, not part of the reference), whose notice reads:
+//
+//   ====================================================
+//   Copyright (C) 1993 by Sun Microsystems, Inc. All rights reserved.
+//
+//   Developed at SunPro, a Sun Microsystems, Inc. business.
+//   Permission to use, copy, modify, and distribute this
+//   software is freely granted, provided that this notice
+//   is preserved.
+//   ====================================================
 __device__ __forceinline__ float sg_atanf(float x)
 {
     const float atanhi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
