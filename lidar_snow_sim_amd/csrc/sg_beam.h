@@ -83,112 +83,248 @@ __device__ __forceinline__ double sg_clear_beam_ratio(double theta_c, double bea
     return sg_clip01(w / (beam_div_deg * (SG_PI / 180.0)));
 }
 
+// ---- beam geometry (simulation.py:89-101; geometry.py:94-106, :133) ------------------------------------------------
+struct SgBeamGeo {
+    double d;                 // range, widened from the row dtype
+    double theta_c;           // azimuth in [0, 2 pi]
+    double theta_r, theta_l;  // beam limits
+    double ar, br, al, bl;    // limit lines a x + b y = 0 (vertical only at exactly pi/2, 3 pi/2)
+    double den_r, den_l;      // sqrt(a^2 + b^2)
+    bool wrap;                // the wedge crosses the 0 / 2 pi seam (simulation.py:361)
+};
+
+// the part of the geometry that follows from the azimuth alone (recomputed, not stored, where a beam's parameters travel)
+__device__ __forceinline__ void sg_geo_limits(SgBeamGeo &g, double beam_div_deg)
+{
+    sg_beam_limits(g.theta_c, beam_div_deg, g.theta_r, g.theta_l);
+    g.wrap = g.theta_r > g.theta_l;
+}
+
+template <typename T>
+__device__ __forceinline__ SgBeamGeo sg_beam_geometry(T px, T py, T pz, double beam_div_deg, bool EXACT_TAN, T &d_t)
+{
+    SgBeamGeo g;
+    if constexpr (SgReal<T>::is_f32) {
+        d_t = sqrtf((px * px + py * py) + pz * pz);             // :89 np.linalg.norm in float32
+        float tc = sg_atan2f(py, px);                           // :91
+        if (tc < 0) tc = tc + (float)SG_TWO_PI;                 // :92 float32 add
+        g.theta_c = (double)tc;
+    } else {
+        d_t = sqrt((px * px + py * py) + pz * pz);
+        g.theta_c = atan2(py, px);
+        if (g.theta_c < 0) g.theta_c = g.theta_c + SG_TWO_PI;
+    }
+    g.d = (double)d_t;
+    sg_geo_limits(g, beam_div_deg);
+    // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
+    if (g.theta_r == SG_PI / 2 || g.theta_r == 3 * SG_PI / 2) { g.ar = 1.0; g.br = 0.0; } else { g.ar = -(EXACT_TAN ? tan(g.theta_r) : sg_tan_0_2pi(g.theta_r)); g.br = 1.0; }
+    if (g.theta_l == SG_PI / 2 || g.theta_l == 3 * SG_PI / 2) { g.al = 1.0; g.bl = 0.0; } else { g.al = -(EXACT_TAN ? tan(g.theta_l) : sg_tan_0_2pi(g.theta_l)); g.bl = 1.0; }
+    g.den_r = sqrt(g.ar * g.ar + g.br * g.br);                  // geometry.py:133
+    g.den_l = sqrt(g.al * g.al + g.bl * g.bl);
+    return g;
+}
+
+// The reference's exact predicates for one flake against one beam (simulation.py:359-389; geometry.py:113-135, :193-223):
+// does the disk intersect the wedge, and if so its interval angles (geometry.py:14-29: a limit ray that cuts the disk
+// replaces the tangent angle on its side).
+__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2)
+{
+    const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
+    const bool centre = (g.theta_r <= phi && phi <= g.theta_l)                        // :359
+                     || (g.wrap && g.theta_r - SG_TWO_PI <= phi && phi <= g.theta_l)  // :360
+                     || (g.wrap && g.theta_r <= phi && phi <= g.theta_l + SG_TWO_PI); // :362
+    // geometry.py:131-135: |a x + b y + 0| / sqrt(a^2 + b^2) < r.  The quotient is only compared, so the
+    // division is done only when the product form num < r * den cannot decide it: outside a band of
+    // 2^-48 around equality both forms agree whatever the rounding of the quotient.
+    const double num_r = fabs((fx * g.ar + fy * g.br) + 0.0), num_l = fabs((fx * g.al + fy * g.bl) + 0.0);
+    const double lim_r = fr * g.den_r, lim_l = fr * g.den_l;
+    bool near_r = num_r < lim_r, near_l = num_l < lim_l;
+    if (fabs(num_r - lim_r) <= lim_r * 3.6e-15) near_r = (num_r / g.den_r) < fr;
+    if (fabs(num_l - lim_l) <= lim_l * 3.6e-15) near_l = (num_l / g.den_l) < fr;
+    const bool hit_r = near_r && sg_forward(g.theta_r, phi);            // :379-384
+    const bool hit_l = near_l && sg_forward(g.theta_l, phi);            // :379-385
+    na1 = hit_r ? g.theta_r : f.t0;                                     // geometry.py:26
+    na2 = hit_l ? g.theta_l : f.t1;                                     // geometry.py:27
+    return centre || hit_r || hit_l;                                    // :389
+}
+
 // ---- beam geometry + phase 1 (candidate scan) for one beam (per lane) -----------------------------------------------
 // LMAX > 0: list capacity, a compile-time constant (lists in LDS).  LMAX == 0: the global-list tier, capacity `rcap`
 // and stride `rstride` at run time.  The scan keeps counting after the list is full: out.n_hits is exact either way.
 // Leaves the intersecting flakes, near -> far, in the list columns: s_a1[j], s_a2[j] interval angles (geometry.py:14-29),
 // s_rho[j] range, j < min(n_hits, capacity); returns that length.  d_t / theta_c: the beam's range (row dtype) and azimuth.
+// The table is filed under 2048 azimuth bins, each sorted by range: the beam visits only the bins its wedge touches and
+// stops at the first flake beyond the hard target.
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int tid, SgBeamOut &out, T &d_t, double &theta_c,
                                             bool EXACT_TAN = false, int rstride = 0, int rcap = 0)
 {
-    constexpr bool F32 = SgReal<T>::is_f32;
     constexpr bool HUGE_TIER = LMAX == 0;
     const int lcap = HUGE_TIER ? rcap : LMAX;
     out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.n_hits = 0;
     out.label = 0; out.new_i = 0; out.k_best = 0;
-
-    // ---- beam geometry (simulation.py:89-101) ----------------------------------------------
-    if constexpr (F32) {
-        d_t = sqrtf((px * px + py * py) + pz * pz);             // :89 np.linalg.norm in float32
-        float tc = sg_atan2f(py, px);                           // :91
-        if (tc < 0) tc = tc + (float)SG_TWO_PI;                 // :92 float32 add
-        theta_c = (double)tc;
-    } else {
-        d_t = sqrt((px * px + py * py) + pz * pz);
-        theta_c = atan2(py, px);
-        if (theta_c < 0) theta_c = theta_c + SG_TWO_PI;
-    }
-    const double d = (double)d_t;
-    double theta_r, theta_l;
-    sg_beam_limits(theta_c, beam_div_deg, theta_r, theta_l);
-
-    // Azimuth bins the wedge touches.  Their offsets are requested now so that the loads fly while the two
-    // tangents below are evaluated (the compiler waits at first use, not here).
+    const SgBeamGeo g = sg_beam_geometry<T>(px, py, pz, beam_div_deg, EXACT_TAN, d_t);
+    theta_c = g.theta_c;
+    const double d = g.d;
     const int nb = (int)tab.n_bins;
-    const int b_lo = sg_bin_of(theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
-    const int b_hi = sg_bin_of(theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+    const int b_lo = sg_bin_of(g.theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+    const int b_hi = sg_bin_of(g.theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
     int span = b_hi - b_lo;
     if (span < 0) span += nb;
-
-    const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
-    const uint32_t st0 = tab.bin_start[b_lo], st1 = tab.bin_start[b_lo + 1];
-    const uint32_t st2 = tab.bin_start[b_nx], st3 = tab.bin_start[b_nx + 1];
-    // touch the first record of the second bin now: its 64-byte line is then on its way while the first bin is scanned
-    const double first_rho1 = tab.entries[st2].rho;
-
-    // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
-    double ar, br, al, bl;
-    if (theta_r == SG_PI / 2 || theta_r == 3 * SG_PI / 2) { ar = 1.0; br = 0.0; } else { ar = -(EXACT_TAN ? tan(theta_r) : sg_tan_0_2pi(theta_r)); br = 1.0; }
-    if (theta_l == SG_PI / 2 || theta_l == 3 * SG_PI / 2) { al = 1.0; bl = 0.0; } else { al = -(EXACT_TAN ? tan(theta_l) : sg_tan_0_2pi(theta_l)); bl = 1.0; }
-    const double den_r = sqrt(ar * ar + br * br);               // geometry.py:133
-    const double den_l = sqrt(al * al + bl * bl);
-    const bool wrap = theta_r > theta_l;                        // simulation.py:361
-
-    // ---- phase 1: candidate scan over the azimuth bins the wedge touches ---------------------
-    // (A split scan -- cheap angular prefilter first, the exact predicates on the survivors only -- was tried and
-    // made no difference: the scan is bound by its dependent record gathers, not by arithmetic.)
     int L = 0, hits = 0;
-    {
-        int b = b_lo;
-        for (int s = 0; s <= span; ++s) {
-            uint32_t e0, e1;
-            if (s == 0) { e0 = st0; e1 = st1; }
-            else if (s == 1) { e0 = st2; e1 = st3; }
-            else { e0 = tab.bin_start[b]; e1 = tab.bin_start[b + 1]; }
-            // software pipeline: the next record is requested before the current one is examined (the entry
-            // array carries one spare record at its end, so e + 1 is always readable)
-            SgEntry nxt = tab.entries[e0];
-            if (s == 1) nxt.rho = first_rho1;
-            for (uint32_t e = e0; e < e1; ++e) {
-                const SgEntry f = nxt;
-                nxt = tab.entries[e + 1];
-                const double rho = f.rho;
-                if (!(rho < d)) break;                          // :345 (bins are sorted by rho)
-                if (s > 0 && !(f.flags & 1u)) continue;         // already met in an earlier bin
-                const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
-                const bool centre = (theta_r <= phi && phi <= theta_l)                      // :359
-                                 || (wrap && theta_r - SG_TWO_PI <= phi && phi <= theta_l)  // :360
-                                 || (wrap && theta_r <= phi && phi <= theta_l + SG_TWO_PI); // :362
-                // geometry.py:131-135: |a x + b y + 0| / sqrt(a^2 + b^2) < r.  The quotient is only compared, so the
-                // division is done only when the product form num < r * den cannot decide it: outside a band of
-                // 2^-48 around equality both forms agree whatever the rounding of the quotient.
-                const double num_r = fabs((fx * ar + fy * br) + 0.0), num_l = fabs((fx * al + fy * bl) + 0.0);
-                const double lim_r = fr * den_r, lim_l = fr * den_l;
-                bool near_r = num_r < lim_r, near_l = num_l < lim_l;
-                if (fabs(num_r - lim_r) <= lim_r * 3.6e-15) near_r = (num_r / den_r) < fr;
-                if (fabs(num_l - lim_l) <= lim_l * 3.6e-15) near_l = (num_l / den_l) < fr;
-                const bool hit_r = near_r && sg_forward(theta_r, phi);            // :379-384
-                const bool hit_l = near_l && sg_forward(theta_l, phi);            // :379-385
-                if (!(centre || hit_r || hit_l)) continue;      // :389
-                ++hits;
-                if (L == lcap) continue;                        // list full: keep counting (the count picks the tier)
-                const double na1 = hit_r ? theta_r : f.t0;      // geometry.py:26
-                const double na2 = hit_l ? theta_l : f.t1;      // geometry.py:27
-                int p = L;                                      // insertion sort by rho (:413-417)
-                while (p > 0 && SG_RHO(p - 1) > rho) {
-                    SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
-                    --p;
+    int b = b_lo;
+    for (int s = 0; s <= span; ++s) {
+        const uint32_t e0 = tab.bin_start[b], e1 = tab.bin_start[b + 1];
+        // software pipeline: the next record is requested before the current one is examined (the entry
+        // array carries one spare record at its end, so e + 1 is always readable)
+        SgEntry nxt = tab.entries[e0];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const SgEntry f = nxt;
+            nxt = tab.entries[e + 1];
+            const double rho = f.rho;
+            if (!(rho < d)) break;                              // :345 (bins are sorted by rho)
+            if (s > 0 && !(f.flags & 1u)) continue;             // already met in an earlier bin
+            double na1, na2;
+            if (!sg_flake_hits(g, f, na1, na2)) continue;
+            ++hits;
+            if (L == lcap) continue;                            // list full: keep counting (the count picks the tier)
+            int p = L;                                          // insertion sort by rho (:413-417)
+            while (p > 0 && SG_RHO(p - 1) > rho) {
+                SG_A1(p) = SG_A1(p - 1); SG_A2(p) = SG_A2(p - 1); SG_RHO(p) = SG_RHO(p - 1);
+                --p;
+            }
+            SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
+            ++L;
+        }
+        if (++b == nb) b = 0;
+    }
+    out.n_hits = hits;
+    if (hits > lcap) out.overflow = 1;
+    return L;
+}
+
+// ---- the same scan, one WAVE for its 64 beams ---------------------------------------------------------------------------
+// A beam tests every record of its bins that is nearer than its target -- a handful for a ground return, dozens for a far
+// wall -- and with one beam per lane a wave is as slow as its farthest beam (SQ counters: 45 % of the lanes active).  Here the
+// wave flattens the work: every lane finds how many records each of its (first two) bins holds before its target (binary
+// search: bins are sorted by range), a prefix sum over the wave numbers the (beam, record) pairs, and the lanes take 64
+// pairs at a time whichever beams they belong to -- the owner's geometry travels by cross-lane reads.  A hit is appended to
+// its owner's list through an LDS counter; every beam sorts its few entries by (range, scan order) afterwards, which is the
+// order the per-lane scan produces.  Bins beyond the second (wedges wider than a bin) keep the per-lane loop.
+// s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries).
+template <typename T, int LMAX, int STRIDE>
+__device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
+                                            double *s_rho, int *s_cnt, int *s_key, int tid, SgBeamOut &out, T &d_t, double &theta_c,
+                                            bool EXACT_TAN)
+{
+    out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.n_hits = 0;
+    out.label = 0; out.new_i = 0; out.k_best = 0;
+    const int lane = tid & 63, wbase = tid & ~63;
+    SgBeamGeo g{};
+    uint32_t st0 = 0, st2 = 0;
+    int n0 = 0, n1 = 0, span = -1, b_lo = 0, nb = 1;
+    d_t = 0; theta_c = 0.0;
+    if (act) {
+        g = sg_beam_geometry<T>(px, py, pz, beam_div_deg, EXACT_TAN, d_t);
+        theta_c = g.theta_c;
+        nb = (int)tab.n_bins;
+        b_lo = sg_bin_of(g.theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        const int b_hi = sg_bin_of(g.theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        span = b_hi - b_lo;
+        if (span < 0) span += nb;
+        const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
+        st0 = tab.bin_start[b_lo];
+        uint32_t hi0 = tab.bin_start[b_lo + 1];
+        st2 = tab.bin_start[b_nx];
+        uint32_t hi1 = span >= 1 ? tab.bin_start[b_nx + 1] : st2;
+        uint32_t lo0 = st0, lo1 = st2;                          // records with rho < d: a prefix of each (sorted) bin
+        while (lo0 < hi0 || lo1 < hi1) {
+            const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
+            const double r0 = lo0 < hi0 ? tab.entries[m0].rho : 0.0, r1 = lo1 < hi1 ? tab.entries[m1].rho : 0.0;
+            if (lo0 < hi0) { if (r0 < g.d) lo0 = m0 + 1; else hi0 = m0; }
+            if (lo1 < hi1) { if (r1 < g.d) lo1 = m1 + 1; else hi1 = m1; }
+        }
+        n0 = (int)(lo0 - st0); n1 = (int)(lo1 - st2);
+    }
+    s_cnt[tid] = 0;                                             // same wave writes and bumps it: LDS operations of a wave keep their order
+    const int cnt = n0 + n1;
+    int incl = cnt;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int excl = incl - cnt;
+    const int total = __shfl(incl, 63);
+    const int vflags = (g.br == 0.0 ? 1 : 0) | (g.bl == 0.0 ? 2 : 0);
+    const unsigned long long ent_bits = (unsigned long long)tab.entries;
+    for (int base = 0; base < total; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < total;
+        int lo = 0, hi = 63;                                    // owner = first lane whose inclusive count exceeds p
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const int v = __shfl(incl, mid);
+            if (v > p) hi = mid; else lo = mid + 1;
+        }
+        const int o = lo & 63;
+        const int j = p - __shfl(excl, o);
+        const int n0o = __shfl(n0, o);
+        const uint32_t st0o = __shfl(st0, o), st2o = __shfl(st2, o);     // (cross-lane reads stay outside divergent code)
+        const uint32_t e = j < n0o ? st0o + (uint32_t)j : st2o + (uint32_t)(j - n0o);
+        SgBeamGeo og;
+        og.d = __shfl(g.d, o); og.theta_c = __shfl(g.theta_c, o);
+        og.ar = __shfl(g.ar, o); og.al = __shfl(g.al, o); og.den_r = __shfl(g.den_r, o); og.den_l = __shfl(g.den_l, o);
+        const int of = __shfl(vflags, o);
+        const SgEntry *oent = (const SgEntry *)(((unsigned long long)__shfl((unsigned)(ent_bits >> 32), o) << 32) | (unsigned long long)__shfl((unsigned)ent_bits, o));
+        if (valid) {
+            og.br = (of & 1) ? 0.0 : 1.0; og.bl = (of & 2) ? 0.0 : 1.0;
+            sg_geo_limits(og, beam_div_deg);
+            const SgEntry f = oent[e];
+            double na1, na2;
+            if (!(j >= n0o && !(f.flags & 1u)) && sg_flake_hits(og, f, na1, na2)) {      // a flake filed under both bins counts once
+                const int col = wbase + o;
+                const int pos = atomicAdd(&s_cnt[col], 1);
+                if (pos < LMAX) {
+                    s_a1[pos * STRIDE + col] = na1; s_a2[pos * STRIDE + col] = na2; s_rho[pos * STRIDE + col] = f.rho;
+                    s_key[pos * STRIDE + col] = p;
                 }
-                SG_A1(p) = na1; SG_A2(p) = na2; SG_RHO(p) = rho;
+            }
+        }
+    }
+    int hits = ((volatile int *)s_cnt)[tid];                    // bumped by other lanes of this wave
+    int L = hits < LMAX ? hits : LMAX;
+    if (act && span >= 2) {                                     // wedges wider than a bin: the further bins, per lane
+        int b = b_lo + 2 >= nb ? b_lo + 2 - nb : b_lo + 2;
+        int key = 0x40000000;
+        for (int s = 2; s <= span; ++s) {
+            const uint32_t e0 = tab.bin_start[b], e1 = tab.bin_start[b + 1];
+            for (uint32_t e = e0; e < e1; ++e) {
+                const SgEntry f = tab.entries[e];
+                if (!(f.rho < g.d)) break;
+                ++key;
+                if (!(f.flags & 1u)) continue;
+                double na1, na2;
+                if (!sg_flake_hits(g, f, na1, na2)) continue;
+                ++hits;
+                if (L == LMAX) continue;
+                s_a1[L * STRIDE + tid] = na1; s_a2[L * STRIDE + tid] = na2; s_rho[L * STRIDE + tid] = f.rho; s_key[L * STRIDE + tid] = key;
                 ++L;
             }
             if (++b == nb) b = 0;
         }
     }
+    // order by (range, scan order): insertion sort of <= LMAX entries (simulation.py:413-417)
+    for (int i = 1; i < L; ++i) {
+        const double r = s_rho[i * STRIDE + tid], x1 = s_a1[i * STRIDE + tid], x2 = s_a2[i * STRIDE + tid];
+        const int k = s_key[i * STRIDE + tid];
+        int q = i;
+        while (q > 0 && (s_rho[(q - 1) * STRIDE + tid] > r || (s_rho[(q - 1) * STRIDE + tid] == r && s_key[(q - 1) * STRIDE + tid] > k))) {
+            s_rho[q * STRIDE + tid] = s_rho[(q - 1) * STRIDE + tid]; s_a1[q * STRIDE + tid] = s_a1[(q - 1) * STRIDE + tid];
+            s_a2[q * STRIDE + tid] = s_a2[(q - 1) * STRIDE + tid]; s_key[q * STRIDE + tid] = s_key[(q - 1) * STRIDE + tid];
+            --q;
+        }
+        s_rho[q * STRIDE + tid] = r; s_a1[q * STRIDE + tid] = x1; s_a2[q * STRIDE + tid] = x2; s_key[q * STRIDE + tid] = k;
+    }
     out.n_hits = hits;
-    if (hits > lcap) out.overflow = 1;
+    if (hits > LMAX) out.overflow = 1;
     return L;
 }
 
@@ -506,6 +642,9 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
     const double floor_ = 0.9966 * amax;
     int nw = 0;
     auto flush = [&]() {
+#ifdef SG_EXP_KP_NOSTAGEB
+        if (nw < 1000) { nw = 0; return; }
+#endif
         for (int w = 0; w < nw; ++w)
             sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
                                              tk1, tamp, td, best, k_best, rstride);

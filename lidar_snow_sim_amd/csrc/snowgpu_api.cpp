@@ -93,6 +93,7 @@ struct snowgpu_ctx {
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
+    int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=1 one beam per lane everywhere, -1 wave scan everywhere
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
@@ -179,6 +180,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     for (hipStream_t *sp : {&ctx->stream, &ctx->aux, &ctx->aux3})
         HIPCHK(ctx, hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
@@ -696,6 +698,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = ctx->exact_math;
+    a.per_lane_scan = ctx->per_lane_scan;
     // Later capacity tiers = classes of the tier lists; the last class is the global-list tier, whose lists hold a whole
     // table if need be (capped at 8192 flakes in one beam).
     const int n_cls = n_tiers;

@@ -221,6 +221,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
     double *s_a2 = s_a1 + ROWS * BLOCK;
     double *s_rho = s_a2 + ROWS * BLOCK;
     double *s_ratio = DICT ? nullptr : s_rho + ROWS * BLOCK;
+    int *s_cnt = DICT ? (int *)(s_rho + ROWS * BLOCK) : nullptr;          // wave scan: flakes met per beam ...
+    int *s_key = DICT ? s_cnt + (BLOCK < 64 ? 64 : BLOCK) : nullptr;      // ... and the scan order of the stored ones
     const int tid = threadIdx.x;
     const int n_las = a.las->n;
     int64_t work_n = 0, work_off = 0;
@@ -289,41 +291,53 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
     int L = 0;                                        // hand-over passes: flakes in the list
     T d_t = 0;
     double theta_c = 0.0;
+    SgTable tab{};
+    bool act = false;                                 // this lane simulates a beam
     if (simulated) {
-        const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
-        if (tab.entries == nullptr) {
-            atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
+        tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
+        if (tab.entries == nullptr) atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
+        else act = true;
+    }
+    if constexpr (DICT) {
+        // The pass over all rows scans as a wave (every lane takes part, whether it has a beam or not): its beams' lists
+        // differ 20-fold in length.  The later tiers hold beams with long lists of similar length; one beam per lane is a
+        // little faster there (measured 0.37 vs 0.41 ms for tier 8).
+        if (LIST ? a.per_lane_scan >= 0 : a.per_lane_scan > 0) {
+            if (act) L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
         } else {
-            if constexpr (DICT) {
-                L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
-                o.has_power = !o.overflow && L > 0;       // k_power builds the dict (phase 2) and everything after it
-                if (!o.overflow && L == 0 && a.dbg_count) {   // debug tap: the dict of a clear beam is its hard target alone
-                    a.dbg_count[g] = 1;
-                    a.dbg_rj[g * a.dbg_cap] = (double)d_t;
-                    a.dbg_ratio[g * a.dbg_cap] = sg_clear_beam_ratio(theta_c, a.beam_div_deg);
-                }
-            } else {
-                int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
-                double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
-                double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
-                sg_beam<T, LMAX, BLOCK>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
-                                        dra, a.exact_math != 0);
+            L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, tid, o, d_t, theta_c,
+                                             a.exact_math != 0);
+        }
+        if (act) {
+            o.has_power = !o.overflow && L > 0;       // k_power builds the dict (phase 2) and everything after it
+            if (!o.overflow && L == 0 && a.dbg_count) {   // debug tap: the dict of a clear beam is its hard target alone
+                a.dbg_count[g] = 1;
+                a.dbg_rj[g * a.dbg_cap] = (double)d_t;
+                a.dbg_ratio[g * a.dbg_cap] = sg_clear_beam_ratio(theta_c, a.beam_div_deg);
             }
-            if (o.overflow) {
-                o.has_power = 0;
-                int k = 0;                            // the first later tier that holds every flake of this beam
-                while (k < a.n_cls && o.n_hits > a.cls_cap[k]) ++k;
-                if (LIST || k >= a.n_cls) {           // a listed beam fits its tier by construction
-                    atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
-                    atomicCAS(&a.status[1], -1, (int32_t)g);
-                } else {
-                    a.flag[g] = (uint8_t)(3 + k);     // k_tier_* build the tier lists from the flags, in sorted-row order
-                    pending = true;
-                }
-            } else if (o.range_error) {
-                atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+        }
+    } else if (act) {
+        int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+        double *drj = a.dbg_count ? a.dbg_rj + g * a.dbg_cap : nullptr;
+        double *dra = a.dbg_count ? a.dbg_ratio + g * a.dbg_cap : nullptr;
+        sg_beam<T, LMAX, BLOCK>(px, py, pz, ch, tab, a.las, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, tid, o, a.dbg_cap, dc, drj,
+                                dra, a.exact_math != 0);
+    }
+    if (act) {
+        if (o.overflow) {
+            o.has_power = 0;
+            int k = 0;                                // the first later tier that holds every flake of this beam
+            while (k < a.n_cls && o.n_hits > a.cls_cap[k]) ++k;
+            if (LIST || k >= a.n_cls) {               // a listed beam fits its tier by construction
+                atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
                 atomicCAS(&a.status[1], -1, (int32_t)g);
+            } else {
+                a.flag[g] = (uint8_t)(3 + k);         // k_tier_* build the tier lists from the flags, in sorted-row order
+                pending = true;
             }
+        } else if (o.range_error) {
+            atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+            atomicCAS(&a.status[1], -1, (int32_t)g);
         }
     }
     if constexpr (DICT) {
@@ -520,7 +534,11 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)cur.g * a.dbg_cap : nullptr;
             const int S = sg_beam_dict<LMAX, BLOCK>(L, cur.tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
             uint32_t rec = 0;                           // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
+#ifdef SG_EXP_KP_NOP3
+            if (S > 1000) {
+#else
             if (S > 0) {
+#endif
                 const T d_t = (T)d;                     // exact
                 sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
                 if (o.range_error) {
@@ -1093,7 +1111,8 @@ static int sg_set_lds(K kernel, size_t lds, bool *attr_set)
 template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
 static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * (size_t)BLOCK * (DICT ? 3 * (size_t)LMAX : 4 * ((size_t)LMAX + 1));
+    const size_t lds = DICT ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX + sizeof(int) * ((size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
+                            : sizeof(double) * (size_t)BLOCK * 4 * ((size_t)LMAX + 1);
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK;

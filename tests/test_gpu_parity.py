@@ -905,3 +905,31 @@ def test_pre_augment_crop_on_device_matches_crop_then_augment(eng, so, tables):
         assert np.array_equal(aug[:, 3:], a0[flag2][:, 3:])
         np.testing.assert_allclose(aug[:, :3], a0[flag2][:, :3], rtol=1e-6, atol=0)
         assert (int(st[0]), int(st[1]), int(st[2])) == (int(s0[0]), int(s0[1]) + int((~flag2).sum()), int(s0[2]))
+
+
+@pytest.mark.parametrize("mode", ["1", "-1"])
+def test_per_lane_and_wave_scan_give_the_same_rows(so, tables, monkeypatch, mode):
+    """The candidate scan has two forms: one beam per lane, and the wave-flattened one (every lane tests one (beam, record)
+    pair, hits appended through LDS counters, each beam's entries ordered afterwards).  By default the pass over all rows
+    uses the second and the tiers the first; SNOWGPU_PER_LANE_SCAN=1 / -1 force one form everywhere -- same bytes, and both
+    equal the oracle.  Wide beams (30 mrad: wedges of ten bins) exercise the per-lane part behind the first two bins."""
+    from lidar_snow_sim_amd import engine
+    tl = _tables64(tables)
+    order = list(range(64))
+    poly = [0.0, 0.01, 2.0]
+    for bd in (float(np.degrees(3e-3)), float(np.degrees(3e-2))):
+        pc = _stretched_subsweep(step=16 if bd < 0.5 else 64, seed=1080)
+        outs = []
+        for env in ("0", mode):
+            monkeypatch.setenv("SNOWGPU_PER_LANE_SCAN", env)
+            e = engine.Engine(0)
+            try:
+                outs.append(e.ctx.augment_batch(pc, [0, pc.shape[0]], [e.table_ids_from_arrays(tl, order)], bd, thr_poly=[poly]))
+            finally:
+                e.ctx.close()
+        (o0, s0, c0, st0, _), (o1, s1, c1, st1, _) = outs
+        n = int(c0[0])
+        assert np.array_equal(c0, c1) and np.array_equal(st0, st1) and np.array_equal(s0[:n], s1[:n]) and o0[:n].tobytes() == o1[:n].tobytes()
+        r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
+        assert tuple(int(v) for v in st0[0]) == tuple(int(v) for v in r_stats)
+        assert np.array_equal(s0[:n], r_src) and np.array_equal(o0[:n, 3:], r_aug[:, 3:])
