@@ -341,6 +341,17 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
                                             double *dbg_rj, double *dbg_ratio, int rstride = 0)
 {
     constexpr bool HUGE_TIER = LMAX == 0;
+    // One pass over the list entries (a1_q, a2_q).  Short lists (capacity <= 8) are walked fully unrolled with every load
+    // issued up front -- the walk is a chain of LDS round trips otherwise, one per entry -- the longer ones four at a time.
+    auto for_entries = [&](auto &&body) {
+        if constexpr (!HUGE_TIER && LMAX <= 8) {
+#pragma unroll
+            for (int q = 0; q < LMAX; ++q) { const double q1 = SG_A1(q), q2 = SG_A2(q); if (q < L) body(q, q1, q2); }
+        } else {
+#pragma unroll 4
+            for (int q = 0; q < L; ++q) { const double q1 = SG_A1(q), q2 = SG_A2(q); body(q, q1, q2); }
+        }
+    };
     double theta_r, theta_l;
     sg_beam_limits(theta_c, beam_div_deg, theta_r, theta_l);
     double ra = theta_r, la = theta_l;
@@ -371,12 +382,11 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         while (e < hi) {                                        // slots i1 .. i2-1 (:277-282)
             bool pre = false;
             double nxt = hi;
-            for (int q = 0; q < L; ++q) {
-                const double q1 = SG_A1(q), q2 = SG_A2(q);
+            for_entries([&](int q, double q1, double q2) {
                 if (q < j && q1 <= e && e < q2) pre = true;     // a nearer flake already owns it (:284)
                 if (q1 > e && q1 < nxt) nxt = q1;
                 if (q2 > e && q2 < nxt) nxt = q2;
-            }
+            });
             if (ra > e && ra < nxt) nxt = ra;
             if (la > e && la < nxt) nxt = la;
             if (!pre) { acc.push(nxt - e); made = true; }       // :266 diffs, :285-286
@@ -398,12 +408,11 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         while (e < e_max) {
             int own = -1;
             double nxt = e_max;
-            for (int q = 0; q < L; ++q) {
-                const double q1 = SG_A1(q), q2 = SG_A2(q);
+            for_entries([&](int q, double q1, double q2) {
                 if (own < 0 && q1 <= e && e < q2) own = q;      // nearest flake covering the slot (:284)
                 if (q1 > e && q1 < nxt) nxt = q1;
                 if (q2 > e && q2 < nxt) nxt = q2;
-            }
+            });
             if (ra > e && ra < nxt) nxt = ra;
             if (la > e && la < nxt) nxt = la;
             const double w = nxt - e;
@@ -436,10 +445,7 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
             // fewer than 7 endpoints strictly inside the interval -> fewer than 8 slots
             const double lo = SG_A1(j), hi = SG_A2(j);
             int inside = (ra > lo && ra < hi) + (la > lo && la < hi);
-            for (int q = 0; q < L; ++q) {
-                const double q1 = SG_A1(q), q2 = SG_A2(q);
-                inside += (q1 > lo && q1 < hi) + (q2 > lo && q2 < hi);
-            }
+            for_entries([&](int, double q1, double q2) { inside += (q1 > lo && q1 < hi) + (q2 > lo && q2 < hi); });
             redo = inside >= 7;
         }
         double sum = 0.0 + SG_RATIO(j);
