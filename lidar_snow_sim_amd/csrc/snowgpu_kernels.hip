@@ -24,7 +24,7 @@
 #define SG_KP_PREFETCH 0     /* 1: k_power requests the slot data of its next item before computing the current one */
 #endif
 #ifndef SG_KP_WAVES
-#define SG_KP_WAVES 4     /* waves per SIMD k_power<4> is compiled for */
+#define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
 // Beams per wave of the per-beam kernels by list capacity (the LDS lists are strided by it).  The first capacity fills
 // whole 256-thread blocks; 8 and 16 entries run full 64-lane waves; the 63-entry tier runs 16 live lanes per wave (32 KB of
