@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
 // PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
 // barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
 // that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
-// then bound by the latency of its first loads.  Here a wave requests the slot data of its NEXT item before it computes
-// the current one.
+// then bound by the latency of its first loads.  (SG_KP_PREFETCH=1 also requests the slot data of a wave's NEXT item before
+// it computes the current one; since phase 2 moved here the registers that costs outweigh the latency it hides.)
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
 __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 1) void k_power(SgBeamArgs a)
 {
