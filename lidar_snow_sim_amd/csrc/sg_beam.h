@@ -239,6 +239,18 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         st2 = tab.bin_start[b_nx];
         uint32_t hi1 = span >= 1 ? tab.bin_start[b_nx + 1] : st2;
         uint32_t lo0 = st0, lo1 = st2;                          // records with rho < d: a prefix of each (sorted) bin
+        if (tab.bin_q) {   // the coarse range index brackets the prefix (counts below the multiples of SG_QSTEP_M around d): the search
+            // below then looks at the one or two records in between instead of halving the whole bin
+            const double dq = g.d * (1.0 / SG_QSTEP_M);
+            const int kk = dq < (double)(SG_QSTEPS - 1) ? (int)dq : SG_QSTEPS - 1;
+            const uint32_t *q0 = tab.bin_q + (size_t)b_lo * SG_QSTEPS + kk, *q1 = tab.bin_q + (size_t)b_nx * SG_QSTEPS + kk;
+            const uint32_t c0 = q0[0], c1 = q1[0];
+            const uint32_t u0 = kk < SG_QSTEPS - 1 ? q0[1] : 0u, u1 = kk < SG_QSTEPS - 1 ? q1[1] : 0u;
+            lo0 = st0 + c0;
+            if (kk < SG_QSTEPS - 1) hi0 = st0 + u0;
+            if (span >= 1) { lo1 = st2 + c1; if (kk < SG_QSTEPS - 1) hi1 = st2 + u1; }
+            if (!(g.d == g.d)) { lo0 = hi0 = st0; lo1 = hi1 = st2; }      // NaN target: no record is nearer
+        }
         while (lo0 < hi0 || lo1 < hi1) {
             const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
             const double r0 = lo0 < hi0 ? tab.entries[m0].rho : 0.0, r1 = lo1 < hi1 ? tab.entries[m1].rho : 0.0;

@@ -23,9 +23,13 @@ struct SgEntry {
     uint32_t src;    // row in the uploaded table
 };
 
+#define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m */
+#define SG_QSTEP_M 8.0
+
 struct SgTable {
     const SgEntry *entries;     // bins concatenated, each bin sorted by rho ascending
     const uint32_t *bin_start;  // n_bins + 1 offsets into entries
+    const uint32_t *bin_q;      // n_bins x SG_QSTEPS: records of the bin nearer than SG_QSTEP_M * k metres (coarse range index)
     uint32_t n_bins;
     uint32_t n_entries;
     double inv_bin_w;           // n_bins / (2 pi)

@@ -22,6 +22,7 @@ namespace {
 struct DeviceTable {
     SgEntry *entries = nullptr;
     uint32_t *bin_start = nullptr;
+    uint32_t *bin_q = nullptr;
     SgTable desc{};
 };
 
@@ -212,6 +213,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (auto &t : ctx->tables) {
         if (t.entries) (void)hipFree(t.entries);
         if (t.bin_start) (void)hipFree(t.bin_start);
+        if (t.bin_q) (void)hipFree(t.bin_q);
     }
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     if (ctx->d_las) (void)hipFree(ctx->d_las);
@@ -313,6 +315,8 @@ static int bin_of(double theta, double inv_w, int nb)
     return b;
 }
 
+extern "C" int sg_table_index(const SgEntry *entries, const uint32_t *start, uint32_t *q, void *stream);   // snowgpu_tables.hip
+
 // hand a filed table (device arrays, owned by the context from here on) to the table list under table_id
 static int register_table(snowgpu_ctx *ctx, int table_id, SgEntry *entries, uint32_t *bin_start, uint32_t n_entries, uint32_t k,
                           uint32_t max_bin)
@@ -322,9 +326,24 @@ static int register_table(snowgpu_ctx *ctx, int table_id, SgEntry *entries, uint
     if (dt.entries || dt.bin_start) (void)hipStreamSynchronize(ctx->stream);     // no batch may still read the old table
     if (dt.entries) (void)hipFree(dt.entries);
     if (dt.bin_start) (void)hipFree(dt.bin_start);
-    dt.entries = entries; dt.bin_start = bin_start;
+    if (dt.bin_q) (void)hipFree(dt.bin_q);
+    dt.entries = entries; dt.bin_start = bin_start; dt.bin_q = nullptr;
+    dt.desc = SgTable{};
+    ctx->tables_dirty = true;
+    uint32_t *q = nullptr;
+    int e = (int)hipMalloc((void **)&q, (size_t)SG_NBINS * SG_QSTEPS * sizeof(uint32_t));
+    if (!e) e = sg_table_index(entries, bin_start, q, ctx->stream);
+    if (!e) e = (int)hipStreamSynchronize(ctx->stream);
+    if (e) {
+        if (q) (void)hipFree(q);
+        (void)hipFree(entries); (void)hipFree(bin_start);
+        dt.entries = nullptr; dt.bin_start = nullptr;
+        return fail(ctx, SNOWGPU_E_HIP, std::string("table index: ") + hipGetErrorString((hipError_t)e));
+    }
+    dt.bin_q = q;
     dt.desc.entries = entries;
     dt.desc.bin_start = bin_start;
+    dt.desc.bin_q = getenv("SNOWGPU_NO_QINDEX") ? nullptr : q;      // (A/B switch: full binary search per bin)
     dt.desc.n_bins = (uint32_t)SG_NBINS;
     dt.desc.n_entries = n_entries;
     dt.desc.inv_bin_w = SG_NBINS / SG_TWO_PI;
@@ -494,6 +513,7 @@ extern "C" int snowgpu_free_table(snowgpu_ctx *ctx, int table_id)
     if (dt.entries || dt.bin_start) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (dt.entries) { (void)hipFree(dt.entries); dt.entries = nullptr; }
     if (dt.bin_start) { (void)hipFree(dt.bin_start); dt.bin_start = nullptr; }
+    if (dt.bin_q) { (void)hipFree(dt.bin_q); dt.bin_q = nullptr; }
     dt.desc = SgTable{};
     ctx->tables_dirty = true;
     return SNOWGPU_OK;

@@ -23,6 +23,9 @@
 #ifndef SG_KP_PREFETCH
 #define SG_KP_PREFETCH 0     /* 1: k_power requests the slot data of its next item before computing the current one */
 #endif
+#ifndef SG_KP_WIN
+#define SG_KP_WIN 3       /* k_power: a work item of the multi-flake beams is this many waves' worth of slots, taken in order of flake count */
+#endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
@@ -408,8 +411,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
 // ------------------------------------------------------------------------------------------------
 // Work items of k_power for the queue of a direct-mode pass: one item = up to `lanes` consecutive live slots of one
 // region (its front run, then its back run).  One thread per region; items are appended with one atomic per wave.
-// item = {first slot, count | (frame + 1) << 7}.
-__global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int n_regions_ub)
+// item = {first slot, count | (frame + 1) << 10}; the back run (beams with several flakes) in items of lanes_back slots.
+__global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int lanes_back, int n_regions_ub)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     int n_items = 0, nf = 0, nb = 0, q_size = 0, f1 = 0;
@@ -431,7 +434,7 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
     if (mine) {
         const unsigned long long c = a.qn[r];
         nf = (int)(c & 0xffffffffull); nb = (int)(c >> 32);
-        n_items = (nf + lanes - 1) / lanes + (nb + lanes - 1) / lanes;
+        n_items = (nf + lanes - 1) / lanes + (nb + lanes_back - 1) / lanes_back;
     }
     int inc = n_items;                                // inclusive scan over the wave, one atomic for its total
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
@@ -440,9 +443,9 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
     if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(a.pw_count, total);
     base = __shfl(base, 63) + inc - n_items;
     for (int k = 0; k < nf; k += lanes)
-        a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 7));
-    for (int k = 0; k < nb; k += lanes)
-        a.pw_items[base++] = make_int2((int)(q_base + q_size - nb + k), (nb - k < lanes ? nb - k : lanes) | (f1 << 7));
+        a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 10));
+    for (int k = 0; k < nb; k += lanes_back)
+        a.pw_items[base++] = make_int2((int)(q_base + q_size - nb + k), (nb - k < lanes_back ? nb - k : lanes_back) | (f1 << 10));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,6 +463,7 @@ template <typename T, int LMAX, int BLOCK, bool LISTQ>
 __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 1) void k_power(SgBeamArgs a)
 {
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
+    constexpr int WIN = BLOCK < 64 ? 1 : SG_KP_WIN;       // waves' worth of slots per work item
     constexpr int P = SG_QPLANES(LMAX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_a1 = (double *)smem;
@@ -474,95 +478,118 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
         work_n = a.tier_info[a.cls];
         if (work_n > a.work_hi) work_n = a.work_hi;
         work_off = a.tier_info[4 + a.cls];
-        n_items = (int)((work_n + LANES - 1) / LANES);
+        n_items = (int)((work_n + LANES * WIN - 1) / (LANES * WIN));
     } else {
         n_items = *a.pw_count;
     }
     const int step = (int)gridDim.x * WAVES;
-    int i = (int)blockIdx.x * WAVES + (tid >> 6);
-    if (i >= n_items) return;
     const double *planes = LISTQ ? a.tq : a.dq;
     const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
-    // slot data of one item, as far as every beam has it: flag word, sorted position, range, azimuth and the first flake
-    struct Item { int64_t slot; int f; bool live; unsigned sc; int32_t g; double d, tc, a1, a2, rho; };
-    auto fetch = [&](int it) -> Item {
-        Item m;
-        int start, cnt;
-        m.f = -1;
+    static_assert(WIN <= 4, "the window's permutation passes through one 64-double row segment of the wave");
+    uint16_t *s_perm = (uint16_t *)(s_ratio + (BLOCK < 64 ? 0 : (tid & ~63)));   // dead between two beams: this wave's columns of row 0
+    int perm[WIN];
+    for (int i = (int)blockIdx.x * WAVES + (tid >> 6); i < n_items; i += step) {
+        int start, cnt, item_f = -1;
         if (LISTQ) {
-            start = it * LANES;
-            cnt = (int)(work_n - start < LANES ? work_n - start : LANES);
+            start = i * (LANES * WIN);
+            cnt = (int)(work_n - start < LANES * WIN ? work_n - start : LANES * WIN);
         } else {
-            const int2 d = a.pw_items[it];
-            start = d.x; cnt = d.y & 127; m.f = (d.y >> 7) - 1;
+            const int2 d = a.pw_items[i];
+            start = d.x; cnt = d.y & 1023; item_f = (d.y >> 10) - 1;
         }
-        m.live = lane < cnt;
-        m.slot = (int64_t)start + lane;
-        m.sc = 0xffffu; m.g = 0; m.d = m.tc = m.a1 = m.a2 = m.rho = 0.0;
-        if (m.live) {
-            m.sc = scs[m.slot];
-            m.g = LISTQ ? a.tier_list[work_off + m.slot] : a.dq_g[m.slot];
-            m.d = planes[sg_qaddr<P>(m.slot, 0)]; m.tc = planes[sg_qaddr<P>(m.slot, 1)];
-            m.a1 = planes[sg_qaddr<P>(m.slot, 2)]; m.a2 = planes[sg_qaddr<P>(m.slot, 3)]; m.rho = planes[sg_qaddr<P>(m.slot, 4)];
-        }
-        return m;
-    };
-    Item cur = fetch(i);
-    for (;;) {
-        const int nxt_i = i + step;
-        const bool more = nxt_i < n_items;             // wave-uniform
-        Item nxt = cur;
-#if SG_KP_PREFETCH
-        if (more) nxt = fetch(nxt_i);                  // in flight while the current item is computed
-#endif
-        const bool live = cur.live && cur.sc != 0xffffu;   // 0xffff: a listed beam without a flake (its record is final)
-        const int L = (int)(cur.sc & 255u), ch = (int)(cur.sc >> 8);
-        int f = 0;
-        SgBeamOut o;
-        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
-        if (live) {
-            f = cur.f >= 0 ? cur.f : sg_frame_of(a, cur.g);
-            s_a1[0 * BLOCK + ltid] = cur.a1; s_a2[0 * BLOCK + ltid] = cur.a2; s_rho[0 * BLOCK + ltid] = cur.rho;
-            for (int j = 1; j < L; ++j) {
-                s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 2 + 3 * j)];
-                s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 3 + 3 * j)];
-                s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(cur.slot, 4 + 3 * j)];
-            }
-            const double d = cur.d;                     // the beam's range (simulation.py:89), widened from the row dtype
-            int32_t *dc = a.dbg_count ? a.dbg_count + cur.g : nullptr;
-            double *drj = a.dbg_count ? a.dbg_rj + (int64_t)cur.g * a.dbg_cap : nullptr;
-            double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)cur.g * a.dbg_cap : nullptr;
-            const int S = sg_beam_dict<LMAX, BLOCK>(L, cur.tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
-            uint32_t rec = 0;                           // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
-#ifdef SG_EXP_KP_NOP3
-            if (S > 1000) {
-#else
-            if (S > 0) {
-#endif
-                const T d_t = (T)d;                     // exact
-                sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
-                if (o.range_error) {
-                    atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
-                    atomicCAS(&a.status[1], -1, cur.g);
+        // A window of several waves' worth of slots is taken in order of flake count: the cost of phases 2 and 3 grows
+        // steeply with the list length, and a wave is as slow as its longest list (counting sort by ballots; the slots of
+        // a window are neighbours in every plane of the queue, so the permuted reads touch the same lines).
+        const bool sorted = WIN > 1 && cnt > LANES;          // wave-uniform
+        if constexpr (WIN > 1) {
+            if (sorted) {
+                int key[WIN], rank[WIN];
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) {
+                    const int idx = r * 64 + lane;
+                    key[r] = 255;                             // past the end of the window: last
+                    if (idx < cnt) { const unsigned sc = scs[(int64_t)start + idx]; key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u); }
+                    rank[r] = 0;
                 }
-                constexpr int NB = LMAX <= 4 ? SG_NB4 : 8;
-                double best = 0.0;
-                int k_best = 0;
-                if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-                else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-                sg_beam_decide(d, ch, a.las, best, k_best, o);
-                rec = sg_pack_record(o);
+                int base = 0;
+                auto place = [&](int c) {
+#pragma unroll
+                    for (int r = 0; r < WIN; ++r) {
+                        const unsigned long long m = __ballot(key[r] == c);
+                        if (key[r] == c) rank[r] = base + (int)__popcll(m & sg_lanemask_lt());
+                        base += (int)__popcll(m);
+                    }
+                };
+                for (int c = 0; c <= LMAX; ++c) place(c);
+                place(254); place(255);
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) s_perm[rank[r]] = (uint16_t)(r * 64 + lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written and read by the lanes of one wave: no barrier, but keep the order
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) perm[r] = s_perm[r * 64 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the lists of the first beam overwrite it)
             }
-            if (LISTQ) a.rec[cur.g] = rec;
-            else a.rec_q[cur.slot] = rec;               // the row's record points here (SG_REC_SLOT)
         }
-        sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
-        if (!more) break;
-#if !SG_KP_PREFETCH
-        nxt = fetch(nxt_i);
-#endif
-        cur = nxt;
-        i = nxt_i;
+        const int rounds = (cnt + LANES - 1) / LANES;
+        for (int r = 0; r < rounds; ++r) {
+            const int idx = r * LANES + lane;
+            const bool in = lane < LANES && idx < cnt;
+            int pos = idx;
+            if constexpr (WIN > 1) {
+                if (sorted) {
+#pragma unroll
+                    for (int q = 0; q < WIN; ++q) if (q == r) pos = perm[q];
+                }
+            }
+            const int64_t slot = (int64_t)start + pos;
+            unsigned sc = 0xffffu;
+            int32_t g = 0;
+            double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
+            if (in) {                                         // everything a beam surely has, in one round of loads
+                sc = scs[slot];
+                g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
+                d = planes[sg_qaddr<P>(slot, 0)];             // the beam's range (simulation.py:89), widened from the row dtype
+                tc = planes[sg_qaddr<P>(slot, 1)];
+                f_a1 = planes[sg_qaddr<P>(slot, 2)]; f_a2 = planes[sg_qaddr<P>(slot, 3)]; f_rho = planes[sg_qaddr<P>(slot, 4)];
+            }
+            const bool live = in && sc != 0xffffu;            // 0xffff: a listed beam without a flake (its record is final)
+            const int L = (int)(sc & 255u), ch = (int)(sc >> 8);
+            int f = 0;
+            SgBeamOut o;
+            o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+            if (live) {
+                f = item_f >= 0 ? item_f : sg_frame_of(a, g);
+                s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
+                for (int j = 1; j < L; ++j) {
+                    s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 2 + 3 * j)];
+                    s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 3 + 3 * j)];
+                    s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
+                }
+                int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+                double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
+                double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)g * a.dbg_cap : nullptr;
+                const int S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+                uint32_t rec = 0;                           // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
+                if (S > 0) {
+                    const T d_t = (T)d;                     // exact
+                    sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
+                    if (o.range_error) {
+                        atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+                        atomicCAS(&a.status[1], -1, g);
+                    }
+                    constexpr int NB = LMAX <= 4 ? SG_NB4 : 8;
+                    double best = 0.0;
+                    int k_best = 0;
+                    if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                    else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                    sg_beam_decide(d, ch, a.las, best, k_best, o);
+                    rec = sg_pack_record(o);
+                }
+                if (LISTQ) a.rec[g] = rec;
+                else a.rec_q[slot] = rec;                   // the row's record points here (SG_REC_SLOT)
+            }
+            sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+        }
     }
 }
 
@@ -1164,7 +1191,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
     if (!LISTQ) {
         const unsigned pg = (unsigned)((a->n_regions_ub + 255) / 256);
         if (pg == 0) return 0;
-        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, (int)a->n_regions_ub);
+        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, LANES * (BLOCK < 64 ? 1 : SG_KP_WIN), (int)a->n_regions_ub);
         SG_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);

@@ -156,6 +156,23 @@ __global__ __launch_bounds__(64) void k_file_sort(const uint32_t *__restrict__ s
     }
 }
 
+// Coarse range index of a filed table: q[b][k] = records of bin b nearer than SG_QSTEP_M * k metres.  The scan pass starts
+// its search for "records nearer than the target" from the two entries around the target's range instead of the whole bin.
+__global__ __launch_bounds__(64) void k_table_index(const SgEntry *__restrict__ entries, const uint32_t *__restrict__ start,
+                                                    uint32_t *__restrict__ q)
+{
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k >= SG_QSTEPS) return;
+    const uint32_t e0 = start[b];
+    uint32_t lo = e0, hi = start[b + 1];
+    const double lim = SG_QSTEP_M * (double)k;
+    while (lo < hi) {
+        const uint32_t m = (lo + hi) >> 1;
+        if (entries[m].rho < lim) lo = m + 1; else hi = m;
+    }
+    q[b * SG_QSTEPS + k] = lo - e0;
+}
+
 // per-flake quantities of a filed table by table row (debug tap): the copy filed under the flake's first bin
 __global__ __launch_bounds__(TB) void k_table_dump(const SgEntry *__restrict__ entries, uint32_t n_entries, double *__restrict__ out /* K x 4 */)
 {
@@ -196,6 +213,13 @@ extern "C" int sg_file_table_stage_b(int64_t k, const SgEntry *fl, const int32_t
         TCHK();
     }
     hipLaunchKernelGGL(k_file_sort, dim3(SG_NBINS), dim3(64), 0, st, start, tmp, entries);
+    TCHK();
+    return 0;
+}
+
+extern "C" int sg_table_index(const SgEntry *entries, const uint32_t *start, uint32_t *q, void *stream)
+{
+    hipLaunchKernelGGL(k_table_index, dim3(SG_NBINS), dim3(64), 0, (hipStream_t)stream, entries, start, q);
     TCHK();
     return 0;
 }
