@@ -26,6 +26,9 @@ struct SgEntry {
 #define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m */
 #define SG_QSTEP_M 8.0
 
+#define SG_SPILL_CAP 8
+#define SG_SPILL_STRIDE (4 + 4 * SG_SPILL_CAP)   /* doubles per spill slot: 3 header values + pad, 4 per flake */
+
 struct SgTable {
     const SgEntry *entries;     // bins concatenated, each bin sorted by rho ascending
     const uint32_t *bin_start;  // n_bins + 1 offsets into entries
@@ -127,6 +130,12 @@ struct SgBeamArgs {
     double *tq;
     uint16_t *tq_sc;
     int32_t tq_cap;
+    // Spill slots of the pass over all rows, one per sorted position (SG_SPILL_STRIDE doubles): a beam that meets more flakes
+    // than its LDS list holds, up to spill_cap, leaves ALL of them here -- range, azimuth, count | channel << 8, then
+    // (a1, a2, rho, scan order) per flake, unsorted -- and its tier's k_power reads them instead of scanning again.
+    double *spill;
+    int32_t spill_cap;           // 0: no spill slots (every over-full beam is scanned again by its tier)
+    int32_t spill_list;          // k_power<.., LISTQ>: the class's flake lists are the spill slots of its rows
     // global-list tier: per-lane lists in global memory, h_cap entries each, h_lanes lanes
     double *h_lists;
     int32_t h_cap, h_lanes;

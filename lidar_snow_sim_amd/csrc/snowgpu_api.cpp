@@ -83,6 +83,7 @@ struct snowgpu_ctx {
     DevBuf<uint16_t> dq_sc;
     DevBuf<unsigned long long> qn;    // per region: front | back << 32
     DevBuf<int2_t> pw_items;          // work items of k_power
+    DevBuf<double> spill;             // spill slots of the 4-entry pass
     DevBuf<int32_t> pw_count;
     DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
@@ -91,6 +92,7 @@ struct snowgpu_ctx {
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
+    int use_spill = 0;                // SNOWGPU_SPILL=1: over-full beams of the 4-entry pass leave their lists in spill slots (off: see DESIGN.md)
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
@@ -178,6 +180,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_SPILL"); ctx->use_spill = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
@@ -222,7 +225,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->rec_q.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->spill.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -758,6 +761,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
     }
+    // Spill slots (SNOWGPU_SPILL=1): the beams the 4-entry pass finds over-full but within 8 flakes leave their lists behind,
+    // and the 8-entry tier starts from those instead of scanning again (288 bytes per sorted position, touched by a few per
+    // cent of them).  Off by default: the scattered stores cost the pass over all rows more (+0.10 ms on the 256-frame batch)
+    // than the tier's scan costs beside the other kernels of the tail; with every kernel alone on the chip it saves 0.27 ms.
+    const bool use_spill = ctx->use_spill && tiers[0] == 4 && n_cls >= 2 && tiers[1] == SG_SPILL_CAP && ctx->per_lane_scan <= 0 &&
+                           n * SG_SPILL_STRIDE * sizeof(double) <= ((size_t)32 << 30);
+    if (use_spill) {
+        ENSURE(ctx, ctx->spill, (n + 256) * SG_SPILL_STRIDE);
+        a.spill = ctx->spill.p; a.spill_cap = SG_SPILL_CAP;
+    }
     if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
@@ -810,6 +823,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             break;
         }
         const int lmax = tiers[k + 1];
+        if (k == 0 && use_spill) {                       // its lists are in the spill slots: received power only
+            a.tq = nullptr; a.tq_sc = nullptr; a.tq_cap = 0; a.spill_list = 1;
+            a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
+            e = sg_launch_power_list(&a, b.dtype, lmax, sk);
+            a.spill_list = 0;
+            continue;
+        }
         a.tq = ctx->tq[k].p; a.tq_sc = ctx->tq_sc[k].p; a.tq_cap = (int32_t)tq_caps[k];
         a.work_lo = 0; a.work_hi = (int32_t)tq_caps[k];
         e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);                       // scan + dict, hand-over

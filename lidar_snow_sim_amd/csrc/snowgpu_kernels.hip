@@ -26,6 +26,9 @@
 #ifndef SG_KP_WIN
 #define SG_KP_WIN 3       /* k_power: a work item of the multi-flake beams is this many waves' worth of slots, taken in order of flake count */
 #endif
+#ifndef SG_FP_WAVES
+#define SG_FP_WAVES 5     /* waves per SIMD the pass over all rows is compiled for = what its LDS lists allow (96 VGPRs; 100 uncapped, which costs the fifth wave; 4 registers go to scratch) */
+#endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
@@ -214,7 +217,7 @@ __device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool liv
 //                 live lanes, 32 KB of LDS per block instead of 131 KB -- a block that needs most of a CU's LDS waits until
 //                 one has drained, and meanwhile holds up everything queued behind it.
 template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
-__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK == 256) ? SG_FP_WAVES : 1) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // hand-over passes keep three LMAX-entry lists (interval angles, range); the in-place passes four of LMAX + 1 entries
@@ -308,8 +311,19 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK) void k_beams(SgBeamArgs a)
         if (LIST ? a.per_lane_scan >= 0 : a.per_lane_scan > 0) {
             if (act) L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
         } else {
+            double *spill_blk = nullptr;              // spill slot of this block's column 0 (sorted positions follow the columns)
+            if (!LIST && a.spill_cap > 0) spill_blk = a.spill + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_SPILL_STRIDE;
             L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, tid, o, d_t, theta_c,
-                                             a.exact_math != 0);
+                                             a.exact_math != 0, spill_blk, spill_blk ? a.spill_cap : 0);
+            if (spill_blk && act && o.overflow && o.n_hits <= a.spill_cap) {   // header and the flakes the LDS list holds
+                double *sp = spill_blk + (size_t)tid * SG_SPILL_STRIDE;
+                sp[0] = (double)d_t; sp[1] = theta_c; sp[2] = __hiloint2double(0, o.n_hits | (ch << 8));
+                for (int j = 0; j < LMAX; ++j) {
+                    double *e = sp + 4 + 4 * j;
+                    e[0] = s_a1[j * BLOCK + tid]; e[1] = s_a2[j * BLOCK + tid]; e[2] = s_rho[j * BLOCK + tid];
+                    e[3] = __hiloint2double(0, s_key[j * BLOCK + tid]);
+                }
+            }
         }
         if (act) {
             o.has_power = !o.overflow && L > 0;       // k_power builds the dict (phase 2) and everything after it
@@ -508,7 +522,12 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                 for (int r = 0; r < WIN; ++r) {
                     const int idx = r * 64 + lane;
                     key[r] = 255;                             // past the end of the window: last
-                    if (idx < cnt) { const unsigned sc = scs[(int64_t)start + idx]; key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u); }
+                    if (idx < cnt) {
+                        unsigned sc;
+                        if (LISTQ && a.spill_list) sc = (unsigned)__double2loint(a.spill[(size_t)a.tier_list[work_off + start + idx] * SG_SPILL_STRIDE + 2]);
+                        else sc = scs[(int64_t)start + idx];
+                        key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
+                    }
                     rank[r] = 0;
                 }
                 int base = 0;
@@ -545,7 +564,13 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             unsigned sc = 0xffffu;
             int32_t g = 0;
             double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
-            if (in) {                                         // everything a beam surely has, in one round of loads
+            const bool from_spill = LISTQ && a.spill_list;    // the class's lists are the spill slots of the pass over all rows
+            const double *sp = nullptr;
+            if (in && from_spill) {
+                g = a.tier_list[work_off + slot];
+                sp = a.spill + (size_t)g * SG_SPILL_STRIDE;
+                d = sp[0]; tc = sp[1]; sc = (unsigned)__double2loint(sp[2]);
+            } else if (in) {                                  // everything a beam surely has, in one round of loads
                 sc = scs[slot];
                 g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
                 d = planes[sg_qaddr<P>(slot, 0)];             // the beam's range (simulation.py:89), widened from the row dtype
@@ -559,11 +584,29 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
             if (live) {
                 f = item_f >= 0 ? item_f : sg_frame_of(a, g);
-                s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
-                for (int j = 1; j < L; ++j) {
-                    s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 2 + 3 * j)];
-                    s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 3 + 3 * j)];
-                    s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
+                if (from_spill) {
+                    // the flakes as the scan met them: insertion sort by (range, scan order) while loading (simulation.py:413-417);
+                    // the scan order rides in the ratio column, which phase 2 overwrites
+                    for (int j = 0; j < L && j < LMAX; ++j) {
+                        const double x1 = sp[4 + 4 * j], x2 = sp[5 + 4 * j], r = sp[6 + 4 * j];
+                        const int k = __double2loint(sp[7 + 4 * j]);
+                        int q = j;
+                        while (q > 0 && (s_rho[(q - 1) * BLOCK + ltid] > r ||
+                                         (s_rho[(q - 1) * BLOCK + ltid] == r && __double2loint(s_ratio[(q - 1) * BLOCK + ltid]) > k))) {
+                            s_rho[q * BLOCK + ltid] = s_rho[(q - 1) * BLOCK + ltid]; s_a1[q * BLOCK + ltid] = s_a1[(q - 1) * BLOCK + ltid];
+                            s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid]; s_ratio[q * BLOCK + ltid] = s_ratio[(q - 1) * BLOCK + ltid];
+                            --q;
+                        }
+                        s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2;
+                        s_ratio[q * BLOCK + ltid] = __hiloint2double(0, k);
+                    }
+                } else {
+                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
+                    for (int j = 1; j < L; ++j) {
+                        s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 2 + 3 * j)];
+                        s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 3 + 3 * j)];
+                        s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
+                    }
                 }
                 int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
                 double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
