@@ -212,10 +212,10 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
 // pairs at a time whichever beams they belong to -- the owner's geometry travels by cross-lane reads.  A hit is appended to
 // its owner's list through an LDS counter; every beam sorts its few entries by (range, scan order) afterwards, which is the
 // order the per-lane scan produces.  Bins beyond the second (wedges wider than a bin) keep the per-lane loop.
-// s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries).
+// s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries); s_st: two ints per lane.
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
-                                            double *s_rho, int *s_cnt, int *s_key, int tid, SgBeamOut &out, T &d_t, double &theta_c,
+                                            double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
                                             bool EXACT_TAN, double *spill = nullptr, int spill_cap = 0)
 {
     // spill: slot of the block's column 0 (slots follow the columns), or null.  Flakes LMAX .. spill_cap - 1 of a beam go to
@@ -262,6 +262,10 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         n0 = (int)(lo0 - st0); n1 = (int)(lo1 - st2);
     }
     s_cnt[tid] = 0;                                             // same wave writes and bumps it: LDS operations of a wave keep their order
+    // first records of the beam's two bins: read by whichever lane tests one of its records -- through LDS, not a cross-lane
+    // register read, so that they need no register during the loop (the kernel sits at the edge of a fifth wave per SIMD)
+    s_st[2 * tid] = (int)st0; s_st[2 * tid + 1] = (int)st2;
+    asm volatile("" ::: "memory");
     const int cnt = n0 + n1;
     int incl = cnt;
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -281,7 +285,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         const int o = lo & 63;
         const int j = p - __shfl(excl, o);
         const int n0o = __shfl(n0, o);
-        const uint32_t st0o = __shfl(st0, o), st2o = __shfl(st2, o);     // (cross-lane reads stay outside divergent code)
+        const uint32_t st0o = (uint32_t)s_st[2 * (wbase + o)], st2o = (uint32_t)s_st[2 * (wbase + o) + 1];
         const uint32_t e = j < n0o ? st0o + (uint32_t)j : st2o + (uint32_t)(j - n0o);
         SgBeamGeo og;
         og.d = __shfl(g.d, o); og.theta_c = __shfl(g.theta_c, o);
@@ -653,10 +657,12 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
 //           Applied to the strongest scatterer covering the bin (the others then being the weaker overlapping
 //           windows only), every bin that matters lies in such a zone; q_t < 1/2 keeps the whole window.
 // WCAP: slots of the per-lane work list (0: run-time capacity `rwcap`, the global-list tier)
+// sg_power_plan: stage A; returns the number of listed groups still to be evaluated (a full list is evaluated on the
+// spot, by this lane alone).  sg_lane_power: stages A and B by one lane.  sg_wave_eval: stage B by the whole wave.
 template <int STRIDE, bool EXACT, int NB, int WCAP>
-__device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
-                                              const double *s_rho, double *s_work, int tid, double &best, int &k_best,
-                                              int rstride = 0, int rwcap = 0)
+__device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
+                                             const double *s_rho, double *s_work, int tid, double &best, int &k_best,
+                                             int rstride = 0, int rwcap = 0)
 {
     best = 0.0;
     k_best = 0;
@@ -671,9 +677,6 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
     const double floor_ = 0.9966 * amax;
     int nw = 0;
     auto flush = [&]() {
-#ifdef SG_EXP_KP_NOSTAGEB
-        if (nw < 1000) { nw = 0; return; }
-#endif
         for (int w = 0; w < nw; ++w)
             sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
                                              tk1, tamp, td, best, k_best, rstride);
@@ -717,7 +720,8 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
             const double delta = (double)sqrtf((float)(1.26 * om)) * (1.0 + 1e-6) + 1e-6;
             const double Rc = s_rho[SG_IDX(t)] + c_tau / 2;
             const double D = delta * (c_tau / SG_PI) + 0.006;      // + half a centimetre of grid rounding
-            const int za = (int)floor((Rc - D) * (1.0 / step)), zb = (int)ceil((Rc + D) * (1.0 / step));
+            // bins whose grid value k * step (+- 0.005 of rounding, inside D) lies in [Rc - D, Rc + D]: one or two of them
+            const int za = (int)ceil((Rc - D) * (1.0 / step)), zb = (int)floor((Rc + D) * (1.0 / step));
             if (za > ka) ka = za;
             if (zb < kb) kb = zb;
         }
@@ -729,8 +733,71 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
             ++nw;
         }
     }
+    return nw;
+}
+
+template <int STRIDE, bool EXACT, int NB, int WCAP>
+__device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
+                                              const double *s_rho, double *s_work, int tid, double &best, int &k_best,
+                                              int rstride = 0, int rwcap = 0)
+{
+    const int nw = sg_power_plan<STRIDE, EXACT, NB, WCAP>(S, rgrid, s_a1, s_a2, s_rho, s_work, tid, best, k_best, rstride, rwcap);
     // ---- stage B ----
-    flush();
+    const double tpk = s_a2[SG_IDX(S)];
+    const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+    const double tamp = s_a1[SG_IDX(S)], td = s_rho[SG_IDX(S)];
+    for (int w = 0; w < nw; ++w)
+        sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td,
+                                         best, k_best, rstride);
+}
+
+// Stage B by the whole wave (every lane of the wave calls it, nw = 0 for a lane without a beam).  The lanes list 0 .. WCAP
+// groups each, and a group costs a dozen sines per scatterer that reaches it: lane by lane, most of a wave idles behind the
+// lane with the longest list (SQ counters: 21 % of the lanes active in this stage, which is 60 % of k_power's instructions).
+// Here the listed groups of all 64 beams are numbered by a prefix sum and taken 64 at a time, whichever beam they belong to
+// -- the evaluating lane reads the owner's scatterer columns -- and every owner then folds the results of its groups, in
+// any order (the first-maximum rule does not depend on it).  colbase: column of the wave's lane 0.
+template <int STRIDE, bool EXACT, int NB>
+__device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__restrict__ rgrid, const double *s_a1, const double *s_a2,
+                                             const double *s_rho, const double *s_work, int colbase, double &best, int &k_best)
+{
+    static_assert(STRIDE > 0, "LDS lists only");
+    const int lane = (int)(threadIdx.x & 63);
+    int incl = nw;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int excl = incl - nw;
+    const int total = __shfl(incl, 63);
+    int maxn = nw;
+    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxn, o); maxn = v > maxn ? v : maxn; }
+    for (int base = 0; base < total; base += 64) {
+        const int p = base + lane;
+        const bool valid = p < total;
+        int lo = 0, hi = 63;                                    // owner = first lane whose inclusive count exceeds p
+        for (int it = 0; it < 6; ++it) {
+            const int mid = (lo + hi) >> 1;
+            const int v = __shfl(incl, mid);
+            if (v > p) hi = mid; else lo = mid + 1;
+        }
+        const int o = lo & 63;
+        const int j = p - __shfl(excl, o);
+        const int So = __shfl(S, o);
+        double gbest = -1.0;
+        int gk = 0x7fffffff;
+        if (valid) {
+            const int tid = colbase + o;                        // the owner's column (SG_IDX)
+            constexpr int rstride = 0;
+            const int g = __double2loint(s_work[SG_IDX(j)]);
+            const double tpk = s_a2[SG_IDX(So)];
+            sg_eval_group<STRIDE, EXACT, NB>(g, 0, So, rgrid, s_a1, s_a2, s_rho, tid, __double2loint(tpk), __double2hiint(tpk),
+                                             s_a1[SG_IDX(So)], s_rho[SG_IDX(So)], gbest, gk, 0);
+        }
+        for (int r = 0; r < maxn; ++r) {                        // (cross-lane reads outside divergent code)
+            const int q = excl + r - base;
+            const double gb = __shfl(gbest, q & 63);
+            const int k = __shfl(gk, q & 63);
+            if (r < nw && q >= 0 && q < 64 && (gb > best || (gb == best && k < k_best))) { best = gb; k_best = k; }
+        }
+    }
 }
 
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------

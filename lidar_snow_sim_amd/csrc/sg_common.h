@@ -85,8 +85,8 @@ struct SgBeamArgs {
     int32_t *status;             // [0] error code, [1] first offending sorted row
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
     int32_t exact_math;          // 1: libm sin / tan + true division (validation mode)
-    int32_t per_lane_scan;       // candidate scan: 0 = the wave flattens it in the pass over all rows, one beam per lane in the tiers;
-                                 // 1 = one beam per lane everywhere; -1 = flattened everywhere (SNOWGPU_PER_LANE_SCAN)
+    int32_t per_lane_scan;       // candidate scan: >= 0: the wave flattens it in the pass over all rows, one beam per lane in the tiers;
+                                 // -1 = flattened everywhere (SNOWGPU_PER_LANE_SCAN)
     // tier classes: a beam of the first pass that met more flakes than its list holds is flagged with the first later
     // tier whose capacity takes all of them (the scan keeps COUNTING after the list is full, so the count is exact)
     int32_t n_cls;               // later tiers (the last one is the global-list tier, capacity = table size)

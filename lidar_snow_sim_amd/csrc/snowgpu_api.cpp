@@ -96,7 +96,7 @@ struct snowgpu_ctx {
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
-    int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=1 one beam per lane everywhere, -1 wave scan everywhere
+    int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;

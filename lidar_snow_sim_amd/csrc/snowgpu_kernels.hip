@@ -29,6 +29,9 @@
 #ifndef SG_FP_WAVES
 #define SG_FP_WAVES 5     /* waves per SIMD the pass over all rows is compiled for = what its LDS lists allow (96 VGPRs; 100 uncapped, which costs the fifth wave; 4 registers go to scratch) */
 #endif
+#ifndef SG_NB_TIERS
+#define SG_NB_TIERS 8
+#endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
@@ -216,7 +219,7 @@ __device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool liv
 //   BLOCK         beams per block = stride of the LDS lists.  BLOCK = 16 (the 63-entry tier) still launches one wave: 16
 //                 live lanes, 32 KB of LDS per block instead of 131 KB -- a block that needs most of a CU's LDS waits until
 //                 one has drained, and meanwhile holds up everything queued behind it.
-template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
+template <typename T, int LMAX, int BLOCK, bool LIST, int DICT>
 __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK == 256) ? SG_FP_WAVES : 1) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
     double *s_ratio = DICT ? nullptr : s_rho + ROWS * BLOCK;
     int *s_cnt = DICT ? (int *)(s_rho + ROWS * BLOCK) : nullptr;          // wave scan: flakes met per beam ...
     int *s_key = DICT ? s_cnt + (BLOCK < 64 ? 64 : BLOCK) : nullptr;      // ... and the scan order of the stored ones
+    int *s_st = DICT ? s_key + LMAX * BLOCK : nullptr;                    // ... and where its two bins start (two ints per lane)
     const int tid = threadIdx.x;
     const int n_las = a.las->n;
     int64_t work_n = 0, work_off = 0;
@@ -246,12 +250,17 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
         const int64_t lo = a.chunk_blk ? a.chunk_blk[a.chunk] : a.blk_lo, hi = a.chunk_blk ? a.chunk_blk[a.chunk + 1] : a.blk_hi;
         blk += lo;
         if (blk >= hi) return;                        // surplus block (the grid is an upper bound)
+        blk = (int64_t)__builtin_amdgcn_readfirstlane((int)blk);   // (scalar: see below)
         if (a.seg_blk) {
-            const int sg = a.seg_of_blk[blk];         // one load instead of a dependent search per block
-            const int off = (int)(blk - a.seg_blk[sg]) * BLOCK + tid;
-            const int fc = a.seg_frame[sg];
+            // block-uniform values, pinned to scalar registers (left to itself the compiler kept the region index in a vector
+            // register pair for the whole kernel -- and spilled it when the kernel was held to five waves per SIMD)
+            const int sg = __builtin_amdgcn_readfirstlane(a.seg_of_blk[blk]);   // one load instead of a dependent search per block
+            const int blk0 = __builtin_amdgcn_readfirstlane((int)a.seg_blk[sg]);
+            const int off = ((int)blk - blk0) * BLOCK + tid;
+            const int fc = __builtin_amdgcn_readfirstlane(a.seg_frame[sg]);
             seg_f = fc & 0x3fffff; seg_ch = (int)((unsigned)fc >> 22);
-            q_base = a.seg_start[sg]; q_size = a.seg_cnt[sg]; region = sg;
+            q_base = (int64_t)__builtin_amdgcn_readfirstlane((int)a.seg_start[sg]);      // segments exist for n_total < 2^31
+            q_size = __builtin_amdgcn_readfirstlane(a.seg_cnt[sg]); region = sg;
             if (tid < BLOCK && off < q_size) seg_g = q_base + off;
         } else {
             region = (int)((blk * BLOCK) / a.q_chunk);
@@ -308,12 +317,12 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
         // The pass over all rows scans as a wave (every lane takes part, whether it has a beam or not): its beams' lists
         // differ 20-fold in length.  The later tiers hold beams with long lists of similar length; one beam per lane is a
         // little faster there (measured 0.37 vs 0.41 ms for tier 8).
-        if (LIST ? a.per_lane_scan >= 0 : a.per_lane_scan > 0) {
+        if (LIST && a.per_lane_scan >= 0) {
             if (act) L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
         } else {
             double *spill_blk = nullptr;              // spill slot of this block's column 0 (sorted positions follow the columns)
-            if (!LIST && a.spill_cap > 0) spill_blk = a.spill + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_SPILL_STRIDE;
-            L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, tid, o, d_t, theta_c,
+            if constexpr (DICT == 2) spill_blk = a.spill + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_SPILL_STRIDE;
+            L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
                                              a.exact_math != 0, spill_blk, spill_blk ? a.spill_cap : 0);
             if (spill_blk && act && o.overflow && o.n_hits <= a.spill_cap) {   // header and the flakes the LDS list holds
                 double *sp = spill_blk + (size_t)tid * SG_SPILL_STRIDE;
@@ -380,7 +389,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
                 const int leader = __ffsll((long long)(mf | mb)) - 1;
                 unsigned long long base = 0;
                 if ((tid & 63) == leader)
-                    base = atomicAdd(&a.qn[region], (unsigned long long)__popcll(mf) | ((unsigned long long)__popcll(mb) << 32));
+                    base = atomicAdd(&a.qn[__builtin_amdgcn_readfirstlane(region)], (unsigned long long)__popcll(mf) | ((unsigned long long)__popcll(mb) << 32));
                 const unsigned blo = __shfl((unsigned)(base & 0xffffffffull), leader), bhi = __shfl((unsigned)(base >> 32), leader);
                 if (o.has_power) {
                     const int64_t slot = front ? q_base + (int)blo + (int)__popcll(mf & sg_lanemask_lt())
@@ -582,6 +591,9 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             int f = 0;
             SgBeamOut o;
             o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+            constexpr int NB = LMAX <= 4 ? SG_NB4 : SG_NB_TIERS;   // bins of the power profile carried together
+            int S = 0, nw = 0, k_best = 0;
+            double best = 0.0;
             if (live) {
                 f = item_f >= 0 ? item_f : sg_frame_of(a, g);
                 if (from_spill) {
@@ -611,20 +623,28 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                 int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
                 double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
                 double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)g * a.dbg_cap : nullptr;
-                const int S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
-                uint32_t rec = 0;                           // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
-                if (S > 0) {
+                S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+                if (S > 0) {                                // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
                     const T d_t = (T)d;                     // exact
                     sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
                     if (o.range_error) {
                         atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
                         atomicCAS(&a.status[1], -1, g);
                     }
-                    constexpr int NB = LMAX <= 4 ? SG_NB4 : 8;
-                    double best = 0.0;
-                    int k_best = 0;
-                    if (a.exact_math) sg_lane_power<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-                    else sg_lane_power<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                    // stage A of the received-power profile, lane by lane: the few groups of bins that can hold its maximum
+                    if (a.exact_math) nw = sg_power_plan<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                    else nw = sg_power_plan<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                } else S = 0;
+            }
+            // stage B, the whole wave over the groups of its 64 beams
+            {
+                const int colbase = BLOCK < 64 ? 0 : (tid & ~63);
+                if (a.exact_math) sg_wave_eval<BLOCK, true, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, colbase, best, k_best);
+                else sg_wave_eval<BLOCK, false, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, colbase, best, k_best);
+            }
+            if (live) {
+                uint32_t rec = 0;
+                if (S > 0) {
                     sg_beam_decide(d, ch, a.las, best, k_best, o);
                     rec = sg_pack_record(o);
                 }
@@ -1178,10 +1198,10 @@ static int sg_set_lds(K kernel, size_t lds, bool *attr_set)
     return 0;
 }
 
-template <typename T, int LMAX, int BLOCK, bool LIST, bool DICT>
+template <typename T, int LMAX, int BLOCK, bool LIST, int DICT>
 static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 {
-    const size_t lds = DICT ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX + sizeof(int) * ((size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
+    const size_t lds = DICT ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX + sizeof(int) * (3 * (size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
                             : sizeof(double) * (size_t)BLOCK * 4 * ((size_t)LMAX + 1);
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
@@ -1209,8 +1229,11 @@ static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 template <typename T, int LMAX, int BLOCK>
 static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStream_t st)
 {
-    if (direct) return launch_beams_t<T, LMAX, BLOCK, false, true>(a, st);
-    return dict_only ? launch_beams_t<T, LMAX, BLOCK, true, true>(a, st) : launch_beams_t<T, LMAX, BLOCK, true, false>(a, st);
+    if (direct) {
+        if constexpr (LMAX == 4) { if (a->spill_cap > 0) return launch_beams_t<T, LMAX, BLOCK, false, 2>(a, st); }   // + spill slots
+        return launch_beams_t<T, LMAX, BLOCK, false, 1>(a, st);
+    }
+    return dict_only ? launch_beams_t<T, LMAX, BLOCK, true, 1>(a, st) : launch_beams_t<T, LMAX, BLOCK, true, 0>(a, st);
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
@@ -1390,3 +1413,4 @@ extern "C" int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t
     SG_CHECK_LAUNCH();
     return 0;
 }
+

@@ -41,11 +41,14 @@ struct PreArgs {
     const double *plane;   // n_frames x 4
     double delta;          // ground band half width (0.5 in the snowfall path)
     int flat_earth;        // wet: incident angle from -z (augmentation.py:61-63)
+    int cos_only;          // snowfall prepass: only cos(incident angle) is ever used -> g_ang holds the cosine itself and
+                           // cos(arccos(c)) is taken as c (a relative difference of ~1e-16, far inside the prepass tolerance);
+                           // saves an acos and two cos per ground row
     int rows_as_f64;       // wet: np.hstack with the float64 height column promotes the ground rows to float64
                            // (augmentation.py:50), so range / mean are float64 whatever the input dtype
     double noise_floor, power_factor;
     // per-row scratch (n_total)
-    double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle; g_norm = NaN for non-ground rows
+    double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle (or its cosine: cos_only); g_norm = NaN for non-ground rows
     // per-tile partials: [frame][tile][k]
     double *part;          // 12 doubles per tile
     int32_t *hist;         // [frame][HX][HY]
@@ -117,8 +120,13 @@ __global__ __launch_bounds__(PB) void k_pre_ground(PreArgs a)
             double c;
             if (a.flat_earth) c = -((double)z / (nrm * 1.0));            // augmentation.py:61-63
             else c = dot / (nrm * wn);                                   // simulation.py:454-455
-            ga = acos(c);
-            gn = (double)inten / cos(ga);                                // augmentation.py:207
+            if (a.cos_only) {
+                ga = fabs(c) <= 1.0 ? c : NAN;                           // arccos outside [-1, 1] is NaN in the reference too
+                gn = (double)inten / ga;
+            } else {
+                ga = acos(c);
+                gn = (double)inten / cos(ga);                            // augmentation.py:207
+            }
             gd = nrm;                                                    // augmentation.py:208
             v[0] += 1.0; v[1] += gd; v[2] += gn;
             ymax = fmax(ymax, gn);
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
         const double gn = gnv[q];
         if (gn != gn) continue;
         const double gd = gdv[q];
-        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * cos(gav[q]);   // augmentation.py:252-253, simulation.py:462
+        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * (a.cos_only ? gav[q] : cos(gav[q]));   // augmentation.py:252-253, simulation.py:462
         // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
         double a2;
         if constexpr (sizeof(T) == 4) { const float xf = (float)gd; a2 = (double)(xf * xf); }
@@ -768,7 +776,7 @@ extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, 
 {
     hipStream_t st = (hipStream_t)stream;
     PreArgs a{};
-    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0;
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
     a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
     int rc = estimate(s, a, dtype, n_total, max_frame, 3, 7 /* SNOWGPU_E_GROUND */, true, st);
     if (rc) return rc;

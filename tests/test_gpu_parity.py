@@ -937,12 +937,13 @@ def test_pre_augment_crop_on_device_matches_crop_then_augment(eng, so, tables):
         assert (int(st[0]), int(st[1]), int(st[2])) == (int(s0[0]), int(s0[1]) + int((~flag2).sum()), int(s0[2]))
 
 
-@pytest.mark.parametrize("mode", ["1", "-1"])
+@pytest.mark.parametrize("mode", ["-1"])
 def test_per_lane_and_wave_scan_give_the_same_rows(so, tables, monkeypatch, mode):
     """The candidate scan has two forms: one beam per lane, and the wave-flattened one (every lane tests one (beam, record)
-    pair, hits appended through LDS counters, each beam's entries ordered afterwards).  By default the pass over all rows
-    uses the second and the tiers the first; SNOWGPU_PER_LANE_SCAN=1 / -1 force one form everywhere -- same bytes, and both
-    equal the oracle.  Wide beams (30 mrad: wedges of ten bins) exercise the per-lane part behind the first two bins."""
+    pair, hits appended through LDS counters, each beam's entries ordered afterwards).  The pass over all rows uses the
+    second and the tiers, by default, the first; SNOWGPU_PER_LANE_SCAN=-1 makes the tiers use the second too -- same bytes,
+    and both equal the oracle.  Wide beams (30 mrad: wedges of ten bins) exercise the per-lane part behind the first two
+    bins; SNOWGPU_FIRST_TIER=8 ... 63 (test_every_first_tier_gives_the_same_rows) runs every capacity in both forms."""
     from lidar_snow_sim_amd import engine
     tl = _tables64(tables)
     order = list(range(64))
