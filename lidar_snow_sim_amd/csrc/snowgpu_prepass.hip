@@ -355,21 +355,26 @@ __global__ __launch_bounds__(PB) void k_pre_moments(PreArgs a)
         const int by = hist_bin(gn, 5.0, fr.ymax, HY);
         if (bx >= 0 && by >= 0) key[q] = bx * HY + by;
     }
-    // Neighbouring rows are neighbouring azimuths of one laser: same range, similar intensity -- most lanes of a
-    // wave hit the same few bins, and same-address atomics serialise in L2.  So each distinct bin of the wave is
-    // counted by ballot and added once.
+    // Neighbouring rows are neighbouring azimuths of one laser: same range, similar intensity -- most rows of a tile hit the
+    // same few bins, and same-address atomics serialise in L2.  The tile's 1024 keys are first counted in an LDS hash table
+    // (open addressing, 2048 slots), then every distinct bin is added to the frame's histogram once.  (Counting per wave
+    // with a ballot loop, one round per distinct key, was three quarters of this kernel's instructions.)
+    __shared__ int t_key[2048], t_cnt[2048];
+    for (int i = threadIdx.x; i < 2048; i += PB) { t_key[i] = -1; t_cnt[i] = 0; }
+    __syncthreads();
     for (int q = 0; q < 4; ++q) {
-        int k = key[q];
-        unsigned long long todo = __ballot(k >= 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int kl = __shfl(k, leader);
-            const unsigned long long same = __ballot(k == kl);
-            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[kl], (int)__popcll(same));
-            if (k == kl) k = -1;
-            todo &= ~same;
+        const int k = key[q];
+        if (k < 0) continue;
+        unsigned slot = ((unsigned)k * 2654435761u) >> 21;
+        for (;;) {
+            const int prev = atomicCAS(&t_key[slot], -1, k);
+            if (prev == -1 || prev == k) { atomicAdd(&t_cnt[slot], 1); break; }
+            slot = (slot + 1) & 2047u;
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += PB)
+        if (t_key[i] >= 0) atomicAdd(&hist[t_key[i]], t_cnt[i]);
     __shared__ double sm[8];
     block_sum<2>(v, sm);
     if (threadIdx.x == 0) {
