@@ -92,6 +92,7 @@ struct snowgpu_ctx {
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
+    int lists_first = 0;              // SNOWGPU_LISTS_FIRST=1: tier lists (and so the tiers) before k_power and the prepass start
     int use_spill = 0;                // SNOWGPU_SPILL=1: over-full beams of the 4-entry pass leave their lists in spill slots (off: see DESIGN.md)
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
@@ -181,6 +182,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SPILL"); ctx->use_spill = v ? std::atoi(v) : 0; }
+    { const char *v = std::getenv("SNOWGPU_LISTS_FIRST"); ctx->lists_first = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
@@ -780,6 +782,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = 0;
+    const bool lists_first = n_chunks == 1 && ctx->lists_first;
     {
         // linear order: regions are runs of 8 blocks, chunk boundaries fall on them
         const int64_t lin_blocks = (b.n_total + first_block - 1) / first_block;
@@ -794,6 +797,15 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             }
             e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
             if (e) break;
+            // SNOWGPU_LISTS_FIRST=1: the tier lists -- three short kernels that the chain lists -> tier scan -> tier power
+            // starts with -- before k_power and the prepass are released.  Whoever reaches the CUs first keeps them: with many
+            // beams in the tiers (C2far: 16 %) the step gains 6 %, with few (C2: 3.5 %) k_power starts behind the tier scans
+            // and the step loses 18 %.  The host does not know the counts when it launches, so the default stays "beside".
+            if (lists_first) {
+                e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
+                                         b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
+                if (e) break;
+            }
             // The pass queued the beams that met a flake: their received-power phase runs on a side stream, next to the
             // following chunks and to the (latency-bound, mostly empty) later capacity tiers.
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
@@ -809,8 +821,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
     // Tier lists from the flag bytes (the scan counted on past a full list, so every flagged beam knows its tier), then
     // the tiers side by side: class 0 on the caller's stream, the others on two side streams.
-    e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
-                             b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
+    if (!lists_first)
+        e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
+                                 b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier list launch: ") + hipGetErrorString((hipError_t)e));
     const bool side3 = n_cls >= 2;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
