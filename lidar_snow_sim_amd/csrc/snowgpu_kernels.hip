@@ -511,14 +511,17 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     static_assert(WIN <= 4, "the window's permutation passes through one 64-double row segment of the wave");
     uint16_t *s_perm = (uint16_t *)(s_ratio + (BLOCK < 64 ? 0 : (tid & ~63)));   // dead between two beams: this wave's columns of row 0
     int perm[WIN];
-    for (int i = (int)blockIdx.x * WAVES + (tid >> 6); i < n_items; i += step) {
+    // (the item index is wave-uniform; said so explicitly, it and everything read through it live in scalar registers)
+    for (int i = (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(tid >> 6); i < n_items; i += step) {
         int start, cnt, item_f = -1;
         if (LISTQ) {
             start = i * (LANES * WIN);
             cnt = (int)(work_n - start < LANES * WIN ? work_n - start : LANES * WIN);
         } else {
             const int2 d = a.pw_items[i];
-            start = d.x; cnt = d.y & 1023; item_f = (d.y >> 10) - 1;
+            start = __builtin_amdgcn_readfirstlane(d.x);
+            const int dy = __builtin_amdgcn_readfirstlane(d.y);
+            cnt = dy & 1023; item_f = (dy >> 10) - 1;
         }
         // A window of several waves' worth of slots is taken in order of flake count: the cost of phases 2 and 3 grows
         // steeply with the list length, and a wave is as slow as its longest list (counting sort by ballots; the slots of
