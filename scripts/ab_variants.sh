@@ -1,4 +1,4 @@
-# usage (GPU side): bash scripts/_ab.sh <rounds> <variant> [<variant> ...]   -- same-box A/B of kernel variants (scripts/build_variant.sh)
+# usage (GPU side): bash scripts/ab_variants.sh <rounds> <variant> [<variant> ...]   -- same-box A/B of kernel variants (scripts/build_variant.sh)
 cd $GRAFT_REPO_ROOT
 R=$1; shift
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-pcie $BENCH_ARGS"
