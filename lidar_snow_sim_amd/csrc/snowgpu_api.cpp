@@ -188,14 +188,17 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
-    for (hipStream_t *sp : {&ctx->stream, &ctx->aux, &ctx->aux3})
-        HIPCHK(ctx, hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
         // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
-        // else.  It gets the highest stream priority.
-        int least = 0, greatest = 0;
+        // else.  It gets the highest stream priority; the others stay at the default.  (SNOWGPU_PRIO=<bits>: 1 aux,
+        // 2 aux2, 4 aux3 -- measured: none 5.04 ms per step, prepass only 4.93, prepass + k_power 4.90, all three 4.96.)
+        int least = 0, greatest = 0, mask = 2;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, greatest));
+        if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, (mask & 2) ? greatest : 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, (mask & 4) ? greatest : 0));
     }
     for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
