@@ -18,19 +18,16 @@
 
 #define SG_BLOCK 256
 #ifndef SG_NB4
-#define SG_NB4 4
-#endif
-#ifndef SG_KP_PREFETCH
-#define SG_KP_PREFETCH 0     /* 1: k_power requests the slot data of its next item before computing the current one */
+#define SG_NB4 4          /* bins of the power profile evaluated together by the 4-entry tier (1, 2, 3 measured slower) ... */
 #endif
 #ifndef SG_KP_WIN
 #define SG_KP_WIN 3       /* k_power: a work item of the multi-flake beams is this many waves' worth of slots, taken in order of flake count */
 #endif
 #ifndef SG_FP_WAVES
-#define SG_FP_WAVES 5     /* waves per SIMD the pass over all rows is compiled for = what its LDS lists allow (96 VGPRs; 100 uncapped, which costs the fifth wave; 4 registers go to scratch) */
+#define SG_FP_WAVES 5     /* waves per SIMD the pass over all rows is compiled for = what its LDS lists allow (<= 96 VGPRs; it uses 90, no scratch -- DESIGN.md section 5 on how it got there from 100) */
 #endif
 #ifndef SG_NB_TIERS
-#define SG_NB_TIERS 8
+#define SG_NB_TIERS 8     /* ... and by the later tiers */
 #endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
@@ -475,13 +472,14 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
 // Everything after the scan for the beams a hand-over pass queued: one lane per queue slot, every lane busy.
 // Phase 2 (occlusion dict), 3a (amplitudes, windows), 3b (pruned power profile and its first maximum), 3c (decision),
 // result record.  Nothing is read but the queue: range, azimuth and flake list of the beam; its channel rides in the slot.
-//   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots)
-//   LISTQ = true   a list-mode pass's hand-over buffer: item i = slots [i LANES, (i + 1) LANES) of the class
+//   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots: 64 one-flake slots, or a
+//                  window of SG_KP_WIN x 64 multi-flake slots)
+//   LISTQ = true   a list-mode pass's hand-over buffer (or the spill slots of its rows): item i = window i of the class
 // PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
 // barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
 // that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
-// then bound by the latency of its first loads.  (SG_KP_PREFETCH=1 also requests the slot data of a wave's NEXT item before
-// it computes the current one; since phase 2 moved here the registers that costs outweigh the latency it hides.)
+// then bound by the latency of its first loads.  (Requesting the slot data of a wave's NEXT item before it computes the
+// current one was measured too: since phase 2 moved here the registers that costs outweigh the latency it hides.)
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
 __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 1) void k_power(SgBeamArgs a)
 {
