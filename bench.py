@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- snowfall-augmentation throughput on MI355X, BASELINE.json's metric on its config C2.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload C2|C2far|C1|C4|C3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--workload C2|C2far|C1|C4|C3|C5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes itself under torch.distributed.run with
+N ranks on 127.0.0.1, one rank per GPU; it fails loudly if the node has fewer devices.
 
 A "step" is one pass of the hot path -- channel sort, noise-threshold prepass, per-beam occlusion /
 received-power simulation, noise-floor filter, compaction, statistics (augment(), simulation.py:427-544,
@@ -13,7 +16,10 @@ batches (frames shard with no data-path collective): weak scaling, value = point
 Prints ONE JSON line on rank 0:
   value                  points/s with rows resident in HBM (the device entry of the C ABI)
   value_pcie_inclusive   the same frames through the HOST entry: H2D of the rows and D2H of the results inside the clock
-                         (page-locked buffers, two contexts), SURVEY 8(d)'s definition of the metric; never `value`
+                         (page-locked buffers, ONE context and host thread: the library pipelines upload / kernels / download
+                         in chunks), SURVEY 8(d)'s definition of the metric; never `value`
+  single_frame           one sweep end to end (upload, all kernels, download, synchronise): through the C ABI with page-locked
+                         buffers, and through the Python augment() with a pageable array, as the reference's callers have it
   roofline               per-beam region: achieved = algorithmic bytes / HIP-event time; `traffic` and `valu` from rocprofv3
                          --pmc passes of this same command, run as child processes (N = 1 only; --no-pmc skips them)
   cpu_baseline           the CPU oracle on four frames of the same workload (all host cores, and one core)
@@ -61,7 +67,11 @@ def make_tables(n_lines=64, snowfall=SNOWFALL, velocity=VELOCITY, distinct=None)
     occ = smp.compute_occupancy(snowfall, velocity)
     rate = smp.snowfall_rate_to_rainfall_rate(snowfall, velocity)
     distinct = n_lines if distinct is None else distinct
-    cache = Path(tempfile.gettempdir()) / f"snowgpu_bench_tables_{snowfall}_{velocity}_{distinct}.npz"
+    import hashlib
+    import inspect
+    key = hashlib.sha1(inspect.getsource(smp).encode()).hexdigest()[:12]      # a change of the sampler invalidates the cache
+    uid = os.getuid() if hasattr(os, "getuid") else 0
+    cache = Path(tempfile.gettempdir()) / f"snowgpu_bench_tables_u{uid}_{key}_{snowfall}_{velocity}_{distinct}.npz"
     tabs = None
     if cache.exists():
         try:
@@ -131,34 +141,154 @@ def pmc_pass(counters, argv, steps_total):
         shutil.rmtree(out, ignore_errors=True)
 
 
+def spawn_ranks(n, dry):
+    """Re-execute this command under torch.distributed.run with n ranks on this node (one per GPU)."""
+    import socket
+    if not dry:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s); refusing to report n_gpus={n}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
+    """BASELINE.json configs[4]: a stream of synthetic STF `.bin` frames sharded round-robin over the ranks, each rank through
+    lidar_snow_sim_amd.stream (read .bin -> upload -> augment -> download -> write .bin; precompute.py:74-106).  The frame files of
+    a rank are hard links to 64 distinct sweeps (bounded disk use; every frame is still read, processed and written); outputs
+    are unlinked right after they have been written.  One "step" = the whole stream; value = points of all ranks / max time."""
+    import random
+    import torch
+    from lidar_snow_sim_amd import dist as sdist
+    from lidar_snow_sim_amd import stream
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+    n_all = args.frames or 10000
+    ids = [f"2018-02-03_{i:05d}" for i in range(n_all)]
+    mine = sdist.shard_indices(n_all, rank, world)
+    base = Path(tempfile.mkdtemp(prefix=f"snowgpu_c5_r{rank}_"))
+    lidar = base / "lidar_hdl64_strongest"
+    lidar.mkdir(parents=True)
+    try:
+        n_dist = min(64, max(len(mine), 1))
+        for i in range(n_dist):
+            synthetic_sweep(64, 2048, seed=1000 + rank * 64 + i, intensity="lambert").tofile(lidar / f"src_{i:05d}.bin")
+        for k, i in enumerate(mine):
+            os.link(lidar / f"src_{k % n_dist:05d}.bin", lidar / f"{ids[i]}.bin")
+        tables = make_tables(64, SNOWFALL, VELOCITY)
+        occ, rate = smp.compute_occupancy(SNOWFALL, VELOCITY), smp.snowfall_rate_to_rainfall_rate(SNOWFALL, VELOCITY)
+        prefix = f"gunn_{rate}_{occ}"
+        kw = dict(modes=("gunn",), combos=[(rate, occ)], batch=64, particles_by_prefix={prefix: tables}, planes=([0.0, 0.0, -1.0], -1.7),
+                  workers=2, readers=6, writers=6, keep_outputs=False, device=local_rank)
+        random.seed(0)                                                        # warm-up: table upload, allocations, page-locked pools
+        stream.run(lidar, [ids[i] for i in mine[:128]], **kw)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        rep = {}
+        random.seed(1)
+        t0 = time.perf_counter()
+        n_files = stream.run(lidar, ids, rank=rank, world=world, report=rep, **kw)
+        torch.cuda.synchronize()
+        elapsed = sdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        tot = sdist.sum_over_ranks([n_files, rep["points_in"], rep["points_out"]], device=dev)
+        seen = ranks_seen()
+        if rank == 0:
+            print(json.dumps({
+                "metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %", "value": tot[1] / elapsed, "unit": "points/s",
+                "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"C5: {n_all}-frame synthetic STF stream (64 x 2048 float32 .bin files), 2.5 mm/h @ 1.6 m/s gunn tables, "
+                                       "sharded round-robin over the ranks, file read + H2D + augment + D2H + file write inside the clock",
+                           "frames": n_all, "files_written": int(tot[0]), "files_per_s": tot[0] / elapsed, "points_out": int(tot[2]),
+                           "sharding": f"frame-parallel x{world}, no collective", "ranks_seen": seen, "batch": 64,
+                           "rank0_stage_busy_s": {k: rep[k] for k in ("read_s", "gpu_s", "write_s")}, "host_logical_cpus": os.cpu_count()},
+                "per_gpu_value": tot[1] / elapsed / world}), flush=True)
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=DEFAULT_FRAMES, help="frames per batch (per GPU)")
+    ap.add_argument("--frames", type=int, default=None, help=f"frames per batch and GPU (default {DEFAULT_FRAMES}); C5: frames of the whole stream (default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic / valu from profiles/)")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the host-entry (PCIe-inclusive) measurement")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-entry (PCIe-inclusive) and single-frame measurements")
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)       # child of a counter pass: timed loop only
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS), help="C2 (default) is BASELINE.json's metric config")
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["C5"], help="C2 (default) is BASELINE.json's metric config")
+    ap.add_argument("--dry", action="store_true", help="launch logic only: gloo on CPU, no GPU work (tests)")
     args = ap.parse_args()
     if args.inner:
         args.no_cpu_baseline = args.no_pmc = args.no_pcie = True
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, args.dry))
 
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree")
     distributed = world > 1
+    import torch
+    dist = None
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.dry:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if args.dry else torch.device("cuda", local_rank)
+    if not args.dry:
+        torch.cuda.set_device(local_rank)
+
+    def ranks_seen():
+        """Every rank adds 1: the collective library's own count of the ranks behind the barrier."""
+        if not distributed:
+            return 1
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(t.item())
+
+    if args.dry:
+        # the launch / sharding / reduction logic of a multi-rank run without a GPU: seeds per rank, barrier, max over ranks
+        from lidar_snow_sim_amd import dist as sdist
+        F = args.frames or DEFAULT_FRAMES
+        seeds = sdist.bench_frame_seeds(rank, F)
+        if distributed:
+            dist.barrier()
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        elapsed = sdist.max_over_ranks(time.perf_counter() - t0)
+        seen = ranks_seen()
+        if rank == 0:
+            print(json.dumps({"metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %", "value": 0.0, "unit": "points/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "dry": True, "ranks_seen": seen, "backend": "gloo" if distributed else None,
+                              "first_seed_of_rank0": seeds[0], "frames_per_step_per_gpu": F}), flush=True)
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    if args.workload == "C5":
+        return run_c5(args, rank, local_rank, world, dist, dev, ranks_seen)
+    if args.frames is None:
+        args.frames = DEFAULT_FRAMES
 
     from lidar_snow_sim_amd import engine
     from lidar_snow_sim_amd.tools.wet_ground.augmentation import noise_threshold_poly
@@ -248,50 +378,86 @@ def main():
         return
 
     # ---- the same frames through the HOST entry: H2D + D2H inside the clock (SURVEY 8 d; precompute.py:78 / :106 are the
-    # reference's boundary).  Two host threads drive two contexts with page-locked buffers, 32-frame sub-batches: the
-    # copies of one overlap the kernels of the other.
-    pcie = None
+    # reference's boundary).  ONE host thread, ONE context: snowgpu_augment_batch pipelines upload / kernels / download in
+    # chunks of whole frames on its own copy streams.
+    pcie, single = None, None
     if not args.no_pcie and not fused_wet:
-        sub = min(32, F)
-        n_sub = F // sub
-        engs = [eng, engine.get_engine(local_rank, 1)]
-        if layers != 64:
-            engs[1].set_lasers(engine.load_lasers() * (layers // 64))
         # the frames sit in page-locked memory, as they do when the application reads its .bin files into such a buffer
-        # (precompute.py:78 np.fromfile -> readinto); results land in per-context page-locked buffers
+        # (precompute.py:78 np.fromfile -> readinto); results land in page-locked buffers too
         pin_in = eng.ctx.pinned_empty((n_total, 5), np.float32)
         pin_in[...] = host_rows
-        bufs = [(e.ctx.pinned_empty((sub * n_per, 5), np.float32), e.ctx.pinned_empty(sub * n_per, np.int32)) for e in engs]
-        sub_off = np.arange(sub + 1, dtype=np.int64) * n_per
-        ids2 = [[e.table_ids_from_arrays(tables, o) for o in orders] for e in engs]
+        pin_out = eng.ctx.pinned_empty((n_total, 5), np.float32)
+        pin_src = eng.ctx.pinned_empty(n_total, np.int32)
+        h_off = np.arange(F + 1, dtype=np.int64) * n_per
+        h_ids = np.asarray(table_ids, np.int32)
+        h_planes = np.asarray(planes, np.float64)
 
-        def host_worker(w, reps):
-            e, (rout, rsrc) = engs[w], bufs[w]
+        def host_call(want_src=True):
+            return eng.ctx.augment_batch(pin_in, h_off, h_ids, BEAM_DIV, plane=h_planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
+
+        def timed(fn, reps):
+            fn()
+            barrier()
+            c0 = time.perf_counter()
             for _ in range(reps):
-                for b in range(w, n_sub, 2):
-                    e.ctx.augment_batch(pin_in[b * sub * n_per:(b + 1) * sub * n_per], sub_off, ids2[w][b * sub:(b + 1) * sub], BEAM_DIV,
-                                        plane=planes[:sub], out_rows=rout, out_src=rsrc)
+                fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - c0
+            if distributed:
+                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dt = float(tt.item())
+            return dt
 
-        for w in (0, 1):
-            host_worker(w, 1)
         reps = max(1, min(args.steps, 4))
-        barrier()
-        c0 = time.perf_counter()
-        th = [threading.Thread(target=host_worker, args=(w, reps)) for w in (0, 1)]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        torch.cuda.synchronize()
-        pcie_s = time.perf_counter() - c0
-        if distributed:
-            tt = torch.tensor([pcie_s], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            pcie_s = float(tt.item())
-        pcie = {"value": reps * n_sub * sub * n_per * world / pcie_s, "steps": reps, "frames_per_call": sub, "contexts": 2,
-                "bytes_per_point": {"h2d": 20, "d2h": 24},
-                "link_bound_points_per_s": PCIE_PEAK / 24.0 * world,
-                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory: H2D, all kernels, D2H of rows + source "
-                        "indices, one synchronisation per call; ceiling = 63 GB/s per direction / 24 B per point (D2H side)"}
+        s_src = timed(lambda: host_call(True), reps)
+        _, _, h_counts, h_stats, _ = host_call(True)
+        d_counts = out_counts.cpu().numpy()
+        host_same = bool(np.array_equal(h_counts, d_counts) and np.array_equal(h_stats, out_stats.cpu().numpy())
+                         and all(np.array_equal(pin_out[f * n_per:f * n_per + int(d_counts[f])],
+                                                out_rows[f * n_per:f * n_per + int(d_counts[f])].cpu().numpy()) for f in (0, F // 2, F - 1)))
+        s_nosrc = timed(lambda: host_call(False), reps)
+        pcie = {"value": reps * n_total * world / s_src, "value_without_src": reps * n_total * world / s_nosrc, "steps": reps,
+                "frames_per_call": F, "contexts": 1, "host_threads": 1,
+                "bytes_per_point": {"h2d": 20, "d2h": 24, "d2h_without_src": 20},
+                "link_bound_points_per_s": PCIE_PEAK / 24.0 * world, "link_bound_points_per_s_without_src": PCIE_PEAK / 20.0 * world,
+                "frac_of_link_bound": reps * n_total / s_src / (PCIE_PEAK / 24.0),
+                "frac_of_link_bound_without_src": reps * n_total / s_nosrc / (PCIE_PEAK / 20.0),
+                "matches_device_entry": host_same,
+                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library "
+                        "uploads chunk c + 1 and downloads chunk c - 1 while chunk c computes (snowgpu_set_pipeline); ceiling = 63 GB/s "
+                        "per direction / 24 B per point (rows + source indices back) or / 20 B (out_src = NULL)"}
+        # ---- one sweep end to end, as the reference's callers use augment() (pointcloud_viewer.py:2807-2810, precompute.py:103-104)
+        if rank == 0:
+            one_off = np.array([0, n_per], np.int64)
 
+            def one_abi():
+                eng.ctx.augment_batch(pin_in[:n_per], one_off, h_ids[:1], BEAM_DIV, plane=h_planes[:1], out_rows=pin_out[:n_per], out_src=pin_src[:n_per])
+
+            from lidar_snow_sim_amd.tools.snowfall.simulation import augment as py_augment
+            pageable = np.array(frames[0])
+
+            def one_py():
+                py_augment(pageable, "unused", BEAM_DIV, only_camera_fov=False, plane=plane, order=orders[0], particles=tables)
+
+            def median_ms(fn, n=40):
+                for _ in range(5):
+                    fn()
+                ts = []
+                for _ in range(n):
+                    c0 = time.perf_counter()
+                    fn()
+                    ts.append(time.perf_counter() - c0)
+                return float(np.median(ts) * 1e3), float(np.min(ts) * 1e3)
+
+            abi_ms, abi_min = median_ms(one_abi)
+            py_ms, py_min = median_ms(one_py)
+            single = {"c_abi_pinned": {"ms": abi_ms, "min_ms": abi_min, "points_per_s": n_per / (abi_ms * 1e-3)},
+                      "python_augment_pageable": {"ms": py_ms, "min_ms": py_min, "points_per_s": n_per / (py_ms * 1e-3)},
+                      "points": n_per,
+                      "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock"}
+
+    seen = ranks_seen()
     if rank == 0:
         pts_per_step = n_total * world
         value = pts_per_step * args.steps / elapsed
@@ -351,7 +517,8 @@ def main():
                                    + (", snowfall + wet ground fused (snowgpu_augment_wet_batch_device)" if fused_wet else ""),
                        "frames_per_step_per_gpu": F, "points_per_frame": n_per,
                        "prepass": "host (outside the timed region)" if args.host_prepass else "device (timed)",
-                       "sharding": f"frame-parallel x{world}, no collective",
+                       "sharding": f"frame-parallel x{world}, no collective", "ranks_seen": seen,
+                       "backend": "nccl (RCCL)" if distributed else None,
                        "beams_per_capacity_tier": [int(n_total)] + [int(v) for v in st[2:6]]},
             "per_gpu_value": value / world,
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -369,6 +536,8 @@ def main():
         if pcie is not None:
             result["value_pcie_inclusive"] = pcie["value"]
             result["pcie_inclusive"] = pcie
+        if single is not None:
+            result["single_frame"] = single
         if not args.no_cpu_baseline and world == 1:      # rank 0, N = 1 only
             from oracle import snow_oracle as so
             # (i) one host core on frame 0, (ii) all host cores (channels on a thread pool, as the reference's

@@ -111,6 +111,11 @@ int snowgpu_table_count(const snowgpu_ctx *ctx);
 int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm,
                          double r_0, uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out);
 
+/* Rows per chunk of the host-pointer entry's upload / compute / download pipeline (default 2^21, i.e. 16 sweeps of
+ * 64 x 2048; environment SNOWGPU_PIPE_ROWS); 0 = no pipeline: one upload, one launch sequence, one download.  The
+ * reference has no counterpart (its arrays never leave the host; precompute.py:78 / :106 are its I/O boundary). */
+int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows);
+
 /* Validation switch for the received-power term A * sin^2(pi (R - r) / (c tau_h)) (simulation.py:549).
  * 0 (default): the engine's own sine (one reduction step + odd polynomial, < 1 ULP) and a multiplication by
  * 1 / (c tau_h); 1: the device math library's sin and a true division, operation for operation what NumPy
@@ -122,7 +127,7 @@ int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
 int snowgpu_debug_table(snowgpu_ctx *ctx, int table_id, double *out, int64_t cap_rows);
 
 /* Status words (int32[8], layout under snowgpu_augment_batch_device) of the last batch that went through a host-pointer
- * entry of this context: e.g. out8[2..5] = beams each later list capacity took. */
+ * entry of this context: e.g. out8[2..5] = beams each later list capacity took (summed over the chunks of a pipelined batch). */
 int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8);
 
 /* The 1230-entry range grid of simulation.py:106-116 as the library computes it (for tests). */
@@ -145,10 +150,16 @@ int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
  *              position); NULL = stable counting sort by channel on the device
  *   out_rows   capacity n_total rows (worst case: nothing removed); compacted per frame, frame f
  *              starts at row frame_offsets[f]
- *   out_src    n_total int32: frame-local input row of each output row
+ *   out_src    n_total int32: frame-local input row of each output row; may be NULL (not downloaded: 20 instead of
+ *              24 bytes per point on the way back)
  *   out_counts n_frames: rows kept per frame
  *   out_stats  n_frames x 3: num_attenuated, num_removed, avg_intensity_diff (simulation.py:525-542)
  *   out_thr_poly optional n_frames x 3: the threshold polynomial actually used
+ *
+ * A batch larger than ~1.5 chunks runs as a PIPELINE of chunks of whole frames (snowgpu_set_pipeline): chunk c + 1
+ * uploads and chunk c - 1 downloads while chunk c computes, on the context's own copy streams -- one host thread and one
+ * context keep both directions of the link and the CUs busy.  Page-locked rows / out_rows (snowgpu_host_alloc) are
+ * what makes the copies asynchronous; pageable memory works and is slower.  The call returns when everything has landed.
  */
 int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets,
                           const void *rows, int dtype, const int32_t *table_ids,

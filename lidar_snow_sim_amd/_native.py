@@ -25,6 +25,7 @@ EXPORTS = [
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
+    "snowgpu_set_pipeline",
 ]
 
 
@@ -93,6 +94,8 @@ def lib():
             L.snowgpu_set_fov.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
             L.snowgpu_sample_table.restype = ctypes.c_int
             L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
+            L.snowgpu_set_pipeline.restype = ctypes.c_int
+            L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
             L.snowgpu_set_exact_math.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_begin.restype = ctypes.c_int
@@ -203,10 +206,11 @@ class Context:
         return arr
 
     def augment_batch(self, rows, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None,
-                      noise_floor=0.7, perm=None, want_thr=False, out_rows=None, out_src=None):
+                      noise_floor=0.7, perm=None, want_thr=False, out_rows=None, out_src=None, want_src=True):
         """rows: N_total x 5 (float32/float64), frame_offsets: n_frames + 1, table_ids: n_frames x n_lasers.
         out_rows / out_src: optional caller-owned result buffers (at least N_total rows; pinned_empty() ones move at
-        PCIe speed and are not page-faulted in on every call).
+        PCIe speed and are not page-faulted in on every call).  want_src=False: the source indices stay on the device
+        (out_src is returned as None).
 
         Returns (out_rows [N_total x 5, only the first counts[f] rows of each frame slot are valid],
                  out_src, counts, stats[n_frames x 3], thr_poly or None)."""
@@ -223,7 +227,9 @@ class Context:
         elif out_rows.dtype != rows.dtype or out_rows.ndim != 2 or out_rows.shape[1] != 5 or out_rows.shape[0] < n \
                 or not out_rows.flags.c_contiguous:
             raise ValueError("out_rows must be a C-contiguous (>= N_total) x 5 array of the input dtype")
-        if out_src is None:
+        if not want_src:
+            out_src = None
+        elif out_src is None:
             out_src = np.empty(n, np.int32)
         elif out_src.dtype != np.int32 or out_src.ndim != 1 or out_src.shape[0] < n or not out_src.flags.c_contiguous:
             raise ValueError("out_src must be a C-contiguous int32 array of >= N_total entries")
@@ -312,6 +318,11 @@ class Context:
         out = np.zeros(8, np.int32)
         self._check(self._L.snowgpu_last_status(self._h, _p(out)))
         return out
+
+    def set_pipeline(self, chunk_rows: int):
+        """Rows per chunk of the host entry's upload / compute / download pipeline (0: off)."""
+        with self._call_lock:
+            self._check(self._L.snowgpu_set_pipeline(self._h, int(chunk_rows)))
 
     def set_exact_math(self, on: bool):
         self._check(self._L.snowgpu_set_exact_math(self._h, int(bool(on))))

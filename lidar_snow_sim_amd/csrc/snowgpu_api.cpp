@@ -16,6 +16,7 @@
 #include "sg_prepass.h"
 
 #define SG_MAX_CHUNKS 16
+#define SG_PIPE_DEPTH 3          /* chunks of a host-pointer batch in flight: one uploading, one computing, one downloading */
 
 namespace {
 
@@ -121,6 +122,19 @@ struct snowgpu_ctx {
     bool prof = false;
     hipStream_t prof_stream = nullptr;
     int exact_math = 0;
+    // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each): chunk c + 1 uploads on
+    // s_h2d and chunk c - 1 downloads on s_d2h while chunk c computes on `stream` -- one host thread, one context, both
+    // directions of the link and the CUs busy at once.  Every slot owns its upload target and its result buffers.
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    struct PipeSlot {
+        DevBuf<uint8_t> rows_in, rows_out;
+        DevBuf<int32_t> out_src;
+        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_d2h = nullptr;
+    } pipe[SG_PIPE_DEPTH];
+    DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
+    DevBuf<int32_t> pipe_status;      // 8 status words per chunk
+    int64_t pipe_rows = (int64_t)1 << 21;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
+    int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -188,7 +202,12 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_PIPE_ROWS"); if (v) ctx->pipe_rows = std::max<int64_t>(std::atoll(v), 0); }
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+    for (auto &sl : ctx->pipe)
+        for (hipEvent_t *ep : {&sl.ev_h2d, &sl.ev_comp, &sl.ev_d2h}) HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
     {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
         // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
         // else.  It gets the highest stream priority; the others stay at the default.  (SNOWGPU_PRIO=<bits>: 1 aux,
@@ -218,6 +237,12 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : {ctx->s_h2d, ctx->s_d2h}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto &sl : ctx->pipe) {
+        sl.rows_in.release(); sl.rows_out.release(); sl.out_src.release();
+        for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_d2h}) if (e) (void)hipEventDestroy(e);
+    }
+    ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
         if (t.entries) (void)hipFree(t.entries);
         if (t.bin_start) (void)hipFree(t.bin_start);
@@ -917,6 +942,123 @@ extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int6
     return run_batch(ctx, b);
 }
 
+// A host-pointer batch as a pipeline of chunks (see snowgpu_ctx::pipe): uploads on s_h2d, kernels on the context's stream,
+// downloads on s_d2h, joined by events; the host enqueues everything and waits once at the end.  Small per-frame arrays
+// (table ids, planes / polynomials, counts, statistics) cross once for the whole batch; a chunk sees its slice of them.
+static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                const int32_t *table_ids, double beam_div_deg, const double *thr_poly, const double *plane,
+                                double noise_floor, const int32_t *perm, void *out_rows, int32_t *out_src, int64_t *out_counts,
+                                int64_t *out_stats, double *out_thr_poly)
+{
+    const size_t esz = dtype == 0 ? 4 : 8, rb = 5 * esz, nf = (size_t)n_frames, nl = (size_t)ctx->h_las.n;
+    const int64_t n_total = frame_offsets[n_frames];
+    hipStream_t st = ctx->stream;
+    // chunks of whole frames, about pipe_rows rows each
+    std::vector<int> c_first;
+    std::vector<int64_t> h_off;                  // chunk-local offsets: chunk c owns h_off[c_pos[c] .. c_pos[c] + frames + 1)
+    std::vector<size_t> c_pos;
+    for (int f = 0; f < n_frames;) {
+        int g = f;
+        const int64_t base = frame_offsets[f];
+        while (g < n_frames && (g == f || frame_offsets[g + 1] - base <= ctx->pipe_rows)) ++g;
+        c_first.push_back(f);
+        c_pos.push_back(h_off.size());
+        for (int k = f; k <= g; ++k) h_off.push_back(frame_offsets[k] - base);
+        f = g;
+    }
+    c_first.push_back(n_frames);
+    const int n_chunks = (int)c_first.size() - 1;
+    ENSURE(ctx, ctx->pipe_off, h_off.size());
+    ENSURE(ctx, ctx->pipe_status, (size_t)n_chunks * 8);
+    ENSURE(ctx, ctx->out_counts, nf);
+    ENSURE(ctx, ctx->out_stats, nf * 3);
+    ENSURE(ctx, ctx->table_ids, nf * nl);
+    ENSURE(ctx, ctx->thr_poly, nf * 3);
+    ENSURE(ctx, ctx->plane, nf * 4);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pipe_off.p, h_off.data(), sizeof(int64_t) * h_off.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, st));
+    const double *d_thr = nullptr;
+    if (thr_poly) {
+        ENSURE(ctx, ctx->user_thr, nf * 3);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, thr_poly, sizeof(double) * 3 * nf, hipMemcpyHostToDevice, st));
+        d_thr = ctx->user_thr.p;
+    } else if (plane) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+    }
+    if (perm) {
+        ENSURE(ctx, ctx->user_perm, (size_t)n_total);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * (size_t)n_total, hipMemcpyHostToDevice, st));
+    }
+    if (out_thr_poly) ENSURE(ctx, ctx->out_thr, nf * 3);
+    // every slot is sized for the largest chunk up front: no allocation (= device-wide wait) once the pipeline runs
+    int64_t max_chunk = 0;
+    for (int c = 0; c < n_chunks; ++c) max_chunk = std::max(max_chunk, frame_offsets[c_first[(size_t)c + 1]] - frame_offsets[c_first[(size_t)c]]);
+    for (int k = 0; k < std::min(n_chunks, SG_PIPE_DEPTH); ++k) {
+        ENSURE(ctx, ctx->pipe[k].rows_in, std::max<size_t>((size_t)max_chunk * rb, 8));
+        ENSURE(ctx, ctx->pipe[k].rows_out, std::max<size_t>((size_t)max_chunk * rb, 8));
+        ENSURE(ctx, ctx->pipe[k].out_src, std::max<size_t>((size_t)max_chunk, 1));
+    }
+    int rc = SNOWGPU_OK;
+    for (int c = 0; c < n_chunks && rc == SNOWGPU_OK; ++c) {
+        snowgpu_ctx::PipeSlot &sl = ctx->pipe[c % SG_PIPE_DEPTH];
+        const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
+        const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
+        const int64_t *lo = &h_off[c_pos[(size_t)c]];
+        // upload: the slot's rows_in is free once the chunk that used it last has been computed
+        if (c >= SG_PIPE_DEPTH) HIPCHK(ctx, hipStreamWaitEvent(ctx->s_h2d, sl.ev_comp, 0));
+        if (cn) HIPCHK(ctx, hipMemcpyAsync(sl.rows_in.p, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(ctx, hipEventRecord(sl.ev_h2d, ctx->s_h2d));
+        // kernels: after the upload, and after the slot's previous results have left
+        HIPCHK(ctx, hipStreamWaitEvent(st, sl.ev_h2d, 0));
+        if (c >= SG_PIPE_DEPTH) HIPCHK(ctx, hipStreamWaitEvent(st, sl.ev_d2h, 0));
+        BatchDev b{};
+        b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = sl.rows_in.p;
+        int64_t mx = 0;
+        for (int k = 0; k < cf; ++k) mx = std::max(mx, lo[k + 1] - lo[k]);
+        bool uni = mx > 0;
+        for (int k = 0; k < cf && uni; ++k) uni = (lo[k + 1] - lo[k]) == mx;
+        b.max_frame = mx; b.uniform_rows = uni ? mx : 0;
+        b.dtype = dtype; b.table_ids = ctx->table_ids.p + (size_t)f0 * nl; b.beam_div_deg = beam_div_deg;
+        b.thr_poly = d_thr ? d_thr + 3 * (size_t)f0 : nullptr;
+        b.plane = (!d_thr && plane) ? ctx->plane.p + 4 * (size_t)f0 : nullptr;
+        b.noise_floor = noise_floor; b.perm = perm ? ctx->user_perm.p + r0 : nullptr;
+        b.out_rows = sl.rows_out.p; b.out_src = sl.out_src.p; b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
+        b.out_thr_poly = out_thr_poly ? ctx->out_thr.p + 3 * (size_t)f0 : nullptr;
+        b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = st;
+        rc = run_batch(ctx, b);
+        if (rc != SNOWGPU_OK) break;
+        HIPCHK(ctx, hipEventRecord(sl.ev_comp, st));
+        // download
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.ev_comp, 0));
+        if (cn) {
+            HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, sl.rows_out.p, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
+            if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + r0, sl.out_src.p, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
+        }
+        HIPCHK(ctx, hipEventRecord(sl.ev_d2h, ctx->s_d2h));
+    }
+    std::vector<int32_t> h_st((size_t)n_chunks * 8, 0);
+    if (rc == SNOWGPU_OK) {
+        HIPCHK(ctx, hipMemcpyAsync(h_st.data(), ctx->pipe_status.p, sizeof(int32_t) * h_st.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * nf, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * nf, hipMemcpyDeviceToHost, st));
+        if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, ctx->out_thr.p, sizeof(double) * 3 * nf, hipMemcpyDeviceToHost, st));
+    }
+    hipError_t se = hipStreamSynchronize(ctx->s_h2d);
+    hipError_t se2 = hipStreamSynchronize(st);
+    hipError_t se3 = hipStreamSynchronize(ctx->s_d2h);
+    if (rc != SNOWGPU_OK) return rc;
+    for (hipError_t e : {se, se2, se3})
+        if (e != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(e));
+    int32_t agg[8] = {0, -1, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < n_chunks; ++c) {
+        const int32_t *s8 = &h_st[(size_t)c * 8];
+        if (agg[0] == 0 && s8[0] != 0) { agg[0] = s8[0]; agg[1] = s8[1]; }
+        for (int k = 2; k < 6; ++k) agg[k] += s8[k];
+    }
+    std::memcpy(ctx->h_status, agg, sizeof agg);
+    return status_to_error(ctx, agg);
+}
+
 static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                       const int32_t *table_ids, double beam_div_deg, const double *thr_poly, const double *plane,
                       double noise_floor, const int32_t *perm, void *out_rows, int32_t *out_src, int64_t *out_counts,
@@ -934,10 +1076,15 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     }
     const int64_t n_total = frame_offsets[n_frames];
     if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
-    if (n_total > 0 && (!rows || !out_rows || !out_src)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    if (n_total > 0 && (!rows || !out_rows)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
     if (!out_counts || !out_stats) return fail(ctx, SNOWGPU_E_INVALID, "null count/stat buffers");
     if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!thr_poly && !plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
+    const bool wants_precrop = ctx->fov.enabled && ctx->fov_pre && !dbg_count && n_total > 0;
+    if (!dbg_count && !perm_out && !wants_precrop && ctx->pipe_rows > 0 && n_frames > 1 && n_total > ctx->pipe_rows + ctx->pipe_rows / 2)
+        return host_batch_pipelined(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_div_deg, thr_poly, plane, noise_floor, perm,
+                                    out_rows, out_src, out_counts, out_stats, out_thr_poly);
     const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total;
     const size_t row_bytes = n * 5 * esz;
     hipStream_t st = ctx->stream;
@@ -1036,7 +1183,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
         if (row_bytes && !precrop) {
             HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, row_bytes, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+            if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
         } else if (precrop && n_used > 0) {
             // source rows in the ORIGINAL frame: output row -> cropped row -> original row; every frame goes back to its own slot
             int e = sg_launch_compose_src(ctx->crop_off.p, ctx->out_counts.p, n_frames, max_frame_used, ctx->out_src.p, ctx->crop_src.p,
@@ -1047,7 +1194,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
                 if (!m) continue;
                 HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)frame_offsets[f] * 5 * esz, (const char *)ctx->rows_out.p + (size_t)crop_off[(size_t)f] * 5 * esz,
                                            m * 5 * esz, hipMemcpyDeviceToHost, st));
-                HIPCHK(ctx, hipMemcpyAsync(out_src + frame_offsets[f], ctx->crop_out_src.p + crop_off[(size_t)f], sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
+                if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + frame_offsets[f], ctx->crop_out_src.p + crop_off[(size_t)f], sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
             }
         }
         if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, d_out_thr.p, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
@@ -1061,6 +1208,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     hipError_t se = hipStreamSynchronize(st);
     if (rc != SNOWGPU_OK) return rc;
     if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    std::memcpy(ctx->h_status, status, sizeof status);
     return status_to_error(ctx, status);
 }
 
@@ -1136,9 +1284,15 @@ extern "C" int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occup
 extern "C" int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8)
 {
     if (!ctx || !out8) return SNOWGPU_E_INVALID;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out8, ctx->d_status, sizeof(int32_t) * 8, hipMemcpyDeviceToHost));
+    std::memcpy(out8, ctx->h_status, sizeof(int32_t) * 8);
+    return SNOWGPU_OK;
+}
+
+// Chunk size of the upload / compute / download pipeline of the host-pointer entry; 0 switches the pipeline off.
+extern "C" int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows)
+{
+    if (!ctx || chunk_rows < 0) return SNOWGPU_E_INVALID;
+    ctx->pipe_rows = chunk_rows;
     return SNOWGPU_OK;
 }
 
@@ -1323,6 +1477,7 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
     hipError_t se = hipStreamSynchronize(st);
     if (rc != SNOWGPU_OK) return rc;
     if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    std::memcpy(ctx->h_status, status, sizeof status);
     return status_to_error(ctx, status);
 }
 

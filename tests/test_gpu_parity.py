@@ -964,3 +964,61 @@ def test_per_lane_and_wave_scan_give_the_same_rows(so, tables, monkeypatch, mode
         r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
         assert tuple(int(v) for v in st0[0]) == tuple(int(v) for v in r_stats)
         assert np.array_equal(s0[:n], r_src) and np.array_equal(o0[:n, 3:], r_aug[:, 3:])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
+    """snowgpu_augment_batch cuts a large host batch into chunks of whole frames and overlaps upload / kernels / download
+    (snowgpu_set_pipeline).  Same bytes as the one-chunk call: ragged frames incl. an empty one, device prepass and caller
+    polynomials, caller permutation, out_src = NULL, out_thr_poly, status words summed over the chunks."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    rng = np.random.default_rng(11)
+    frames = []
+    for f in range(11):
+        full = synthetic_sweep(64, 2048, seed=1100 + f, intensity="lambert").reshape(64, 2048, 5)
+        step = int(rng.integers(20, 60))
+        frames.append(np.ascontiguousarray(full[:, f % 7::step, :].reshape(-1, 5)).astype(dtype))
+    frames[4] = np.zeros((0, 5), dtype)
+    rows = np.concatenate(frames)
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+    F = len(frames)
+    tl = _tables64(tables)
+    tids = [eng.table_ids_from_arrays(tl, list(rng.permutation(64))) for _ in range(F)]
+    bd = float(np.degrees(3e-3))
+    planes = [[0.0, 0.0, -1.0, -1.7]] * F
+    polys = [[1e-4 * f, 0.01, 2.0] for f in range(F)]
+    perm = np.concatenate([np.argsort(f[:, 4], kind="stable") for f in frames]).astype(np.int32)
+
+    def run(chunk_rows, **kw):
+        eng.ctx.set_pipeline(chunk_rows)
+        try:
+            o, s, c, st, thr = eng.ctx.augment_batch(rows, off, tids, bd, **kw)
+            return o.copy(), None if s is None else s.copy(), c.copy(), st.copy(), thr, eng.ctx.last_status().copy()
+        finally:
+            eng.ctx.set_pipeline(1 << 21)
+
+    for kw in (dict(plane=planes, want_thr=True), dict(thr_poly=polys), dict(thr_poly=polys, perm=perm), dict(plane=planes, want_src=False)):
+        one = run(0, **kw)
+        for chunk_rows in (2500, 9000):                      # ~11 and ~4 chunks
+            many = run(chunk_rows, **kw)
+            assert np.array_equal(one[2], many[2]) and np.array_equal(one[3], many[3])
+            for f in range(F):
+                a, n = int(off[f]), int(one[2][f])
+                assert one[0][a:a + n].tobytes() == many[0][a:a + n].tobytes()
+                if one[1] is not None:
+                    assert np.array_equal(one[1][a:a + n], many[1][a:a + n])
+            assert (one[1] is None) == (many[1] is None)
+            if kw.get("want_thr"):
+                assert np.array_equal(one[4], many[4])
+            assert np.array_equal(one[5][2:6], many[5][2:6])
+    # an error in a middle chunk is reported like in the one-chunk call (range >= 120 m -> SNOWGPU_E_RANGE)
+    from lidar_snow_sim_amd import _native
+    bad = rows.copy()
+    bad[int(off[6]) + 3, :3] = (150.0, 0.0, 0.0)
+    eng.ctx.set_pipeline(2500)
+    try:
+        with pytest.raises(_native.SnowGPUError) as ei:
+            eng.ctx.augment_batch(bad, off, tids, bd, thr_poly=polys)
+        assert ei.value.code == _native.E_RANGE
+    finally:
+        eng.ctx.set_pipeline(1 << 21)

@@ -239,6 +239,25 @@ def test_two_rank_gloo_round_trip(tmp_path):
         assert float(line[3]) == 10.0 and float(line[4]) == 45.0  # every frame owned exactly once
 
 
+def test_bench_gpus_2_spawns_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher environment must start two ranks itself (it used to run one and
+    print n_gpus from WORLD_SIZE only).  --dry keeps the launch / barrier / reduction logic and skips the GPU work."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry", "--frames", "8"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                           # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+    assert rec["ms_per_step"] >= 20.0                                          # max over ranks: rank 1 sleeps 20 ms
+    # a launcher environment that disagrees with --gpus is an error, not a silently different run
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
 def test_stream_driver_bookkeeping(tmp_path):
     """precompute.py's frame order, (rate, velocity) combos and output layout -- no GPU involved."""
     from lidar_snow_sim_amd import stream
