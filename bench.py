@@ -379,11 +379,24 @@ def main():
 
     # ---- the same frames through the HOST entry: H2D + D2H inside the clock (SURVEY 8 d; precompute.py:78 / :106 are the
     # reference's boundary).  ONE host thread, ONE context: snowgpu_augment_batch pipelines upload / kernels / download in
-    # chunks of whole frames on its own copy streams.
+    # chunks of whole frames on its own streams.  Measured in a CHILD process that never loads PyTorch (scripts/pcie_bench.py):
+    # the C ABI does not need it, and inside a process that has initialised PyTorch the HIP runtime moves device-to-host copies
+    # with a full-grid blit kernel instead of the DMA engine (traced), which stalls every kernel beside it.  The in-process
+    # figure is reported next to it.
     pcie, single = None, None
     if not args.no_pcie and not fused_wet:
-        # the frames sit in page-locked memory, as they do when the application reads its .bin files into such a buffer
-        # (precompute.py:78 np.fromfile -> readinto); results land in page-locked buffers too
+        child = None
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            barrier()
+            r = subprocess.run([sys.executable, str(ROOT / "scripts" / "pcie_bench.py"), "--frames", str(F), "--reps", str(max(1, min(args.steps, 4))),
+                                "--workload", args.workload, "--device", str(local_rank), "--seed-base", str(1000 + rank * F)],
+                               capture_output=True, text=True, timeout=900, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            child = json.loads(lines[-1]) if r.returncode == 0 and lines else None
+        except Exception:
+            child = None
+        # in-process (PyTorch initialised): same call, for comparison and as the fallback
         pin_in = eng.ctx.pinned_empty((n_total, 5), np.float32)
         pin_in[...] = host_rows
         pin_out = eng.ctx.pinned_empty((n_total, 5), np.float32)
@@ -395,67 +408,42 @@ def main():
         def host_call(want_src=True):
             return eng.ctx.augment_batch(pin_in, h_off, h_ids, BEAM_DIV, plane=h_planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
 
-        def timed(fn, reps):
-            fn()
-            barrier()
-            c0 = time.perf_counter()
-            for _ in range(reps):
-                fn()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - c0
-            if distributed:
-                tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dt = float(tt.item())
-            return dt
-
-        reps = max(1, min(args.steps, 4))
-        s_src = timed(lambda: host_call(True), reps)
+        host_call(True)
+        barrier()
+        c0 = time.perf_counter()
         _, _, h_counts, h_stats, _ = host_call(True)
+        inproc_s = time.perf_counter() - c0
         d_counts = out_counts.cpu().numpy()
         host_same = bool(np.array_equal(h_counts, d_counts) and np.array_equal(h_stats, out_stats.cpu().numpy())
                          and all(np.array_equal(pin_out[f * n_per:f * n_per + int(d_counts[f])],
                                                 out_rows[f * n_per:f * n_per + int(d_counts[f])].cpu().numpy()) for f in (0, F // 2, F - 1)))
-        s_nosrc = timed(lambda: host_call(False), reps)
-        pcie = {"value": reps * n_total * world / s_src, "value_without_src": reps * n_total * world / s_nosrc, "steps": reps,
-                "frames_per_call": F, "contexts": 1, "host_threads": 1,
+        digest = [int(h_counts.sum()), int(h_stats[:, 0].sum()), int(h_stats[:, 1].sum()), int(h_stats[:, 2].sum()),
+                  float(pin_out[:int(h_counts[0]), 3].sum()), int(pin_src[:int(h_counts[0])].astype(np.int64).sum())]
+        mine = [child["points_per_s"], child["points_per_s_without_src"]] if child else [n_total / inproc_s, n_total / inproc_s]
+        if distributed:
+            tt = torch.tensor(mine, dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            mine = [float(v) for v in tt.tolist()]
+        pcie = {"value": mine[0], "value_without_src": mine[1], "steps": max(1, min(args.steps, 4)),
+                "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
                 "bytes_per_point": {"h2d": 20, "d2h": 24, "d2h_without_src": 20},
                 "link_bound_points_per_s": PCIE_PEAK / 24.0 * world, "link_bound_points_per_s_without_src": PCIE_PEAK / 20.0 * world,
-                "frac_of_link_bound": reps * n_total / s_src / (PCIE_PEAK / 24.0),
-                "frac_of_link_bound_without_src": reps * n_total / s_nosrc / (PCIE_PEAK / 20.0),
-                "matches_device_entry": host_same,
-                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library "
-                        "uploads chunk c + 1 and downloads chunk c - 1 while chunk c computes (snowgpu_set_pipeline); ceiling = 63 GB/s "
-                        "per direction / 24 B per point (rows + source indices back) or / 20 B (out_src = NULL)"}
-        # ---- one sweep end to end, as the reference's callers use augment() (pointcloud_viewer.py:2807-2810, precompute.py:103-104)
-        if rank == 0:
-            one_off = np.array([0, n_per], np.int64)
-
-            def one_abi():
-                eng.ctx.augment_batch(pin_in[:n_per], one_off, h_ids[:1], BEAM_DIV, plane=h_planes[:1], out_rows=pin_out[:n_per], out_src=pin_src[:n_per])
-
-            from lidar_snow_sim_amd.tools.snowfall.simulation import augment as py_augment
-            pageable = np.array(frames[0])
-
-            def one_py():
-                py_augment(pageable, "unused", BEAM_DIV, only_camera_fov=False, plane=plane, order=orders[0], particles=tables)
-
-            def median_ms(fn, n=40):
-                for _ in range(5):
-                    fn()
-                ts = []
-                for _ in range(n):
-                    c0 = time.perf_counter()
-                    fn()
-                    ts.append(time.perf_counter() - c0)
-                return float(np.median(ts) * 1e3), float(np.min(ts) * 1e3)
-
-            abi_ms, abi_min = median_ms(one_abi)
-            py_ms, py_min = median_ms(one_py)
-            single = {"c_abi_pinned": {"ms": abi_ms, "min_ms": abi_min, "points_per_s": n_per / (abi_ms * 1e-3)},
-                      "python_augment_pageable": {"ms": py_ms, "min_ms": py_min, "points_per_s": n_per / (py_ms * 1e-3)},
+                "frac_of_link_bound": mine[0] / (PCIE_PEAK / 24.0 * world),
+                "frac_of_link_bound_without_src": mine[1] / (PCIE_PEAK / 20.0 * world),
+                "in_process_with_pytorch": n_total / inproc_s,
+                "matches_device_entry": host_same and (child is None or child["digest"] == digest),
+                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
+                        "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
+                        "(snowgpu_set_pipeline); ceiling = 63 GB/s per direction / 24 B per point (rows + source indices back) or / 20 B "
+                        "(out_src = NULL)"}
+        if child and rank == 0:
+            single = {"c_abi_pinned": {"ms": child["single_frame_c_abi_ms"], "min_ms": child["single_frame_c_abi_min_ms"],
+                                       "points_per_s": n_per / (child["single_frame_c_abi_ms"] * 1e-3)},
+                      "python_augment_pageable": {"ms": child["single_frame_python_ms"], "min_ms": child["single_frame_python_min_ms"],
+                                                  "points_per_s": n_per / (child["single_frame_python_ms"] * 1e-3)},
                       "points": n_per,
-                      "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock"}
+                      "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock "
+                              "(child process without PyTorch)"}
 
     seen = ranks_seen()
     if rank == 0:

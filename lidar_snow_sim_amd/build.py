@@ -41,13 +41,21 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         return LIB
     objs = []
     (CSRC / "_obj").mkdir(exist_ok=True)
+    headers = [p for p in CSRC.glob("*.h")] + [PKG.parent / "include" / "snowgpu.h"]
+    newest_header = max(p.stat().st_mtime for p in headers)
+    procs = []
     for src in SOURCES:
         obj = CSRC / "_obj" / (src.rsplit(".", 1)[0] + ".o")
+        objs.append(str(obj))
+        if not force and obj.exists() and obj.stat().st_mtime > max((CSRC / src).stat().st_mtime, newest_header):
+            continue                                               # this translation unit is up to date
         cmd = [hipcc(), *FLAGS, "-x", "hip", "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(str(obj))
+        procs.append((cmd, subprocess.Popen(cmd)))                 # the translation units compile side by side
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *objs]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -1,5 +1,6 @@
 // sg_common.h -- types shared by the host API (snowgpu_api.cpp) and the gfx950 kernels.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define SG_PI 3.141592653589793 /* np.pi (simulation.py:26) */
@@ -184,6 +185,8 @@ int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const ui
                       void *stream);
 int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
                          int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles, void *stream);
+// device -> page-locked host memory (or any two device-visible ranges) by a small-grid kernel; bytes % 4 == 0
+int sg_launch_copy_link(void *dst, const void *src, size_t bytes, int blocks, void *stream);
 int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,
                            int n_frames, const int32_t *tile_base, void *out_rows, int32_t *crop_src, int64_t max_tiles, void *stream);
 #ifdef __cplusplus

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -16,7 +17,6 @@
 #include "sg_prepass.h"
 
 #define SG_MAX_CHUNKS 16
-#define SG_PIPE_DEPTH 3          /* chunks of a host-pointer batch in flight: one uploading, one computing, one downloading */
 
 namespace {
 
@@ -122,18 +122,17 @@ struct snowgpu_ctx {
     bool prof = false;
     hipStream_t prof_stream = nullptr;
     int exact_math = 0;
-    // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each): chunk c + 1 uploads on
-    // s_h2d and chunk c - 1 downloads on s_d2h while chunk c computes on `stream` -- one host thread, one context, both
-    // directions of the link and the CUs busy at once.  Every slot owns its upload target and its result buffers.
+    // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each); see host_batch_pipelined.
+    int link_blocks = 0;                  // SNOWGPU_LINK_BLOCKS: 0 = downloads by the runtime's copy (the DMA engine, unless the process has
+                                          // initialised PyTorch: then a full-grid blit kernel); n > 0 = by a kernel of ours with n workgroups.
+                                          // Measured (scripts/probe/chain_probe.hip): while ANY kernel writes host memory, every kernel boundary
+                                          // on the device waits for its outstanding writes -- 3 us per dependent launch become 17 us beside a
+                                          // 16-workgroup copy, 41 us beside 64 -- whereas DMA traffic in either direction costs nothing
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
-    struct PipeSlot {
-        DevBuf<uint8_t> rows_in, rows_out;
-        DevBuf<int32_t> out_src;
-        hipEvent_t ev_h2d = nullptr, ev_comp = nullptr, ev_d2h = nullptr;
-    } pipe[SG_PIPE_DEPTH];
+    std::vector<hipEvent_t> pipe_ev;      // [2 c] chunk c has been uploaded, [2 c + 1] computed
     DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
     DevBuf<int32_t> pipe_status;      // 8 status words per chunk
-    int64_t pipe_rows = (int64_t)1 << 21;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
+    int64_t pipe_rows = (int64_t)3 << 20;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
 };
 
@@ -182,6 +181,44 @@ extern "C" int snowgpu_range_grid(double *out)
 
 extern "C" const char *snowgpu_last_error(const snowgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// streams and events of one launch sequence (a user-visible context, or a lane of its host pipeline)
+static int init_streams(snowgpu_ctx *ctx)
+{
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
+        // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
+        // else.  It gets the highest stream priority; the others stay at the default.  (SNOWGPU_PRIO=<bits>: 1 aux,
+        // 2 aux2, 4 aux3 -- measured: none 5.04 ms per step, prepass only 4.93, prepass + k_power 4.90, all three 4.96.)
+        int least = 0, greatest = 0, mask = 2;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, (mask & 2) ? greatest : 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, (mask & 4) ? greatest : 0));
+    }
+    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
+        HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
+    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
+    return SNOWGPU_OK;
+}
+
+// Upload / download streams and chunk events of the host pipeline: made on the first pipelined batch, so that a context that
+// only ever sees device-resident batches keeps the normal-priority queue pool to its own streams (see host_batch_pipelined).
+static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks)
+{
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (const char *v = std::getenv("SNOWGPU_PIPE_PRIO")) { if (v[0] == '0') least = greatest = 0; }     // A/B: everything in the normal pool
+    if (!ctx->s_h2d) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_h2d, hipStreamNonBlocking, greatest));
+    if (!ctx->s_d2h) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_d2h, hipStreamNonBlocking, least));
+    while ((int)ctx->pipe_ev.size() < 2 * n_chunks) {
+        hipEvent_t e;
+        HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pipe_ev.push_back(e);
+    }
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
 {
     if (!out) return SNOWGPU_E_INVALID;
@@ -203,25 +240,9 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PIPE_ROWS"); if (v) ctx->pipe_rows = std::max<int64_t>(std::atoll(v), 0); }
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
-    for (auto &sl : ctx->pipe)
-        for (hipEvent_t *ep : {&sl.ev_h2d, &sl.ev_comp, &sl.ev_d2h}) HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
-    {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
-        // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
-        // else.  It gets the highest stream priority; the others stay at the default.  (SNOWGPU_PRIO=<bits>: 1 aux,
-        // 2 aux2, 4 aux3 -- measured: none 5.04 ms per step, prepass only 4.93, prepass + k_power 4.90, all three 4.96.)
-        int least = 0, greatest = 0, mask = 2;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, (mask & 2) ? greatest : 0));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, (mask & 4) ? greatest : 0));
-    }
-    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
-        HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
-    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
+    { const char *v = std::getenv("SNOWGPU_LINK_BLOCKS"); if (v) ctx->link_blocks = std::min(std::max(std::atoi(v), 0), 4096); }
+    int rc = init_streams(ctx);
+    if (rc) return rc;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_rgrid, sizeof(double) * SG_RBINS));
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_status, sizeof(int32_t) * 8));
@@ -237,11 +258,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (hipStream_t st : {ctx->s_h2d, ctx->s_d2h}) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-    for (auto &sl : ctx->pipe) {
-        sl.rows_in.release(); sl.rows_out.release(); sl.out_src.release();
-        for (hipEvent_t e : {sl.ev_h2d, sl.ev_comp, sl.ev_d2h}) if (e) (void)hipEventDestroy(e);
-    }
+    for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
         if (t.entries) (void)hipFree(t.entries);
@@ -634,15 +652,17 @@ struct BatchDev {
 
 static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
 {
-    if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
+    snowgpu_ctx *R = ctx;
+    if (R->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     if (b.beam_div_deg <= 0 || b.beam_div_deg >= 45.0)
         return fail(ctx, SNOWGPU_E_INVALID, "beam divergence must be in (0, 45) degrees");
-    int rc = sync_tables(ctx);
+    int rc = sync_tables(R);
     if (rc) return rc;
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
-    hipStream_t s_aux = ctx->serial ? st : ctx->aux, s_aux2 = ctx->serial ? st : ctx->aux2, s_aux3 = ctx->serial ? st : ctx->aux3;
+    const bool serial = R->serial;
+    hipStream_t s_aux = serial ? st : ctx->aux, s_aux2 = serial ? st : ctx->aux2, s_aux3 = serial ? st : ctx->aux3;
     HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
     HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));   // status[1] = first offending row, -1 = none
     if (n == 0) {
@@ -671,7 +691,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
-        if (ctx->prepass_early) { int prc = launch_prepass(); if (prc) return prc; }
+        if (R->prepass_early) { int prc = launch_prepass(); if (prc) return prc; }
     } else if (b.out_thr_poly) {
         HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
     }
@@ -692,16 +712,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 1b. on the side stream, next to the prepass: table descriptors per (frame, channel) and the launch order of the
     // first pass -- by flake table (segments of the device sort) unless the caller brought the
     // permutation (no channel histogram then) or table ids are too sparse for the segment builder.
-    const int64_t n_ft = (int64_t)b.n_frames * ctx->h_las.n;
+    const int64_t n_ft = (int64_t)b.n_frames * R->h_las.n;
     ENSURE(ctx, ctx->frame_tables, (size_t)n_ft);
     int tiers[4], n_tiers = 0;
-    choose_tiers(ctx, b.beam_div_deg, tiers, &n_tiers);
+    choose_tiers(R, b.beam_div_deg, tiers, &n_tiers);
     const int first_block = sg_beams_block(tiers[0]);
-    const bool use_seg = !b.perm && !ctx->linear_order && ctx->tables.size() <= 65536 && b.n_frames <= (1 << 22)
+    const bool use_seg = !b.perm && !R->linear_order && R->tables.size() <= 65536 && b.n_frames <= (1 << 22)
                          && b.n_total < ((int64_t)1 << 31);
     if (use_seg) {
         const size_t P = (size_t)b.n_frames * 256;
-        ENSURE(ctx, ctx->seg_tbl_cnt, ctx->tables.size() + 1); ENSURE(ctx, ctx->seg_tbl_base, ctx->tables.size() + 1);
+        ENSURE(ctx, ctx->seg_tbl_cnt, R->tables.size() + 1); ENSURE(ctx, ctx->seg_tbl_base, R->tables.size() + 1);
         ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
         ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
@@ -712,14 +732,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // them), so sharing a CU only trades waves -- hence one launch by default; SNOWGPU_CHUNKS keeps the experiment at hand.
     const int64_t total_blocks_ub = (b.n_total + first_block - 1) / first_block + (use_seg ? (int64_t)b.n_frames * 256 : 0);
     int n_chunks = 1;
-    if (ctx->chunks_override > 0) n_chunks = std::min(ctx->chunks_override, SG_MAX_CHUNKS);
+    if (R->chunks_override > 0) n_chunks = std::min(R->chunks_override, SG_MAX_CHUNKS);
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
     HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
     {
-        int e = sg_launch_resolve_tables(ctx->d_tables, (int)ctx->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
+        int e = sg_launch_resolve_tables(R->d_tables, (int)R->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
         if (use_seg) {
-            e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, ctx->h_las.n, (int)ctx->tables.size(), first_block,
+            e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, R->h_las.n, (int)R->tables.size(), first_block,
                                    ctx->seg_tbl_cnt.p, ctx->seg_tbl_base.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p,
                                    ctx->seg_n.p, ctx->seg_of_blk.p, n_chunks, ctx->chunk_blk.p, s_aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
@@ -746,17 +766,17 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
-    a.las = ctx->d_las; a.frame_tables = ctx->frame_tables.p;
-    a.rgrid = ctx->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
+    a.las = R->d_las; a.frame_tables = ctx->frame_tables.p;
+    a.rgrid = R->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
     a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
-    a.exact_math = ctx->exact_math;
-    a.per_lane_scan = ctx->per_lane_scan;
+    a.exact_math = R->exact_math;
+    a.per_lane_scan = R->per_lane_scan;
     // Later capacity tiers = classes of the tier lists; the last class is the global-list tier, whose lists hold a whole
     // table if need be (capped at 8192 flakes in one beam).
     const int n_cls = n_tiers;
     const int h_lanes = 256;
-    const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(ctx->max_flakes, 64u), 8192u);
+    const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(R->max_flakes, 64u), 8192u);
     a.n_cls = n_cls;
     for (int k = 0; k + 1 < n_cls; ++k) a.cls_cap[k] = tiers[k + 1];
     a.cls_cap[n_cls - 1] = h_cap;
@@ -765,7 +785,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p;
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int k = 0; k + 1 < n_cls; ++k) {
-        tq_caps[k] = tier_queue_cap(ctx, tiers[k + 1], b.n_total);
+        tq_caps[k] = tier_queue_cap(R, tiers[k + 1], b.n_total);
         ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * (3 * (size_t)tiers[k + 1] + 2));
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
     }
@@ -786,7 +806,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
         a.blk_rows = first_block;
-        a.kp_lds_quarters = ctx->kp_quarters;
+        a.kp_lds_quarters = R->kp_quarters;
         ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
@@ -795,7 +815,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // and the 8-entry tier starts from those instead of scanning again (288 bytes per sorted position, touched by a few per
     // cent of them).  Off by default: the scattered stores cost the pass over all rows more (+0.10 ms on the 256-frame batch)
     // than the tier's scan costs beside the other kernels of the tail; with every kernel alone on the chip it saves 0.27 ms.
-    const bool use_spill = ctx->use_spill && tiers[0] == 4 && n_cls >= 2 && tiers[1] == SG_SPILL_CAP && ctx->per_lane_scan <= 0 &&
+    const bool use_spill = R->use_spill && tiers[0] == 4 && n_cls >= 2 && tiers[1] == SG_SPILL_CAP && R->per_lane_scan <= 0 &&
                            n * SG_SPILL_STRIDE * sizeof(double) <= ((size_t)32 << 30);
     if (use_spill) {
         ENSURE(ctx, ctx->spill, (n + 256) * SG_SPILL_STRIDE);
@@ -810,7 +830,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = 0;
-    const bool lists_first = n_chunks == 1 && ctx->lists_first;
+    const bool lists_first = n_chunks == 1 && R->lists_first;
     {
         // linear order: regions are runs of 8 blocks, chunk boundaries fall on them
         const int64_t lin_blocks = (b.n_total + first_block - 1) / first_block;
@@ -889,7 +909,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
     e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          ctx->diff2.p, b.no_fov ? nullptr : &ctx->fov, max_tiles, st);
+                          ctx->diff2.p, b.no_fov ? nullptr : &R->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
 }
@@ -942,9 +962,32 @@ extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int6
     return run_batch(ctx, b);
 }
 
-// A host-pointer batch as a pipeline of chunks (see snowgpu_ctx::pipe): uploads on s_h2d, kernels on the context's stream,
-// downloads on s_d2h, joined by events; the host enqueues everything and waits once at the end.  Small per-frame arrays
-// (table ids, planes / polynomials, counts, statistics) cross once for the whole batch; a chunk sees its slice of them.
+// The device-visible address of a page-locked host range (hipHostMalloc / hipHostRegister), or null for pageable memory.
+static void *device_view(const void *host, size_t bytes)
+{
+    if (!host || !bytes) return nullptr;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    hipPointerAttribute_t end{};
+    if (hipPointerGetAttributes(&end, (const char *)host + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (end.type != hipMemoryTypeHost || !end.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
+// A host-pointer batch as a pipeline of chunks of whole frames.  What the traces of the first versions taught:
+// the runtime keeps a pool of (by default four) hardware queues PER stream priority, and streams beyond that share a queue
+// with another stream -- whose packets they then wait behind, events and copies included; its device-to-host copy is a
+// full-grid blit kernel in a process that has initialised PyTorch and stalls every kernel beside it; a chunk's launch
+// sequence is a third faster with its side streams than on one stream.  So:
+//   * the upload of ALL chunks is one stream of DMA copies (high-priority pool) into a batch-sized buffer -- it never waits
+//     for anything -- with one event per chunk;
+//   * the chunks compute one after the other on the context's own four streams, exactly like a device-resident batch,
+//     into a batch-sized result buffer;
+//   * the downloads run on one more stream (low-priority pool: a hardware queue of its own) as a small-grid kernel of ours
+//     that writes page-locked memory directly (sg_launch_copy_link), each after its chunk's event.
+// The host enqueues everything and waits once at the end.  Small per-frame arrays (table ids, planes / polynomials, counts,
+// statistics) cross once for the whole batch; a chunk sees its slice of them.
 static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                                 const int32_t *table_ids, double beam_div_deg, const double *thr_poly, const double *plane,
                                 double noise_floor, const int32_t *perm, void *out_rows, int32_t *out_src, int64_t *out_counts,
@@ -968,51 +1011,72 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     }
     c_first.push_back(n_frames);
     const int n_chunks = (int)c_first.size() - 1;
+    {
+        int prc = ensure_pipeline(ctx, n_chunks);
+        if (prc) return prc;
+    }
+    static const bool trace = std::getenv("SNOWGPU_PIPE_TRACE") != nullptr;
+    static const int kick = std::getenv("SNOWGPU_PIPE_KICK") ? std::atoi(std::getenv("SNOWGPU_PIPE_KICK")) : 0;    // A/B switches
     ENSURE(ctx, ctx->pipe_off, h_off.size());
     ENSURE(ctx, ctx->pipe_status, (size_t)n_chunks * 8);
     ENSURE(ctx, ctx->out_counts, nf);
     ENSURE(ctx, ctx->out_stats, nf * 3);
     ENSURE(ctx, ctx->table_ids, nf * nl);
-    ENSURE(ctx, ctx->thr_poly, nf * 3);
     ENSURE(ctx, ctx->plane, nf * 4);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pipe_off.p, h_off.data(), sizeof(int64_t) * h_off.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, st));
+    ENSURE(ctx, ctx->rows_in, std::max<size_t>((size_t)n_total * rb, 8));
+    ENSURE(ctx, ctx->rows_out, std::max<size_t>((size_t)n_total * rb, 8));
+    ENSURE(ctx, ctx->out_src, std::max<size_t>((size_t)n_total, 1));
+    // The small arrays lead the upload stream (chunk 0's event covers them).  On the compute stream they would leave it
+    // "after a DMA copy" for the whole batch: 28 instead of 20 ms for 256 sweeps (measured).
+    hipStream_t up = (kick & 16) ? st : ctx->s_h2d;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pipe_off.p, h_off.data(), sizeof(int64_t) * h_off.size(), hipMemcpyHostToDevice, up));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, up));
     const double *d_thr = nullptr;
     if (thr_poly) {
         ENSURE(ctx, ctx->user_thr, nf * 3);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, thr_poly, sizeof(double) * 3 * nf, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, thr_poly, sizeof(double) * 3 * nf, hipMemcpyHostToDevice, up));
         d_thr = ctx->user_thr.p;
     } else if (plane) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, up));
     }
     if (perm) {
         ENSURE(ctx, ctx->user_perm, (size_t)n_total);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * (size_t)n_total, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * (size_t)n_total, hipMemcpyHostToDevice, up));
     }
     if (out_thr_poly) ENSURE(ctx, ctx->out_thr, nf * 3);
-    // every slot is sized for the largest chunk up front: no allocation (= device-wide wait) once the pipeline runs
-    int64_t max_chunk = 0;
-    for (int c = 0; c < n_chunks; ++c) max_chunk = std::max(max_chunk, frame_offsets[c_first[(size_t)c + 1]] - frame_offsets[c_first[(size_t)c]]);
-    for (int k = 0; k < std::min(n_chunks, SG_PIPE_DEPTH); ++k) {
-        ENSURE(ctx, ctx->pipe[k].rows_in, std::max<size_t>((size_t)max_chunk * rb, 8));
-        ENSURE(ctx, ctx->pipe[k].rows_out, std::max<size_t>((size_t)max_chunk * rb, 8));
-        ENSURE(ctx, ctx->pipe[k].out_src, std::max<size_t>((size_t)max_chunk, 1));
+    // Page-locked result buffers are written by our small-grid kernel; anything else goes through hipMemcpyAsync.
+    // SNOWGPU_LINK_BLOCKS=0 keeps the runtime's copy for page-locked memory too.
+    char *d_out_rows = ctx->link_blocks > 0 ? (char *)device_view(out_rows, (size_t)n_total * rb) : nullptr;
+    char *d_out_src = (ctx->link_blocks > 0 && out_src) ? (char *)device_view(out_src, (size_t)n_total * 4) : nullptr;
+    if (kick & 8) HIPCHK(ctx, hipStreamSynchronize(st));
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    std::vector<hipEvent_t> tev;                  // SNOWGPU_PIPE_TRACE: timed events -- base, then per chunk: uploaded, compute begins, computed, downloaded
+    if (trace) {
+        tev.resize(1 + 4 * (size_t)n_chunks);
+        for (auto &e : tev) HIPCHK(ctx, hipEventCreate(&e));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipEventRecord(tev[0], ctx->s_h2d));
     }
+    // uploads: all of them, back to back (the scratch of an earlier batch on this context has been drained: every host entry
+    // ends with a synchronisation)
+    for (int c = 0; c < n_chunks; ++c) {
+        const int64_t r0 = frame_offsets[c_first[(size_t)c]], cn = frame_offsets[c_first[(size_t)c + 1]] - r0;
+        if (cn) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c], ctx->s_h2d));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[1 + 4 * (size_t)c], ctx->s_h2d));
+        if (kick & 1) (void)hipStreamQuery(ctx->s_h2d);
+    }
+    const double t_up = now();
     int rc = SNOWGPU_OK;
     for (int c = 0; c < n_chunks && rc == SNOWGPU_OK; ++c) {
-        snowgpu_ctx::PipeSlot &sl = ctx->pipe[c % SG_PIPE_DEPTH];
         const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
         const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
         const int64_t *lo = &h_off[c_pos[(size_t)c]];
-        // upload: the slot's rows_in is free once the chunk that used it last has been computed
-        if (c >= SG_PIPE_DEPTH) HIPCHK(ctx, hipStreamWaitEvent(ctx->s_h2d, sl.ev_comp, 0));
-        if (cn) HIPCHK(ctx, hipMemcpyAsync(sl.rows_in.p, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
-        HIPCHK(ctx, hipEventRecord(sl.ev_h2d, ctx->s_h2d));
-        // kernels: after the upload, and after the slot's previous results have left
-        HIPCHK(ctx, hipStreamWaitEvent(st, sl.ev_h2d, 0));
-        if (c >= SG_PIPE_DEPTH) HIPCHK(ctx, hipStreamWaitEvent(st, sl.ev_d2h, 0));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->pipe_ev[2 * (size_t)c], 0));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[2 + 4 * (size_t)c], st));
         BatchDev b{};
-        b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = sl.rows_in.p;
+        b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = ctx->rows_in.p + (size_t)r0 * rb;
         int64_t mx = 0;
         for (int k = 0; k < cf; ++k) mx = std::max(mx, lo[k + 1] - lo[k]);
         bool uni = mx > 0;
@@ -1022,33 +1086,49 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.thr_poly = d_thr ? d_thr + 3 * (size_t)f0 : nullptr;
         b.plane = (!d_thr && plane) ? ctx->plane.p + 4 * (size_t)f0 : nullptr;
         b.noise_floor = noise_floor; b.perm = perm ? ctx->user_perm.p + r0 : nullptr;
-        b.out_rows = sl.rows_out.p; b.out_src = sl.out_src.p; b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
+        b.out_rows = ctx->rows_out.p + (size_t)r0 * rb; b.out_src = ctx->out_src.p + r0;
+        b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
         b.out_thr_poly = out_thr_poly ? ctx->out_thr.p + 3 * (size_t)f0 : nullptr;
         b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = st;
         rc = run_batch(ctx, b);
         if (rc != SNOWGPU_OK) break;
-        HIPCHK(ctx, hipEventRecord(sl.ev_comp, st));
-        // download
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, sl.ev_comp, 0));
+        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], st));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[3 + 4 * (size_t)c], st));
+        if (kick & 2) (void)hipStreamQuery(st);
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
         if (cn) {
-            HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, sl.rows_out.p, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
-            if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + r0, sl.out_src.p, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
+            int e = 0;
+            if (d_out_rows) e = sg_launch_copy_link(d_out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, ctx->link_blocks, ctx->s_d2h);
+            else HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
+            if (!e && out_src && d_out_src) e = sg_launch_copy_link(d_out_src + (size_t)r0 * 4, b.out_src, (size_t)cn * 4, ctx->link_blocks, ctx->s_d2h);
+            else if (!e && out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
+            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("download launch: ") + hipGetErrorString((hipError_t)e));
         }
-        HIPCHK(ctx, hipEventRecord(sl.ev_d2h, ctx->s_d2h));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
+        if (kick & 4) (void)hipStreamQuery(ctx->s_d2h);
     }
-    std::vector<int32_t> h_st((size_t)n_chunks * 8, 0);
-    if (rc == SNOWGPU_OK) {
-        HIPCHK(ctx, hipMemcpyAsync(h_st.data(), ctx->pipe_status.p, sizeof(int32_t) * h_st.size(), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * nf, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * nf, hipMemcpyDeviceToHost, st));
-        if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, ctx->out_thr.p, sizeof(double) * 3 * nf, hipMemcpyDeviceToHost, st));
-    }
+    if (trace) fprintf(stderr, "pipe: %d chunks; uploads enqueued in %.3f ms, everything in %.3f ms\n", n_chunks, t_up - t_begin, now() - t_begin);
     hipError_t se = hipStreamSynchronize(ctx->s_h2d);
-    hipError_t se2 = hipStreamSynchronize(st);
-    hipError_t se3 = hipStreamSynchronize(ctx->s_d2h);
+    for (hipStream_t w : {st, ctx->s_d2h}) {
+        hipError_t e = hipStreamSynchronize(w);
+        if (se == hipSuccess) se = e;
+    }
+    if (trace) {
+        fprintf(stderr, "pipe: drained at %.3f ms\n", now() - t_begin);
+        for (int c = 0; c < n_chunks; ++c) {
+            float t[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 4; ++k) (void)hipEventElapsedTime(&t[k], tev[0], tev[1 + 4 * (size_t)c + k]);
+            fprintf(stderr, "pipe chunk %2d: uploaded %7.3f  compute %7.3f .. %7.3f  downloaded %7.3f ms\n", c, t[0], t[1], t[2], t[3]);
+        }
+        for (auto &e : tev) (void)hipEventDestroy(e);
+    }
     if (rc != SNOWGPU_OK) return rc;
-    for (hipError_t e : {se, se2, se3})
-        if (e != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(e));
+    if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    std::vector<int32_t> h_st((size_t)n_chunks * 8, 0);
+    HIPCHK(ctx, hipMemcpy(h_st.data(), ctx->pipe_status.p, sizeof(int32_t) * h_st.size(), hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_counts, ctx->out_counts.p, sizeof(int64_t) * nf, hipMemcpyDeviceToHost));
+    HIPCHK(ctx, hipMemcpy(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * nf, hipMemcpyDeviceToHost));
+    if (out_thr_poly) HIPCHK(ctx, hipMemcpy(out_thr_poly, ctx->out_thr.p, sizeof(double) * 3 * nf, hipMemcpyDeviceToHost));
     int32_t agg[8] = {0, -1, 0, 0, 0, 0, 0, 0};
     for (int c = 0; c < n_chunks; ++c) {
         const int32_t *s8 = &h_st[(size_t)c * 8];

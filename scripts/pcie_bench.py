@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive throughput of the C-ABI host entry (snowgpu_augment_batch) in a process WITHOUT PyTorch.
+
+    python scripts/pcie_bench.py [--frames 256] [--reps 4] [--workload C2]
+
+The frames sit in page-locked memory; one call per step; upload, all kernels and download inside the clock.  bench.py runs
+this as a child process for its `value_pcie_inclusive` leg: inside a process that has initialised PyTorch, the HIP runtime
+moves device-to-host copies with a blit kernel instead of the DMA engine (traced), which stalls the kernels beside it."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--seed-base", type=int, default=1000)
+    args = ap.parse_args()
+    import bench                      # helpers only: bench.py imports torch lazily, inside main()
+    assert "torch" not in sys.modules
+    import random
+    from lidar_snow_sim_amd import engine
+    layers, azimuths, snowfall, velocity, rscale = bench.WORKLOADS[args.workload]
+    eng = engine.get_engine(args.device)
+    if layers != 64:
+        eng.set_lasers(engine.load_lasers() * (layers // 64))
+    tables = bench.make_tables(layers, snowfall, velocity, distinct=min(layers, 64))
+    F = args.frames
+    frames, ids = [], []
+    for f in range(F):
+        seed = args.seed_base + f
+        frames.append(bench.make_frame(layers, azimuths, seed, rscale))
+        random.seed(seed)
+        order = list(range(layers))
+        random.shuffle(order)
+        ids.append(eng.table_ids_from_arrays(tables, order))
+    n_per = frames[0].shape[0]
+    n_total = n_per * F
+    pin_in = eng.ctx.pinned_empty((n_total, 5), np.float32)
+    np.concatenate(frames, out=pin_in)
+    pin_out = eng.ctx.pinned_empty((n_total, 5), np.float32)
+    pin_src = eng.ctx.pinned_empty(n_total, np.int32)
+    off = np.arange(F + 1, dtype=np.int64) * n_per
+    h_ids = np.asarray(ids, np.int32)
+    planes = np.asarray([[0.0, 0.0, -1.0, -1.7]] * F)
+
+    def call(want_src):
+        return eng.ctx.augment_batch(pin_in, off, h_ids, bench.BEAM_DIV, plane=planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
+
+    def timed(want_src):
+        call(want_src)
+        best = 1e9
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            c0 = time.perf_counter()
+            call(want_src)
+            best = min(best, time.perf_counter() - c0)
+        return (time.perf_counter() - t0) / args.reps, best
+
+    s_src, b_src = timed(True)
+    _, _, counts, stats, _ = call(True)
+    digest = [int(counts.sum()), int(stats[:, 0].sum()), int(stats[:, 1].sum()), int(stats[:, 2].sum()),
+              float(pin_out[:int(counts[0]), 3].sum()), int(pin_src[:int(counts[0])].astype(np.int64).sum())]
+    s_nosrc, b_nosrc = timed(False)
+    # one sweep end to end through the C ABI (page-locked) and through the Python augment() (pageable input)
+    one_off = np.array([0, n_per], np.int64)
+
+    def one_abi():
+        eng.ctx.augment_batch(pin_in[:n_per], one_off, h_ids[:1], bench.BEAM_DIV, plane=planes[:1], out_rows=pin_out[:n_per], out_src=pin_src[:n_per])
+
+    def med(fn, n=40):
+        for _ in range(5):
+            fn()
+        ts = []
+        for _ in range(n):
+            c0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - c0)
+        return float(np.median(ts) * 1e3), float(np.min(ts) * 1e3)
+
+    abi_ms, abi_min = med(one_abi)
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment as py_augment
+    pageable = np.array(frames[0])
+    order0 = list(range(layers))
+    random.seed(args.seed_base)
+    random.shuffle(order0)
+
+    def one_py():
+        py_augment(pageable, "unused", bench.BEAM_DIV, only_camera_fov=False, plane=([0.0, 0.0, -1.0], -1.7), order=order0, particles=tables)
+
+    py_ms, py_min = med(one_py)
+    print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_best": n_total / b_src, "points_per_s_without_src": n_total / s_nosrc,
+                      "points_per_s_without_src_best": n_total / b_nosrc, "frames": F, "reps": args.reps, "points_per_frame": n_per,
+                      "digest": digest, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
+                      "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules}))
+
+
+if __name__ == "__main__":
+    main()

@@ -978,26 +978,31 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
         full = synthetic_sweep(64, 2048, seed=1100 + f, intensity="lambert").reshape(64, 2048, 5)
         step = int(rng.integers(20, 60))
         frames.append(np.ascontiguousarray(full[:, f % 7::step, :].reshape(-1, 5)).astype(dtype))
-    frames[4] = np.zeros((0, 5), dtype)
-    rows = np.concatenate(frames)
-    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
     F = len(frames)
     tl = _tables64(tables)
     tids = [eng.table_ids_from_arrays(tl, list(rng.permutation(64))) for _ in range(F)]
     bd = float(np.degrees(3e-3))
     planes = [[0.0, 0.0, -1.0, -1.7]] * F
     polys = [[1e-4 * f, 0.01, 2.0] for f in range(F)]
-    perm = np.concatenate([np.argsort(f[:, 4], kind="stable") for f in frames]).astype(np.int32)
+    rows = off = None
 
     def run(chunk_rows, **kw):
+        nonlocal rows, off
+        fr = list(frames)
+        if "thr_poly" in kw:
+            fr[4] = np.zeros((0, 5), dtype)                  # an empty frame (with a plane the reference raises on it: Q7)
+        rows = np.concatenate(fr)
+        off = np.concatenate(([0], np.cumsum([f.shape[0] for f in fr]))).astype(np.int64)
+        if "perm" in kw:
+            kw = dict(kw, perm=np.concatenate([np.argsort(f[:, 4], kind="stable") for f in fr]).astype(np.int32))
         eng.ctx.set_pipeline(chunk_rows)
         try:
             o, s, c, st, thr = eng.ctx.augment_batch(rows, off, tids, bd, **kw)
             return o.copy(), None if s is None else s.copy(), c.copy(), st.copy(), thr, eng.ctx.last_status().copy()
         finally:
-            eng.ctx.set_pipeline(1 << 21)
+            eng.ctx.set_pipeline(3 << 20)
 
-    for kw in (dict(plane=planes, want_thr=True), dict(thr_poly=polys), dict(thr_poly=polys, perm=perm), dict(plane=planes, want_src=False)):
+    for kw in (dict(plane=planes, want_thr=True), dict(thr_poly=polys), dict(thr_poly=polys, perm=True), dict(plane=planes, want_src=False)):
         one = run(0, **kw)
         for chunk_rows in (2500, 9000):                      # ~11 and ~4 chunks
             many = run(chunk_rows, **kw)
@@ -1013,6 +1018,7 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
             assert np.array_equal(one[5][2:6], many[5][2:6])
     # an error in a middle chunk is reported like in the one-chunk call (range >= 120 m -> SNOWGPU_E_RANGE)
     from lidar_snow_sim_amd import _native
+    run(0, thr_poly=polys)
     bad = rows.copy()
     bad[int(off[6]) + 3, :3] = (150.0, 0.0, 0.0)
     eng.ctx.set_pipeline(2500)
@@ -1021,4 +1027,4 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
             eng.ctx.augment_batch(bad, off, tids, bd, thr_poly=polys)
         assert ei.value.code == _native.E_RANGE
     finally:
-        eng.ctx.set_pipeline(1 << 21)
+        eng.ctx.set_pipeline(3 << 20)
