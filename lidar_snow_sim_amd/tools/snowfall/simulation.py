@@ -55,7 +55,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                   calib=None, pre_crop: bool = False):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
-    frames      sequence of N_i x 5 arrays (one dtype for the whole batch)
+    frames      sequence of N_i x 5 arrays (one dtype for the whole batch); further columns are carried through
     planes      optional per-frame (w, h); default: calculate_plane(frame) per frame, like the reference
     orders      optional per-frame channel permutations; default: range(64), shuffled with the global
                 `random` module when shuffle=True, one draw per frame in frame order
@@ -71,6 +71,9 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     rows = [_as_rows(f) for f in frames]
     if not rows:
         return []
+    # columns beyond the fifth ride through untouched, as in the reference (it indexes whole rows, simulation.py:447, :508-523)
+    extra = any(r.shape[1] > 5 for r in rows)
+    want_src = return_src or extra
     dt = rows[0].dtype
     if any(r.dtype != dt for r in rows):
         raise TypeError("all frames of a batch must share one dtype")
@@ -115,7 +118,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                     out, src, counts, stats, _ = eng.ctx.augment_batch(
                         flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
                         plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
-                        out_rows=out_rows, out_src=out_src)
+                        out_rows=out_rows, out_src=out_src, want_src=want_src)
                     break
                 except _native.SnowGPUError as err:
                     if attempt == 0 and err.code == _native.E_CHANNELS:
@@ -129,6 +132,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     for i in range(len(rows)):
         a, n = int(offsets[i]), int(counts[i])
         aug = out[a:a + n]
+        if rows[i].shape[1] > 5:
+            aug = np.concatenate((aug, rows[i][src[a:a + n], 5:]), axis=1)
         st = (np.int64(stats[i, 0]), np.int64(stats[i, 1]), int(stats[i, 2]))
         results.append((st, aug, src[a:a + n]) if return_src else (st, aug))
     return results
@@ -161,7 +166,6 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
     res = augment_batch([pc], particle_file_prefix, beam_divergence, shuffle=shuffle, noise_floor=noise_floor,
                         root_path=root_path, planes=None if plane is None else [plane],
                         orders=None if order is None else [order], particles=particles,
-                        thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=True,
+                        thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=return_src,
                         device_prepass=device_prepass, calib=cal)[0]
-    stats, aug_pc, src = res
-    return (stats, aug_pc, src) if return_src else (stats, aug_pc)
+    return res

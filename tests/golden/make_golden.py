@@ -352,5 +352,47 @@ def main():
     print(f"    L7: R0=80 table has {len(t)} flakes")
     save("L7_dart_throwing", **l7)
 
+    # ---- L8 viewer chain: augment(...) then ground_water_augmentation(..., replace=False) with the keyword arguments of
+    # pointcloud_viewer.py:2807-2821, tables looked up under <repo>/npy (no root_path, sim:326-327) --------------------
+    import shutil
+    l8 = dict(bd=np.array(BEAM_DIV))
+    with tempfile.TemporaryDirectory() as fake_repo:
+        (Path(fake_repo) / "npy").mkdir()
+        (Path(fake_repo) / "calib").mkdir()
+        for line in range(1, 65):
+            np.save(Path(fake_repo) / "npy" / f"{PREFIX}_{line}.npy", tabs[(line - 1) % len(tabs)])
+        shutil.copy(REF / "calib" / "20171102_64E_S3.yaml", Path(fake_repo) / "calib" / "20171102_64E_S3.yaml")
+        real_file = sim.__file__
+        sim.__file__ = str(Path(fake_repo) / "tools" / "snowfall" / "simulation.py")      # Path(__file__).parent.parent.parent
+        orig_sim_plane, orig_wet_plane = sim.calculate_plane, wet.calculate_plane
+        try:
+            case = 0
+            for dt in (np.float32, np.float64):
+                for inject in (False, True):
+                    pc = small_frame(56, seed=1500 + case, dtype=dt)
+                    pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(dt)
+                    if inject:
+                        sim.calculate_plane = lambda _pc: (np.asarray([0.0, 0.0, -1.0]), -1.7)
+                        wet.calculate_plane = lambda _pc: (np.asarray([0.0, 0.0, -1.0]), -1.7)
+                    else:
+                        sim.calculate_plane, wet.calculate_plane = orig_sim_plane, orig_wet_plane
+                    random.seed(40 + case)
+                    stats, snow = sim.augment(pc=pc6, only_camera_fov=False, particle_file_prefix=PREFIX, noise_floor=0.7,
+                                              beam_divergence=float(np.degrees(3e-3)), shuffle=True, show_progressbar=False)
+                    out = wet.ground_water_augmentation(snow[:, :5], water_height=0.0008, pavement_depth=0.001, noise_floor=0.7,
+                                                        power_factor=15, flat_earth=False, estimation_method="linear",
+                                                        debug=False, delta=0.5, replace=False)
+                    l8.update({f"c{case}_pc": pc, f"c{case}_seed": np.array(40 + case), f"c{case}_inject": np.array(inject),
+                               f"c{case}_stats": np.array(stats, np.int64), f"c{case}_snow": snow[:, :5],
+                               f"c{case}_snow_src": snow[:, 5].astype(np.int64), f"c{case}_out": out})
+                    print(f"    L8 case {case}: {np.dtype(dt).name} plane={'inj' if inject else 'fallback'} stats={tuple(int(v) for v in stats)} "
+                          f"snow {snow.shape} -> wet {out.shape} {out.dtype} labels={np.bincount(out[:, 4].astype(int), minlength=3)}")
+                    case += 1
+            l8["n_cases"] = np.array(case)
+        finally:
+            sim.__file__ = real_file
+            sim.calculate_plane, wet.calculate_plane = orig_sim_plane, orig_wet_plane
+    save("L8_viewer_chain", **l8)
+
 
 main()

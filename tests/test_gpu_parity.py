@@ -1028,3 +1028,78 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
         assert ei.value.code == _native.E_RANGE
     finally:
         eng.ctx.set_pipeline(3 << 20)
+
+
+# ---- the literal drop-in call: tables in .npy files, permutation from the seeded global `random`, no keyword extras ----------
+def _write_table_files(directory, tables, prefix="gunn_x_y"):
+    directory.mkdir(parents=True, exist_ok=True)
+    for line in range(1, 65):
+        np.save(directory / f"{prefix}_{line}.npy", tables["t"][(line - 1) % 4])
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_L5_literal_drop_in_call(eng, golden, tables, tmp_path, case):
+    """Exactly the call the L5 fixtures were captured with (tests/golden/make_golden.py): <root>/training/snowflakes/npy/
+    <prefix>_<1..64>.npy on disk, random.seed(s), augment(pc6, prefix, bd, shuffle=..., only_camera_fov=False, root_path=root)
+    with a sixth source-index column riding through (simulation.py:447-523).  Fallback-plane cases (even) go through the real
+    calculate_plane; the injected-plane cases pass the fixture's plane, the one keyword extra they need."""
+    import random
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    d = golden("L5_augment")
+    _write_table_files(tmp_path / "training" / "snowflakes" / "npy", tables)
+    pc = d[f"c{case}_pc"]
+    pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(pc.dtype)
+    shuffle, seed = ((True, 3), (False, 0))[(case // 2) % 2]
+    injected = bool(d[f"c{case}_injected"])
+    kw = dict(plane=(d[f"c{case}_plane_w"], float(d[f"c{case}_plane_h"]))) if injected else {}
+    random.seed(seed)
+    stats, aug = augment(pc6, "gunn_x_y", float(d["bd"]), shuffle=shuffle, show_progressbar=False, only_camera_fov=False,
+                         noise_floor=0.7, root_path=str(tmp_path), **kw)
+    assert tuple(int(s) for s in stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+    assert aug.shape[1] == 6 and aug.dtype == pc.dtype
+    a1, s1 = canonical(aug[:, :5], aug[:, 5].astype(np.int64))
+    a2, s2 = canonical(d[f"c{case}_aug"], d[f"c{case}_src"])
+    assert np.array_equal(s1, s2)                              # the sixth column came through: bit-exact kept-point indices
+    assert np.array_equal(a1[:, 3:], a2[:, 3:])
+    np.testing.assert_allclose(a1[:, :3], a2[:, :3], rtol=1e-6 if pc.dtype == np.float32 else 1e-12, atol=0)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_L8_viewer_chain_literal(eng, golden, tables, tmp_path, case):
+    """pointcloud_viewer.py:2807-2821 with its keyword arguments: augment(pc=..., only_camera_fov=..., particle_file_prefix=...,
+    noise_floor=..., beam_divergence=..., shuffle=True, show_progressbar=True) reading <repo>/npy, then
+    ground_water_augmentation(pc, ..., debug=False, delta=..., replace=False); against what the reference returned (L8)."""
+    import random
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import ground_water_augmentation
+    from test_oracle_golden import match_rows_by_xyz
+    d = golden("L8_viewer_chain")
+    _write_table_files(tmp_path / "npy", tables)
+    pc = d[f"c{case}_pc"]
+    pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(pc.dtype)
+    kw = dict(plane=PLANE) if bool(d[f"c{case}_inject"]) else {}
+    engine.set_particle_dir(tmp_path / "npy")                  # the reference's <repo>/npy (simulation.py:326-327)
+    try:
+        random.seed(int(d[f"c{case}_seed"]))
+        stats, snow = augment(pc=pc6, only_camera_fov=False, particle_file_prefix="gunn_x_y", noise_floor=0.7,
+                              beam_divergence=float(np.degrees(3e-3)), shuffle=True, show_progressbar=True, **kw)
+    finally:
+        engine.set_particle_dir(None)
+    assert tuple(int(s) for s in stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+    a1, s1 = canonical(snow[:, :5], snow[:, 5].astype(np.int64))
+    a2, s2 = canonical(d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+    assert np.array_equal(s1, s2) and np.array_equal(a1[:, 3:], a2[:, 3:])
+    tol = 1e-6 if pc.dtype == np.float32 else 1e-12
+    np.testing.assert_allclose(a1[:, :3], a2[:, :3], rtol=tol, atol=0)
+    out = ground_water_augmentation(snow[:, :5], water_height=0.0008, pavement_depth=0.001, noise_floor=0.7, power_factor=15,
+                                    flat_earth=False, estimation_method="linear", debug=False, delta=0.5, replace=False, **kw)
+    ref = d[f"c{case}_out"]
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    ids = match_rows_by_xyz(out, snow[:, :5], snow[:, 5].astype(np.int64))
+    ref_ids = match_rows_by_xyz(ref, d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+    assert np.array_equal(np.sort(ids), np.sort(ref_ids))      # same rows kept by both stages
+    o1, o2 = out[np.argsort(ids, kind="stable")], ref[np.argsort(ref_ids, kind="stable")]
+    assert np.array_equal(o1[:, 4], o2[:, 4])
+    np.testing.assert_allclose(o1[:, :3], o2[:, :3], rtol=tol, atol=0)
+    np.testing.assert_allclose(o1[:, 3], o2[:, 3], rtol=1e-7 if pc.dtype == np.float32 else 1e-9, atol=0)

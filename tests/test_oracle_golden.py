@@ -151,6 +151,43 @@ def test_L6_wet_ground(golden, case):
         np.testing.assert_allclose(out[:, 3], ref[:, 3], rtol=1e-10, atol=0)
 
 
+def match_rows_by_xyz(rows, ref_rows, ref_ids):
+    """ids of `rows` through exact equality of their coordinates with `ref_rows` (ground_water_augmentation moves no point)."""
+    key = {r[:3].tobytes(): int(i) for r, i in zip(np.ascontiguousarray(ref_rows[:, :3], np.float64), ref_ids)}
+    assert len(key) == len(ref_ids)
+    return np.array([key[r.tobytes()] for r in np.ascontiguousarray(rows[:, :3], np.float64)], np.int64)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_L8_viewer_chain(golden, tables, case):
+    """augment(...) then ground_water_augmentation(..., replace=False) as pointcloud_viewer.py:2807-2821 chains them, captured from
+    the reference with that call's keyword arguments, global `random` seeded, tables under <repo>/npy."""
+    import random
+    d = golden("L8_viewer_chain")
+    pc = d[f"c{case}_pc"]
+    plane = PLANE if bool(d[f"c{case}_inject"]) else None
+    random.seed(int(d[f"c{case}_seed"]))
+    order = list(range(64))
+    random.shuffle(order)                                                   # sim:483-486
+    stats, snow, src = so.augment(pc, [tables["t"][i % 4] for i in range(64)], float(d["bd"]), order, plane=plane)
+    assert tuple(stats) == tuple(int(v) for v in d[f"c{case}_stats"])
+    a1, s1 = canonical(snow, src)
+    a2, s2 = canonical(d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+    assert np.array_equal(s1, s2) and np.array_equal(a1, a2)
+    out, wsrc = so.ground_water_augmentation(snow, replace=False, plane=plane, return_src=True, **WET_KW)
+    ref = d[f"c{case}_out"]
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    ids = src[wsrc]
+    ref_ids = match_rows_by_xyz(ref, d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+    o1, o2 = out[np.argsort(ids, kind="stable")], ref[np.argsort(ref_ids, kind="stable")]
+    assert np.array_equal(np.sort(ids), np.sort(ref_ids))
+    assert np.array_equal(o1[:, [0, 1, 2, 4]], o2[:, [0, 1, 2, 4]])
+    if numpy_is_portable():
+        assert np.array_equal(o1[:, 3], o2[:, 3])
+    else:
+        np.testing.assert_allclose(o1[:, 3], o2[:, 3], rtol=1e-10, atol=0)
+
+
 def test_L6_pieces(golden):
     d = golden("L6_wet_ground")
     rel, thr = so.estimate_laser_parameters(d["elp_pc"], d["elp_angle"])
