@@ -52,7 +52,7 @@ def _raise_like_reference(err: _native.SnowGPUError):
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
                   thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0,
-                  calib=None, pre_crop: bool = False):
+                  calib=None, pre_crop: bool = False, q8: str = 'first'):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch); further columns are carried through
@@ -65,6 +65,11 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 compaction kernels, (1024, 1920) image; num_removed counts the cropped rows (:538)
     pre_crop    with calib: also crop every frame to the camera's view BEFORE it is augmented, on the device, as
                 tools/snowfall/precompute.py:96-99 does on the host
+    q8          'first' (default): the noise-threshold fit takes the FIRST minimum of every histogram row -- what
+                np.argpartition(hist, 2)[:, 0] (wet_ground/augmentation.py:236) returns through NumPy's portable selection
+                code, on the device.  'numpy': the fit is made on the host with THIS process' NumPy, so the result follows
+                whatever the reference itself would compute on this machine (AVX2 / AVX-512 builds of NumPy pick a different
+                one of the three smallest bins); everything else still runs on the device
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
     """
     eng = _engine.get_engine(device, slot)
@@ -77,6 +82,10 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     dt = rows[0].dtype
     if any(r.dtype != dt for r in rows):
         raise TypeError("all frames of a batch must share one dtype")
+    if q8 not in ('first', 'numpy'):
+        raise ValueError("q8 must be 'first' or 'numpy'")
+    if q8 == 'numpy':
+        device_prepass = False
     nl = eng.n_lasers
     table_ids, polys, plane_rows = [], [], []
     for i, r in enumerate(rows):
@@ -97,7 +106,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             plane_rows.append([float(w[0]), float(w[1]), float(w[2]), float(h)])
             if not device_prepass:
                 srt = r[np.argsort(r[:, 4], kind="stable")]
-                polys.append(noise_threshold_poly(srt[:, :5], w, h, noise_floor))
+                polys.append(noise_threshold_poly(srt[:, :5], w, h, noise_floor, q8=q8))
     offsets = np.zeros(len(rows) + 1, np.int64)
     offsets[1:] = np.cumsum([r.shape[0] for r in rows])
     with eng.batch_lock:
@@ -142,7 +151,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
 def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
             show_progressbar: bool = False, only_camera_fov: bool = True, noise_floor: float = 0.7,
             root_path: str = None, *, plane=None, order=None, particles=None, thr_poly=None, calib=None,
-            device: int = 0, return_src: bool = False, device_prepass: bool = True) -> Tuple:
+            device: int = 0, return_src: bool = False, device_prepass: bool = True, q8: str = 'first') -> Tuple:
     """
     :param pc:                      N-by-5 array containing original pointcloud (x, y, z, intensity, channel).
     :param particle_file_prefix:    Prefix of the particle tables, f'{mode}_{rain_rate}_{occupancy}'.
@@ -157,7 +166,7 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
     :return:                        ((num_attenuated, num_removed, avg_intensity_diff), N'-by-5 array)
 
     Keyword-only extras: plane=(w, h), order=<permutation>, particles=<tables>, thr_poly, calib, device,
-    return_src (append the source-row index of every output row to the result).
+    return_src (append the source-row index of every output row to the result), q8 ('first' | 'numpy', see augment_batch).
     """
     cal = None
     if only_camera_fov:                                                     # simulation.py:532-533
@@ -167,5 +176,5 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
                         root_path=root_path, planes=None if plane is None else [plane],
                         orders=None if order is None else [order], particles=particles,
                         thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=return_src,
-                        device_prepass=device_prepass, calib=cal)[0]
+                        device_prepass=device_prepass, calib=cal, q8=q8)[0]
     return res

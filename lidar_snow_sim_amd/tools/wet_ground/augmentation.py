@@ -13,14 +13,16 @@ from .planes import calculate_plane
 
 
 def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, power_factor=15, noise_floor=0.7,
-                              debug=True, estimation_method='linear'):
+                              debug=True, estimation_method='linear', *, q8='first'):
     """(relative_output_intensity, adaptive_noise_threshold, p, stat_values) -- augmentation.py:195-266.
 
     Host (NumPy/SciPy) version of the estimate, 'linear' mode.  The per-row minimum of the 50 x 2555
     histogram is taken as the FIRST minimum of the row, which is what ``np.argpartition(hist, 2)[:, 0]``
     (:236) returns through NumPy's portable selection code; NumPy's AVX2/AVX-512 builds return a
     different one of the three smallest bins, so the reference's own answer is
-    machine-dependent there and this mirror pins the portable one.
+    machine-dependent there and this mirror pins the portable one by default (``q8='first'``).
+    ``q8='numpy'`` evaluates the reference's expression with THIS process' NumPy instead -- whatever its
+    selection code returns on this CPU, i.e. what the reference itself prints here.
     """
     from scipy.stats import linregress
     if estimation_method != 'linear':
@@ -37,7 +39,12 @@ def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, powe
     hist, xedges, yedges = np.histogram2d(distance, normalized, bins=(50, 2555),
                                           range=((10, 70), (5, np.abs(np.max(normalized)))))   # :232-233
     hist[hist == 0] = len(pointcloud_planes)                                       # :234-235
-    ymins = np.argmin(hist, axis=1)                                                # :236 (see docstring)
+    if q8 == 'numpy':
+        ymins = np.argpartition(hist, 2)[:, 0]                                     # :236, verbatim: follows the local NumPy build
+    elif q8 == 'first':
+        ymins = np.argmin(hist, axis=1)                                            # :236 through NumPy's portable selection code
+    else:
+        raise ValueError("q8 must be 'first' or 'numpy'")
     min_vals = yedges[ymins]                                                       # :237
     sel = np.where(min_vals > 5)[0]                                                # :238
     min_vals = min_vals[sel]
@@ -47,7 +54,7 @@ def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, powe
     return relative_output_intensity, adaptive_noise_threshold, p, stat_values
 
 
-def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7):
+def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7, q8='first'):
     """Quadratic (p0, p1, p2) of the per-point noise threshold over range -- simulation.py:450-467 (host)."""
     w = np.asarray(w)
     height = np.matmul(pc_sorted[:, :3], w) + h
@@ -55,7 +62,7 @@ def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7):
     pc_ground = pc_sorted[ground]
     angle = np.arccos(np.divide(np.matmul(pc_ground[:, :3], w),
                                 np.linalg.norm(pc_ground[:, :3], axis=1) * np.linalg.norm(w)))
-    _, thr, _, _ = estimate_laser_parameters(pc_ground, angle, noise_floor=noise_floor, debug=False)
+    _, thr, _, _ = estimate_laser_parameters(pc_ground, angle, noise_floor=noise_floor, debug=False, q8=q8)
     if thr is None:
         raise TypeError("unsupported operand type(s) for *=: 'NoneType' and 'float' "
                         "(fewer than 3 ground points, simulation.py:462)")
