@@ -116,7 +116,7 @@ struct SgBeamArgs {
     int32_t *dq_g;               // per slot: sorted position of the beam
     uint16_t *dq_sc;             // per slot: flakes in the list | channel << 8
     unsigned long long *qn;      // per region
-    int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 7}
+    int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 10}
     int32_t *pw_count;           // items planned (reset per chunk)
     int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
     int32_t blk_rows;            // rows per block of the direct-mode pass
@@ -151,7 +151,7 @@ struct SgBeamArgs {
 // lidar_to_rect) and P2 (3 x 4) in float64, image h x w.  enabled = 0: no crop.
 struct SgFov {
     int32_t enabled;
-    int32_t pre;                 // 1: crop on the ORIGINAL coordinates before anything else (precompute.py:96-99)
+    int32_t reserved_;           // (the pre-augment crop of precompute.py:96-99 is a context switch: snowgpu_set_fov_precrop)
     double m[12];                // lidar_to_rect: rect = [x y z 1] . m   (row-major 4 x 3)
     double p[12];                // P2 (row-major 3 x 4)
     double img_h, img_w;

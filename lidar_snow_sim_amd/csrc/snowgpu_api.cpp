@@ -925,7 +925,9 @@ static int status_to_error(snowgpu_ctx *ctx, const int32_t st[8])
     case SNOWGPU_E_CHANNELS:
         return fail(ctx, SNOWGPU_E_CHANNELS, "channel column holds values other than integers in [0, 255]; pass an explicit permutation");
     case SNOWGPU_E_OVERFLOW:
-        snprintf(buf, sizeof buf, "more than %d flakes intersect one beam (sorted row %d)", SG_LCAP, st[1]);
+        snprintf(buf, sizeof buf, "more than %d flakes intersect one beam (sorted row %d): beyond the global-list tier "
+                 "(capacity = the largest uploaded table, at most SNOWGPU_MAX_FLAKES_GLOBAL)",
+                 (int)std::min<uint32_t>(std::max<uint32_t>(ctx->max_flakes, 64u), 8192u), st[1]);
         return fail(ctx, SNOWGPU_E_OVERFLOW, buf);
     case SNOWGPU_E_GROUND:
         return fail(ctx, SNOWGPU_E_GROUND, "fewer than 3 ground points in a frame");

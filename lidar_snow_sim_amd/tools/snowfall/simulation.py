@@ -38,6 +38,20 @@ def _as_rows(pc) -> np.ndarray:
     return pc
 
 
+def _rows_for_plane(r, calib, pre_crop):
+    """What calculate_plane sees: with the pre-augment camera crop (precompute.py:96-99) the reference fits the plane on the
+    CROPPED cloud (precompute.py:96-104 calls augment() with it).  The device crops later, so the host applies the same crop to
+    the few rows of the plane fit's own window (planes.py:21-27) -- that window is all calculate_plane looks at."""
+    if calib is None or not pre_crop:
+        return r
+    from ...calibration import get_fov_flag
+    from ..wet_ground.planes import ground_crop
+    sub = r[ground_crop(r)]
+    if sub.shape[0] == 0:
+        return sub
+    return sub[get_fov_flag(calib.lidar_to_rect(sub[:, 0:3]), (1024, 1920), calib)]
+
+
 def _raise_like_reference(err: _native.SnowGPUError):
     """Map library status codes onto the exception types the reference raises (SURVEY 8 b, 'Errors')."""
     if err.code == _native.E_RANGE:
@@ -102,7 +116,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         if thr_polys is not None:
             polys.append(np.asarray(thr_polys[i], np.float64))
         else:
-            w, h = calculate_plane(r) if planes is None else planes[i]      # simulation.py:449
+            w, h = calculate_plane(_rows_for_plane(r, calib, pre_crop)) if planes is None else planes[i]      # simulation.py:449
             plane_rows.append([float(w[0]), float(w[1]), float(w[2]), float(h)])
             if not device_prepass:
                 srt = r[np.argsort(r[:, 4], kind="stable")]
@@ -119,6 +133,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         # The device counting sort handles integer channel values 0..255 and reports anything else
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
         perm = None
+        crop_idx = None
         if calib is not None:
             eng.ctx.set_fov(calib, (1024, 1920), pre_crop=pre_crop)              # simulation.py:536
         try:
@@ -131,7 +146,22 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                     break
                 except _native.SnowGPUError as err:
                     if attempt == 0 and err.code == _native.E_CHANNELS:
-                        perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows]).astype(np.int32)
+                        if calib is not None and pre_crop:
+                            # the device pre-crop takes no caller permutation: crop here (precompute.py:96-99), sort the cropped
+                            # rows, run without the device pre-crop and map the source rows back afterwards
+                            from ...calibration import get_fov_flag
+                            crop_idx = [np.where(get_fov_flag(calib.lidar_to_rect(r[:, 0:3]), (1024, 1920), calib))[0] for r in rows]
+                            rows_run = [r[ix] for r, ix in zip(rows, crop_idx)]
+                            offsets = np.zeros(len(rows) + 1, np.int64)
+                            offsets[1:] = np.cumsum([r.shape[0] for r in rows_run])
+                            flat = eng.staging_in(int(offsets[-1]), dt)
+                            if int(offsets[-1]):
+                                np.concatenate([r[:, :5] for r in rows_run], out=flat)
+                            eng.ctx.set_fov(calib, (1024, 1920), pre_crop=False)
+                            want_src = True
+                        else:
+                            rows_run = rows
+                        perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows_run]).astype(np.int32)
                         continue
                     _raise_like_reference(err)
         finally:
@@ -141,10 +171,13 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     for i in range(len(rows)):
         a, n = int(offsets[i]), int(counts[i])
         aug = out[a:a + n]
+        src_i = None if src is None else src[a:a + n]
+        if crop_idx is not None:
+            src_i = crop_idx[i][src_i].astype(np.int32)
         if rows[i].shape[1] > 5:
-            aug = np.concatenate((aug, rows[i][src[a:a + n], 5:]), axis=1)
+            aug = np.concatenate((aug, rows[i][src_i, 5:]), axis=1)
         st = (np.int64(stats[i, 0]), np.int64(stats[i, 1]), int(stats[i, 2]))
-        results.append((st, aug, src[a:a + n]) if return_src else (st, aug))
+        results.append((st, aug, src_i) if return_src else (st, aug))
     return results
 
 

@@ -514,3 +514,64 @@ int so_flake_table(const double *xyr, int64_t K, double *out /* K x 5 */)
     free(fl);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Multi-core driver for the CPU baseline (SURVEY 8 d: "all host cores -- state the count").
+ * A work item is a run of consecutive beams of one (frame, channel): exactly process_channel on
+ * those rows (beams are independent, simulation.py:118).  Threads take items off a shared counter.
+ * The reference's own parallelism is ThreadPool(cpu_count()) over the 64 channels of ONE frame
+ * (simulation.py:498); here frames, channels and beam runs are all in flight, which is what a
+ * multi-core C port of the same per-beam algorithm would do. */
+#include <pthread.h>
+
+typedef struct {
+    int32_t is_f32;
+    int32_t rc;            /* out: 0, -1, -2 as process_channel */
+    const void *pts_in;
+    void *pts_out;
+    int64_t M;
+    const double *table_xyr;
+    int64_t K;
+    double beam_div_deg;
+    so_laser las;
+    double diff_sum;       /* out */
+} so_item;
+
+typedef struct {
+    so_item *items;
+    int64_t n;
+    int64_t next;
+    const double *R;
+} so_pool;
+
+static void *so_worker(void *arg)
+{
+    so_pool *p = (so_pool *)arg;
+    for (;;) {
+        const int64_t i = __atomic_fetch_add(&p->next, 1, __ATOMIC_RELAXED);
+        if (i >= p->n) break;
+        so_item *it = &p->items[i];
+        it->rc = process_channel(it->is_f32, it->pts_in, it->M, it->table_xyr, it->K, it->beam_div_deg, &it->las, p->R,
+                                 it->pts_out, &it->diff_sum, NULL, NULL, NULL, NULL, 0, NULL);
+    }
+    return NULL;
+}
+
+/* Returns the number of threads that ran (>= 1), or -1 on failure. */
+int so_process_items_mt(so_item *items, int64_t n, const double *R, int n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if ((int64_t)n_threads > n) n_threads = (int)(n > 0 ? n : 1);
+    so_pool pool = {items, n, 0, R};
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    if (!th) return -1;
+    int started = 0;
+    for (int t = 0; t < n_threads - 1; t++) {
+        if (pthread_create(&th[started], NULL, so_worker, &pool) != 0) break;
+        started++;
+    }
+    so_worker(&pool);                                      /* the caller is a worker too */
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+    return started + 1;
+}

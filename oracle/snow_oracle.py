@@ -44,10 +44,19 @@ PI = np.pi
 C_LIGHT = 299792458.0  # scipy.constants.speed_of_light, sim:17
 
 
+class _Item(ctypes.Structure):      # so_item (snow_oracle.c): one run of beams of one (frame, channel)
+    pass
+
+
 class _Laser(ctypes.Structure):
     _fields_ = [("channel", ctypes.c_int32), ("min_intensity", ctypes.c_int32),
                 ("max_intensity", ctypes.c_int32), ("focal_slope", ctypes.c_double),
                 ("focal_offset", ctypes.c_double)]
+
+
+_Item._fields_ = [("is_f32", ctypes.c_int32), ("rc", ctypes.c_int32), ("pts_in", ctypes.c_void_p), ("pts_out", ctypes.c_void_p),
+                  ("M", ctypes.c_int64), ("table_xyr", ctypes.c_void_p), ("K", ctypes.c_int64), ("beam_div_deg", ctypes.c_double),
+                  ("las", _Laser), ("diff_sum", ctypes.c_double)]
 
 
 def build(force: bool = False) -> Path:
@@ -56,7 +65,7 @@ def build(force: bool = False) -> Path:
     so = _BUILD / "libsnow_oracle.so"
     src = _HERE / "snow_oracle.c"
     if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
+        cmd = ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-pthread",
                "-o", str(so), str(src), "-lm"]
         subprocess.check_call(cmd)
     return so
@@ -72,6 +81,8 @@ def _lib():
             fn = getattr(lib, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [p, i64, p, i64, dbl, ctypes.POINTER(_Laser), p, p, p, p, p, p, p, i64, p]
+        lib.so_process_items_mt.restype = ctypes.c_int
+        lib.so_process_items_mt.argtypes = [p, i64, p, ctypes.c_int]
         lib.so_get_occlusions.restype = ctypes.c_int
         lib.so_get_occlusions.argtypes = [p, p, i64, p, i64, dbl, p, p, p, p, i64, p, p]
         lib.so_occlusion_dict.restype = ctypes.c_int
@@ -326,6 +337,77 @@ def augment(pc, tables, beam_divergence, order, noise_floor=0.7, plane=None, las
         return stats, aug, src, dict(full=full, keep=keep, perm=perm, thr=thr, thr_poly=np.asarray(thr_poly),
                                      diff_sum=diff_sum)
     return stats, aug, src
+
+
+def augment_many(frames, tables, beam_divergence, orders, noise_floor=0.7, planes=None, lasers=None, thr_polys=None,
+                 threads=None, beams_per_item=256):
+    """augment() (sim:427-544, only_camera_fov=False) for several frames with the per-beam work spread over `threads` host
+    threads by snow_oracle.c's pthread driver: work item = a run of `beams_per_item` beams of one (frame, channel).  Same
+    results as one augment() call per frame (beams are independent, and the per-channel intensity-difference sums are sums of
+    multiples of 0.5: exact in any order).  Returns ([(stats, aug_pc, src), ...], threads used)."""
+    import os
+    lasers = load_lasers() if lasers is None else lasers
+    num_channels = len(lasers)
+    threads = (os.cpu_count() or 1) if threads is None else int(threads)
+    grid = range_grid()
+    prepared, items, keep_alive = [], [], []
+    tabs = [np.ascontiguousarray(t, dtype=np.float64) for t in tables]
+    for f, pc in enumerate(frames):
+        pc = np.asarray(pc)
+        if pc.dtype not in (np.float32, np.float64):
+            pc = pc.astype(np.float64)
+        perm = np.argsort(pc[:, 4], kind="stable")                      # sim:447 (canonical: stable)
+        pcs = np.ascontiguousarray(pc[perm][:, :5])
+        poly = None if thr_polys is None else thr_polys[f]
+        if poly is None:
+            w, h = FLAT_EARTH if planes is None else planes[f]
+            poly = noise_threshold_poly(pcs, w, h, noise_floor)
+        aug = pcs.copy()
+        spans = []
+        for ch in range(num_channels):
+            rows = np.where(pcs[:, 4] == ch)[0]                         # sim:80; contiguous: pcs is channel-sorted
+            if rows.size == 0:
+                continue
+            lo, hi = int(rows[0]), int(rows[-1]) + 1
+            tab = tabs[orders[f][ch]]
+            for a in range(lo, hi, beams_per_item):
+                b = min(a + beams_per_item, hi)
+                it = _Item()
+                it.is_f32 = 1 if pcs.dtype == np.float32 else 0
+                it.pts_in = pcs[a:b].ctypes.data
+                it.pts_out = aug[a:b].ctypes.data
+                it.M = b - a
+                it.table_xyr = tab.ctypes.data
+                it.K = tab.shape[0]
+                it.beam_div_deg = float(beam_divergence)
+                it.las = _laser_struct(lasers, ch)
+                items.append(it)
+                spans.append(len(items) - 1)
+        keep_alive.append((pcs, aug))
+        prepared.append((perm, pcs, aug, np.asarray(poly, np.float64), spans))
+    arr = (_Item * len(items))(*items)
+    used = _lib().so_process_items_mt(ctypes.byref(arr), len(items), _ptr(grid), threads) if items else 1
+    if used < 1:
+        raise MemoryError("snow_oracle.c thread pool failure")
+    results = []
+    for perm, pcs, aug, poly, spans in prepared:
+        diff_sum = 0.0
+        for i in spans:                                                 # item order = channel order, beams in order (sim:510)
+            if arr[i].rc == -2:
+                raise IndexError("range >= 120 m: index out of bounds for the 1230-bin grid (sim:149)")
+            if arr[i].rc != 0:
+                raise MemoryError("snow_oracle.c allocation failure")
+            diff_sum += arr[i].diff_sum
+        distances = np.linalg.norm(pcs[:, :3], axis=1)                  # sim:465
+        thr = poly[0] * distances ** 2 + poly[1] * distances + poly[2]  # sim:469
+        aug[:, 3] = np.round(aug[:, 3])                                 # sim:516
+        keep = np.logical_or(aug[:, 4] == 2, aug[:, 3] > thr)           # sim:518-520
+        num_removed = int(np.logical_not(keep).sum())                   # sim:522
+        out = aug[keep]
+        num_att = int((out[:, 4] == 1).sum())                           # sim:525
+        avg = int(diff_sum / num_att) if num_att > 0 else 0             # sim:527-530
+        results.append(((num_att, num_removed, avg), out, perm[keep]))
+    return results, used
 
 
 # ---------------------------------------------------------------------------------------------------

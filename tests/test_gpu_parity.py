@@ -1103,3 +1103,36 @@ def test_L8_viewer_chain_literal(eng, golden, tables, tmp_path, case):
     assert np.array_equal(o1[:, 4], o2[:, 4])
     np.testing.assert_allclose(o1[:, :3], o2[:, :3], rtol=tol, atol=0)
     np.testing.assert_allclose(o1[:, 3], o2[:, 3], rtol=1e-7 if pc.dtype == np.float32 else 1e-9, atol=0)
+
+
+def test_pre_crop_with_odd_channel_values_and_plane_from_the_cropped_cloud(eng, so, tables):
+    """Two advisor findings on the pre-augment crop (precompute.py:96-104).  (1) Channel values the device sort refuses make the
+    mirror sort on the host; with pre_crop that used to fail (the device pre-crop takes no caller permutation): the retry now
+    crops on the host.  (2) With planes=None the plane has to be fitted on the CROPPED cloud, as the reference does: the rows
+    handed to calculate_plane are the camera-view part of its own crop window."""
+    from lidar_snow_sim_amd.calibration import Calibration, get_fov_flag
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall import simulation as sim
+    from lidar_snow_sim_amd.tools.wet_ground.planes import ground_crop
+    cal = Calibration(P2=np.array([[700.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
+                      V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
+    pc = np.ascontiguousarray(synthetic_sweep(64, 2048, seed=29, intensity="lambert").reshape(64, 2048, 5)[:, ::4, :].reshape(-1, 5))
+    pc[5::37, 4] = 3.5
+    pc[7::41, 4] = 300.0
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    order = list(range(64))
+    (st, aug, src), = sim.augment_batch([pc], "unused", bd, particles=tl, orders=[order], planes=[PLANE], return_src=True, calib=cal,
+                                        pre_crop=True)
+    flag1 = so.fov_flag(pc[:, :3], cal.V2C, cal.R0, cal.P2, (1024, 1920))
+    kept1 = np.where(flag1)[0]
+    s0, a0, src0 = so.augment(pc[flag1], tl, bd, order, plane=PLANE)
+    flag2 = so.fov_flag(a0[:, :3], cal.V2C, cal.R0, cal.P2, (1024, 1920))
+    assert np.array_equal(src, kept1[src0][flag2]) and np.array_equal(aug[:, 3:], a0[flag2][:, 3:])
+    assert (int(st[0]), int(st[1]), int(st[2])) == (int(s0[0]), int(s0[1]) + int((~flag2).sum()), int(s0[2]))
+    # (2) what calculate_plane is given
+    sub = sim._rows_for_plane(pc, cal, True)
+    win = pc[ground_crop(pc)]
+    exp = win[get_fov_flag(cal.lidar_to_rect(win[:, 0:3]), (1024, 1920), cal)]
+    assert np.array_equal(sub, exp) and 0 < sub.shape[0] <= win.shape[0]
+    assert sim._rows_for_plane(pc, cal, False) is pc and sim._rows_for_plane(pc, None, True) is pc

@@ -205,3 +205,21 @@ def test_L7_dart_throwing(golden):
         assert np.array_equal(t, d[f"t{i}"])
     with pytest.raises(NotImplementedError):      # Q13
         so.dart_throwing(1e-6, 10.0, 5.0, np.random.default_rng(0), "sekhon_srivastava")
+
+
+def test_multi_core_driver_equals_the_per_frame_oracle(tables):
+    """bench.py's cpu_baseline runs the oracle under a pthread driver (work item = a run of beams of one (frame, channel)):
+    same rows, labels, intensities and statistics as one augment() per frame, for either dtype and any item size."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    tl = [tables["t"][i % 4] for i in range(64)]
+    frames = [synthetic_sweep(64, 2048, seed=1700 + f, intensity="lambert").reshape(64, 2048, 5)[:, f::64].reshape(-1, 5) for f in range(3)]
+    frames[1] = frames[1].astype(np.float64)
+    rng = np.random.default_rng(9)
+    orders = [list(rng.permutation(64)) for _ in frames]
+    bd = float(np.degrees(3e-3))
+    for threads, per_item in ((1, 1000), (4, 7), (3, 32)):
+        res, used = so.augment_many(frames, tl, bd, orders, planes=[PLANE] * 3, threads=threads, beams_per_item=per_item)
+        assert used == threads
+        for f, (st, aug, src) in enumerate(res):
+            s0, a0, src0 = so.augment(frames[f], tl, bd, orders[f], plane=PLANE)
+            assert tuple(st) == tuple(s0) and np.array_equal(aug, a0) and np.array_equal(src, src0)
