@@ -110,6 +110,25 @@ def cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """(threads worth starting, description): the logical CPUs this process may run on, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            quota = None
+    use = n if quota is None else max(1, min(n, int(quota + 0.999)))
+    return use, {"logical_cpus": os.cpu_count(), "affinity": n, "cgroup_cpu_quota": quota}
+
+
 def short_kernel(name):
     return re.sub(r"\(.*", "", name).replace("void ", "")
 
@@ -531,7 +550,7 @@ def main():
             # (i) one host core on frame 0; (ii) ALL logical CPUs on frames 0..15 through the pthread driver of
             # oracle/snow_oracle.c (work item = 256 beams of one (frame, channel); SURVEY 8 d).  The prepass (NumPy, one core,
             # ~15 ms per frame) is inside both clocks, as it is inside the reference's augment().
-            cores = os.cpu_count() or 1
+            cores, cpu_info = usable_cpus()
             n_cpu = min(16, F)
             las = so.load_lasers() * (layers // 64)
             c0 = time.perf_counter()
@@ -560,11 +579,12 @@ def main():
                     ok = ok and tuple(int(v) for v in out_stats[fi].cpu().numpy()) == tuple(int(v) for v in s_ref)
                 same = same and bool(ok)
             result["cpu_baseline"] = {"value": n_cpu * n_per / cpu_s, "unit": "points/s", "cores": used, "kind": "port",
-                                      "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(),
+                                      "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "host_cpus_usable": cpu_info,
                                       "sample": f"frames 0..{n_cpu - 1} of the batch ({n_cpu * n_per} points): oracle/snow_oracle.c (scalar C "
                                                 f"restatement, per-beam scan of the whole table, float64) under its pthread driver -- work item = "
-                                                f"256 beams of one (frame, channel), {used} threads = every logical CPU -- plus the NumPy frame "
-                                                f"driver, {cpu_s:.1f} s wall; one core on frame 0: {n_per / one_s:.0f} points/s ({one_s:.1f} s)",
+                                                f"256 beams of one (frame, channel), {used} threads = every CPU this process may use "
+                                                f"(affinity / cgroup quota) -- plus the NumPy frame driver, {cpu_s:.1f} s wall; one core on frame 0: "
+                                                f"{n_per / one_s:.0f} points/s ({one_s:.1f} s)",
                                       "single_core_value": n_per / one_s,
                                       "gpu_output_matches": bool(same)}
         print(json.dumps(result), flush=True)

@@ -18,6 +18,7 @@
 //     reference computes in the input dtype (range, beam azimuth, hard-target window) are float32.
 #pragma once
 #include "sg_math.h"
+#include "sg_atan_cr.h"
 
 template <typename T> struct SgReal;
 template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
@@ -111,7 +112,7 @@ __device__ __forceinline__ SgBeamGeo sg_beam_geometry(T px, T py, T pz, double b
         g.theta_c = (double)tc;
     } else {
         d_t = sqrt((px * px + py * py) + pz * pz);
-        g.theta_c = atan2(py, px);
+        g.theta_c = sg_atan2_cr(py, px);                        // :91 in float64: rounded correctly (sg_atan_cr.h)
         if (g.theta_c < 0) g.theta_c = g.theta_c + SG_TWO_PI;
     }
     g.d = (double)d_t;

@@ -128,6 +128,12 @@ struct snowgpu_ctx {
                                           // Measured (scripts/probe/chain_probe.hip): while ANY kernel writes host memory, every kernel boundary
                                           // on the device waits for its outstanding writes -- 3 us per dependent launch become 17 us beside a
                                           // 16-workgroup copy, 41 us beside 64 -- whereas DMA traffic in either direction costs nothing
+    // The small arrays of a host-pointer batch cross the link as ONE block each way, through page-locked mailboxes: frame
+    // offsets | table ids | planes or polynomials going up, status | counts | statistics | polynomials coming back (a
+    // single sweep otherwise spends a quarter of its time on seven tiny dependent copies).
+    char *mail_up_h = nullptr, *mail_dn_h = nullptr;
+    size_t mail_up_cap = 0, mail_dn_cap = 0;
+    DevBuf<uint8_t> mail_up_d, mail_dn_d;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
     std::vector<hipEvent_t> pipe_ev;      // [2 c] chunk c has been uploaded, [2 c + 1] computed
     DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
@@ -259,6 +265,9 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
+    if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
+    ctx->mail_up_d.release(); ctx->mail_dn_d.release();
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
@@ -1141,6 +1150,27 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     return status_to_error(ctx, agg);
 }
 
+static int ensure_mail(snowgpu_ctx *ctx, size_t up, size_t dn)
+{
+    if (up > ctx->mail_up_cap) {
+        if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
+        ctx->mail_up_h = nullptr; ctx->mail_up_cap = 0;
+        const size_t want = up + up / 2 + 4096;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->mail_up_h, want, hipHostMallocDefault));
+        ctx->mail_up_cap = want;
+    }
+    if (dn > ctx->mail_dn_cap) {
+        if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
+        ctx->mail_dn_h = nullptr; ctx->mail_dn_cap = 0;
+        const size_t want = dn + dn / 2 + 4096;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->mail_dn_h, want, hipHostMallocDefault));
+        ctx->mail_dn_cap = want;
+    }
+    ENSURE(ctx, ctx->mail_up_d, ctx->mail_up_cap);
+    ENSURE(ctx, ctx->mail_dn_d, ctx->mail_dn_cap);
+    return SNOWGPU_OK;
+}
+
 static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                       const int32_t *table_ids, double beam_div_deg, const double *thr_poly, const double *plane,
                       double noise_floor, const int32_t *perm, void *out_rows, int32_t *out_src, int64_t *out_counts,
@@ -1173,38 +1203,39 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     ENSURE(ctx, ctx->rows_in, std::max<size_t>(row_bytes, 8));
     ENSURE(ctx, ctx->rows_out, std::max<size_t>(row_bytes, 8));
     ENSURE(ctx, ctx->out_src, std::max<size_t>(n, 1));
-    ENSURE(ctx, ctx->frame_off, (size_t)n_frames + 1);
-    ENSURE(ctx, ctx->out_counts, (size_t)n_frames);
-    ENSURE(ctx, ctx->out_stats, (size_t)n_frames * 3);
-    ENSURE(ctx, ctx->table_ids, (size_t)n_frames * (size_t)ctx->h_las.n);
     ENSURE(ctx, ctx->thr_poly, (size_t)n_frames * 3);
-    ENSURE(ctx, ctx->plane, (size_t)n_frames * 4);
-    if (row_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * (size_t)n_frames * (size_t)ctx->h_las.n, hipMemcpyHostToDevice, st));
-    // the user polynomial goes to its own buffer so that the prepass scratch (ctx->thr_poly) stays free
-    DevBuf<double> &user_thr = ctx->user_thr;
-    const double *d_thr = nullptr;
-    if (thr_poly) {
-        if (user_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for thr_poly");
-        HIPCHK(ctx, hipMemcpyAsync(user_thr.p, thr_poly, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyHostToDevice, st));
-        d_thr = user_thr.p;
-    } else if (plane) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    // the small arrays: one block up (offsets | polynomials or planes | table ids), one block down (status | counts | stats | polynomials)
+    const size_t nfz = (size_t)n_frames, nlz = (size_t)ctx->h_las.n;
+    const size_t up_off = 0, up_par = up_off + 8 * (nfz + 1), up_ids = up_par + 8 * 4 * nfz, up_bytes = up_ids + 4 * nfz * nlz;
+    const size_t dn_st = 0, dn_cnt = 32, dn_stats = dn_cnt + 8 * nfz, dn_thr = dn_stats + 24 * nfz, dn_bytes = dn_thr + 24 * nfz;
+    {
+        int mrc = ensure_mail(ctx, up_bytes, dn_bytes);
+        if (mrc) return mrc;
     }
+    std::memcpy(ctx->mail_up_h + up_off, frame_offsets, 8 * (nfz + 1));
+    if (thr_poly) std::memcpy(ctx->mail_up_h + up_par, thr_poly, 24 * nfz);
+    else std::memcpy(ctx->mail_up_h + up_par, plane, 32 * nfz);
+    std::memcpy(ctx->mail_up_h + up_ids, table_ids, 4 * nfz * nlz);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->mail_up_d.p, ctx->mail_up_h, up_bytes, hipMemcpyHostToDevice, st));
+    if (row_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
+    const int64_t *d_frame_off = (const int64_t *)(ctx->mail_up_d.p + up_off);
+    const int32_t *d_table_ids = (const int32_t *)(ctx->mail_up_d.p + up_ids);
+    const double *d_thr = thr_poly ? (const double *)(ctx->mail_up_d.p + up_par) : nullptr;
+    const double *d_plane = thr_poly ? nullptr : (const double *)(ctx->mail_up_d.p + up_par);
+    int32_t *d_status = (int32_t *)(ctx->mail_dn_d.p + dn_st);
+    int64_t *d_counts = (int64_t *)(ctx->mail_dn_d.p + dn_cnt), *d_stats = (int64_t *)(ctx->mail_dn_d.p + dn_stats);
+    double *d_thr_out = (double *)(ctx->mail_dn_d.p + dn_thr);
     DevBuf<int32_t> &user_perm = ctx->user_perm;
     if (perm) {
         if (user_perm.ensure(std::max<size_t>(n, 1))) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for perm");
         if (n) HIPCHK(ctx, hipMemcpyAsync(user_perm.p, perm, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
     }
-    DevBuf<double> &d_out_thr = ctx->out_thr;
-    if (out_thr_poly && d_out_thr.ensure((size_t)n_frames * 3)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
     // Pre-augment camera crop (precompute.py:96-99): the frames are compacted on the device before anything else sees
     // them; only the per-frame counts visit the host (the frame offsets of the cropped batch are made there).
     const bool precrop = ctx->fov.enabled && ctx->fov_pre && !dbg_count && n > 0;
     std::vector<int64_t> crop_off;
     const void *d_rows_used = ctx->rows_in.p;
-    const int64_t *d_off_used = ctx->frame_off.p;
+    const int64_t *d_off_used = d_frame_off;
     int64_t n_used = n_total, max_frame_used = max_frame;
     if (precrop) {
         if (perm) return fail(ctx, SNOWGPU_E_INVALID, "a caller-supplied permutation cannot be combined with the pre-augment crop");
@@ -1218,7 +1249,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         ENSURE(ctx, ctx->rows_crop, row_bytes);
         ENSURE(ctx, ctx->crop_src, n);
         ENSURE(ctx, ctx->crop_out_src, n);
-        int e = sg_launch_crop_count(ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, ctx->keep.p, ctx->ctile_cnt.p, ctx->ctile_base.p,
+        int e = sg_launch_crop_count(ctx->rows_in.p, dtype, d_frame_off, n_frames, ctx->keep.p, ctx->ctile_cnt.p, ctx->ctile_base.p,
                                      ctx->crop_counts.p, ctx->crop_stats.p, &ctx->fov, max_tiles, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("crop launch: ") + hipGetErrorString((hipError_t)e));
         std::vector<int64_t> cnt((size_t)n_frames);
@@ -1232,7 +1263,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         }
         n_used = crop_off[(size_t)n_frames];
         HIPCHK(ctx, hipMemcpyAsync(ctx->crop_off.p, crop_off.data(), sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
-        e = sg_launch_crop_scatter(ctx->rows_in.p, dtype, ctx->keep.p, ctx->frame_off.p, ctx->crop_off.p, n_frames, ctx->ctile_base.p,
+        e = sg_launch_crop_scatter(ctx->rows_in.p, dtype, ctx->keep.p, d_frame_off, ctx->crop_off.p, n_frames, ctx->ctile_base.p,
                                    ctx->rows_crop.p, ctx->crop_src.p, max_tiles, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("crop launch: ") + hipGetErrorString((hipError_t)e));
         d_rows_used = ctx->rows_crop.p; d_off_used = ctx->crop_off.p;
@@ -1245,10 +1276,10 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         for (int f = 0; f < n_frames && uni; ++f) uni = (ho[f + 1] - ho[f]) == max_frame_used;
         b.uniform_rows = uni ? max_frame_used : 0;
     }
-    b.dtype = dtype; b.table_ids = ctx->table_ids.p; b.beam_div_deg = beam_div_deg; b.thr_poly = d_thr;
-    b.plane = (!thr_poly && plane) ? ctx->plane.p : nullptr; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
-    b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = ctx->out_counts.p; b.out_stats = ctx->out_stats.p;
-    b.out_thr_poly = out_thr_poly ? d_out_thr.p : nullptr; b.status = ctx->d_status; b.stream = st;
+    b.dtype = dtype; b.table_ids = d_table_ids; b.beam_div_deg = beam_div_deg; b.thr_poly = d_thr;
+    b.plane = d_plane; b.noise_floor = noise_floor; b.perm = perm ? user_perm.p : nullptr;
+    b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = d_counts; b.out_stats = d_stats;
+    b.out_thr_poly = out_thr_poly ? d_thr_out : nullptr; b.status = d_status; b.stream = st;
     b.no_fov = dbg_count != nullptr;
     if (dbg_count) {
         ENSURE(ctx, ctx->dbg_count, std::max<size_t>(n, 1));
@@ -1260,15 +1291,13 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     int rc = run_batch(ctx, b);
     int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
     if (rc == SNOWGPU_OK) {
-        HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(out_counts, ctx->out_counts.p, sizeof(int64_t) * (size_t)n_frames, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(out_stats, ctx->out_stats.p, sizeof(int64_t) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->mail_dn_h, ctx->mail_dn_d.p, out_thr_poly ? dn_bytes : dn_thr, hipMemcpyDeviceToHost, st));
         if (row_bytes && !precrop) {
             HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, row_bytes, hipMemcpyDeviceToHost, st));
             if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
         } else if (precrop && n_used > 0) {
             // source rows in the ORIGINAL frame: output row -> cropped row -> original row; every frame goes back to its own slot
-            int e = sg_launch_compose_src(ctx->crop_off.p, ctx->out_counts.p, n_frames, max_frame_used, ctx->out_src.p, ctx->crop_src.p,
+            int e = sg_launch_compose_src(ctx->crop_off.p, d_counts, n_frames, max_frame_used, ctx->out_src.p, ctx->crop_src.p,
                                           ctx->crop_out_src.p, st);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compose launch: ") + hipGetErrorString((hipError_t)e));
             for (int f = 0; f < n_frames; ++f) {
@@ -1279,7 +1308,6 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
                 if (out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + frame_offsets[f], ctx->crop_out_src.p + crop_off[(size_t)f], sizeof(int32_t) * m, hipMemcpyDeviceToHost, st));
             }
         }
-        if (out_thr_poly) HIPCHK(ctx, hipMemcpyAsync(out_thr_poly, d_out_thr.p, sizeof(double) * 3 * (size_t)n_frames, hipMemcpyDeviceToHost, st));
         if (dbg_count && n) {
             HIPCHK(ctx, hipMemcpyAsync(dbg_count, ctx->dbg_count.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipMemcpyAsync(dbg_rj, ctx->dbg_rj.p, sizeof(double) * n * (size_t)dbg_cap, hipMemcpyDeviceToHost, st));
@@ -1290,6 +1318,10 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     hipError_t se = hipStreamSynchronize(st);
     if (rc != SNOWGPU_OK) return rc;
     if (se != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("stream synchronize: ") + hipGetErrorString(se));
+    std::memcpy(status, ctx->mail_dn_h + dn_st, sizeof status);
+    std::memcpy(out_counts, ctx->mail_dn_h + dn_cnt, 8 * nfz);
+    std::memcpy(out_stats, ctx->mail_dn_h + dn_stats, 24 * nfz);
+    if (out_thr_poly) std::memcpy(out_thr_poly, ctx->mail_dn_h + dn_thr, 24 * nfz);
     std::memcpy(ctx->h_status, status, sizeof status);
     return status_to_error(ctx, status);
 }

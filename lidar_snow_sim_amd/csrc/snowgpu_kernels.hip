@@ -495,15 +495,19 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     const int ltid = BLOCK < 64 ? lane : tid;          // column of the LDS lists
     int64_t work_n = 0, work_off = 0;
     int n_items;
+    const int step = (int)gridDim.x * WAVES;
+    // A class that the resident waves take in ONE round of single-wave items gains nothing from windows (a wave would walk
+    // three rounds while two thirds of the chip idle): small batches and the rare long-list tiers run one item per wave.
+    int item_slots = LANES * WIN;
     if (LISTQ) {
         work_n = a.tier_info[a.cls];
         if (work_n > a.work_hi) work_n = a.work_hi;
         work_off = a.tier_info[4 + a.cls];
-        n_items = (int)((work_n + LANES * WIN - 1) / (LANES * WIN));
+        if (WIN > 1 && work_n <= (int64_t)step * LANES) item_slots = LANES;
+        n_items = (int)((work_n + item_slots - 1) / item_slots);
     } else {
         n_items = *a.pw_count;
     }
-    const int step = (int)gridDim.x * WAVES;
     const double *planes = LISTQ ? a.tq : a.dq;
     const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
     static_assert(WIN <= 4, "the window's permutation passes through one 64-double row segment of the wave");
@@ -513,8 +517,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     for (int i = (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(tid >> 6); i < n_items; i += step) {
         int start, cnt, item_f = -1;
         if (LISTQ) {
-            start = i * (LANES * WIN);
-            cnt = (int)(work_n - start < LANES * WIN ? work_n - start : LANES * WIN);
+            start = i * item_slots;
+            cnt = (int)(work_n - start < item_slots ? work_n - start : item_slots);
         } else {
             const int2 d = a.pw_items[i];
             start = __builtin_amdgcn_readfirstlane(d.x);
@@ -1258,7 +1262,12 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
     if (!LISTQ) {
         const unsigned pg = (unsigned)((a->n_regions_ub + 255) / 256);
         if (pg == 0) return 0;
-        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, LANES * (BLOCK < 64 ? 1 : SG_KP_WIN), (int)a->n_regions_ub);
+        // back runs (beams with several flakes, ~7 % of the rows of a sweep) as windows of SG_KP_WIN waves' worth of slots, taken
+        // in order of flake count -- unless the resident waves take them all in about two rounds of single-wave items anyway
+        // (small batches: a wave walking a window would serialise what the idle rest of the chip could do at once)
+        const int64_t back_est = a->n_total / 10;
+        const int lanes_back = (BLOCK < 64 || back_est <= (int64_t)blocks * (THREADS / 64) * LANES * 5 / 2) ? LANES : LANES * SG_KP_WIN;
+        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
         SG_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);

@@ -6,13 +6,16 @@
 // the flakes are binned by azimuth (2048 bins, every bin a flake's angular interval +- 1e-6 rad touches) and sorted by
 // range inside each bin.  snowgpu_upload_table does this on the host with glibc's libm -- the bit-exact path for the
 // reference's .npy tables.  This file does the same on the device for tables that are BORN there (snowgpu_sample_table),
-// so that they never visit the host: derive -> per-bin histogram -> scan -> scatter -> per-bin rank sort.  The device's
-// atan / atan2 / asin are OCML's, which may differ from glibc's in the last bit; for a sampled table, whose flakes have no
-// reference counterpart, that is immaterial (DESIGN.md "on-device sampler").
+// so that they never visit the host: derive -> per-bin histogram -> scan -> scatter -> per-bin rank sort.  atan2 / atan are
+// rounded correctly here (sg_atan_cr.h: double-double arithmetic), which glibc's are not quite -- 0.5056 ULP observed, 7 in
+// 10^4 inputs differ in the last bit -- so a device-filed table equals the host-filed one up to that (and asin, OCML's, only
+// widens the bin range a flake is filed under); for a sampled table, whose flakes have no reference counterpart, it is
+// immaterial either way (DESIGN.md "on-device sampler").
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 #include "sg_common.h"
+#include "sg_atan_cr.h"
 
 #define TB 256
 
@@ -29,7 +32,7 @@ __device__ __forceinline__ bool tb_derive(double x, double y, double r, SgEntry 
     f.x = x; f.y = y; f.r = r;
     f.rho = sqrt(x * x + y * y);                                          // simulation.py:332
     if (!(f.rho > r)) return false;                                       // disk contains the origin
-    f.phi = atan2(y, x);                                                  // simulation.py:351
+    f.phi = sg_atan2_cr(y, x);                                            // simulation.py:351 (rounded correctly, sg_atan_cr.h)
     if (f.phi < 0) f.phi = f.phi + SG_TWO_PI;                             // :352
     double a[2], b[2];
     const double disc = r * sqrt(x * x + y * y - r * r);                  // geometry.py:161
@@ -43,7 +46,7 @@ __device__ __forceinline__ bool tb_derive(double x, double y, double r, SgEntry 
     }
     double ang[2];
     for (int i = 0; i < 2; ++i) {                                         // geometry.py:47-72
-        double ray1 = atan(-a[i] / b[i]);
+        double ray1 = sg_atan_cr(-a[i] / b[i]);
         double ray2 = ray1 + SG_PI;
         if (ray1 < 0) ray1 = ray1 + SG_TWO_PI;
         ray1 = fabs(ray1);

@@ -96,7 +96,9 @@ def test_sampled_tables_feed_the_simulation(smp):
 def test_filed_per_flake_quantities_match_the_reference_geometry(golden):
     """The per-flake quantities hoisted out of get_occlusions' beam loop -- range, azimuth, tangent angles (geometry.py:138-190,
     :32-80) -- read back through the debug tap against the reference's own L1 outputs: bit for bit when the table is filed on
-    the host (snowgpu_upload_table, glibc libm), to the last bits when it is filed by the device kernels (OCML atan / atan2)."""
+    the host (snowgpu_upload_table, glibc libm); when it is filed by the device kernels, whose atan2 / atan are rounded correctly
+    (csrc/sg_atan_cr.h) where glibc's are off by up to 0.506 ULP, all but a few values in a thousand are identical and the rest
+    differ by one ULP."""
     import torch
     from lidar_snow_sim_amd import engine
     d = golden("L1_geometry")
@@ -110,8 +112,8 @@ def test_filed_per_flake_quantities_match_the_reference_geometry(golden):
     qh, qd = eng.ctx.debug_table(t_host, k), eng.ctx.debug_table(t_dev, k)
     want = np.column_stack((d["rho"], d["phi"], d["tangent_angles"]))
     assert np.array_equal(qh, want)                                  # host filing: the reference's numbers exactly
-    np.testing.assert_allclose(qd, want, rtol=4e-16, atol=0)         # device filing: within 2 ulp
-    assert (qd != want).mean() < 0.5
+    np.testing.assert_allclose(qd, want, rtol=2.3e-16, atol=0)       # device filing: within 1 ulp ...
+    assert (qd != want).mean() < 0.005                               # ... and that only where glibc is not correctly rounded
     # both filings put every flake into the same bins in the same order: a sweep over either gives the same rows
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     full = synthetic_sweep(64, 2048, seed=77, intensity="lambert").reshape(64, 2048, 5)
