@@ -58,6 +58,10 @@ WORKLOADS = {   # name: (layers, azimuths, snowfall mm/h, terminal velocity m/s,
     "C3": (64, 2048, 2.5, 1.6, 1.0),       # configs[2]: the C2 sweeps through snowfall + wet ground, fused on the device
 }
 REGION_KERNELS = ("k_beams", "k_power", "k_tier")    # the per-beam region of roofline.avg_launch_ms
+# rocprofv3's FETCH_SIZE x 1024 B is HALF the bytes a kernel reads on gfx950, for every access shape the engine uses (4- and
+# 8-byte streams, 20-byte rows field by field, 64-byte records: ratio 0.5000 each), WRITE_SIZE x 1024 B is exact for streams:
+# measured with kernels of known byte counts, scripts/probe/pmc_calib.hip -> profiles/r03_pmc_calibration.json.
+FETCH_FACTOR, WRITE_FACTOR = 2.0, 1.0
 
 
 def make_tables(n_lines=64, snowfall=SNOWFALL, velocity=VELOCITY, distinct=None):
@@ -484,14 +488,23 @@ def main():
                           inner_argv, 3) if write else None
             if fetch and write:
                 in_region = lambda k: k.startswith(REGION_KERNELS)      # noqa: E731
-                fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in fetch.items() if in_region(k)) * 1024
-                wb = sum(v.get("WRITE_SIZE", 0.0) for k, v in write.items() if in_region(k)) * 1024
+                fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in fetch.items() if in_region(k)) * 1024 * FETCH_FACTOR
+                wb = sum(v.get("WRITE_SIZE", 0.0) for k, v in write.items() if in_region(k)) * 1024 * WRITE_FACTOR
                 traffic = fb + wb
+                whole = (sum(v.get("FETCH_SIZE", 0.0) for v in fetch.values()) * FETCH_FACTOR
+                         + sum(v.get("WRITE_SIZE", 0.0) for v in write.values()) * WRITE_FACTOR) * 1024
                 traffic_src = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes of this command (--steps 2 --warmup 1), "
-                                         "kernels k_beams* / k_power* / k_tier*, raw counters x 1024 B (4- and 8-byte accesses: the gfx950 "
-                                         "x2 correction for wide coalesced reads does not apply)",
-                               "fetch_bytes": fb, "write_bytes": wb,
-                               "whole_step_bytes": (sum(v.get("FETCH_SIZE", 0.0) for v in fetch.values()) + sum(v.get("WRITE_SIZE", 0.0) for v in write.values())) * 1024}
+                                         "kernels k_beams* / k_power* / k_tier*; counter x 1024 B x calibration factor (FETCH_SIZE x 2.0, "
+                                         "WRITE_SIZE x 1.0: kernels of known byte counts, profiles/r03_pmc_calibration.json)",
+                               "fetch_bytes": fb, "write_bytes": wb, "whole_step_bytes": whole,
+                               "whole_step_over_algorithmic": whole / alg_bytes}
+                dump = os.environ.get("SNOWGPU_BENCH_PMC_DUMP")
+                if dump:                                    # per-kernel table for profiles/ (scripts/collect_profiles.sh)
+                    with open(dump, "w") as fh:
+                        fh.write("kernel,FETCH_SIZE_KB_per_step_raw,WRITE_SIZE_KB_per_step_raw,read_bytes_per_step_calibrated,written_bytes_per_step\n")
+                        for k in sorted(set(fetch) | set(write)):
+                            f_kb, w_kb = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
+                            fh.write('"%s",%.1f,%.1f,%.0f,%.0f\n' % (k, f_kb, w_kb, f_kb * 1024 * FETCH_FACTOR, w_kb * 1024 * WRITE_FACTOR))
             if sq:
                 dom = max((k for k in sq if k.startswith("k_beams")), key=lambda k: sq[k].get("SQ_INSTS_VALU", 0.0), default=None)
                 if dom:

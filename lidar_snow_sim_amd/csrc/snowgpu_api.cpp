@@ -123,6 +123,7 @@ struct snowgpu_ctx {
     hipStream_t prof_stream = nullptr;
     int exact_math = 0;
     // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each); see host_batch_pipelined.
+    bool pipe_serial = true;
     int link_blocks = 0;                  // SNOWGPU_LINK_BLOCKS: 0 = downloads by the runtime's copy (the DMA engine, unless the process has
                                           // initialised PyTorch: then a full-grid blit kernel); n > 0 = by a kernel of ours with n workgroups.
                                           // Measured (scripts/probe/chain_probe.hip): while ANY kernel writes host memory, every kernel boundary
@@ -246,6 +247,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PIPE_ROWS"); if (v) ctx->pipe_rows = std::max<int64_t>(std::atoll(v), 0); }
+    { const char *v = std::getenv("SNOWGPU_PIPE_SERIAL"); if (v) ctx->pipe_serial = v[0] != '0'; }
     { const char *v = std::getenv("SNOWGPU_LINK_BLOCKS"); if (v) ctx->link_blocks = std::min(std::max(std::atoi(v), 0), 4096); }
     int rc = init_streams(ctx);
     if (rc) return rc;
@@ -657,6 +659,7 @@ struct BatchDev {
     int dbg_cap = 0;
     int32_t *perm_out = nullptr;   // where the permutation actually used lives (device)
     bool no_fov = false;           // debug tap: never crop
+    bool serial = false;           // every kernel on `stream`: no fork / join events (chunks of the host pipeline)
 };
 
 static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
@@ -670,7 +673,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
-    const bool serial = R->serial;
+    const bool serial = R->serial || b.serial;
     hipStream_t s_aux = serial ? st : ctx->aux, s_aux2 = serial ? st : ctx->aux2, s_aux3 = serial ? st : ctx->aux3;
     HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
     HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));   // status[1] = first offending row, -1 = none
@@ -1101,6 +1104,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
         b.out_thr_poly = out_thr_poly ? ctx->out_thr.p + 3 * (size_t)f0 : nullptr;
         b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = st;
+        // Beside a saturated link every cross-stream event costs more (the queues' completion signals live in host memory), so a
+        // chunk keeps its kernels on one stream: 1.80 instead of 1.76 G points/s (2.09 / 1.96 without source indices), although
+        // the same chunk alone is faster with its side streams.  SNOWGPU_PIPE_SERIAL=0: side streams.
+        b.serial = ctx->pipe_serial;
         rc = run_batch(ctx, b);
         if (rc != SNOWGPU_OK) break;
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], st));

@@ -154,17 +154,15 @@ class Engine:
         with self._lock:
             return self._new_id()
 
+    def file_table_id(self, particle_file_prefix, line, root_path=None):
+        """Device table id of <prefix>_<line>.npy under the reference's directories (simulation.py:324-329)."""
+        base = (Path(root_path) / "training" / "snowflakes" / "npy") if root_path else particle_dir()
+        path = base / f"{particle_file_prefix}_{line}.npy"
+        return self.table_id(("file", str(path)), lambda p=path: np.load(str(p)))
+
     def table_ids_from_files(self, particle_file_prefix, order, root_path=None):
         """The reference's lookup (simulation.py:78, :324-329): channel c reads <prefix>_<order[c]+1>.npy."""
-        if root_path:
-            base = Path(root_path) / "training" / "snowflakes" / "npy"
-        else:
-            base = particle_dir()
-        ids = []
-        for ch in range(self.n_lasers):
-            path = base / f"{particle_file_prefix}_{order[ch] + 1}.npy"
-            ids.append(self.table_id(("file", str(path)), lambda p=path: np.load(str(p))))
-        return ids
+        return [self.file_table_id(particle_file_prefix, order[ch] + 1, root_path) for ch in range(self.n_lasers)]
 
     def table_ids_from_arrays(self, particles, order):
         """particles: sequence (index = line - 1) of K x 3 arrays; channel c uses particles[order[c]]."""

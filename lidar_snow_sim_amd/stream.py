@@ -10,7 +10,8 @@ skipping outputs that already exist (:91-92).
 The reference walks mode -> frame -> combo one augment() at a time.  Here the same work items are grouped into batches
 per (mode, combo) -- one flake-table set per batch -- and flow through three stages joined by bounded queues:
 
-    reader threads  np.fromfile of the batch's frames, `depth` batches ahead
+    reader threads  read the batch's .bin files straight into ONE page-locked batch buffer (no per-frame array, no staging
+                    copy on the GPU worker's thread), `depth` batches ahead
     GPU workers     one host thread + engine context (stream, scratch, page-locked staging) each: upload, crop on the device,
                     augment, crop again (augment's only_camera_fov), download; the copies of one context overlap the
                     kernels of the other
@@ -37,7 +38,7 @@ import numpy as np
 
 from . import dist as sdist
 from .tools.snowfall.sampling import compute_occupancy, snowfall_rate_to_rainfall_rate
-from .tools.snowfall.simulation import augment_batch
+from .tools.snowfall.simulation import FlatBatch, augment_batch
 
 SNOWFALL_RATES = [0.5, 1.0, 2.0, 2.5, 1.5]        # mm/h   (precompute.py:20)
 TERMINAL_VELOCITIES = [2.0, 1.6, 2.0, 1.6, 0.6]   # m/s    (precompute.py:21)
@@ -62,11 +63,18 @@ def output_path(lidar_folder: Path, mode: str, rainfall_rate: float, sample_id: 
             f'{lidar_folder.name}_rainrate_{int(rainfall_rate)}' / f'{sample_id}.bin')
 
 
-def plan(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
+def plan_iter(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
     """The work items in the reference's order (precompute.py:70-92: mode -> frame -> combo, existing outputs skipped), one
-    `random.shuffle` per item in that order (simulation.py:483-486), regrouped into batches of one (mode, combo)."""
+    `random.shuffle` per item in that order (simulation.py:483-486), regrouped into batches of one (mode, combo).  A generator:
+    a batch is handed out as soon as its group holds `batch` items, so the pipeline runs while later permutations are drawn."""
     import random
     groups = {}
+
+    def job(mode, ci, items):
+        rainfall_rate, occupancy = combos[ci]
+        prefix = f'{mode}_{rainfall_rate}_{occupancy}'                                   # precompute.py:101
+        return (mode, rainfall_rate, prefix, [c[0] for c in items], [c[1] for c in items])
+
     for mode in modes:
         for s in mine:
             for ci, (rainfall_rate, _occ) in enumerate(combos):
@@ -74,15 +82,18 @@ def plan(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_l
                     continue
                 order = list(range(n_lasers))
                 random.shuffle(order)
-                groups.setdefault((mode, ci), []).append((s, order))
-    jobs = []
+                items = groups.setdefault((mode, ci), [])
+                items.append((s, order))
+                if len(items) >= batch:
+                    yield job(mode, ci, items)
+                    groups[(mode, ci)] = []
     for (mode, ci), items in groups.items():
-        rainfall_rate, occupancy = combos[ci]
-        prefix = f'{mode}_{rainfall_rate}_{occupancy}'                                   # precompute.py:101
-        for b0 in range(0, len(items), batch):
-            chunk = items[b0:b0 + batch]
-            jobs.append((mode, rainfall_rate, prefix, [c[0] for c in chunk], [c[1] for c in chunk]))
-    return jobs
+        if items:
+            yield job(mode, ci, items)
+
+
+def plan(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
+    return list(plan_iter(lidar_folder, mine, modes, combos, batch, n_lasers))
 
 
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
@@ -100,18 +111,47 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
     combos = rate_combos() if combos is None else combos
     ids = list(sample_ids)
     mine = [ids[i] for i in sdist.shard_indices(len(ids), rank, world)]
-    jobs = plan(lidar_folder, mine, modes, combos, batch)
+    jobs = plan_iter(lidar_folder, mine, modes, combos, batch)      # drawn by the feeder thread while the pipeline runs
+    n_jobs = [0]
     t_start = time.perf_counter()
     tally = {'files': 0, 'points_in': 0, 'points_out': 0, 'read_s': 0.0, 'gpu_s': 0.0, 'write_s': 0.0}
     tally_lock = threading.Lock()
     errors = []
 
+    # page-locked batch buffers, recycled: a reader fills one, the GPU worker uploads from it and hands it back
+    from . import engine as _engine
+    pin_pool, pin_lock = [], threading.Lock()
+
+    def take_buffer(n_rows):
+        with pin_lock:
+            for i, b in enumerate(pin_pool):
+                if b.shape[0] >= n_rows:
+                    return pin_pool.pop(i)
+        return _engine.get_engine(device, 0).ctx.pinned_empty((max(n_rows, 1) * 9 // 8 + 1024, 5), np.float32)
+
+    def give_buffer(b):
+        with pin_lock:
+            if len(pin_pool) < 2 * (max(workers, 1) + max(depth, 1)):
+                pin_pool.append(b)
+
     def read_job(job):
         t0 = time.perf_counter()
-        frames = [np.fromfile(str(lidar_folder / f'{s}.bin'), dtype=np.float32).reshape(-1, 5) for s in job[3]]   # :78
+        paths = [lidar_folder / f'{s}.bin' for s in job[3]]
+        sizes = [p.stat().st_size // 20 for p in paths]                                 # float32 N x 5 rows (precompute.py:78)
+        off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        buf = take_buffer(int(off[-1]))
+        for p, a, b in zip(paths, off[:-1], off[1:]):
+            with open(p, 'rb', buffering=0) as fh:
+                view = memoryview(buf[int(a):int(b)]).cast('B')
+                got = fh.readinto(view)
+                while got < len(view):                                                  # short reads
+                    more = fh.readinto(view[got:])
+                    if not more:
+                        raise OSError(f'{p}: truncated')
+                    got += more
         with tally_lock:
             tally['read_s'] += time.perf_counter() - t0
-        return frames
+        return FlatBatch(buf, off)
 
     def write_job(job, results):
         t0 = time.perf_counter()
@@ -134,10 +174,15 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
     with ThreadPoolExecutor(max_workers=max(readers, 1)) as read_pool, ThreadPoolExecutor(max_workers=max(writers, 1)) as write_pool:
 
         def feeder():
-            for job in jobs:
-                q_read.put((job, read_pool.submit(read_job, job)))
-            for _ in range(max(workers, 1)):
-                q_read.put(None)
+            try:
+                for job in jobs:
+                    n_jobs[0] += 1
+                    q_read.put((job, read_pool.submit(read_job, job)))
+            except BaseException as e:                                                   # noqa: BLE001 -- reported after the drain
+                errors.append(e)
+            finally:
+                for _ in range(max(workers, 1)):
+                    q_read.put(None)
 
         def gpu_worker(slot):
             while True:
@@ -148,13 +193,16 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
                 try:
                     frames = fut.result()
                     t0 = time.perf_counter()
-                    results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
-                                            particles=None if particles_by_prefix is None else particles_by_prefix[job[2]],
-                                            planes=None if planes is None else [planes] * len(frames),
-                                            orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None)
+                    try:
+                        results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
+                                                particles=None if particles_by_prefix is None else particles_by_prefix[job[2]],
+                                                planes=None if planes is None else [planes] * len(frames),
+                                                orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None)
+                    finally:
+                        give_buffer(frames.rows)
                     with tally_lock:
                         tally['gpu_s'] += time.perf_counter() - t0
-                        tally['points_in'] += sum(f.shape[0] for f in frames)
+                        tally['points_in'] += int(frames.offsets[-1])
                     q_write.put(write_pool.submit(write_job, job, results))
                 except BaseException as e:                                               # noqa: BLE001 -- reported after the drain
                     errors.append(e)
@@ -181,7 +229,7 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
     if errors:
         raise errors[0]
     if report is not None:
-        report.update(tally, wall_s=time.perf_counter() - t_start, batches=len(jobs), workers=workers, readers=readers,
+        report.update(tally, wall_s=time.perf_counter() - t_start, batches=n_jobs[0], workers=workers, readers=readers,
                       writers=writers, batch=batch)
     return tally['files']
 

@@ -38,6 +38,43 @@ def _as_rows(pc) -> np.ndarray:
     return pc
 
 
+class _LazyFileIds:
+    """Device table ids of <prefix>_<line>.npy, loaded on first use only (a frame touches the lines its permutation names)."""
+
+    def __init__(self, eng, prefix, root_path):
+        self.eng, self.prefix, self.root_path, self.ids = eng, prefix, root_path, {}
+
+    def __getitem__(self, lines):
+        out = np.empty(len(lines), np.int32)
+        for c, k in enumerate(lines):
+            k = int(k)
+            if k not in self.ids:
+                self.ids[k] = self.eng.file_table_id(self.prefix, k + 1, self.root_path)
+            out[c] = self.ids[k]
+        return out
+
+
+class FlatBatch:
+    """Frames that already lie back to back in ONE N_total x 5 array (ideally page-locked: Context.pinned_empty), with their
+    offsets -- what a reader that fills a batch buffer straight from the .bin files hands to augment_batch, which then skips
+    its own staging copy (precompute.py:78 np.fromfile -> the upload buffer, no intermediate array)."""
+
+    def __init__(self, rows: np.ndarray, offsets, pinned: bool = True):
+        self.rows = rows
+        self.offsets = np.ascontiguousarray(offsets, np.int64)
+        self.pinned = pinned
+        if rows.ndim != 2 or rows.shape[1] != 5 or rows.dtype not in (np.float32, np.float64) or not rows.flags.c_contiguous:
+            raise ValueError("a FlatBatch is a C-contiguous float32 / float64 N x 5 array")
+        if self.offsets[0] != 0 or self.offsets[-1] > rows.shape[0] or np.any(np.diff(self.offsets) < 0):
+            raise ValueError("bad frame offsets")
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def frame(self, i):
+        return self.rows[int(self.offsets[i]):int(self.offsets[i + 1])]
+
+
 def _rows_for_plane(r, calib, pre_crop):
     """What calculate_plane sees: with the pre-augment camera crop (precompute.py:96-99) the reference fits the plane on the
     CROPPED cloud (precompute.py:96-104 calls augment() with it).  The device crops later, so the host applies the same crop to
@@ -87,7 +124,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
     """
     eng = _engine.get_engine(device, slot)
-    rows = [_as_rows(f) for f in frames]
+    flat_in = frames if isinstance(frames, FlatBatch) else None
+    rows = [flat_in.frame(i) for i in range(len(flat_in))] if flat_in is not None else [_as_rows(f) for f in frames]
     if not rows:
         return []
     # columns beyond the fifth ride through untouched, as in the reference (it indexes whole rows, simulation.py:447, :508-523)
@@ -102,6 +140,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         device_prepass = False
     nl = eng.n_lasers
     table_ids, polys, plane_rows = [], [], []
+    ids_by_line = None                                                      # device table id of line - 1, looked up once per batch
     for i, r in enumerate(rows):
         if orders is not None:
             order = list(orders[i])
@@ -109,10 +148,13 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             order = list(range(nl))                                         # simulation.py:483
             if shuffle:
                 random.shuffle(order)                                       # simulation.py:485-486
-        if particles is not None:
-            table_ids.append(eng.table_ids_from_arrays(particles, order))
-        else:
-            table_ids.append(eng.table_ids_from_files(particle_file_prefix, order, root_path))
+        if ids_by_line is None:
+            lines = range(max(nl, max(order) + 1))
+            if particles is not None:
+                ids_by_line = np.asarray([eng.array_table_id(particles[k]) if k < len(particles) else -1 for k in lines], np.int32)
+            else:
+                ids_by_line = _LazyFileIds(eng, particle_file_prefix, root_path)
+        table_ids.append(ids_by_line[np.asarray(order[:nl], np.int64)])     # channel c reads line order[c] + 1 (simulation.py:78)
         if thr_polys is not None:
             polys.append(np.asarray(thr_polys[i], np.float64))
         else:
@@ -124,11 +166,14 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
     offsets = np.zeros(len(rows) + 1, np.int64)
     offsets[1:] = np.cumsum([r.shape[0] for r in rows])
     with eng.batch_lock:
-        flat = eng.staging_in(int(offsets[-1]), dt)                              # page-locked: PCIe speed, no page faults
-        if len(rows) > 1:
-            np.concatenate([r[:, :5] for r in rows], out=flat)
+        if flat_in is not None:
+            flat = flat_in.rows[:int(offsets[-1])]                               # the caller's (page-locked) batch buffer as it is
         else:
-            flat[...] = rows[0][:, :5]
+            flat = eng.staging_in(int(offsets[-1]), dt)                          # page-locked: PCIe speed, no page faults
+            if len(rows) > 1:
+                np.concatenate([r[:, :5] for r in rows], out=flat)
+            else:
+                flat[...] = rows[0][:, :5]
         out_rows, out_src = eng.result_buffers(int(offsets[-1]), dt)
         # The device counting sort handles integer channel values 0..255 and reports anything else
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
