@@ -1,20 +1,25 @@
 #!/bin/bash
-# GPU side (run through gpurun): the evidence profiles/ is built from.  Every rocprofv3 pass is separate (kernel trace +
-# stats; FETCH_SIZE; WRITE_SIZE; two SQ passes) and runs under its own timeout.   usage: scripts/collect_profiles.sh [tag]
+# GPU side (run through gpurun): the evidence profiles/ is built from.  Every pass runs under its own timeout.
+#   usage: scripts/collect_profiles.sh [tag]          (scripts/make_profiles.py turns gpurun_out/evidence into profiles/<tag>_*)
 export R=$GRAFT_REPO_ROOT; cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/evidence; rm -rf $O; mkdir -p $O
 B="python $R/bench.py --no-cpu-baseline --no-pmc --no-pcie"
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $B --steps 10 --warmup 2 > $O/stats.log 2>&1
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o b --output-format csv -- $B --steps 2 --warmup 1 > $O/fetch.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o b --output-format csv -- $B --steps 2 --warmup 1 > $O/write.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --kernel-trace -d $O/sq_a -o b --output-format csv -- $B --steps 2 --warmup 1 > $O/sq_a.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR --kernel-trace -d $O/sq_b -o b --output-format csv -- $B --steps 2 --warmup 1 > $O/sq_b.log 2>&1
+# 1. per-kernel time summary + one-step timeline of the default command's timed loop
+timeout 200 rocprofv3 --kernel-trace --stats -d $O/stats -o b --output-format csv -- $B --steps 10 --warmup 2 > $O/stats.log 2>&1
+# 2. counter calibration: kernels of known byte counts (scripts/probe/pmc_calib.hip), one pass per counter
+timeout 90 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/calib_f -o c -- $R/scripts/probe/pmc_calib > /dev/null 2>&1
+timeout 90 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/calib_w -o c -- $R/scripts/probe/pmc_calib > /dev/null 2>&1
+# 3. SQ counters of the per-beam kernels
+timeout 150 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --kernel-trace -d $O/sq -o b --output-format csv -- $B --steps 2 --warmup 1 > $O/sq.log 2>&1
 cd $R
+python scripts/pmc_calibration.py $O/calib_f $O/calib_w $O/pmc_calibration.json > $O/pmc_calibration.txt
 python scripts/trace_timeline.py $O/stats > $O/timeline.txt
-SNOWGPU_SERIAL=1 timeout 300 rocprofv3 --kernel-trace -d $O/serial -o b --output-format csv -- $B --steps 6 --warmup 2 > $O/serial.log 2>&1
-python scripts/trace_timeline.py $O/serial > $O/timeline_serial.txt
-timeout 600 python bench.py > $O/bench_C2.json 2> $O/bench_C2.err
-for w in C2far C1 C4 C3; do timeout 400 python bench.py --workload $w --no-pmc $( [ $w = C4 ] && echo --frames 128 ) > $O/bench_$w.json 2> $O/bench_$w.err; done
-timeout 900 python scripts/gpu_stream_c5.py --frames 10000 --batch 64 > $O/stream_c5.log 2>&1; cp gpurun_out/stream_c5.json $O/ 2>/dev/null
-tail -c 600 $O/bench_C2.json; tail -3 $O/timeline.txt; tail -1 $O/stream_c5.log | cut -c1-400
+# 4. the bench line itself (its own FETCH_SIZE / WRITE_SIZE / SQ child passes; per-kernel byte table dumped on the way)
+SNOWGPU_BENCH_PMC_DUMP=$O/pmc_fetch_write_per_kernel.csv timeout 400 python bench.py > $O/bench_C2.json 2> $O/bench_C2.err
+# 5. the other workloads of BASELINE.json
+for w in ${WORKLOADS:-C4 C3}; do timeout 200 python bench.py --workload $w --no-pmc --no-cpu-baseline $( [ $w = C4 ] && echo --frames 128 ) > $O/bench_$w.json 2> $O/bench_$w.err; done
+timeout 300 python bench.py --workload C5 --frames ${C5_FRAMES:-10000} > $O/bench_C5.json 2> $O/bench_C5.err
+# 6. the pipeline's own event trace (upload / compute / download per chunk)
+SNOWGPU_PIPE_TRACE=1 timeout 120 python scripts/pcie_bench.py --reps 1 2>&1 | grep "^pipe" | tail -14 > $O/pipeline_trace.txt
+tail -c 400 $O/bench_C2.json; tail -3 $O/timeline.txt; cut -c1-300 $O/bench_C5.json

@@ -7,7 +7,7 @@ from collections import defaultdict
 from pathlib import Path
 root = Path(__file__).resolve().parent.parent
 ev = root / "gpurun_out" / "evidence"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 prof = root / "profiles"
 REGION = ("k_beams", "k_power", "k_tier")
 
@@ -31,32 +31,27 @@ shutil.copy(ev / "stats" / "b_kernel_stats.csv", prof / f"{tag}_rocprofv3_kernel
 for name in ("timeline", "timeline_serial"):
     if (ev / f"{name}.txt").exists():
         shutil.copy(ev / f"{name}.txt", prof / f"{tag}_{name}_one_step.txt")
-# ---- HBM-side bytes per kernel ----------------------------------------------------------------------------------------
-per = defaultdict(lambda: defaultdict(list))
-for which, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    with open(ev / which / "b_counter_collection.csv", newline="") as fh:
-        for row in csv.DictReader(fh):
-            if row["Counter_Name"] == counter:
-                per[short(row["Kernel_Name"])][counter].append(float(row["Counter_Value"]))
-steps = 3   # --steps 2 --warmup 1
-with open(prof / f"{tag}_pmc_fetch_write_per_kernel.csv", "w") as fh:
-    fh.write("kernel,launches_per_step,FETCH_SIZE_KB_per_step,WRITE_SIZE_KB_per_step\n")
-    for k in sorted(per):
-        f, w = per[k]["FETCH_SIZE"], per[k]["WRITE_SIZE"]
-        fh.write('"%s",%.1f,%.1f,%.1f\n' % (k, len(f) / steps, sum(f) / steps, sum(w) / steps))
-fetch = sum(sum(v["FETCH_SIZE"]) for k, v in per.items() if k.startswith(REGION)) / steps
-write = sum(sum(v["WRITE_SIZE"]) for k, v in per.items() if k.startswith(REGION)) / steps
-rec = {"round": int(tag[1:]), "frames": 256, "workload": "C2",
-       "kernel": "per-beam region of one step: k_beams* (scan pass and later tiers), k_power_plan, k_power*, k_tier_* (the region of roofline.avg_launch_ms)",
-       "FETCH_SIZE_KB_per_launch": fetch, "WRITE_SIZE_KB_per_launch": write, "bytes_per_launch": (fetch + write) * 1024,
-       "whole_step_bytes": 1024 * sum(sum(v["FETCH_SIZE"]) + sum(v["WRITE_SIZE"]) for v in per.values()) / steps,
-       "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 2 --warmup 1`, summed over the kernels of "
-               "the timed region and averaged over the 3 steps; raw counter values (KB).  MI355X_MICROARCH.md: FETCH_SIZE reads exactly 1/2 of the "
-               "bytes of a WIDE (16 B/lane) coalesced stream on gfx950; these kernels read 4-byte row fields, 8-byte queue planes and 64-byte table "
-               "records, for which the counter is uncalibrated, so no correction is applied."}
-(prof / "hbm_traffic.json").write_text(json.dumps(rec, indent=1))
+# ---- HBM-side bytes per kernel (dumped by bench.py's own counter passes) + counter calibration ------------------------
+for name in ("pmc_fetch_write_per_kernel.csv", "pmc_calibration.json", "pmc_calibration.txt", "pipeline_trace.txt"):
+    if (ev / name).exists():
+        shutil.copy(ev / name, prof / f"{tag}_{name}")
+if bench and bench.get("roofline", {}).get("traffic"):
+    rl = bench["roofline"]
+    rec = {"round": int(tag[1:]), "frames": 256, "workload": "C2",
+           "kernel": "per-beam region of one step: k_beams* (scan pass and later tiers), k_power_plan, k_power*, k_tier_* (the region of roofline.avg_launch_ms)",
+           "bytes_per_launch": rl["traffic"], "detail": rl.get("traffic_detail"),
+           "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child passes of `bench.py --steps 2 --warmup 1`, summed over the kernels "
+                   "of the timed region, averaged over the 3 steps, counters x 1024 B x calibration factor (FETCH_SIZE x 2.0 on gfx950: "
+                   f"{tag}_pmc_calibration.json, kernels of known byte counts)"}
+    (prof / "hbm_traffic.json").write_text(json.dumps(rec, indent=1))
+for w in ("C5",):
+    f = ev / f"bench_{w}.json"
+    if f.exists():
+        got = [l for l in f.read_text().splitlines() if l.startswith("{")]
+        if got:
+            (prof / f"{tag}_bench_{w}.json").write_text(got[-1] + "\n")
 # ---- SQ counters of the per-beam kernels (per launch) --------------------------------------------------------------------
-sq = subprocess.run([sys.executable, str(root / "scripts" / "pmc_summary.py"), str(ev / "sq_a"), str(ev / "sq_b"), "--filter", "k_"],
+sq = subprocess.run([sys.executable, str(root / "scripts" / "pmc_summary.py"), str(ev / "sq"), "--filter", "k_"],
                     capture_output=True, text=True).stdout
 keep, cur = [], []
 for ln in sq.splitlines() + [""]:
