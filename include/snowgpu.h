@@ -111,8 +111,8 @@ int snowgpu_table_count(const snowgpu_ctx *ctx);
 int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm,
                          double r_0, uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out);
 
-/* Rows per chunk of the host-pointer entry's upload / compute / download pipeline (default 3 * 2^20, i.e. 24 sweeps of
- * 64 x 2048; environment SNOWGPU_PIPE_ROWS); 0 = no pipeline: one upload, one launch sequence, one download.  The
+/* Rows per chunk of the host-pointer entry's upload / compute / download pipeline (default 3 * 2^19, i.e. 12 sweeps of
+ * 64 x 2048; environment SNOWGPU_PIPE_ROWS; chunks alternate between SNOWGPU_PIPE_LANES = 2 compute lanes); 0 = no pipeline: one upload, one launch sequence, one download.  The
  * reference has no counterpart (its arrays never leave the host; precompute.py:78 / :106 are its I/O boundary). */
 int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows);
 
@@ -157,8 +157,8 @@ int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
  *   out_thr_poly optional n_frames x 3: the threshold polynomial actually used
  *
  * A batch larger than ~1.5 chunks runs as a PIPELINE of chunks of whole frames (snowgpu_set_pipeline): all uploads stream
- * through one DMA queue, the chunks compute one after the other, and each chunk's results leave on a third stream while
- * the next chunk computes -- one host thread and one context keep both directions of the link and the CUs busy.
+ * through one DMA queue, the chunks compute on two alternating lanes, and each chunk's results leave on a third stream while
+ * the next chunks compute -- one host thread and one context keep both directions of the link and the CUs busy.
  * Page-locked rows / out_rows / out_src (snowgpu_host_alloc) make the upload asynchronous and let the download be a small
  * kernel that writes host memory directly; pageable memory works and is slower.  The call returns when everything has landed.
  */

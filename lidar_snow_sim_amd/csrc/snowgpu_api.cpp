@@ -124,6 +124,9 @@ struct snowgpu_ctx {
     int exact_math = 0;
     // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each); see host_batch_pipelined.
     bool pipe_serial = true;
+    snowgpu_ctx *root = nullptr;          // set in a lane: the context whose tables, lasers and settings it computes with
+    std::vector<snowgpu_ctx *> lanes;     // further compute lanes of the host pipeline (own stream, events and scratch), made on first use
+    int pipe_lanes = 2;                   // SNOWGPU_PIPE_LANES: chunks computing side by side (lane 0 is the context itself)
     int link_blocks = 0;                  // SNOWGPU_LINK_BLOCKS: 0 = downloads by the runtime's copy (the DMA engine, unless the process has
                                           // initialised PyTorch: then a full-grid blit kernel); n > 0 = by a kernel of ours with n workgroups.
                                           // Measured (scripts/probe/chain_probe.hip): while ANY kernel writes host memory, every kernel boundary
@@ -139,7 +142,7 @@ struct snowgpu_ctx {
     std::vector<hipEvent_t> pipe_ev;      // [2 c] chunk c has been uploaded, [2 c + 1] computed
     DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
     DevBuf<int32_t> pipe_status;      // 8 status words per chunk
-    int64_t pipe_rows = (int64_t)3 << 20;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
+    int64_t pipe_rows = (int64_t)3 << 19;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
 };
 
@@ -211,7 +214,7 @@ static int init_streams(snowgpu_ctx *ctx)
 
 // Upload / download streams and chunk events of the host pipeline: made on the first pipelined batch, so that a context that
 // only ever sees device-resident batches keeps the normal-priority queue pool to its own streams (see host_batch_pipelined).
-static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks)
+static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks, int n_lanes)
 {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -222,6 +225,16 @@ static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks)
         hipEvent_t e;
         HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pipe_ev.push_back(e);
+    }
+    while ((int)ctx->lanes.size() < n_lanes - 1) {       // lane 0 is the context itself; the others: ONE stream each (low-priority pool)
+        snowgpu_ctx *ln = new snowgpu_ctx();
+        ln->device = ctx->device;
+        ln->root = ctx;
+        ctx->lanes.push_back(ln);
+        if (hipStreamCreateWithPriority(&ln->stream, hipStreamNonBlocking, least) != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, "lane stream");
+        for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3})
+            HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
+        for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_fp[c], hipEventDisableTiming));
     }
     return SNOWGPU_OK;
 }
@@ -248,6 +261,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PIPE_ROWS"); if (v) ctx->pipe_rows = std::max<int64_t>(std::atoll(v), 0); }
     { const char *v = std::getenv("SNOWGPU_PIPE_SERIAL"); if (v) ctx->pipe_serial = v[0] != '0'; }
+    { const char *v = std::getenv("SNOWGPU_PIPE_LANES"); if (v) ctx->pipe_lanes = std::min(std::max(std::atoi(v), 1), 4); }
     { const char *v = std::getenv("SNOWGPU_LINK_BLOCKS"); if (v) ctx->link_blocks = std::min(std::max(std::atoi(v), 0), 4096); }
     int rc = init_streams(ctx);
     if (rc) return rc;
@@ -265,6 +279,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (snowgpu_ctx *ln : ctx->lanes) snowgpu_destroy(ln);      // a lane owns a stream, events and scratch only
+    ctx->lanes.clear();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
@@ -664,12 +680,12 @@ struct BatchDev {
 
 static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
 {
-    snowgpu_ctx *R = ctx;
+    snowgpu_ctx *R = ctx->root ? ctx->root : ctx;      // a lane computes on the tables / lasers / settings of its root
     if (R->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     if (b.beam_div_deg <= 0 || b.beam_div_deg >= 45.0)
         return fail(ctx, SNOWGPU_E_INVALID, "beam divergence must be in (0, 45) degrees");
     int rc = sync_tables(R);
-    if (rc) return rc;
+    if (rc) { if (R != ctx) ctx->err = R->err; return rc; }
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
     hipStream_t st = b.stream;
@@ -996,8 +1012,9 @@ static void *device_view(const void *host, size_t bytes)
 // sequence is a third faster with its side streams than on one stream.  So:
 //   * the upload of ALL chunks is one stream of DMA copies (high-priority pool) into a batch-sized buffer -- it never waits
 //     for anything -- with one event per chunk;
-//   * the chunks compute one after the other on the context's own four streams, exactly like a device-resident batch,
-//     into a batch-sized result buffer;
+//   * the chunks compute into a batch-sized result buffer, each as ONE chain of launches on one stream, alternating between
+//     two lanes (the context itself and a sub-context with its own stream, events and scratch in the low-priority pool): a
+//     chunk starts the moment its upload lands, and the launch latency of one chain hides behind the other;
 //   * the downloads run on one more stream (low-priority pool: a hardware queue of its own) as a small-grid kernel of ours
 //     that writes page-locked memory directly (sg_launch_copy_link), each after its chunk's event.
 // The host enqueues everything and waits once at the end.  Small per-frame arrays (table ids, planes / polynomials, counts,
@@ -1025,8 +1042,9 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     }
     c_first.push_back(n_frames);
     const int n_chunks = (int)c_first.size() - 1;
+    const int L = std::max(1, std::min(ctx->pipe_lanes, n_chunks));
     {
-        int prc = ensure_pipeline(ctx, n_chunks);
+        int prc = ensure_pipeline(ctx, n_chunks, L);
         if (prc) return prc;
     }
     static const bool trace = std::getenv("SNOWGPU_PIPE_TRACE") != nullptr;
@@ -1087,8 +1105,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
         const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
         const int64_t *lo = &h_off[c_pos[(size_t)c]];
-        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->pipe_ev[2 * (size_t)c], 0));
-        if (trace) HIPCHK(ctx, hipEventRecord(tev[2 + 4 * (size_t)c], st));
+        snowgpu_ctx *lc = (c % L) == 0 ? ctx : ctx->lanes[(size_t)(c % L) - 1];     // chunk c computes on lane c mod L
+        hipStream_t cs = lc->stream;
+        HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->pipe_ev[2 * (size_t)c], 0));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[2 + 4 * (size_t)c], cs));
         BatchDev b{};
         b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = ctx->rows_in.p + (size_t)r0 * rb;
         int64_t mx = 0;
@@ -1103,16 +1123,16 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.out_rows = ctx->rows_out.p + (size_t)r0 * rb; b.out_src = ctx->out_src.p + r0;
         b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
         b.out_thr_poly = out_thr_poly ? ctx->out_thr.p + 3 * (size_t)f0 : nullptr;
-        b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = st;
+        b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = cs;
         // Beside a saturated link every cross-stream event costs more (the queues' completion signals live in host memory), so a
         // chunk keeps its kernels on one stream: 1.80 instead of 1.76 G points/s (2.09 / 1.96 without source indices), although
         // the same chunk alone is faster with its side streams.  SNOWGPU_PIPE_SERIAL=0: side streams.
-        b.serial = ctx->pipe_serial;
-        rc = run_batch(ctx, b);
-        if (rc != SNOWGPU_OK) break;
-        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], st));
-        if (trace) HIPCHK(ctx, hipEventRecord(tev[3 + 4 * (size_t)c], st));
-        if (kick & 2) (void)hipStreamQuery(st);
+        b.serial = ctx->pipe_serial || L > 1;              // a further lane has one stream only
+        rc = run_batch(lc, b);
+        if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
+        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
+        if (trace) HIPCHK(ctx, hipEventRecord(tev[3 + 4 * (size_t)c], cs));
+        if (kick & 2) (void)hipStreamQuery(cs);
         HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
         if (cn) {
             int e = 0;
@@ -1127,6 +1147,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     }
     if (trace) fprintf(stderr, "pipe: %d chunks; uploads enqueued in %.3f ms, everything in %.3f ms\n", n_chunks, t_up - t_begin, now() - t_begin);
     hipError_t se = hipStreamSynchronize(ctx->s_h2d);
+    for (int l = 1; l < L; ++l) {
+        hipError_t e = hipStreamSynchronize(ctx->lanes[(size_t)l - 1]->stream);
+        if (se == hipSuccess) se = e;
+    }
     for (hipStream_t w : {st, ctx->s_d2h}) {
         hipError_t e = hipStreamSynchronize(w);
         if (se == hipSuccess) se = e;

@@ -1000,7 +1000,7 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
             o, s, c, st, thr = eng.ctx.augment_batch(rows, off, tids, bd, **kw)
             return o.copy(), None if s is None else s.copy(), c.copy(), st.copy(), thr, eng.ctx.last_status().copy()
         finally:
-            eng.ctx.set_pipeline(3 << 20)
+            eng.ctx.set_pipeline(3 << 19)
 
     for kw in (dict(plane=planes, want_thr=True), dict(thr_poly=polys), dict(thr_poly=polys, perm=True), dict(plane=planes, want_src=False)):
         one = run(0, **kw)
@@ -1027,7 +1027,7 @@ def test_pipelined_host_entry_equals_the_single_chunk_call(eng, tables, dtype):
             eng.ctx.augment_batch(bad, off, tids, bd, thr_poly=polys)
         assert ei.value.code == _native.E_RANGE
     finally:
-        eng.ctx.set_pipeline(3 << 20)
+        eng.ctx.set_pipeline(3 << 19)
 
 
 # ---- the literal drop-in call: tables in .npy files, permutation from the seeded global `random`, no keyword extras ----------
@@ -1136,3 +1136,38 @@ def test_pre_crop_with_odd_channel_values_and_plane_from_the_cropped_cloud(eng, 
     exp = win[get_fov_flag(cal.lidar_to_rect(win[:, 0:3]), (1024, 1920), cal)]
     assert np.array_equal(sub, exp) and 0 < sub.shape[0] <= win.shape[0]
     assert sim._rows_for_plane(pc, cal, False) is pc and sim._rows_for_plane(pc, None, True) is pc
+
+
+@pytest.mark.parametrize("lanes", ["2", "3"])
+def test_pipeline_compute_lanes_give_the_same_rows(tables, monkeypatch, lanes):
+    """SNOWGPU_PIPE_LANES > 1: chunk c of a pipelined host batch computes on lane c mod L -- a sub-context with its own stream,
+    events and scratch on the root's tables -- so that the launch chains of consecutive chunks overlap.  Same bytes as the
+    one-chunk call, device prepass and caller polynomials, ragged frames."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    rng = np.random.default_rng(13)
+    frames = []
+    for f in range(9):
+        full = synthetic_sweep(64, 2048, seed=1200 + f, intensity="lambert").reshape(64, 2048, 5)
+        frames.append(np.ascontiguousarray(full[:, f % 5::int(rng.integers(24, 50)), :].reshape(-1, 5)))
+    rows = np.concatenate(frames)
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    planes = [[0.0, 0.0, -1.0, -1.7]] * len(frames)
+    polys = [[1e-4 * f, 0.01, 2.0] for f in range(len(frames))]
+    monkeypatch.setenv("SNOWGPU_PIPE_LANES", lanes)
+    e = engine.Engine(0)
+    try:
+        tids = [e.table_ids_from_arrays(tl, list(rng.permutation(64))) for _ in frames]
+        for kw in (dict(plane=planes), dict(thr_poly=polys)):
+            e.ctx.set_pipeline(0)
+            one = [np.copy(x) if x is not None else None for x in e.ctx.augment_batch(rows, off, tids, bd, **kw)[:4]]
+            e.ctx.set_pipeline(3000)                             # ~8 chunks over the lanes
+            many = e.ctx.augment_batch(rows, off, tids, bd, **kw)
+            assert np.array_equal(one[2], many[2]) and np.array_equal(one[3], many[3])
+            for f in range(len(frames)):
+                a, n = int(off[f]), int(one[2][f])
+                assert one[0][a:a + n].tobytes() == many[0][a:a + n].tobytes() and np.array_equal(one[1][a:a + n], many[1][a:a + n])
+    finally:
+        e.ctx.close()
