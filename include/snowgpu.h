@@ -250,6 +250,12 @@ int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *fram
                              double *out_rows, int32_t *out_src, int64_t *out_counts,
                              int32_t *out_flags);
 
+/* The two lines estimate_laser_parameters fits (augmentation.py:216-219 p = linregress(range, I / cos); :248-251 the noise
+ * line through the sparsest histogram bins, quirk Q8) for the NEXT snowgpu_wet_ground_batch of this context, supplied by a
+ * caller that fits them itself -- with its own NumPy, whose argpartition build decides Q8 -- instead of the device's
+ * first-minimum fit: n_frames x 4 doubles (p slope, p intercept, noise-line slope, noise-line intercept).  One use; NULL clears. */
+int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines);
+
 /*
  * augment() followed by ground_water_augmentation() on its output, as pointcloud_viewer.py:2807-2821 chains them
  * (snow first, then wet with replace=False), as ONE launch sequence: the intermediate cloud never leaves the device.

@@ -25,7 +25,7 @@ EXPORTS = [
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
-    "snowgpu_set_pipeline",
+    "snowgpu_set_pipeline", "snowgpu_set_wet_lines",
 ]
 
 
@@ -94,6 +94,8 @@ def lib():
             L.snowgpu_set_fov.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
             L.snowgpu_sample_table.restype = ctypes.c_int
             L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
+            L.snowgpu_set_wet_lines.restype = ctypes.c_int
+            L.snowgpu_set_wet_lines.argtypes = [vp, ctypes.c_int, vp]
             L.snowgpu_set_pipeline.restype = ctypes.c_int
             L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
@@ -376,7 +378,8 @@ class Context:
         return out_rows, out_src, counts, stats, flags
 
     def wet_ground_batch(self, rows, frame_offsets, plane, water_height, pavement_depth, noise_floor, power_factor,
-                         flat_earth, delta, replace):
+                         flat_earth, delta, replace, lines=None):
+        """lines: optional n_frames x 4 (p slope, p intercept, noise-line slope, intercept) fitted by the caller (quirk Q8)."""
         rows = np.ascontiguousarray(rows)
         code = _dtype_code(rows.dtype)
         off = np.ascontiguousarray(frame_offsets, np.int64)
@@ -388,6 +391,9 @@ class Context:
         counts = np.zeros(nf, np.int64)
         flags = np.zeros(nf, np.int32)
         with self._call_lock:
+            if lines is not None:
+                ln = np.ascontiguousarray(lines, np.float64).reshape(nf, 4)
+                self._check(self._L.snowgpu_set_wet_lines(self._h, nf, _p(ln)))
             self._check(self._L.snowgpu_wet_ground_batch(self._h, nf, _p(off), _p(rows), code, _p(pl), float(water_height),
                                                          float(pavement_depth), float(noise_floor), float(power_factor),
                                                          int(bool(flat_earth)), float(delta), int(bool(replace)),

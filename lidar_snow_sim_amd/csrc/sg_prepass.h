@@ -11,6 +11,7 @@ struct SgPrepassScratch {
 struct SgWetParams {
     double water_height, pavement_depth, noise_floor, power_factor, delta;
     int flat_earth, replace;
+    const double *lines;        // optional DEVICE array n_frames x 4: the two fitted lines supplied by the caller (snowgpu_set_wet_lines)
 };
 
 #ifdef __cplusplus

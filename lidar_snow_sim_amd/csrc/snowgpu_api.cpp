@@ -143,6 +143,8 @@ struct snowgpu_ctx {
     DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
     DevBuf<int32_t> pipe_status;      // 8 status words per chunk
     int64_t pipe_rows = (int64_t)3 << 19;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
+    std::vector<double> wet_lines;    // snowgpu_set_wet_lines: consumed by the next snowgpu_wet_ground_batch
+    DevBuf<double> d_wet_lines;
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
 };
 
@@ -285,7 +287,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
     if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
-    ctx->mail_up_d.release(); ctx->mail_dn_d.release();
+    ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release();
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
@@ -1441,6 +1443,18 @@ extern "C" int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows)
     return SNOWGPU_OK;
 }
 
+// The two fitted lines of estimate_laser_parameters (wet_ground/augmentation.py:216-219, :248-251) for the NEXT
+// snowgpu_wet_ground_batch of this context, from a caller who fits them itself -- e.g. with its own NumPy, whose argpartition
+// decides quirk Q8 -- instead of the device's fit: n_frames x 4 (p slope, p intercept, noise-line slope, noise-line intercept).
+// Everything else (ground rows, incident angles, the < 1000-ground-rows rule, Fresnel chain, noise drop) stays on the device.
+extern "C" int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !lines) { ctx->wet_lines.clear(); return SNOWGPU_OK; }
+    ctx->wet_lines.assign(lines, lines + (size_t)n_frames * 4);
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
@@ -1691,6 +1705,14 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    if (!ctx->wet_lines.empty()) {                      // the caller's lines (one use)
+        if (ctx->wet_lines.size() != (size_t)n_frames * 4) { ctx->wet_lines.clear(); return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_wet_lines was given another number of frames"); }
+        ENSURE(ctx, ctx->d_wet_lines, ctx->wet_lines.size());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_wet_lines.p, ctx->wet_lines.data(), sizeof(double) * ctx->wet_lines.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        wp.lines = ctx->d_wet_lines.p;
+        ctx->wet_lines.clear();
+    }
     int e = sg_wet_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame, ctx->plane.p, &wp,
                        (double *)ctx->rows_out.p, ctx->out_src.p, ctx->out_counts.p, ctx->dbg_count.p, ctx->d_status, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));

@@ -47,6 +47,7 @@ struct PreArgs {
     int rows_as_f64;       // wet: np.hstack with the float64 height column promotes the ground rows to float64
                            // (augmentation.py:50), so range / mean are float64 whatever the input dtype
     double noise_floor, power_factor;
+    const double *lines_override;   // optional n_frames x 4 (p slope, p intercept, noise-line slope, intercept): replaces the two fitted lines
     // per-row scratch (n_total)
     double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle (or its cosine: cos_only); g_norm = NaN for non-ground rows
     // per-tile partials: [frame][tile][k]
@@ -464,6 +465,17 @@ __global__ __launch_bounds__(64) void k_pre_lines(PreArgs a, int xmean_f32)
     else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
 }
 
+// The caller's lines instead of the fitted ones (snowgpu_set_wet_lines: a host that fits them with its own NumPy, quirk Q8).
+__global__ void k_pre_override_lines(PreArgs a)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    PreFrame &fr = a.fr[f];
+    fr.p0 = a.lines_override[4 * f]; fr.p1 = a.lines_override[4 * f + 1];
+    fr.pmin0 = a.lines_override[4 * f + 2]; fr.pmin1 = a.lines_override[4 * f + 3];
+    fr.need_mean32 = 0;
+}
+
 // ---- P6: normal-equation partials of polyfit(ground_dist, thr * cos(angle), 2) (simulation.py:462-467) ----------
 template <typename T>
 __global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
@@ -762,6 +774,10 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
     LCHK();
     hipLaunchKernelGGL(k_pre_lines, dim3((unsigned)a.n_frames), dim3(64), 0, st, a, (dtype == 0 && !a.rows_as_f64) ? 1 : 0);
     LCHK();
+    if (a.lines_override) {
+        hipLaunchKernelGGL(k_pre_override_lines, dim3((unsigned)((a.n_frames + 63) / 64)), dim3(64), 0, st, a);
+        LCHK();
+    }
     if (dtype == 0 && exact_f32_mean) {
         // only frames whose noise line fell back to p = linregress(range, I / cos) need the float32 mean; the two
         // kernels below leave at once for every other frame
@@ -801,6 +817,7 @@ extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, cons
     hipStream_t st = (hipStream_t)stream;
     WetArgs w{};
     PreArgs &a = w.p;
+    a.lines_override = wp->lines;
     a.rows = rows; a.frame_off = frame_off; a.frame_cnt = frame_cnt; a.n_frames = n_frames; a.plane = plane; a.delta = wp->delta;
     a.flat_earth = wp->flat_earth; a.rows_as_f64 = 1; a.noise_floor = wp->noise_floor; a.power_factor = wp->power_factor; a.status = status;
     int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, false, st);

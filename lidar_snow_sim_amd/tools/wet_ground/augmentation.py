@@ -13,7 +13,7 @@ from .planes import calculate_plane
 
 
 def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, power_factor=15, noise_floor=0.7,
-                              debug=True, estimation_method='linear', *, q8='first'):
+                              debug=True, estimation_method='linear', *, q8='first', return_lines=False):
     """(relative_output_intensity, adaptive_noise_threshold, p, stat_values) -- augmentation.py:195-266.
 
     Host (NumPy/SciPy) version of the estimate, 'linear' mode.  The per-row minimum of the 50 x 2555
@@ -51,6 +51,8 @@ def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, powe
     x = (xedges[sel] + xedges[sel + 1]) / 2                                        # :240-241
     pmin = linregress(x, min_vals) if len(min_vals) > 3 else p                     # :248-251
     adaptive_noise_threshold = noise_floor * (pmin[0] * distance + pmin[1])        # :252-253
+    if return_lines:
+        return relative_output_intensity, adaptive_noise_threshold, p, stat_values, [pmin[0], pmin[1]]
     return relative_output_intensity, adaptive_noise_threshold, p, stat_values
 
 
@@ -72,11 +74,14 @@ def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7, q8='first'):
 
 def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0012, noise_floor=0.7, power_factor=15,
                               estimation_method='linear', flat_earth=False, debug=True, delta=0.5, replace=True,
-                              *, plane=None, device=0, return_src=False):
+                              *, plane=None, device=0, return_src=False, q8='first'):
     """Drop-in for tools/wet_ground/augmentation.py::ground_water_augmentation (:25-161).
 
     `debug` is accepted and ignored (the reference's debug branch only draws matplotlib figures).
-    Extra keyword-only arguments: plane=(w, h) to skip the plane estimate, device, return_src.
+    Extra keyword-only arguments: plane=(w, h) to skip the plane estimate, device, return_src, and q8: 'first' (default) fits
+    the noise line on the device through the FIRST sparsest histogram bin of every range row; 'numpy' fits the two lines on the
+    host with THIS process' NumPy (np.argpartition verbatim, quirk Q8: what the reference itself computes on this machine) and
+    hands them to the device, which does everything else.
     Returns a float64 N' x 5 array (:150); the input object itself when fewer than 1000 ground rows
     exist (:51-52).
     """
@@ -86,9 +91,27 @@ def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0
     rows = pc if pc.dtype in (np.float32, np.float64) else pc.astype(np.float64)
     w, h = calculate_plane(rows) if plane is None else plane
     eng = _engine.get_engine(device)
+    lines = None
+    if q8 == 'numpy':
+        # the reference's own steps up to the two fitted lines (augmentation.py:44-76), with the local NumPy
+        wv = np.asarray(w)
+        hog = np.matmul(rows[:, :3], wv)
+        ground = np.logical_and(hog + h < delta, hog + h > -delta)
+        planes = np.hstack((rows[ground, :5], hog.reshape((len(hog), 1))[ground]))
+        if planes.shape[0] >= 1000:
+            if not flat_earth:
+                angle = np.arccos(np.divide(np.matmul(planes[:, :3], wv), np.linalg.norm(planes[:, :3], axis=1) * np.linalg.norm(w)))
+            else:
+                angle = np.arccos(-np.divide(np.matmul(planes[:, :3], np.asarray([0, 0, 1])),
+                                             np.linalg.norm(planes[:, :3], axis=1) * np.linalg.norm([0, 0, 1])))
+            _, _, p, _, pmin = estimate_laser_parameters(planes, angle, noise_floor=noise_floor, power_factor=power_factor, debug=False,
+                                                         q8='numpy', return_lines=True)
+            lines = [[p[0], p[1], pmin[0], pmin[1]]]
+    elif q8 != 'first':
+        raise ValueError("q8 must be 'first' or 'numpy'")
     out, src, counts, flags = eng.ctx.wet_ground_batch(
         np.ascontiguousarray(rows[:, :5]), [0, rows.shape[0]], [[w[0], w[1], w[2], h]], water_height,
-        pavement_depth, noise_floor, power_factor, flat_earth, delta, replace)
+        pavement_depth, noise_floor, power_factor, flat_earth, delta, replace, lines=lines)
     if flags[0]:
         return (pointcloud, np.arange(rows.shape[0])) if return_src else pointcloud
     n = int(counts[0])
