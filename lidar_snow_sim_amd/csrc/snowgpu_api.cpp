@@ -645,6 +645,10 @@ static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[
 static int64_t tier_queue_cap(const snowgpu_ctx *ctx, int lmax, int64_t n)
 {
     if (ctx->tier_cap_override > 0) return std::min<int64_t>(ctx->tier_cap_override, std::max<int64_t>(n, 1));
+    // small batches: a buffer for every row costs little (<= 1 GiB) and saves the launch of the in-place fallback pass -- a
+    // chip-sized grid that finds nothing to do but sits in the chain of dependent launches a small batch is bound by
+    const int64_t slot_bytes = (int64_t)sizeof(double) * (3 * (int64_t)lmax + 2) + 2;
+    if (std::max<int64_t>(n, 1) * slot_bytes <= ((int64_t)1 << 30)) return std::max<int64_t>(n, 1);
     const int64_t div = lmax <= 8 ? 4 : (lmax <= 16 ? 16 : 64);
     return std::min<int64_t>(std::max<int64_t>(n, 1), std::max<int64_t>(n / div, 4096));
 }

@@ -260,3 +260,43 @@ def test_L6_wet_ground_follows_the_local_numpy_with_q8_numpy(golden, capsys):
         bad_q8 += not same_rows or (rel is not None and rel > (1e-7 if pc.dtype == np.float32 else 1e-9))
     if not numpy_is_portable():
         assert bad_default > 0 and bad_q8 == 0, (bad_default, bad_q8)
+
+
+def test_L8_viewer_chain_follows_the_local_numpy_with_q8_numpy(golden, tables, capsys, tmp_path):
+    """The viewer chain (pointcloud_viewer.py:2807-2821) with q8='numpy' in both stages against the NATIVE-flavour L8 fixture:
+    what the reference prints on a SIMD-dispatching NumPy.  Rows by source index, labels and snowfall intensities exactly."""
+    import random
+    from conftest import canonical, numpy_is_portable
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import ground_water_augmentation
+    from test_oracle_golden import match_rows_by_xyz
+    d = golden("L8_viewer_chain", "native")
+    tl = [tables["t"][i % 4] for i in range(64)]
+    plane = (np.array([0.0, 0.0, -1.0]), -1.7)
+    bad = 0
+    for case in range(int(d["n_cases"])):
+        pc = d[f"c{case}_pc"]
+        pc6 = np.column_stack((pc, np.arange(len(pc)))).astype(pc.dtype)
+        kw = dict(plane=plane) if bool(d[f"c{case}_inject"]) else {}
+        random.seed(int(d[f"c{case}_seed"]))
+        stats, snow = augment(pc=pc6, only_camera_fov=False, particle_file_prefix="unused", noise_floor=0.7, particles=tl,
+                              beam_divergence=float(np.degrees(3e-3)), shuffle=True, show_progressbar=True, q8="numpy", **kw)
+        a1, s1 = canonical(snow[:, :5], snow[:, 5].astype(np.int64))
+        a2, s2 = canonical(d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+        snow_ok = tuple(int(v) for v in stats) == tuple(int(v) for v in d[f"c{case}_stats"]) and np.array_equal(s1, s2) \
+            and np.array_equal(a1[:, 3:], a2[:, 3:])
+        out = ground_water_augmentation(snow[:, :5], water_height=0.0008, pavement_depth=0.001, noise_floor=0.7, power_factor=15,
+                                        flat_earth=False, estimation_method="linear", debug=False, delta=0.5, replace=False, q8="numpy", **kw)
+        ref = d[f"c{case}_out"]
+        wet_ok = False
+        if snow_ok and out.shape == ref.shape:
+            ids = match_rows_by_xyz(out, snow[:, :5], snow[:, 5].astype(np.int64))
+            ref_ids = match_rows_by_xyz(ref, d[f"c{case}_snow"], d[f"c{case}_snow_src"])
+            o1, o2 = out[np.argsort(ids, kind="stable")], ref[np.argsort(ref_ids, kind="stable")]
+            wet_ok = bool(np.array_equal(np.sort(ids), np.sort(ref_ids)) and np.array_equal(o1[:, 4], o2[:, 4])
+                          and np.allclose(o1[:, 3], o2[:, 3], rtol=1e-7 if pc.dtype == np.float32 else 1e-9, atol=0))
+        _report(capsys, {"fixture": f"L8 native case {case}", "dtype": pc.dtype.name, "snow_equal": bool(snow_ok), "wet_equal": wet_ok,
+                         "numpy_dispatch": "portable" if numpy_is_portable() else "simd"})
+        bad += not (snow_ok and wet_ok)
+    if not numpy_is_portable():
+        assert bad == 0
