@@ -1054,7 +1054,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         if (prc) return prc;
     }
     static const bool trace = std::getenv("SNOWGPU_PIPE_TRACE") != nullptr;
-    static const int kick = std::getenv("SNOWGPU_PIPE_KICK") ? std::atoi(std::getenv("SNOWGPU_PIPE_KICK")) : 0;    // A/B switches
     ENSURE(ctx, ctx->pipe_off, h_off.size());
     ENSURE(ctx, ctx->pipe_status, (size_t)n_chunks * 8);
     ENSURE(ctx, ctx->out_counts, nf);
@@ -1066,7 +1065,7 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     ENSURE(ctx, ctx->out_src, std::max<size_t>((size_t)n_total, 1));
     // The small arrays lead the upload stream (chunk 0's event covers them).  On the compute stream they would leave it
     // "after a DMA copy" for the whole batch: 28 instead of 20 ms for 256 sweeps (measured).
-    hipStream_t up = (kick & 16) ? st : ctx->s_h2d;
+    hipStream_t up = ctx->s_h2d;
     HIPCHK(ctx, hipMemcpyAsync(ctx->pipe_off.p, h_off.data(), sizeof(int64_t) * h_off.size(), hipMemcpyHostToDevice, up));
     HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, up));
     const double *d_thr = nullptr;
@@ -1086,7 +1085,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // SNOWGPU_LINK_BLOCKS=0 keeps the runtime's copy for page-locked memory too.
     char *d_out_rows = ctx->link_blocks > 0 ? (char *)device_view(out_rows, (size_t)n_total * rb) : nullptr;
     char *d_out_src = (ctx->link_blocks > 0 && out_src) ? (char *)device_view(out_src, (size_t)n_total * 4) : nullptr;
-    if (kick & 8) HIPCHK(ctx, hipStreamSynchronize(st));
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     std::vector<hipEvent_t> tev;                  // SNOWGPU_PIPE_TRACE: timed events -- base, then per chunk: uploaded, compute begins, computed, downloaded
@@ -1103,7 +1101,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         if (cn) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c], ctx->s_h2d));
         if (trace) HIPCHK(ctx, hipEventRecord(tev[1 + 4 * (size_t)c], ctx->s_h2d));
-        if (kick & 1) (void)hipStreamQuery(ctx->s_h2d);
     }
     const double t_up = now();
     int rc = SNOWGPU_OK;
@@ -1138,7 +1135,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
         if (trace) HIPCHK(ctx, hipEventRecord(tev[3 + 4 * (size_t)c], cs));
-        if (kick & 2) (void)hipStreamQuery(cs);
         HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
         if (cn) {
             int e = 0;
@@ -1149,7 +1145,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("download launch: ") + hipGetErrorString((hipError_t)e));
         }
         if (trace) HIPCHK(ctx, hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
-        if (kick & 4) (void)hipStreamQuery(ctx->s_d2h);
     }
     if (trace) fprintf(stderr, "pipe: %d chunks; uploads enqueued in %.3f ms, everything in %.3f ms\n", n_chunks, t_up - t_begin, now() - t_begin);
     hipError_t se = hipStreamSynchronize(ctx->s_h2d);
