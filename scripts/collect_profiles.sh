@@ -21,5 +21,10 @@ SNOWGPU_BENCH_PMC_DUMP=$O/pmc_fetch_write_per_kernel.csv timeout 400 python benc
 for w in ${WORKLOADS:-C4 C3}; do timeout 200 python bench.py --workload $w --no-pmc --no-cpu-baseline $( [ $w = C4 ] && echo --frames 128 ) > $O/bench_$w.json 2> $O/bench_$w.err; done
 timeout 300 python bench.py --workload C5 --frames ${C5_FRAMES:-10000} > $O/bench_C5.json 2> $O/bench_C5.err
 # 6. the pipeline's own event trace (upload / compute / download per chunk)
-SNOWGPU_PIPE_TRACE=1 timeout 120 python scripts/pcie_bench.py --reps 1 2>&1 | grep "^pipe" | tail -14 > $O/pipeline_trace.txt
+SNOWGPU_PIPE_TRACE=1 timeout 120 python scripts/pcie_bench.py --reps 1 2>&1 | grep "^pipe" | tail -25 > $O/pipeline_trace.txt
+# 7. copies and kernels of one pipelined call on one time axis (the profiler slows the host: read the structure, not the times)
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $O/pipe_trace -o t -- python $R/scripts/pcie_bench.py --reps 1 --frames 96 > /dev/null 2>&1
+cd $R
+python scripts/trace_pipe.py $O/pipe_trace 8 > $O/pipeline_timeline.txt 2>/dev/null
 tail -c 400 $O/bench_C2.json; tail -3 $O/timeline.txt; cut -c1-300 $O/bench_C5.json

@@ -32,7 +32,7 @@ for name in ("timeline", "timeline_serial"):
     if (ev / f"{name}.txt").exists():
         shutil.copy(ev / f"{name}.txt", prof / f"{tag}_{name}_one_step.txt")
 # ---- HBM-side bytes per kernel (dumped by bench.py's own counter passes) + counter calibration ------------------------
-for name in ("pmc_fetch_write_per_kernel.csv", "pmc_calibration.json", "pmc_calibration.txt", "pipeline_trace.txt"):
+for name in ("pmc_fetch_write_per_kernel.csv", "pmc_calibration.json", "pmc_calibration.txt", "pipeline_trace.txt", "pipeline_timeline.txt"):
     if (ev / name).exists():
         shutil.copy(ev / name, prof / f"{tag}_{name}")
 if bench and bench.get("roofline", {}).get("traffic"):
