@@ -44,3 +44,16 @@ def canonical(aug, src):
     """Rows in source-index order (the reference's within-channel order is implementation-defined)."""
     o = np.argsort(src, kind="stable")
     return aug[o], src[o]
+
+
+def numpy_matches_native_fixtures() -> bool:
+    """The `*_native.npz` fixtures were made by the reference on an AVX-512 host with NumPy's default dispatch (x86-simd-sort's
+    AVX-512 argpartition, SVML loops).  A host reproduces them only if its NumPy dispatches the same way: SIMD dispatch on
+    (not portable) and AVX-512 present.  On anything else q8='numpy' follows THAT host's NumPy, which no committed fixture holds."""
+    if numpy_is_portable():
+        return False
+    try:
+        flags = next(line for line in open("/proc/cpuinfo") if line.startswith("flags"))
+    except (OSError, StopIteration):
+        return False
+    return " avx512f" in flags and " avx512dq" in flags
