@@ -1171,3 +1171,41 @@ def test_pipeline_compute_lanes_give_the_same_rows(tables, monkeypatch, lanes):
                 assert one[0][a:a + n].tobytes() == many[0][a:a + n].tobytes() and np.array_equal(one[1][a:a + n], many[1][a:a + n])
     finally:
         e.ctx.close()
+
+
+def test_device_fov_crop_against_the_float32_numpy_projection(eng, tables):
+    """Advisor finding: OpenPCDet's lidar_to_rect / rect_to_img run in the cloud's dtype (float32 GEMMs for STF clouds), the
+    device crop in float64 with a fixed operation order.  The two can only disagree for points whose image lies within float32
+    rounding of the picture's edge or of depth 0: count them on 260 k points spread over the whole sweep, and check that every
+    disagreement sits within 1e-3 px / 1e-4 m of a boundary (parity with the reference itself is unpinned anyway: SURVEY 8 c)."""
+    from lidar_snow_sim_amd.calibration import Calibration, get_fov_flag
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    cal = Calibration(P2=np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]], np.float32),
+                      R0=np.array([[0.9999239, 0.00983776, -0.007445048], [-0.009869795, 0.9999421, -0.004278459],
+                                   [0.007402527, 0.004351614, 0.9999631]], np.float32),
+                      V2C=np.array([[0.007533745, -0.9999714, -0.000616602, -0.004069766], [0.01480249, 0.0007280733, -0.9998902, -0.07631618],
+                                    [0.9998621, 0.00752379, 0.01480755, -0.2717806]], np.float32))
+    frames = [synthetic_sweep(64, 2048, seed=1800 + f, intensity="lambert") for f in range(2)]
+    poly = [0.0, 0.0, -1.0]                                               # keep every row: only the crop decides
+    kw = dict(particles=_tables64(tables), orders=[list(range(64))] * 2, thr_polys=[poly, poly], return_src=True)
+    res = augment_batch(frames, "unused", float(np.degrees(3e-3)), calib=cal, **kw)
+    everything = augment_batch(frames, "unused", float(np.degrees(3e-3)), **kw)          # no crop: the label of every row
+    n_diff = 0
+    for pc, (st, aug, src), (_, aug_all, src_all) in zip(frames, res, everything):
+        assert aug_all.shape[0] == pc.shape[0]
+        kept = np.zeros(pc.shape[0], bool)
+        kept[src] = True
+        unmoved = np.ones(pc.shape[0], bool)
+        unmoved[src_all[aug_all[:, 4] == 2]] = False                     # scattered points are cropped at their NEW position
+        ref = get_fov_flag(cal.lidar_to_rect(pc[:, 0:3]), (1024, 1920), cal)          # float32 all the way, as in the reference
+        diff = np.where((kept != ref) & unmoved)[0]
+        n_diff += diff.size
+        if diff.size:
+            x64 = pc[diff, :3].astype(np.float64)
+            rect = np.hstack((x64, np.ones((diff.size, 1)))) @ (cal.V2C.astype(np.float64).T @ cal.R0.astype(np.float64).T)
+            hom = np.hstack((rect, np.ones((diff.size, 1)))) @ cal.P2.astype(np.float64).T
+            u, v, depth = hom[:, 0] / hom[:, 2], hom[:, 1] / hom[:, 2], hom[:, 2] - float(cal.P2[2, 3])
+            edge = np.minimum.reduce([np.abs(u), np.abs(u - 1920), np.abs(v), np.abs(v - 1024)])
+            assert np.all((edge < 1e-3) | (np.abs(depth) < 1e-4)), (edge.max(), np.abs(depth).min())
+    assert n_diff <= 20          # a handful of boundary points in 262 144, if any
