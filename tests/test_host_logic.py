@@ -666,3 +666,40 @@ def test_correctly_rounded_atan2_equals_glibc_where_glibc_is(tmp_path):
         assert abs(t - Decimal(o)) < ulp / 2 < abs(t - Decimal(g)), line
         checked += 1
     assert checked > 0
+
+
+def test_flat_batch_validates_its_layout():
+    """simulation.FlatBatch (frames back to back in one array, what the stream driver's readers fill) refuses anything the
+    upload could not take as it is -- before a device is touched."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import FlatBatch
+    rows = np.zeros((10, 5), np.float32)
+    fb = FlatBatch(rows, [0, 4, 4, 10])
+    assert len(fb) == 3 and fb.frame(0).shape == (4, 5) and fb.frame(1).shape == (0, 5) and fb.frame(2).base is rows
+    for bad_rows, bad_off in ((np.zeros((10, 6), np.float32), [0, 10]), (np.zeros((10, 5), np.int32), [0, 10]),
+                              (np.zeros((10, 5), np.float32)[::2], [0, 5]), (rows, [1, 10]), (rows, [0, 11]), (rows, [0, 6, 4])):
+        with pytest.raises(ValueError):
+            FlatBatch(bad_rows, bad_off)
+
+
+def test_stream_plan_iter_hands_batches_out_as_they_fill(tmp_path):
+    """stream.plan_iter is the lazy form of stream.plan: same items, same permutations (one random.shuffle per item in the
+    reference's nesting order), a batch as soon as its (mode, combo) group is full."""
+    import random
+    from lidar_snow_sim_amd import stream
+    lidar = tmp_path / "lidar_hdl64_strongest"
+    lidar.mkdir()
+    ids = [f"a_{i}" for i in range(7)]
+    combos = [(10.5, 1e-6), (20.5, 2e-6)]
+    random.seed(3)
+    eager = stream.plan(lidar, ids, ("gunn",), combos, batch=3)
+    random.seed(3)
+    it = stream.plan_iter(lidar, ids, ("gunn",), combos, batch=3)
+    first = next(it)
+    state_after_first = random.getstate()
+    rest = list(it)
+    assert [first] + rest == eager
+    assert len(first[3]) == 3 and first[3] == ["a_0", "a_1", "a_2"]
+    random.seed(3)
+    for _ in range(5):                                     # the first full batch needs the draws of items 0 .. 4 (two combos interleave)
+        random.shuffle(list(range(64)))
+    assert random.getstate() == state_after_first
