@@ -541,6 +541,9 @@ def main():
                        "backend": "nccl (RCCL)" if distributed else None,
                        "beams_per_capacity_tier": [int(n_total)] + [int(v) for v in st[2:6]]},
             "per_gpu_value": value / world,
+            "value_note": "rows resident in HBM when the clock starts (the device entry of the C ABI), as the measurement contract of this "
+                          "build prescribes; SURVEY 8(d)'s definition of the metric -- upload and download inside the clock -- is "
+                          "value_pcie_inclusive",
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_detail": traffic_src,
                          "frac_tables_counted": alg_bytes_tables / (avg_ms * 1e-3) / HBM_PEAK if avg_ms > 0 else 0.0,
