@@ -208,7 +208,8 @@ def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
         occ, rate = smp.compute_occupancy(SNOWFALL, VELOCITY), smp.snowfall_rate_to_rainfall_rate(SNOWFALL, VELOCITY)
         prefix = f"gunn_{rate}_{occ}"
         kw = dict(modes=("gunn",), combos=[(rate, occ)], batch=64, particles_by_prefix={prefix: tables}, planes=([0.0, 0.0, -1.0], -1.7),
-                  workers=2, readers=6, writers=6, keep_outputs=False, device=local_rank)
+                  workers=2, readers=int(os.environ.get("SNOWGPU_C5_READERS", "6")), writers=int(os.environ.get("SNOWGPU_C5_WRITERS", "8")),
+                  keep_outputs=False, device=local_rank)
         random.seed(0)                                                        # warm-up: table upload, allocations, page-locked pools
         stream.run(lidar, [ids[i] for i in mine[:128]], **kw)
         torch.cuda.synchronize()

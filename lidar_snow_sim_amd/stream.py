@@ -153,13 +153,17 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
             tally['read_s'] += time.perf_counter() - t0
         return FlatBatch(buf, off)
 
+    made_dirs = set()
+
     def write_job(job, results):
         t0 = time.perf_counter()
         mode, rainfall_rate = job[0], job[1]
         n_out = 0
         for s, (stats, aug) in zip(job[3], results):
             out = output_path(lidar_folder, mode, rainfall_rate, s)
-            out.parent.mkdir(parents=True, exist_ok=True)
+            if out.parent not in made_dirs:                                              # one mkdir per output folder, not per file
+                out.parent.mkdir(parents=True, exist_ok=True)
+                made_dirs.add(out.parent)
             aug.astype(np.float32, copy=False).tofile(out)                               # :106
             n_out += aug.shape[0]
             if not keep_outputs:
