@@ -54,10 +54,13 @@ struct SgLasers {
 //   bits 0..7   new intensity (simulation.py:188, an integer in [min_i, max_i] <= 255), labels 1 / 2 only
 //   bits 8..9   label: 0 unchanged, 1 attenuated, 2 scattered (simulation.py:160, :174)
 //   bit  10     copy-through row: its channel has no laser (Q5), column 4 keeps the channel value
+//   bit  11     label 0: bits 0..7 are the row's original intensity (SG_REC_HAS_I)
 //   bits 12..22 argmax bin of the power profile (simulation.py:151), label 2: the point moves to k / 10 - c tau / 2
 //   bit  31     reference: the record is rec_q[bits 0..30] (written by k_power, densely, in queue order)
 #define SG_REC_LABEL_SHIFT 8
 #define SG_REC_COPY (1u << 10)
+#define SG_REC_HAS_I (1u << 11) /* label 0 only: bits 0..7 hold the row's ORIGINAL intensity (an integer in [0, 255]), so the
+                                   noise-floor pass need not read the row; set by the pass over all rows for beams it finishes itself */
 #define SG_REC_SLOT (1u << 31)  /* the record proper is rec_q[low 31 bits]: the row's slot in the hand-over queue */
 #define SG_REC_K_SHIFT 12
 #define SG_MAX_CLASSES 4        /* later capacity tiers incl. the global-list tier */
@@ -82,6 +85,8 @@ struct SgBeamArgs {
     double beam_div_deg;
     uint32_t *rec;               // per sorted position: result record (SG_REC_*)
     uint32_t *rec_q;             // per queue slot of the direct-mode pass: result record of the beam queued there
+    void *rng;                   // per sorted position: the beam's range in the row dtype (simulation.py:89), written by the pass over
+                                 // all rows for every simulated beam: the noise-floor pass reads 4 bytes instead of gathering the row
     uint8_t *flag;               // per sorted position: 0, or 3 + k for a beam that needs later capacity tier k
     int32_t *status;             // [0] error code, [1] first offending sorted row
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
@@ -178,7 +183,7 @@ int sg_beams_block(int lmax);
 int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *tier_info,
                          int32_t *status_counts, int32_t cap, int n_cls, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
-int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,

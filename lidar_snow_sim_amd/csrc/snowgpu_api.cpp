@@ -80,6 +80,7 @@ struct snowgpu_ctx {
     DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk;
     DevBuf<int64_t> seg_start;
     DevBuf<uint32_t> rec, rec_q;      // result records: one per sorted position / per queue slot
+    DevBuf<uint8_t> rng;              // range of every simulated beam, per sorted position, in the row dtype
     DevBuf<double> dq;                // dict queue of the first pass (SoA planes)
     DevBuf<int32_t> dq_g;
     DevBuf<uint16_t> dq_sc;
@@ -311,7 +312,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->rec_q.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->spill.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->spill.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -792,6 +793,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 3. beams
     ENSURE(ctx, ctx->rec, n);
     ENSURE(ctx, ctx->rec_q, n);
+    ENSURE(ctx, ctx->rng, n * (b.dtype == 0 ? 4 : 8));
     ENSURE(ctx, ctx->keep, n);
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
     ENSURE(ctx, ctx->tier_list, n);
@@ -812,6 +814,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.las = R->d_las; a.frame_tables = ctx->frame_tables.p;
     a.rgrid = R->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
     a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
+    static const bool no_rng = std::getenv("SNOWGPU_NO_RNG") != nullptr;      // A/B: the noise-floor pass gathers every row again
+    a.rng = no_rng ? nullptr : ctx->rng.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = R->exact_math;
     a.per_lane_scan = R->per_lane_scan;
@@ -950,7 +954,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats
     // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
-    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
                           ctx->diff2.p, b.no_fov ? nullptr : &R->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));

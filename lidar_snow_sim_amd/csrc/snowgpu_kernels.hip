@@ -281,12 +281,14 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
     const bool live = g >= 0;
     int f = 0, ch = 0;
     T px = 0, py = 0, pz = 0;
+    [[maybe_unused]] T pint = 0;
     bool simulated = false;
     if (live) {
         f = (!LIST && seg_f >= 0) ? seg_f : sg_frame_of(a, g);
         const int64_t src = a.frame_off[f] + a.perm[g];
         const T *row = (const T *)a.rows + src * 5;
         px = row[0]; py = row[1]; pz = row[2];
+        if constexpr (!LIST && DICT) pint = row[3];   // the pass over all rows leaves range + intensity for the noise-floor pass
         if (!LIST && seg_f >= 0) {                    // the device sort only builds segments of integer channels
             ch = seg_ch;
             simulated = ch < n_las;
@@ -330,6 +332,9 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
                     e[3] = __hiloint2double(0, s_key[j * BLOCK + tid]);
                 }
             }
+        }
+        if constexpr (!LIST) {
+            if (act && a.rng) ((T *)a.rng)[g] = d_t;  // simulation.py:89, for the noise-floor pass (:465-469, :518-520)
         }
         if (act) {
             o.has_power = !o.overflow && L > 0;       // k_power builds the dict (phase 2) and everything after it
@@ -423,6 +428,14 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
             rec = sg_pack_record(o);
         }
         sg_add_diff2(a.diff2, live, f, (long long)o.diff2);
+    }
+    if constexpr (!LIST && DICT) {
+        // a beam this pass finishes itself (no flake met: label 0) carries its original intensity in the record, if that is an
+        // integer in [0, 255] as in every STF sweep: together with the range above the noise-floor pass then never reads the row
+        if (live && !pending && rec == 0u && act && a.rng) {
+            const int iv = (int)pint;
+            if ((T)iv == pint && iv >= 0 && iv <= 255) rec = SG_REC_HAS_I | (uint32_t)iv;
+        }
     }
     if (live && !pending) a.rec[g] = rec;
     } while (LIST && (chunk += stride) < work_n);
@@ -942,7 +955,7 @@ __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, do
 // (num_attenuated counts those, before the camera crop: simulation.py:525 precedes :532-540).
 template <typename T>
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
-                                                            const uint32_t *__restrict__ rec_q, const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
+                                                            const uint32_t *__restrict__ rec_q, const T *__restrict__ rng, const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
                                                             int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
 {
@@ -959,13 +972,30 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         // (simulation.py:465, :469, :518-520)
         uint32_t rc = rec[base + r];
         if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
-        const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rc);
-        const T dd2 = o.dd * o.dd;
-        const double thr = (p0 * (double)dd2 + p1 * (double)o.dd) + p2;
-        const bool noise_ok = (o.lab == (T)2) || ((double)o.i > thr);
-        bool k = noise_ok;
-        if (fov.enabled && k) k = sg_in_fov(fov, (double)o.x, (double)o.y, (double)o.z);   // :532-540
-        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0) | ((noise_ok && o.lab == (T)1) ? 4 : 0));   // bit 2: counts in num_attenuated
+        const int lab_i = (int)((rc >> SG_REC_LABEL_SHIFT) & 3u);
+        // Without the camera crop the decision needs the label, the (new or original) intensity and the original range only: a
+        // beam the pass over all rows simulated left its range in rng, and the record holds the intensity unless the beam came
+        // back unchanged from a later kernel -- those, and rows without a laser, read the row as before.
+        const bool from_rec = rng != nullptr && !fov.enabled && !(rc & SG_REC_COPY) && (lab_i != 0 || (rc & SG_REC_HAS_I));
+        bool noise_ok, is_att;
+        bool k;
+        if (from_rec) {
+            const T dd = rng[base + r];
+            const T dd2 = dd * dd;
+            const double thr = (p0 * (double)dd2 + p1 * (double)dd) + p2;
+            noise_ok = (lab_i == 2) || ((double)(T)(int)(rc & 255u) > thr);
+            is_att = lab_i == 1;
+            k = noise_ok;
+        } else {
+            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rc);
+            const T dd2 = o.dd * o.dd;
+            const double thr = (p0 * (double)dd2 + p1 * (double)o.dd) + p2;
+            noise_ok = (o.lab == (T)2) || ((double)o.i > thr);
+            is_att = o.lab == (T)1;
+            k = noise_ok;
+            if (fov.enabled && k) k = sg_in_fov(fov, (double)o.x, (double)o.y, (double)o.z);   // :532-540
+        }
+        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0) | ((noise_ok && is_att) ? 4 : 0));   // bit 2: counts in num_attenuated
         c += k;
     }
     __shared__ int s[4];
@@ -1372,7 +1402,7 @@ extern "C" int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_
     return 0;
 }
 
-extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                                  int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, void *stream)
@@ -1382,8 +1412,8 @@ extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *re
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     SgFov fv{};
     if (fov) fv = *fov;
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, (const float *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, (const double *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
