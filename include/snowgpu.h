@@ -145,6 +145,8 @@ int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
  *   thr_poly   n_frames x 3 quadratic (p0, p1, p2) of the per-point noise threshold over range
  *              (simulation.py:467-469), or NULL to run the prepass (simulation.py:449-467) on the
  *              device with plane (plane_w[3], plane_h) per frame: n_frames x 4 doubles (wx, wy, wz, h)
+ *   plane      or NULL as well: calculate_plane (simulation.py:449, planes.py:12-50) runs on the device too, by the
+ *              context's method (snowgpu_set_plane_method; default: the plane the reference returns today)
  *   noise_floor  augment()'s noise_floor (only used by the device prepass)
  *   perm       optional n_total int32 permutation (frame-local source row of each channel-sorted
  *              position); NULL = stable counting sort by channel on the device
@@ -213,6 +215,35 @@ int snowgpu_set_fov(snowgpu_ctx *ctx, int enabled, const double *v2c, const doub
  * Host-pointer entry only (the per-frame counts of the cropped batch are read back to lay the batch out). */
 int snowgpu_set_fov_precrop(snowgpu_ctx *ctx, int on);
 
+/* ---- ground plane ------------------------------------------------------------------------------ */
+
+/*
+ * calculate_plane (tools/wet_ground/planes.py:12-50; called at simulation.py:449 and wet_ground/augmentation.py:41) on the
+ * device.  The reference crops the cloud to a strip in front of the car (planes.py:21-27), returns the flat-earth plane
+ * ([0, 0, 1], -1.55) for a crop of no more rows than the array has columns (:29-32) and otherwise fits z = c0 x + c1 y + b with
+ * scikit-learn's RANSACRegressor (:35) -- unseeded, and with scikit-learn >= 1.2 the call raises, so the except branch (:43-48)
+ * returns the flat-earth plane for every cloud.  Methods of this library (parity unpinned by construction):
+ *   SNOWGPU_PLANE_REFERENCE  (default) what the reference returns today: ([0, 0, 1], standard_height), no row is read
+ *   SNOWGPU_PLANE_LSQ        least squares over the crop (float64, fixed summation order); w = [c0, c1, -1] / |.|, h = b (:36-41)
+ *   SNOWGPU_PLANE_RANSAC     RANSAC as scikit-learn < 1.2 ran it for the reference (3-point samples, threshold = MAD of z,
+ *                            most inliers, refit on them), samples from Philox4x32-10 keyed by (seed, frame, trial)
+ * Both estimators return the flat-earth plane for a crop of <= min_rows rows (the reference: 5, the column count) or when no
+ * model can be fitted.  The method applies to every later batch of this context that brings neither plane nor thr_poly
+ * (plane == NULL), to snowgpu_wet_ground_batch / snowgpu_augment_wet_batch with a NULL plane, and to snowgpu_estimate_planes.
+ */
+enum { SNOWGPU_PLANE_REFERENCE = 0, SNOWGPU_PLANE_LSQ = 1, SNOWGPU_PLANE_RANSAC = 2 };
+int snowgpu_set_plane_method(snowgpu_ctx *ctx, int method, uint64_t seed, int max_trials /* 0 = 1024 */, int min_rows,
+                             double standard_height);
+/* The planes themselves, for frames in host memory: out_planes n_frames x 4 (wx, wy, wz, h); out_info (optional) n_frames x 4
+ * int32: rows in the crop (-1: not counted, reference method), model used (0 flat earth, 1 least squares, 2 ransac), rows the
+ * final fit used, valid RANSAC trials. */
+int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                            double *out_planes, int32_t *out_info);
+/* ... and with every array in device memory, asynchronous on the caller's stream (semantics of snowgpu_augment_batch_device). */
+int snowgpu_estimate_planes_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
+                                   const int64_t *d_frame_offsets, const void *d_rows, int dtype, double *d_out_planes,
+                                   int32_t *d_out_info, void *stream);
+
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 
 /* Record a HIP event pair around every launch of the per-beam kernel (the dominant kernel) on the stream
@@ -241,7 +272,7 @@ int snowgpu_host_free(snowgpu_ctx *ctx, void *ptr);
  * the input dtype (augmentation.py:150), ordered [non-ground rows ; kept ground rows]
  * (augmentation.py:151-152).  A frame with fewer than 1000 ground rows is returned unchanged
  * (augmentation.py:51-52) with out_flags[f] = 1.
- *   plane  n_frames x 4 (wx, wy, wz, h)
+ *   plane  n_frames x 4 (wx, wy, wz, h), or NULL: calculate_plane (augmentation.py:41) on the device (snowgpu_set_plane_method)
  */
 int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets,
                              const void *rows, int dtype, const double *plane,
@@ -259,7 +290,8 @@ int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines);
 /*
  * augment() followed by ground_water_augmentation() on its output, as pointcloud_viewer.py:2807-2821 chains them
  * (snow first, then wet with replace=False), as ONE launch sequence: the intermediate cloud never leaves the device.
- * Arguments are those of snowgpu_augment_batch followed by those of snowgpu_wet_ground_batch (wet_plane: n_frames x 4).
+ * Arguments are those of snowgpu_augment_batch followed by those of snowgpu_wet_ground_batch (wet_plane: n_frames x 4, or
+ * NULL: estimated on the device from the snowfall stage's result, as the chained reference calls do).
  * out_stats are the snowfall statistics; out_rows (float64) / out_counts / out_flags the wet-ground result;
  * out_src maps every final row to its row in the original input frame.
  */

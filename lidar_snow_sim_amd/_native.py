@@ -25,8 +25,11 @@ EXPORTS = [
     "snowgpu_profile_begin", "snowgpu_profile_end", "snowgpu_set_exact_math", "snowgpu_augment_wet_batch",
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
-    "snowgpu_set_pipeline", "snowgpu_set_wet_lines",
+    "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
+    "snowgpu_estimate_planes_device",
 ]
+
+PLANE_METHODS = {"reference": 0, "lsq": 1, "ransac": 2}
 
 
 class SnowGPUError(RuntimeError):
@@ -96,6 +99,12 @@ def lib():
             L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
             L.snowgpu_set_wet_lines.restype = ctypes.c_int
             L.snowgpu_set_wet_lines.argtypes = [vp, ctypes.c_int, vp]
+            L.snowgpu_set_plane_method.restype = ctypes.c_int
+            L.snowgpu_set_plane_method.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, dbl]
+            L.snowgpu_estimate_planes.restype = ctypes.c_int
+            L.snowgpu_estimate_planes.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]
+            L.snowgpu_estimate_planes_device.restype = ctypes.c_int
+            L.snowgpu_estimate_planes_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, vp, vp]
             L.snowgpu_set_pipeline.restype = ctypes.c_int
             L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
@@ -269,7 +278,7 @@ class Context:
         rc = self._L.snowgpu_augment_wet_batch_device(
             self._h, int(n_frames), int(n_total), int(max_frame_rows), vp(d_frame_off), vp(d_rows), int(dtype_code),
             vp(d_table_ids), float(beam_divergence), vp(d_thr_poly or None), vp(d_plane or None), float(noise_floor),
-            vp(d_perm or None), vp(d_wet_plane), float(water_height), float(pavement_depth), float(wet_noise_floor),
+            vp(d_perm or None), vp(d_wet_plane or None), float(water_height), float(pavement_depth), float(wet_noise_floor),
             float(power_factor), int(bool(flat_earth)), float(delta), int(bool(replace)), vp(d_out_rows), vp(d_out_src),
             vp(d_out_counts), vp(d_out_stats), vp(d_out_flags), vp(d_status), vp(stream or None))
         self._check(rc)
@@ -287,6 +296,27 @@ class Context:
             r0 = np.ascontiguousarray(calib.R0, np.float64).reshape(3, 3)
             p2 = np.ascontiguousarray(calib.P2, np.float64).reshape(3, 4)
             self._check(self._L.snowgpu_set_fov(self._h, 1, _p(v2c), _p(r0), _p(p2), int(img_shape[0]), int(img_shape[1])))
+
+    def set_plane_method(self, method="reference", seed=0, trials=1000, min_rows=5, standard_height=-1.55):
+        """How this context estimates the ground plane when a call brings none (planes.py:12-50): 'reference' (what the
+        reference returns today: the flat-earth plane), 'lsq' or 'ransac' (Philox-seeded)."""
+        if method not in PLANE_METHODS:
+            raise ValueError("plane method must be 'reference', 'lsq' or 'ransac'")
+        with self._call_lock:
+            self._check(self._L.snowgpu_set_plane_method(self._h, PLANE_METHODS[method], ctypes.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                                         int(trials), int(min_rows), float(standard_height)))
+
+    def estimate_planes(self, rows, frame_offsets):
+        """(planes n_frames x 4 (wx, wy, wz, h), info n_frames x 4 int32) by the context's plane method."""
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf = len(off) - 1
+        planes = np.zeros((nf, 4), np.float64)
+        info = np.zeros((nf, 4), np.int32)
+        with self._call_lock:
+            self._check(self._L.snowgpu_estimate_planes(self._h, nf, _p(off), _p(rows), code, _p(planes), _p(info)))
+        return planes, info
 
     def sample_table(self, table_id, occupancy_ratio, diameter_scale_mm, r_0, seed, want_rows=True):
         """Sample a snowflake table on the device (and file it there under table_id >= 0).  Returns the K x 3 rows, or K
@@ -367,7 +397,7 @@ class Context:
         flags = np.zeros(nf, np.int32)
         thr = None if thr_poly is None else np.ascontiguousarray(thr_poly, np.float64).reshape(nf, 3)
         pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
-        wpl = np.ascontiguousarray(wet_plane, np.float64).reshape(nf, 4)
+        wpl = None if wet_plane is None else np.ascontiguousarray(wet_plane, np.float64).reshape(nf, 4)
         pm = None if perm is None else np.ascontiguousarray(perm, np.int32)
         with self._call_lock:
             self._check(self._L.snowgpu_augment_wet_batch(
@@ -385,7 +415,7 @@ class Context:
         off = np.ascontiguousarray(frame_offsets, np.int64)
         nf = len(off) - 1
         n = int(off[-1])
-        pl = np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
         out_rows = np.empty((n, 5), np.float64)
         out_src = np.empty(n, np.int32)
         counts = np.zeros(nf, np.int64)

@@ -16,6 +16,7 @@
 #include "../../include/snowgpu.h"
 #include "sg_common.h"
 #include "sg_prepass.h"
+#include "sg_plane.h"
 
 #define SG_MAX_CHUNKS 16
 
@@ -113,6 +114,11 @@ struct snowgpu_ctx {
     DevBuf<unsigned long long> diff2;
     DevBuf<SgTable> frame_tables;
     SgPrepassScratch prepass{};
+    // ground plane estimated on the device when a batch brings neither a plane nor a polynomial (planes.py:12-50)
+    SgPlaneScratch plane_scr{};
+    SgPlaneParams plane_par{SG_PLANE_REFERENCE, 1024, 5, 0, -1.55};
+    DevBuf<double> plane_est, wet_plane_est;
+    DevBuf<int32_t> plane_info;
     // fused snow + wet (snowgpu_augment_wet_batch*): the snowfall result stays here
     DevBuf<uint8_t> snow_rows;
     DevBuf<int32_t> snow_src, wet_src, wet_flags;
@@ -324,6 +330,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->wet_counts.release(); ctx->wet_rows.release(); ctx->wet_plane.release();
     ctx->rows_crop.release(); ctx->crop_src.release(); ctx->crop_out_src.release(); ctx->crop_counts.release(); ctx->crop_off.release(); ctx->crop_stats.release();
     sg_prepass_release(&ctx->prepass);
+    sg_plane_release(&ctx->plane_scr);
+    ctx->plane_est.release(); ctx->wet_plane_est.release(); ctx->plane_info.release();
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3})
@@ -722,7 +730,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     auto launch_prepass = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
         HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
-        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, b.plane,
+        const double *pl = b.plane;
+        if (!pl) {                                  // simulation.py:449 calculate_plane(pc): on the device, by the context's method
+            ENSURE(ctx, ctx->plane_est, (size_t)b.n_frames * 4);
+            ENSURE(ctx, ctx->plane_info, (size_t)b.n_frames * 4);
+            int pe = sg_plane_run(&ctx->plane_scr, &R->plane_par, b.rows, b.dtype, b.frame_off, nullptr, b.n_frames, b.n_total, b.max_frame,
+                                  ctx->plane_est.p, ctx->plane_info.p, s_aux2);
+            if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+            pl = ctx->plane_est.p;
+        }
+        int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, pl,
                                b.noise_floor, ctx->thr_poly.p, b.status, s_aux2);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         if (b.out_thr_poly)
@@ -732,7 +749,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         return SNOWGPU_OK;
     };
     if (!thr) {
-        if (!b.plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
         if (R->prepass_early) { int prc = launch_prepass(); if (prc) return prc; }
@@ -1237,7 +1253,6 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     if (!out_counts || !out_stats) return fail(ctx, SNOWGPU_E_INVALID, "null count/stat buffers");
     if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (!thr_poly && !plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
     const bool wants_precrop = ctx->fov.enabled && ctx->fov_pre && !dbg_count && n_total > 0;
     if (!dbg_count && !perm_out && !wants_precrop && ctx->pipe_rows > 0 && n_frames > 1 && n_total > ctx->pipe_rows + ctx->pipe_rows / 2)
         return host_batch_pipelined(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_div_deg, thr_poly, plane, noise_floor, perm,
@@ -1259,14 +1274,14 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     }
     std::memcpy(ctx->mail_up_h + up_off, frame_offsets, 8 * (nfz + 1));
     if (thr_poly) std::memcpy(ctx->mail_up_h + up_par, thr_poly, 24 * nfz);
-    else std::memcpy(ctx->mail_up_h + up_par, plane, 32 * nfz);
+    else if (plane) std::memcpy(ctx->mail_up_h + up_par, plane, 32 * nfz);          // neither: the plane is estimated on the device
     std::memcpy(ctx->mail_up_h + up_ids, table_ids, 4 * nfz * nlz);
     HIPCHK(ctx, hipMemcpyAsync(ctx->mail_up_d.p, ctx->mail_up_h, up_bytes, hipMemcpyHostToDevice, st));
     if (row_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_frame_off = (const int64_t *)(ctx->mail_up_d.p + up_off);
     const int32_t *d_table_ids = (const int32_t *)(ctx->mail_up_d.p + up_ids);
     const double *d_thr = thr_poly ? (const double *)(ctx->mail_up_d.p + up_par) : nullptr;
-    const double *d_plane = thr_poly ? nullptr : (const double *)(ctx->mail_up_d.p + up_par);
+    const double *d_plane = (thr_poly || !plane) ? nullptr : (const double *)(ctx->mail_up_d.p + up_par);
     int32_t *d_status = (int32_t *)(ctx->mail_dn_d.p + dn_st);
     int64_t *d_counts = (int64_t *)(ctx->mail_dn_d.p + dn_cnt), *d_stats = (int64_t *)(ctx->mail_dn_d.p + dn_stats);
     double *d_thr_out = (double *)(ctx->mail_dn_d.p + dn_thr);
@@ -1541,7 +1556,7 @@ extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, 
                                                 int32_t *d_out_flags, int32_t *d_status, void *stream)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
-    if (n_frames <= 0 || n_total < 0 || !d_frame_offsets || (n_total > 0 && !d_rows) || !d_table_ids || !d_wet_plane || !d_out_rows ||
+    if (n_frames <= 0 || n_total < 0 || !d_frame_offsets || (n_total > 0 && !d_rows) || !d_table_ids || !d_out_rows ||
         !d_out_src || !d_out_counts || !d_out_stats || !d_out_flags || !d_status || (dtype != 0 && dtype != 1))
         return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch_device: null pointer or bad dtype");
     if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
@@ -1569,7 +1584,14 @@ extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, 
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = wet_noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
-    int e = sg_wet_run(&ctx->prepass, ctx->snow_rows.p, dtype, d_frame_offsets, ctx->snow_counts.p, n_frames, n_total, b.max_frame,
+    int e = 0;
+    if (!d_wet_plane) {      // wet_ground/augmentation.py:41 calculate_plane(pointcloud) -- here the snowfall result -- on the device
+        ENSURE(ctx, ctx->wet_plane_est, (size_t)n_frames * 4);
+        e = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->snow_rows.p, dtype, d_frame_offsets, ctx->snow_counts.p, n_frames, n_total, b.max_frame,
+                         ctx->wet_plane_est.p, nullptr, b.stream);
+        d_wet_plane = ctx->wet_plane_est.p;
+    }
+    if (!e) e = sg_wet_run(&ctx->prepass, ctx->snow_rows.p, dtype, d_frame_offsets, ctx->snow_counts.p, n_frames, n_total, b.max_frame,
                        d_wet_plane, &wp, d_out_rows, ctx->wet_src.p, d_out_counts, d_out_flags, d_status, b.stream);
     if (!e) e = sg_launch_compose_src(d_frame_offsets, d_out_counts, n_frames, b.max_frame, ctx->wet_src.p, ctx->snow_src.p, d_out_src, b.stream);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
@@ -1585,10 +1607,9 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
                                          int64_t *out_counts, int64_t *out_stats, int32_t *out_flags)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
-    if (n_frames <= 0 || !frame_offsets || !table_ids || !wet_plane || !out_counts || !out_stats || !out_flags || (dtype != 0 && dtype != 1))
+    if (n_frames <= 0 || !frame_offsets || !table_ids || !out_counts || !out_stats || !out_flags || (dtype != 0 && dtype != 1))
         return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_wet_batch: null pointer or bad dtype");
     if (frame_offsets[0] != 0) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets[0] must be 0");
-    if (!thr_poly && !plane) return fail(ctx, SNOWGPU_E_INVALID, "either thr_poly or plane must be given");
     if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     int64_t max_frame = 0;
     bool uni = true;
@@ -1616,13 +1637,13 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
     if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->wet_plane.p, wet_plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+    if (wet_plane) HIPCHK(ctx, hipMemcpyAsync(ctx->wet_plane.p, wet_plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
     const double *d_thr = nullptr;
     if (thr_poly) {
         ENSURE(ctx, ctx->user_thr, nf * 3);
         HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, thr_poly, sizeof(double) * 3 * nf, hipMemcpyHostToDevice, st));
         d_thr = ctx->user_thr.p;
-    } else {
+    } else if (plane) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
     }
     if (perm) {
@@ -1630,8 +1651,8 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
         if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
     }
     int rc = snowgpu_augment_wet_batch_device(ctx, n_frames, n_total, uni ? max_frame : std::max<int64_t>(max_frame, 1) , ctx->frame_off.p,
-                                              ctx->rows_in.p, dtype, ctx->table_ids.p, beam_divergence_deg, d_thr, d_thr ? nullptr : ctx->plane.p,
-                                              noise_floor, perm ? ctx->user_perm.p : nullptr, ctx->wet_plane.p, water_height,
+                                              ctx->rows_in.p, dtype, ctx->table_ids.p, beam_divergence_deg, d_thr, (d_thr || !plane) ? nullptr : ctx->plane.p,
+                                              noise_floor, perm ? ctx->user_perm.p : nullptr, wet_plane ? ctx->wet_plane.p : nullptr, water_height,
                                               pavement_depth, wet_noise_floor, power_factor, flat_earth, delta, replace, ctx->wet_rows.p,
                                               ctx->out_src.p, ctx->wet_counts.p, ctx->out_stats.p, ctx->wet_flags.p, ctx->d_status, st);
     int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
@@ -1691,7 +1712,7 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
                                         int32_t *out_src, int64_t *out_counts, int32_t *out_flags)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
-    if (n_frames <= 0 || !frame_offsets || !plane || !out_counts || !out_flags || (dtype != 0 && dtype != 1))
+    if (n_frames <= 0 || !frame_offsets || !out_counts || !out_flags || (dtype != 0 && dtype != 1))
         return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_wet_ground_batch: null pointer or bad dtype");
     int64_t max_frame = 0;
     for (int f = 0; f < n_frames; ++f) {
@@ -1712,7 +1733,12 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     ENSURE(ctx, ctx->dbg_count, (size_t)n_frames);   // reused as the per-frame "returned unchanged" flags
     if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    if (plane) HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
+    else {                   // wet_ground/augmentation.py:41 calculate_plane(pointcloud) on the device
+        int pe = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame,
+                              ctx->plane.p, nullptr, st);
+        if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+    }
     HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t) * 8, st));
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
@@ -1734,6 +1760,72 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
         HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return SNOWGPU_OK;
+}
+
+
+// ---- ground plane (tools/wet_ground/planes.py:12-50) -------------------------------------------------------------------
+extern "C" int snowgpu_set_plane_method(snowgpu_ctx *ctx, int method, uint64_t seed, int max_trials, int min_rows, double standard_height)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (method < SG_PLANE_REFERENCE || method > SG_PLANE_RANSAC || max_trials < 0 || max_trials > (1 << 16) || min_rows < 0)
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_plane_method: method 0 (reference), 1 (least squares) or 2 (ransac); 0 <= trials <= 65536");
+    ctx->plane_par.method = method;
+    ctx->plane_par.seed = seed;
+    ctx->plane_par.trials = max_trials > 0 ? max_trials : 1024;
+    ctx->plane_par.min_rows = min_rows;
+    ctx->plane_par.std_height = standard_height;
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_estimate_planes_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
+                                              const int64_t *d_frame_offsets, const void *d_rows, int dtype, double *d_out_planes,
+                                              int32_t *d_out_info, void *stream)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || n_total < 0 || !d_frame_offsets || (n_total > 0 && !d_rows) || !d_out_planes || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_estimate_planes_device: null pointer or bad dtype");
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int64_t mf = (max_frame_rows > 0 && max_frame_rows <= n_total) ? max_frame_rows : n_total;
+    int e = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, d_rows, dtype, d_frame_offsets, nullptr, n_frames, n_total, mf, d_out_planes, d_out_info,
+                         stream ? (hipStream_t)stream : ctx->stream);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                       double *out_planes, int32_t *out_info)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !frame_offsets || !out_planes || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_estimate_planes: null pointer or bad dtype");
+    if (frame_offsets[0] != 0) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets[0] must be 0");
+    int64_t max_frame = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets must be non-decreasing");
+        max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    }
+    const int64_t n_total = frame_offsets[n_frames];
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    if (n_total > 0 && !rows) return fail(ctx, SNOWGPU_E_INVALID, "null row buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, nf = (size_t)n_frames;
+    hipStream_t st = ctx->stream;
+    ENSURE(ctx, ctx->frame_off, nf + 1);
+    ENSURE(ctx, ctx->plane_est, nf * 4);
+    ENSURE(ctx, ctx->plane_info, nf * 4);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
+    if (ctx->plane_par.method != SG_PLANE_REFERENCE && n_total > 0) {       // (the reference-today plane reads no row)
+        ENSURE(ctx, ctx->rows_in, (size_t)n_total * 5 * esz);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, (size_t)n_total * 5 * esz, hipMemcpyHostToDevice, st));
+    }
+    int e = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame,
+                         ctx->plane_est.p, ctx->plane_info.p, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    HIPCHK(ctx, hipMemcpyAsync(out_planes, ctx->plane_est.p, sizeof(double) * 4 * nf, hipMemcpyDeviceToHost, st));
+    if (out_info) HIPCHK(ctx, hipMemcpyAsync(out_info, ctx->plane_info.p, sizeof(int32_t) * 4 * nf, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return SNOWGPU_OK;
 }

@@ -18,15 +18,17 @@ per (mode, combo) -- one flake-table set per batch -- and flow through three sta
     writer threads  float32 `.bin` files
 
 The channel permutations are drawn from the global `random` in the reference's nesting order -- per mode, per frame, per
-combo, one shuffle per output that does not exist yet -- BEFORE the items are regrouped, so a seeded run gives every
-(frame, combo) the permutation the reference's sequential loop gives it.  Frames are independent, so a multi-GPU run
-shards the frame list round-robin over ranks (lidar_snow_sim_amd.dist).
+combo, one shuffle per output that does not exist yet -- BEFORE the items are regrouped AND before they are sharded: every
+rank of a multi-GPU run draws for all frames and keeps the items of its own (frame i belongs to rank i mod W,
+lidar_snow_sim_amd.dist), so a seeded run gives every (mode, frame, combo) the permutation the reference's sequential loop
+gives it, on one rank or on eight.  "Exists" is decided against a listing taken before the run writes anything.
 
     python -m lidar_snow_sim_amd.stream --lidar <dir> --split <file> --particles <npy dir> [--batch 32]
 """
 from __future__ import annotations
 
 import argparse
+import os
 import queue
 import threading
 import time
@@ -63,11 +65,37 @@ def output_path(lidar_folder: Path, mode: str, rainfall_rate: float, sample_id: 
             f'{lidar_folder.name}_rainrate_{int(rainfall_rate)}' / f'{sample_id}.bin')
 
 
-def plan_iter(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
+def existing_outputs(lidar_folder: Path, modes, combos):
+    """The outputs that exist NOW, as a set of paths: one directory listing per (mode, combo) folder.  Taken once, before the
+    pipeline starts -- the reference's skip test (precompute.py:91-92) is then a set lookup that neither the writers of this run
+    nor the other ranks of a sharded run can change while the permutations are being drawn."""
+    have = set()
+    for mode in modes:
+        for rainfall_rate, _occ in combos:
+            folder = output_path(lidar_folder, mode, rainfall_rate, 'x').parent
+            try:
+                have.update(str(folder / name) for name in os.listdir(folder))
+            except FileNotFoundError:
+                pass
+    return have
+
+
+def plan_iter(lidar_folder: Path, ids: Sequence[str], modes, combos, batch: int, n_lasers: int = 64, rank: int = 0, world: int = 1,
+              existing=None):
     """The work items in the reference's order (precompute.py:70-92: mode -> frame -> combo, existing outputs skipped), one
     `random.shuffle` per item in that order (simulation.py:483-486), regrouped into batches of one (mode, combo).  A generator:
-    a batch is handed out as soon as its group holds `batch` items, so the pipeline runs while later permutations are drawn."""
+    a batch is handed out as soon as its group holds `batch` items, so the pipeline runs while later permutations are drawn.
+
+    Sharding (rank r of `world` owns frames r, r + world, ...) happens AFTER the draw: every rank walks ALL ids and draws every
+    item's permutation from the global `random`, keeping its own items only -- so a seeded run gives (mode, frame, combo) the
+    permutation the reference's sequential loop gives it whatever the number of ranks (64-int shuffles: 10 000 frames x 10 items
+    are ~1 s per rank).  `existing`: the set of output paths present when the run started (existing_outputs); the skip test never
+    looks at the live file system, whose state changes while writers and other ranks run.  An item planned earlier in this
+    generator counts as existing too (two combos with the same int(rainfall_rate), a repeated id)."""
     import random
+    if existing is None:
+        existing = existing_outputs(lidar_folder, modes, combos)
+    planned = set()
     groups = {}
 
     def job(mode, ci, items):
@@ -76,12 +104,16 @@ def plan_iter(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int
         return (mode, rainfall_rate, prefix, [c[0] for c in items], [c[1] for c in items])
 
     for mode in modes:
-        for s in mine:
+        for si, s in enumerate(ids):
             for ci, (rainfall_rate, _occ) in enumerate(combos):
-                if output_path(lidar_folder, mode, rainfall_rate, s).is_file():          # :91-92
+                out = str(output_path(lidar_folder, mode, rainfall_rate, s))
+                if out in existing or out in planned:                                    # :91-92
                     continue
+                planned.add(out)
                 order = list(range(n_lasers))
                 random.shuffle(order)
+                if si % world != rank:                                                   # another rank's frame: drawn, not kept
+                    continue
                 items = groups.setdefault((mode, ci), [])
                 items.append((s, order))
                 if len(items) >= batch:
@@ -92,26 +124,35 @@ def plan_iter(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int
             yield job(mode, ci, items)
 
 
-def plan(lidar_folder: Path, mine: Sequence[str], modes, combos, batch: int, n_lasers: int = 64):
-    return list(plan_iter(lidar_folder, mine, modes, combos, batch, n_lasers))
+def plan(lidar_folder: Path, ids: Sequence[str], modes, combos, batch: int, n_lasers: int = 64, rank: int = 0, world: int = 1,
+         existing=None):
+    return list(plan_iter(lidar_folder, ids, modes, combos, batch, n_lasers, rank, world, existing))
 
 
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
         batch: int = 32, calib=None, device: int = 0, rank: int = 0, world: int = 1, particles_by_prefix=None,
         planes=None, workers: int = 2, readers: int = 4, writers: int = 4, depth: int = 4, keep_outputs: bool = True,
-        report: dict = None) -> int:
+        report: dict = None, plane_method: str = 'reference', plane_seed: int = 0, existing=None) -> int:
     """Process this rank's share of `sample_ids`; returns the number of files written.
 
     workers   GPU worker threads, each with its own engine context on `device`
     readers / writers   file I/O threads; depth: batches the readers may run ahead, results the writers may lag behind
-    planes    None (calculate_plane per frame, as the reference) or one (w, h) used for every frame
+    planes    None (calculate_plane per frame on the device, by `plane_method`: 'reference' = the plane the reference returns today,
+              'lsq', 'ransac' seeded with `plane_seed`) or one (w, h) used for every frame
+    existing  set of output paths to treat as present (default: a listing of the output folders taken before anything is
+              written).  Ranks of a sharded run must agree on it: start them against a quiescent output tree (they each list it
+              before writing; a launcher-started run lists behind a barrier, see main()), or pass the same set to all
     keep_outputs=False  unlink every output right after it has been written (throughput dry runs on a small disk)
     report    optional dict that receives wall time, files, points in / out and the per-stage busy times"""
     lidar_folder = Path(lidar_folder)
     combos = rate_combos() if combos is None else combos
     ids = list(sample_ids)
-    mine = [ids[i] for i in sdist.shard_indices(len(ids), rank, world)]
-    jobs = plan_iter(lidar_folder, mine, modes, combos, batch)      # drawn by the feeder thread while the pipeline runs
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if existing is None:
+        existing = existing_outputs(lidar_folder, modes, combos)   # before the first write of this run (and see `existing` above)
+    # drawn by the feeder thread while the pipeline runs; every rank draws for ALL ids and keeps its own (see plan_iter)
+    jobs = plan_iter(lidar_folder, ids, modes, combos, batch, rank=rank, world=world, existing=existing)
     n_jobs = [0]
     t_start = time.perf_counter()
     tally = {'files': 0, 'points_in': 0, 'points_out': 0, 'read_s': 0.0, 'gpu_s': 0.0, 'write_s': 0.0}
@@ -137,7 +178,12 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
     def read_job(job):
         t0 = time.perf_counter()
         paths = [lidar_folder / f'{s}.bin' for s in job[3]]
-        sizes = [p.stat().st_size // 20 for p in paths]                                 # float32 N x 5 rows (precompute.py:78)
+        sizes = []
+        for p in paths:
+            nbytes = p.stat().st_size
+            if nbytes % 20:                                                             # np.fromfile(...).reshape((-1, 5)) raises there (precompute.py:78)
+                raise ValueError(f'{p}: {nbytes} bytes is not a whole number of float32 N x 5 rows')
+            sizes.append(nbytes // 20)
         off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
         buf = take_buffer(int(off[-1]))
         for p, a, b in zip(paths, off[:-1], off[1:]):
@@ -201,7 +247,8 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
                         results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
                                                 particles=None if particles_by_prefix is None else particles_by_prefix[job[2]],
                                                 planes=None if planes is None else [planes] * len(frames),
-                                                orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None)
+                                                orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None,
+                                                plane_method=plane_method, plane_seed=plane_seed)
                     finally:
                         give_buffer(frames.rows)
                     with tally_lock:
@@ -248,6 +295,8 @@ def main(argv=None):
     ap.add_argument('--workers', type=int, default=2, help='GPU worker threads (engine contexts) per GPU')
     ap.add_argument('--readers', type=int, default=4)
     ap.add_argument('--writers', type=int, default=4)
+    ap.add_argument('--seed', type=int, default=None, help='random.seed() before the permutations are drawn (same on every rank)')
+    ap.add_argument('--plane-method', default='reference', choices=('reference', 'lsq', 'ransac'))
     args = ap.parse_args(argv)
     rank, local_rank, world = sdist.env_rank_world()
     calib = None
@@ -255,8 +304,19 @@ def main(argv=None):
         from .calibration import Calibration
         calib = Calibration(args.calib)
     rep = {}
+    existing = None
+    if world > 1:
+        # every rank lists the outputs BEFORE any rank writes: the skip decisions (and with them the permutations a seeded run
+        # draws) are then the same on all ranks.  gloo is enough: this barrier is the only collective of the driver.
+        existing = existing_outputs(Path(args.lidar), ('gunn', 'sekhon'), rate_combos())
+        d = sdist.init('gloo', rank, world)
+        d.barrier()
+    if args.seed is not None:
+        import random
+        random.seed(args.seed)                                  # the same seed on every rank: the reference's sequential draw order
     n = run(args.lidar, read_split(args.split), particle_root=args.particles, batch=args.batch, calib=calib,
-            device=local_rank, rank=rank, world=world, workers=args.workers, readers=args.readers, writers=args.writers, report=rep)
+            device=local_rank, rank=rank, world=world, workers=args.workers, readers=args.readers, writers=args.writers, report=rep,
+            existing=existing, plane_method=args.plane_method)
     print(f'rank {rank}/{world}: wrote {n} files in {rep.get("wall_s", 0.0):.1f} s')
 
 

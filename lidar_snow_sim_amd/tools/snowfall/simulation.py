@@ -24,7 +24,6 @@ import numpy as np
 from ... import _native
 from ... import engine as _engine
 from ..wet_ground.augmentation import noise_threshold_poly
-from ..wet_ground.planes import calculate_plane
 
 PI = np.pi
 
@@ -38,20 +37,72 @@ def _as_rows(pc) -> np.ndarray:
     return pc
 
 
-class _LazyFileIds:
-    """Device table ids of <prefix>_<line>.npy, loaded on first use only (a frame touches the lines its permutation names)."""
+class _LineIds:
+    """Device table id per table line (index = line - 1), resolved on first use; a frame's 64 ids are one fancy index."""
 
-    def __init__(self, eng, prefix, root_path):
-        self.eng, self.prefix, self.root_path, self.ids = eng, prefix, root_path, {}
+    def __init__(self, eng, n_known=64):
+        self.eng = eng
+        self.ids = np.full(max(int(n_known), 1), -2, np.int32)               # -2: not resolved yet
+
+    def resolve(self, k):
+        raise NotImplementedError
 
     def __getitem__(self, lines):
-        out = np.empty(len(lines), np.int32)
-        for c, k in enumerate(lines):
-            k = int(k)
-            if k not in self.ids:
-                self.ids[k] = self.eng.file_table_id(self.prefix, k + 1, self.root_path)
-            out[c] = self.ids[k]
+        lines = np.asarray(lines, np.int64)
+        if lines.size and (lines.min() < 0 or lines.max() >= self.ids.shape[0]):
+            if lines.min() < 0:
+                raise IndexError("negative table line in `order`")
+            grown = np.full(int(lines.max()) + 1, -2, np.int32)
+            grown[:self.ids.shape[0]] = self.ids
+            self.ids = grown
+        out = self.ids[lines]
+        if (out == -2).any():
+            for k in np.unique(lines[out == -2]):
+                self.ids[int(k)] = self.resolve(int(k))
+            out = self.ids[lines]
         return out
+
+
+class _LazyFileIds(_LineIds):
+    """<prefix>_<line>.npy, loaded on first use only (a frame touches the lines its permutation names)."""
+
+    def __init__(self, eng, prefix, root_path):
+        super().__init__(eng)
+        self.prefix, self.root_path = prefix, root_path
+
+    def resolve(self, k):
+        return self.eng.file_table_id(self.prefix, k + 1, self.root_path)
+
+
+class _ArrayIds(_LineIds):
+    """Caller-owned tables (index = line - 1), uploaded on first use; a line beyond the sequence is the caller's error and says
+    so here rather than as a device status later."""
+
+    def __init__(self, eng, particles):
+        super().__init__(eng, len(particles))
+        self.particles = particles
+
+    def resolve(self, k):
+        if k >= len(self.particles):
+            raise IndexError(f"order names line {k + 1}, but only {len(self.particles)} particle tables were given")
+        return self.eng.array_table_id(self.particles[k])
+
+
+def _device_planes(eng, frames, dt, method, seed, trials, ncols):
+    """calculate_plane for every frame of a batch, one device call (planes of the host-side polynomial fit)."""
+    if method == 'reference':
+        from ..wet_ground.planes import flat_earth
+        return [flat_earth()] * len(frames)
+    off = np.zeros(len(frames) + 1, np.int64)
+    off[1:] = np.cumsum([f.shape[0] for f in frames])
+    flat = np.concatenate([f[:, :5] for f in frames]).astype(dt, copy=False) if len(frames) else np.zeros((0, 5), dt)
+    with eng.batch_lock:
+        eng.ctx.set_plane_method(method, seed=seed, trials=trials, min_rows=ncols)
+        try:
+            pl, _ = eng.ctx.estimate_planes(flat, off)
+        finally:
+            eng.ctx.set_plane_method('reference')
+    return [(pl[i, :3].copy(), float(pl[i, 3])) for i in range(len(frames))]
 
 
 class FlatBatch:
@@ -75,20 +126,6 @@ class FlatBatch:
         return self.rows[int(self.offsets[i]):int(self.offsets[i + 1])]
 
 
-def _rows_for_plane(r, calib, pre_crop):
-    """What calculate_plane sees: with the pre-augment camera crop (precompute.py:96-99) the reference fits the plane on the
-    CROPPED cloud (precompute.py:96-104 calls augment() with it).  The device crops later, so the host applies the same crop to
-    the few rows of the plane fit's own window (planes.py:21-27) -- that window is all calculate_plane looks at."""
-    if calib is None or not pre_crop:
-        return r
-    from ...calibration import get_fov_flag
-    from ..wet_ground.planes import ground_crop
-    sub = r[ground_crop(r)]
-    if sub.shape[0] == 0:
-        return sub
-    return sub[get_fov_flag(calib.lidar_to_rect(sub[:, 0:3]), (1024, 1920), calib)]
-
-
 def _raise_like_reference(err: _native.SnowGPUError):
     """Map library status codes onto the exception types the reference raises (SURVEY 8 b, 'Errors')."""
     if err.code == _native.E_RANGE:
@@ -103,11 +140,16 @@ def _raise_like_reference(err: _native.SnowGPUError):
 def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
                   thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0,
-                  calib=None, pre_crop: bool = False, q8: str = 'first'):
+                  calib=None, pre_crop: bool = False, q8: str = 'first', plane_method: str = 'reference', plane_seed: int = 0,
+                  plane_trials: int = 1000):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch); further columns are carried through
-    planes      optional per-frame (w, h); default: calculate_plane(frame) per frame, like the reference
+    planes      optional per-frame (w, h); default (None): calculate_plane (simulation.py:449) runs ON THE DEVICE for every frame,
+                by `plane_method`: 'reference' (default) = what the reference returns today, the flat-earth plane
+                ([0, 0, 1], -1.55) (its RANSAC call raises with scikit-learn >= 1.2, planes.py:35-48); 'lsq' = least squares over
+                the strip of planes.py:21-27; 'ransac' = RANSAC seeded with `plane_seed` (`plane_trials` trials).  With pre_crop
+                the plane comes from the cropped cloud, as in precompute.py:96-104
     orders      optional per-frame channel permutations; default: range(64), shuffled with the global
                 `random` module when shuffle=True, one draw per frame in frame order
     particles   optional sequence of K x 3 tables (index = line - 1) instead of <prefix>_<line>.npy files
@@ -138,7 +180,18 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         raise ValueError("q8 must be 'first' or 'numpy'")
     if q8 == 'numpy':
         device_prepass = False
+    if plane_method not in _native.PLANE_METHODS:
+        raise ValueError("plane_method must be 'reference', 'lsq' or 'ransac'")
     nl = eng.n_lasers
+    ncols = rows[0].shape[1]
+    host_fit = thr_polys is None and not device_prepass          # the polynomial is fitted here (q8='numpy', device_prepass=False)
+    fit_rows = rows
+    if host_fit and calib is not None and pre_crop:
+        # precompute.py:96-104 hands augment() the CROPPED cloud: plane and polynomial are fitted on it
+        from ...calibration import get_fov_flag
+        fit_rows = [r[get_fov_flag(calib.lidar_to_rect(r[:, 0:3]), (1024, 1920), calib)] for r in rows]
+    if host_fit and planes is None:
+        planes = _device_planes(eng, fit_rows, dt, plane_method, plane_seed, plane_trials, ncols)
     table_ids, polys, plane_rows = [], [], []
     ids_by_line = None                                                      # device table id of line - 1, looked up once per batch
     for i, r in enumerate(rows):
@@ -149,19 +202,16 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             if shuffle:
                 random.shuffle(order)                                       # simulation.py:485-486
         if ids_by_line is None:
-            lines = range(max(nl, max(order) + 1))
-            if particles is not None:
-                ids_by_line = np.asarray([eng.array_table_id(particles[k]) if k < len(particles) else -1 for k in lines], np.int32)
-            else:
-                ids_by_line = _LazyFileIds(eng, particle_file_prefix, root_path)
-        table_ids.append(ids_by_line[np.asarray(order[:nl], np.int64)])     # channel c reads line order[c] + 1 (simulation.py:78)
+            ids_by_line = _ArrayIds(eng, particles) if particles is not None else _LazyFileIds(eng, particle_file_prefix, root_path)
+        table_ids.append(ids_by_line[order[:nl]])                           # channel c reads line order[c] + 1 (simulation.py:78)
         if thr_polys is not None:
             polys.append(np.asarray(thr_polys[i], np.float64))
-        else:
-            w, h = calculate_plane(_rows_for_plane(r, calib, pre_crop)) if planes is None else planes[i]      # simulation.py:449
+        elif planes is not None:
+            w, h = planes[i]                                                 # simulation.py:449
             plane_rows.append([float(w[0]), float(w[1]), float(w[2]), float(h)])
-            if not device_prepass:
-                srt = r[np.argsort(r[:, 4], kind="stable")]
+            if host_fit:
+                fr = fit_rows[i]
+                srt = fr[np.argsort(fr[:, 4], kind="stable")]
                 polys.append(noise_threshold_poly(srt[:, :5], w, h, noise_floor, q8=q8))
     offsets = np.zeros(len(rows) + 1, np.int64)
     offsets[1:] = np.cumsum([r.shape[0] for r in rows])
@@ -181,12 +231,15 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         crop_idx = None
         if calib is not None:
             eng.ctx.set_fov(calib, (1024, 1920), pre_crop=pre_crop)              # simulation.py:536
+        device_plane = not polys and not plane_rows                              # neither given: calculate_plane on the device
+        if device_plane:
+            eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=ncols)
         try:
             for attempt in (0, 1):
                 try:
                     out, src, counts, stats, _ = eng.ctx.augment_batch(
                         flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
-                        plane=None if polys else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
+                        plane=None if (polys or device_plane) else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
                         out_rows=out_rows, out_src=out_src, want_src=want_src)
                     break
                 except _native.SnowGPUError as err:
@@ -212,6 +265,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         finally:
             if calib is not None:
                 eng.ctx.set_fov(None)
+            if device_plane and plane_method != 'reference':
+                eng.ctx.set_plane_method('reference')
     results = []
     for i in range(len(rows)):
         a, n = int(offsets[i]), int(counts[i])
@@ -229,7 +284,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
 def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, shuffle: bool = True,
             show_progressbar: bool = False, only_camera_fov: bool = True, noise_floor: float = 0.7,
             root_path: str = None, *, plane=None, order=None, particles=None, thr_poly=None, calib=None,
-            device: int = 0, return_src: bool = False, device_prepass: bool = True, q8: str = 'first') -> Tuple:
+            device: int = 0, return_src: bool = False, device_prepass: bool = True, q8: str = 'first',
+            plane_method: str = 'reference', plane_seed: int = 0, plane_trials: int = 1000) -> Tuple:
     """
     :param pc:                      N-by-5 array containing original pointcloud (x, y, z, intensity, channel).
     :param particle_file_prefix:    Prefix of the particle tables, f'{mode}_{rain_rate}_{occupancy}'.
@@ -244,7 +300,8 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
     :return:                        ((num_attenuated, num_removed, avg_intensity_diff), N'-by-5 array)
 
     Keyword-only extras: plane=(w, h), order=<permutation>, particles=<tables>, thr_poly, calib, device,
-    return_src (append the source-row index of every output row to the result), q8 ('first' | 'numpy', see augment_batch).
+    return_src (append the source-row index of every output row to the result), q8 ('first' | 'numpy', see augment_batch),
+    plane_method / plane_seed / plane_trials (how calculate_plane, simulation.py:449, runs on the device when plane is None).
     """
     cal = None
     if only_camera_fov:                                                     # simulation.py:532-533
@@ -254,5 +311,6 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
                         root_path=root_path, planes=None if plane is None else [plane],
                         orders=None if order is None else [order], particles=particles,
                         thr_polys=None if thr_poly is None else [thr_poly], device=device, return_src=return_src,
-                        device_prepass=device_prepass, calib=cal, q8=q8)[0]
+                        device_prepass=device_prepass, calib=cal, q8=q8, plane_method=plane_method, plane_seed=plane_seed,
+                        plane_trials=plane_trials)[0]
     return res

@@ -74,11 +74,14 @@ def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7, q8='first'):
 
 def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0012, noise_floor=0.7, power_factor=15,
                               estimation_method='linear', flat_earth=False, debug=True, delta=0.5, replace=True,
-                              *, plane=None, device=0, return_src=False, q8='first'):
+                              *, plane=None, device=0, return_src=False, q8='first', plane_method='reference', plane_seed=0,
+                              plane_trials=1000):
     """Drop-in for tools/wet_ground/augmentation.py::ground_water_augmentation (:25-161).
 
     `debug` is accepted and ignored (the reference's debug branch only draws matplotlib figures).
-    Extra keyword-only arguments: plane=(w, h) to skip the plane estimate, device, return_src, and q8: 'first' (default) fits
+    Extra keyword-only arguments: plane=(w, h) to skip the plane estimate -- without it calculate_plane (:41) runs on the device by
+    `plane_method` ('reference': the flat-earth plane the reference returns today; 'lsq'; 'ransac' seeded with `plane_seed`) --,
+    device, return_src, and q8: 'first' (default) fits
     the noise line on the device through the FIRST sparsest histogram bin of every range row; 'numpy' fits the two lines on the
     host with THIS process' NumPy (np.argpartition verbatim, quirk Q8: what the reference itself computes on this machine) and
     hands them to the device, which does everything else.
@@ -89,10 +92,12 @@ def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0
         raise NotImplementedError("only estimation_method='linear' is reproducible (augmentation.py:171-192)")
     pc = np.asarray(pointcloud)
     rows = pc if pc.dtype in (np.float32, np.float64) else pc.astype(np.float64)
-    w, h = calculate_plane(rows) if plane is None else plane
     eng = _engine.get_engine(device)
     lines = None
+    if q8 == 'numpy' and plane is None:           # the two lines are fitted here, so the plane is needed here
+        plane = calculate_plane(pc, method=plane_method, seed=plane_seed, trials=plane_trials, device=device)
     if q8 == 'numpy':
+        w, h = plane
         # the reference's own steps up to the two fitted lines (augmentation.py:44-76), with the local NumPy
         wv = np.asarray(w)
         hog = np.matmul(rows[:, :3], wv)
@@ -109,9 +114,17 @@ def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0
             lines = [[p[0], p[1], pmin[0], pmin[1]]]
     elif q8 != 'first':
         raise ValueError("q8 must be 'first' or 'numpy'")
-    out, src, counts, flags = eng.ctx.wet_ground_batch(
-        np.ascontiguousarray(rows[:, :5]), [0, rows.shape[0]], [[w[0], w[1], w[2], h]], water_height,
-        pavement_depth, noise_floor, power_factor, flat_earth, delta, replace, lines=lines)
+    with eng.batch_lock:
+        if plane is None:                         # augmentation.py:41 calculate_plane(pointcloud): on the device
+            eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=pc.shape[1])
+        try:
+            out, src, counts, flags = eng.ctx.wet_ground_batch(
+                np.ascontiguousarray(rows[:, :5]), [0, rows.shape[0]],
+                None if plane is None else [[plane[0][0], plane[0][1], plane[0][2], plane[1]]], water_height,
+                pavement_depth, noise_floor, power_factor, flat_earth, delta, replace, lines=lines)
+        finally:
+            if plane is None and plane_method != 'reference':
+                eng.ctx.set_plane_method('reference')
     if flags[0]:
         return (pointcloud, np.arange(rows.shape[0])) if return_src else pointcloud
     n = int(counts[0])

@@ -1113,7 +1113,6 @@ def test_pre_crop_with_odd_channel_values_and_plane_from_the_cropped_cloud(eng, 
     from lidar_snow_sim_amd.calibration import Calibration, get_fov_flag
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     from lidar_snow_sim_amd.tools.snowfall import simulation as sim
-    from lidar_snow_sim_amd.tools.wet_ground.planes import ground_crop
     cal = Calibration(P2=np.array([[700.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
                       V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
     pc = np.ascontiguousarray(synthetic_sweep(64, 2048, seed=29, intensity="lambert").reshape(64, 2048, 5)[:, ::4, :].reshape(-1, 5))
@@ -1130,12 +1129,31 @@ def test_pre_crop_with_odd_channel_values_and_plane_from_the_cropped_cloud(eng, 
     flag2 = so.fov_flag(a0[:, :3], cal.V2C, cal.R0, cal.P2, (1024, 1920))
     assert np.array_equal(src, kept1[src0][flag2]) and np.array_equal(aug[:, 3:], a0[flag2][:, 3:])
     assert (int(st[0]), int(st[1]), int(st[2])) == (int(s0[0]), int(s0[1]) + int((~flag2).sum()), int(s0[2]))
-    # (2) what calculate_plane is given
-    sub = sim._rows_for_plane(pc, cal, True)
-    win = pc[ground_crop(pc)]
-    exp = win[get_fov_flag(cal.lidar_to_rect(win[:, 0:3]), (1024, 1920), cal)]
-    assert np.array_equal(sub, exp) and 0 < sub.shape[0] <= win.shape[0]
-    assert sim._rows_for_plane(pc, cal, False) is pc and sim._rows_for_plane(pc, None, True) is pc
+    # (2) planes=None: calculate_plane runs on the device AFTER the device crop, i.e. on the cropped cloud.  A narrow camera
+    # (the strip of planes.py:21-27 is wider than its view) and a road that banks outside the view make the two planes differ.
+    from lidar_snow_sim_amd.tools.wet_ground.planes import calculate_plane
+    narrow = Calibration(P2=np.array([[7000.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
+                         V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
+    road = np.ascontiguousarray(synthetic_sweep(64, 2048, seed=31, intensity="lambert"))
+    bank = np.abs(road[:, 1]) > 1.0
+    road[bank, 2] -= (0.02 * (np.abs(road[bank, 1]) - 1.0)).astype(np.float32)
+    seen = get_fov_flag(narrow.lidar_to_rect(road[:, 0:3]), (1024, 1920), narrow)
+    w_all, h_all = calculate_plane(road, method="lsq")
+    w_crop, h_crop = calculate_plane(road[seen], method="lsq")
+    assert abs(h_all - h_crop) > 1e-3                                    # the crop matters for this cloud
+    (st1, a1, s1), = sim.augment_batch([road], "unused", bd, particles=tl, orders=[order], return_src=True, calib=narrow, pre_crop=True,
+                                       plane_method="lsq")
+    (st2, a2, s2), = sim.augment_batch([road], "unused", bd, particles=tl, orders=[order], return_src=True, calib=narrow, pre_crop=True,
+                                       planes=[(w_crop, h_crop)])
+    assert tuple(st1) == tuple(st2) and np.array_equal(s1, s2) and np.array_equal(a1, a2)
+    # (3) the host-fitted polynomial (q8='numpy' forces it) sees the cropped cloud too (advisor, round 3): same result as
+    # cropping first and augmenting the cropped cloud without the pre-crop
+    (st3, a3, s3), = sim.augment_batch([road], "unused", bd, particles=tl, orders=[order], return_src=True, calib=narrow, pre_crop=True,
+                                       planes=[(w_crop, h_crop)], q8="numpy")
+    kept = np.where(seen)[0]
+    (st4, a4, s4), = sim.augment_batch([road[seen]], "unused", bd, particles=tl, orders=[order], return_src=True, calib=narrow,
+                                       planes=[(w_crop, h_crop)], q8="numpy")
+    assert tuple(st3) == tuple(st4) and np.array_equal(s3, kept[s4]) and np.array_equal(a3, a4)
 
 
 @pytest.mark.parametrize("lanes", ["2", "3"])

@@ -144,14 +144,21 @@ def test_estimate_laser_parameters_L6(golden):
     assert estimate_laser_parameters(d["elp_pc"][:2], d["elp_angle"][:2]) == (None, None, None, None)
 
 
-def test_calculate_plane_fallback_and_crop():
+def test_calculate_plane_reference_method_and_crop_mask():
+    """The default estimator is the plane the reference returns today (planes.py:43-48 under scikit-learn >= 1.2) and needs
+    no device; the host-side crop mask equals the reference's expression (planes.py:21-26) in the cloud's dtype."""
     from lidar_snow_sim_amd.tools.wet_ground.planes import calculate_plane, ground_crop
     pc = np.zeros((10, 5), np.float32)
-    assert calculate_plane(pc) == ([0, 0, 1], -1.55)             # empty crop (planes.py:29-32)
-    pc = np.array([[20.0, 0.0, -1.7, 10, 0]] * 40, np.float32)
-    assert ground_crop(pc).all()
-    w, h = calculate_plane(pc)                                   # sklearn >= 1.2 rejects loss='squared_loss' -> fallback
-    assert len(w) == 3
+    assert calculate_plane(pc) == ([0, 0, 1], -1.55)
+    assert calculate_plane(pc, -1.6) == ([0, 0, 1], -1.6)
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        pc = np.column_stack((rng.uniform(0, 90, 4000), rng.uniform(-5, 5, 4000), rng.uniform(-2.8, -1.3, 4000),
+                              np.ones(4000), np.zeros(4000))).astype(dt)
+        want = (pc[:, 2] < -1.55) & (pc[:, 2] > -1.86 - 0.01 * pc[:, 0]) & (pc[:, 0] > 10) & (pc[:, 0] < 70) & (pc[:, 1] > -3) & (pc[:, 1] < 3)
+        assert np.array_equal(ground_crop(pc), want) and 0 < want.sum() < 4000
+    with pytest.raises(ValueError):
+        calculate_plane(pc, method="sklearn")
 
 
 def test_laser_constants_follow_the_calibration():
@@ -627,6 +634,16 @@ def test_stream_plan_draws_permutations_in_the_reference_order(tmp_path):
     jobs = stream.plan(lidar, ids, ("gunn", "sekhon"), combos, batch=2)
     got = {(mode, rr, s): o for mode, rr, prefix, ss, orders in jobs for s, o in zip(ss, orders)}
     assert got == want and len(got) == 11
+    # the skip decisions come from a listing taken up front: files that appear while the plan is drawn change nothing
+    random.seed(11)
+    it = stream.plan_iter(lidar, ids, ("gunn", "sekhon"), combos, batch=2)
+    first = next(it)
+    for s in ids:
+        late = stream.output_path(lidar, "sekhon", 10.5, s)
+        late.parent.mkdir(parents=True, exist_ok=True)
+        late.write_bytes(b"")
+    jobs2 = [first] + list(it)
+    assert {(mode, rr, s): o for mode, rr, prefix, ss, orders in jobs2 for s, o in zip(ss, orders)} == want
     assert all(len(j[3]) <= 2 for j in jobs)
     assert {j[2] for j in jobs} == {f"{m}_{rr}_{occ}" for m in ("gunn", "sekhon") for rr, occ in combos}
 
@@ -703,3 +720,96 @@ def test_stream_plan_iter_hands_batches_out_as_they_fill(tmp_path):
     for _ in range(5):                                     # the first full batch needs the draws of items 0 .. 4 (two combos interleave)
         random.shuffle(list(range(64)))
     assert random.getstate() == state_after_first
+
+
+# ---- a seeded sharded stream == the unsharded one (precompute.py:70-92, simulation.py:482-486) -------------
+def _plan_items(jobs):
+    return {(mode, rr, s): tuple(o) for mode, rr, prefix, ss, orders in jobs for s, o in zip(ss, orders)}
+
+
+def _stream_fixture(tmp_path, n_ids=23):
+    from lidar_snow_sim_amd import stream
+    lidar = tmp_path / "lidar_hdl64_strongest"
+    lidar.mkdir(exist_ok=True)
+    ids = [f"2018-02-03_{i:05d}" for i in range(n_ids)]
+    combos = [(10.5, 1e-6), (20.5, 2e-6), (20.9, 3e-6)]            # the last two share int(rainfall_rate): one output path
+    for s in (ids[2], ids[7]):                                     # outputs that already exist draw nothing (precompute.py:91-92)
+        done = stream.output_path(lidar, "gunn", 10.5, s)
+        done.parent.mkdir(parents=True, exist_ok=True)
+        done.write_bytes(b"")
+    return lidar, ids, combos
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_union_of_the_ranks_plans_is_the_single_rank_plan(tmp_path, world):
+    import random
+    from lidar_snow_sim_amd import stream
+    lidar, ids, combos = _stream_fixture(tmp_path)
+    random.seed(5)
+    whole = _plan_items(stream.plan(lidar, ids, ("gunn", "sekhon"), combos, batch=4))
+    assert len(whole) == 2 * len(ids) * 2 - 2                      # two distinct output paths per (mode, frame); two exist already
+    union = {}
+    for rank in range(world):
+        random.seed(5)                                             # every rank seeds alike, as the reference's one process does once
+        part = _plan_items(stream.plan(lidar, ids, ("gunn", "sekhon"), combos, batch=4, rank=rank, world=world))
+        assert all(ids.index(k[2]) % world == rank for k in part)  # round-robin ownership
+        assert not set(part) & set(union)
+        union.update(part)
+    assert union == whole                                          # item for item, permutation for permutation
+
+
+_PLAN_WORKER = r"""
+import json, os, random, sys
+sys.path.insert(0, {root!r})
+from pathlib import Path
+from lidar_snow_sim_amd import dist as sd, stream
+rank, world, port, lidar = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], Path(sys.argv[4])
+os.environ["MASTER_PORT"] = port
+ids = [f"2018-02-03_{{i:05d}}" for i in range(23)]
+combos = [(10.5, 1e-6), (20.5, 2e-6), (20.9, 3e-6)]
+existing = stream.existing_outputs(lidar, ("gunn", "sekhon"), combos)
+d = sd.init("gloo", rank, world)
+d.barrier()                                                        # every rank has listed before any rank writes
+random.seed(5)
+items = []
+for mode, rr, prefix, ss, orders in stream.plan_iter(lidar, ids, ("gunn", "sekhon"), combos, 4, rank=rank, world=world, existing=existing):
+    for s, o in zip(ss, orders):
+        out = stream.output_path(lidar, mode, rr, s)               # "write" while the other rank is still planning
+        out.parent.mkdir(parents=True, exist_ok=True)
+        out.write_bytes(b"x")
+        items.append([mode, rr, s, o])
+d.barrier()
+print("PLAN", json.dumps(items), flush=True)
+d.destroy_process_group()
+"""
+
+
+def test_two_process_sharded_plan_equals_the_single_rank_plan(tmp_path):
+    """Two gloo ranks plan AND write concurrently; their union must still be the one-rank plan (the skip test reads the listing
+    taken before the barrier, not the live tree the other rank is filling)."""
+    import json
+    import random
+    from lidar_snow_sim_amd import stream
+    lidar, ids, combos = _stream_fixture(tmp_path)
+    random.seed(5)
+    whole = _plan_items(stream.plan(lidar, ids, ("gunn", "sekhon"), combos, batch=4))
+    script = tmp_path / "plan_worker.py"
+    script.write_text(_PLAN_WORKER.format(root=str(ROOT)))
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(lidar)], stdout=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    union = {}
+    for out in outs:
+        for mode, rr, s, o in json.loads([ln for ln in out.splitlines() if ln.startswith("PLAN")][0][5:]):
+            assert (mode, rr, s) not in union
+            union[(mode, rr, s)] = tuple(o)
+    assert union == whole
+
+
+def test_stream_reader_rejects_a_truncated_bin(tmp_path):
+    """np.fromfile(...).reshape((-1, 5)) raises on a file that is not whole rows (precompute.py:78); so does the reader --
+    checked without a GPU through the size test it runs before it touches the device."""
+    from lidar_snow_sim_amd import stream
+    src = open(stream.__file__).read()
+    assert "nbytes % 20" in src and "not a whole number of float32 N x 5 rows" in src
