@@ -443,7 +443,9 @@ def main():
                                                 out_rows[f * n_per:f * n_per + int(d_counts[f])].cpu().numpy()) for f in (0, F // 2, F - 1)))
         digest = [int(h_counts.sum()), int(h_stats[:, 0].sum()), int(h_stats[:, 1].sum()), int(h_stats[:, 2].sum()),
                   float(pin_out[:int(h_counts[0]), 3].sum()), int(pin_src[:int(h_counts[0])].astype(np.int64).sum())]
+        dp = (child or {}).get("default_plane") or {}
         mine = [child["points_per_s"], child["points_per_s_without_src"]] if child else [n_total / inproc_s, n_total / inproc_s]
+        mine += [dp.get("c_abi_points_per_s_reference", 0.0), dp.get("c_abi_points_per_s_lsq", 0.0)]
         if distributed:
             tt = torch.tensor(mine, dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
@@ -456,6 +458,7 @@ def main():
                 "frac_of_link_bound_without_src": mine[1] / (PCIE_PEAK / 20.0 * world),
                 "in_process_with_pytorch": n_total / inproc_s,
                 "matches_device_entry": host_same and (child is None or child["digest"] == digest),
+                "default_plane": dp or None, "default_plane_all_ranks": {"reference": mine[2], "lsq": mine[3]} if dp else None,
                 "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
                         "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
                         "(snowgpu_set_pipeline); ceiling = 63 GB/s per direction / 24 B per point (rows + source indices back) or / 20 B "
@@ -465,6 +468,10 @@ def main():
                                        "points_per_s": n_per / (child["single_frame_c_abi_ms"] * 1e-3)},
                       "python_augment_pageable": {"ms": child["single_frame_python_ms"], "min_ms": child["single_frame_python_min_ms"],
                                                   "points_per_s": n_per / (child["single_frame_python_ms"] * 1e-3)},
+                      "python_augment_default": {"ms": child.get("single_frame_python_default_ms"), "min_ms": child.get("single_frame_python_default_min_ms"),
+                                                 "note": "augment(pc, prefix, bd, only_camera_fov=False) with no plane and no order: calculate_plane on the "
+                                                         "device by the default method (the plane the reference returns today), random.shuffle on the host"},
+                      "python_augment_lsq_plane": {"ms": child.get("single_frame_python_lsq_ms"), "min_ms": child.get("single_frame_python_lsq_min_ms")},
                       "points": n_per,
                       "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock "
                               "(child process without PyTorch)"}
@@ -557,8 +564,13 @@ def main():
                          "note": "40 B/point (20 read + 20 written); tables cache-resident across the batch, so SURVEY 8(d)'s table term "
                                  "(24 B per flake per channel per frame) is dropped -- frac_tables_counted keeps it (251.3 B/point on C2)"},
         }
+        result["value_metric_definition"] = ("value: rows resident in HBM (device entry); SURVEY 8(d)'s metric with H2D + D2H inside the clock is "
+                                             "value_pcie_inclusive (plane injected) / value_pcie_inclusive_default_plane (plane = NULL: estimated on the device)")
         if pcie is not None:
             result["value_pcie_inclusive"] = pcie["value"]
+            if pcie.get("default_plane_all_ranks"):
+                result["value_pcie_inclusive_default_plane"] = pcie["default_plane_all_ranks"]["reference"]
+                result["value_pcie_inclusive_lsq_plane"] = pcie["default_plane_all_ranks"]["lsq"]
             result["pcie_inclusive"] = pcie
         if single is not None:
             result["single_frame"] = single

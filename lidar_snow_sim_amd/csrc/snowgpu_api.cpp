@@ -663,8 +663,10 @@ static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[
 static int64_t tier_queue_cap(const snowgpu_ctx *ctx, int lmax, int64_t n)
 {
     if (ctx->tier_cap_override > 0) return std::min<int64_t>(ctx->tier_cap_override, std::max<int64_t>(n, 1));
-    // small batches: a buffer for every row costs little (<= 1 GiB) and saves the launch of the in-place fallback pass -- a
-    // chip-sized grid that finds nothing to do but sits in the chain of dependent launches a small batch is bound by
+    // A buffer for every row while that costs at most 1 GiB per tier: it saves the launch of the in-place fallback pass -- a
+    // chip-sized grid that finds nothing to do but sits in the chain of dependent launches a small batch is bound by.  This
+    // includes the 1.5 M-row chunks of the host pipeline: 0.33 GB (8 entries) + 0.63 GB (16 entries) per context and compute
+    // lane, i.e. about 1 GB per lane of the 288 GB (DESIGN.md section 3 lists it).  Beyond 1 GiB: the fractions below.
     const int64_t slot_bytes = (int64_t)sizeof(double) * (3 * (int64_t)lmax + 2) + 2;
     if (std::max<int64_t>(n, 1) * slot_bytes <= ((int64_t)1 << 30)) return std::max<int64_t>(n, 1);
     const int64_t div = lmax <= 8 ? 4 : (lmax <= 16 ? 16 : 64);
@@ -1133,14 +1135,18 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     }
     const double t_up = now();
     int rc = SNOWGPU_OK;
+    // A failure inside the loop must not return while copies from / into the caller's buffers (and from h_off) are in flight:
+    // every exit goes through the drain below.
+#define PIPECHK(call)                                                                                              \
+    { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e__); rc = SNOWGPU_E_HIP; break; } }
     for (int c = 0; c < n_chunks && rc == SNOWGPU_OK; ++c) {
         const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
         const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
         const int64_t *lo = &h_off[c_pos[(size_t)c]];
         snowgpu_ctx *lc = (c % L) == 0 ? ctx : ctx->lanes[(size_t)(c % L) - 1];     // chunk c computes on lane c mod L
         hipStream_t cs = lc->stream;
-        HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->pipe_ev[2 * (size_t)c], 0));
-        if (trace) HIPCHK(ctx, hipEventRecord(tev[2 + 4 * (size_t)c], cs));
+        PIPECHK(hipStreamWaitEvent(cs, ctx->pipe_ev[2 * (size_t)c], 0));
+        if (trace) PIPECHK(hipEventRecord(tev[2 + 4 * (size_t)c], cs));
         BatchDev b{};
         b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = ctx->rows_in.p + (size_t)r0 * rb;
         int64_t mx = 0;
@@ -1162,19 +1168,20 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.serial = ctx->pipe_serial || L > 1;              // a further lane has one stream only
         rc = run_batch(lc, b);
         if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
-        HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
-        if (trace) HIPCHK(ctx, hipEventRecord(tev[3 + 4 * (size_t)c], cs));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
+        PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
+        if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
+        PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
         if (cn) {
             int e = 0;
             if (d_out_rows) e = sg_launch_copy_link(d_out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, ctx->link_blocks, ctx->s_d2h);
-            else HIPCHK(ctx, hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
+            else PIPECHK(hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
             if (!e && out_src && d_out_src) e = sg_launch_copy_link(d_out_src + (size_t)r0 * 4, b.out_src, (size_t)cn * 4, ctx->link_blocks, ctx->s_d2h);
-            else if (!e && out_src) HIPCHK(ctx, hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
-            if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("download launch: ") + hipGetErrorString((hipError_t)e));
+            else if (!e && out_src) PIPECHK(hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
+            if (e) { rc = fail(ctx, SNOWGPU_E_HIP, std::string("download launch: ") + hipGetErrorString((hipError_t)e)); break; }
         }
-        if (trace) HIPCHK(ctx, hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
+        if (trace) PIPECHK(hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
     }
+#undef PIPECHK
     if (trace) fprintf(stderr, "pipe: %d chunks; uploads enqueued in %.3f ms, everything in %.3f ms\n", n_chunks, t_up - t_begin, now() - t_begin);
     hipError_t se = hipStreamSynchronize(ctx->s_h2d);
     for (int l = 1; l < L; ++l) {
@@ -1204,7 +1211,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     int32_t agg[8] = {0, -1, 0, 0, 0, 0, 0, 0};
     for (int c = 0; c < n_chunks; ++c) {
         const int32_t *s8 = &h_st[(size_t)c * 8];
-        if (agg[0] == 0 && s8[0] != 0) { agg[0] = s8[0]; agg[1] = s8[1]; }
+        if (agg[0] == 0 && s8[0] != 0) {           // the offending row is chunk-local on the device: report it as a row of the batch
+            agg[0] = s8[0];
+            agg[1] = s8[1] >= 0 ? (int32_t)std::min<int64_t>(s8[1] + frame_offsets[c_first[(size_t)c]], INT32_MAX) : -1;
+        }
         for (int k = 2; k < 6; ++k) agg[k] += s8[k];
     }
     std::memcpy(ctx->h_status, agg, sizeof agg);

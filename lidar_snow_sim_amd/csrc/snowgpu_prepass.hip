@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <algorithm>
+#include <cstdlib>
 #include "sg_common.h"
 #include "sg_prepass.h"
 
@@ -30,7 +31,14 @@ struct PreFrame {          // per-frame state shared by the kernels
     double poly[3];        // simulation.py:467
     int32_t unchanged;     // wet path: < 1000 ground rows (augmentation.py:51-52)
     int32_t need_mean32;   // float32 rows and the noise line falls back to p (augmentation.py:250-251)
+    // lean snowfall prepass (k_lean_*): centred second moments of (range, I / cos) and the sums of the quadratic fit
+    double sxx, sxy;
+    double q[11];          // LQ_* below
 };
+// q: sums over the ground rows with a1 = range, a2 = range^2 (a float32 product for float32 rows, as np.polyfit has it), c = cos(angle)
+enum { LQ_A2A2 = 0, LQ_A2A1, LQ_A2, LQ_A1A1, LQ_A1, LQ_A2GC, LQ_A2C, LQ_A1GC, LQ_A1C, LQ_GC, LQ_C };
+#define LP_COLS 20         /* doubles per tile of the lean path's partials */
+enum { LP_N = 0, LP_SX, LP_SY, LP_YMAX, LP_MXX, LP_MXY, LP_PREFIX, LP_Q0 = 8 /* .. LP_Q0 + 10 */ };
 
 struct PreArgs {
     const void *rows;
@@ -554,6 +562,307 @@ __global__ __launch_bounds__(64) void k_pre_poly_solve(PreArgs a, double *thr_po
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
 }
 
+
+// ================================================================================================================
+// Lean snowfall prepass (round 4).  The chain above moves every ground row through three float64 scratch arrays (range,
+// I / cos, cos: written once, read twice -- 2.8 GB per 256-sweep step, more than the per-beam kernels fetch).  The snowfall
+// path needs less: k_lean_stats streams the rows ONCE and leaves, per 1024-row tile, everything that is a plain sum --
+// count, sums and tile-centred second moments of (range, I / cos) for the regression line, the maximum for the histogram
+// range, and the sums of the quadratic fit, which are LINEAR in the noise line (y_i = nf (pmin0 d_i + pmin1) c_i, so
+// sum a y = nf (pmin0 sum a d c + pmin1 sum a c)) and can therefore be taken before the line is known; k_lean_hist streams
+// the rows a second time for the 50 x 2555 histogram (its bin edges need the maximum), recomputing the three per-row values
+// instead of loading them.  Tiles are combined per frame in a fixed order (Chan's pairwise update for the centred
+// moments), so a batch is reproducible run to run.  No per-row scratch at all.
+template <typename T>
+__device__ __forceinline__ bool lean_row(const PreArgs &a, double w0, double w1, double w2, double h, double wn, T x, T y, T z, T inten,
+                                         double &gd, double &gn, double &gc)
+{
+    const double dot = ((double)x * w0 + (double)y * w1) + (double)z * w2;   // np.matmul(pc[:, :3], w)
+    const double hog = dot + h;
+    if (!(hog < a.delta && hog > -a.delta)) return false;                    // simulation.py:450-451
+    double nrm;
+    if (sizeof(T) == 4) nrm = (double)sqrtf((float)((x * x + y * y) + z * z));   // float32 norm (simulation.py:455)
+    else { const double xd = (double)x, yd = (double)y, zd = (double)z; nrm = sqrt((xd * xd + yd * yd) + zd * zd); }
+    const double c = dot / (nrm * wn);                                       // simulation.py:454-455; cos(arccos(c)) taken as c
+    gc = fabs(c) <= 1.0 ? c : NAN;                                           // arccos outside [-1, 1] is NaN in the reference too
+    gn = (double)inten / gc;                                                 // augmentation.py:207
+    gd = nrm;                                                                // augmentation.py:208
+    return true;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PB) void k_lean_stats(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const double *pl = a.plane + 4 * f;
+    const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
+    const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);              // np.linalg.norm(w)
+    const T *rows = (const T *)a.rows;
+    T rx[4], ry[4], rz[4], ri[4];                // all loads of the tile in flight before the first use
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const T *p = rows + (base + (r < n ? r : 0)) * 5;
+        rx[q] = p[0]; ry[q] = p[1]; rz[q] = p[2]; ri[q] = p[3];
+    }
+    bool g[4];
+    double gd[4], gn[4], gc[4];
+    double v[3] = {0.0, 0.0, 0.0};
+    double ymax = -INFINITY;
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        g[q] = r < n && lean_row<T>(a, w0, w1, w2, h, wn, rx[q], ry[q], rz[q], ri[q], gd[q], gn[q], gc[q]);
+        if (g[q]) { v[0] += 1.0; v[1] += gd[q]; v[2] += gn[q]; ymax = fmax(ymax, gn[q]); }
+    }
+    __shared__ double sm[4 * 13];
+    __shared__ double smax[4];
+    __shared__ double s_mean[2];
+    block_sum<3>(v, sm);
+    ymax = wave_max(ymax);
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = ymax;
+    if (threadIdx.x == 0) { s_mean[0] = v[0] > 0 ? v[1] / v[0] : 0.0; s_mean[1] = v[0] > 0 ? v[2] / v[0] : 0.0; }
+    __syncthreads();
+    const double mx = s_mean[0], my = s_mean[1];
+    const double cnt = v[0], sx = v[1], sy = v[2];      // (valid in thread 0 only)
+    double u[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) {
+        if (!g[q] || gn[q] != gn[q]) continue;
+        const double dx = gd[q] - mx, dy = gn[q] - my;
+        u[0] += dx * dx; u[1] += dx * dy;
+        // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
+        double a2;
+        if constexpr (sizeof(T) == 4) { const float xf = (float)gd[q]; a2 = (double)(xf * xf); }
+        else a2 = gd[q] * gd[q];
+        const double a1 = gd[q], c = gc[q], dc = gd[q] * c;
+        u[2 + LQ_A2A2] += a2 * a2; u[2 + LQ_A2A1] += a2 * a1; u[2 + LQ_A2] += a2; u[2 + LQ_A1A1] += a1 * a1; u[2 + LQ_A1] += a1;
+        u[2 + LQ_A2GC] += a2 * dc; u[2 + LQ_A2C] += a2 * c; u[2 + LQ_A1GC] += a1 * dc; u[2 + LQ_A1C] += a1 * c;
+        u[2 + LQ_GC] += dc; u[2 + LQ_C] += c;
+    }
+    block_sum<13>(u, sm);
+    if (threadIdx.x == 0) {
+        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS;
+        o[LP_N] = cnt; o[LP_SX] = sx; o[LP_SY] = sy;
+        o[LP_YMAX] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+        o[LP_MXX] = u[0]; o[LP_MXY] = u[1];
+        for (int k = 0; k < 11; ++k) o[LP_Q0 + k] = u[2 + k];
+    }
+}
+
+// one wave per frame: exclusive prefix of the tile counts, means, maximum, centred moments and the fit's sums
+__global__ __launch_bounds__(64) void k_lean_means(PreArgs a, int min_ground, int err_code)
+{
+    const int f = blockIdx.x;
+    if (f >= a.n_frames) return;
+    const int lane = threadIdx.x;
+    const int64_t n = pre_rows(a, f);
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    double *part = a.part + (int64_t)f * a.max_tiles * LP_COLS;
+    double run = 0.0, ym = -INFINITY, sx = 0.0, sy = 0.0;
+    for (int64_t t0 = 0; t0 < tiles; t0 += 64) {
+        const int64_t t = t0 + lane;
+        const double c = t < tiles ? part[t * LP_COLS + LP_N] : 0.0;
+        if (t < tiles) { ym = fmax(ym, part[t * LP_COLS + LP_YMAX]); sx += part[t * LP_COLS + LP_SX]; sy += part[t * LP_COLS + LP_SY]; }
+        double inc = c;                                          // inclusive scan across the wave (exact: integers)
+        for (int o = 1; o < 64; o <<= 1) { const double v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        if (t < tiles) part[t * LP_COLS + LP_PREFIX] = run + inc - c;    // ground rows in earlier tiles
+        run += __shfl(inc, 63);
+    }
+    for (int o = 32; o > 0; o >>= 1) { ym = fmax(ym, __shfl_xor(ym, o)); sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); }
+    const double cnt = run;
+    const double xm = cnt > 0 ? sx / cnt : 0.0, ymn = cnt > 0 ? sy / cnt : 0.0;
+    // M2 = sum over tiles of (tile-centred M2 + n_t (tile mean - frame mean)^2): lane l takes tiles l, l + 64, .., fixed tree
+    double mxx = 0.0, mxy = 0.0, q[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t t = lane; t < tiles; t += 64) {
+        const double *o = part + t * LP_COLS;
+        const double nt = o[LP_N];
+        if (nt > 0) {
+            const double dxm = o[LP_SX] / nt - xm, dym = o[LP_SY] / nt - ymn;
+            mxx += o[LP_MXX] + nt * (dxm * dxm);
+            mxy += o[LP_MXY] + nt * (dxm * dym);
+        }
+        for (int k = 0; k < 11; ++k) q[k] += o[LP_Q0 + k];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mxx += __shfl_xor(mxx, o); mxy += __shfl_xor(mxy, o);
+        for (int k = 0; k < 11; ++k) q[k] += __shfl_xor(q[k], o);
+    }
+    if (lane == 0) {
+        PreFrame &fr = a.fr[f];
+        fr.n_ground = cnt;
+        fr.xmean = xm; fr.ymean = ymn;
+        fr.xmean32 = (double)(float)xm;         // refined by k_pre_mean32 when the value is actually used
+        fr.need_mean32 = 0;
+        fr.ymax = fabs(ym);                                              // np.abs(np.max(...)), augmentation.py:233
+        fr.unchanged = 0;
+        fr.sxx = mxx; fr.sxy = mxy;
+        for (int k = 0; k < 11; ++k) fr.q[k] = q[k];
+        if (cnt < (double)min_ground) {
+            if (err_code) atomicCAS(&a.status[0], 0, err_code);          // TypeError in the reference (Q7)
+            fr.unchanged = 1;
+        }
+    }
+}
+
+// the 50 x 2555 histogram from the rows themselves (second and last pass over them)
+template <typename T>
+__global__ __launch_bounds__(PB) void k_lean_hist(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    if (a.part[((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS + LP_N] == 0.0) return;       // no ground row in this tile
+    const double *pl = a.plane + 4 * f;
+    const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
+    const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);
+    const double ymaxv = a.fr[f].ymax;
+    const T *rows = (const T *)a.rows;
+    int32_t *hist = a.hist + (int64_t)f * HX * HY;
+    T rx[4], ry[4], rz[4], ri[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const T *p = rows + (base + (r < n ? r : 0)) * 5;
+        rx[q] = p[0]; ry[q] = p[1]; rz[q] = p[2]; ri[q] = p[3];
+    }
+    int key[4] = {-1, -1, -1, -1};
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        double gd, gn, gc;
+        if (r < n && lean_row<T>(a, w0, w1, w2, h, wn, rx[q], ry[q], rz[q], ri[q], gd, gn, gc) && gn == gn) {
+            const int bx = hist_bin(gd, 10.0, 70.0, HX);                 // augmentation.py:232-233
+            const int by = hist_bin(gn, 5.0, ymaxv, HY);
+            if (bx >= 0 && by >= 0) key[q] = bx * HY + by;
+        }
+    }
+    // the tile's keys are counted in an LDS hash table first, then one atomic per distinct bin (see k_pre_moments)
+    __shared__ int t_key[2048], t_cnt[2048];
+    for (int i = threadIdx.x; i < 2048; i += PB) { t_key[i] = -1; t_cnt[i] = 0; }
+    __syncthreads();
+    for (int q = 0; q < 4; ++q) {
+        const int k = key[q];
+        if (k < 0) continue;
+        unsigned slot = ((unsigned)k * 2654435761u) >> 21;
+        for (;;) {
+            const int prev = atomicCAS(&t_key[slot], -1, k);
+            if (prev == -1 || prev == k) { atomicAdd(&t_cnt[slot], 1); break; }
+            slot = (slot + 1) & 2047u;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += PB)
+        if (t_key[i] >= 0) atomicAdd(&hist[t_key[i]], t_cnt[i]);
+}
+
+// the two lines from the frame's centred moments (k_lean_means) and the histogram's row minima
+__global__ __launch_bounds__(64) void k_lean_lines(PreArgs a, int xmean_f32)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    PreFrame &fr = a.fr[f];
+    const double ng = fr.n_ground;
+    double slope = 0, icpt = 0;
+    if (ng >= 3) {
+        slope = (fr.sxy / ng) / (fr.sxx / ng);                           // scipy linregress: ssxym / ssxm
+        const double xm = xmean_f32 ? fr.xmean32 : fr.xmean;             // np.mean of a float32 column is a float32 (augmentation.py:216)
+        icpt = fr.ymean - slope * xm;
+    }
+    fr.p0 = slope; fr.p1 = icpt;
+    double xs[HX], ys[HX];
+    int m = 0;
+    const double xstep = (70.0 - 10.0) / HX;
+    for (int r = 0; r < HX; ++r) {
+        const double mv = a.rowmin[(int64_t)f * HX + r];
+        if (mv > 5) {                                                    // augmentation.py:238
+            const double e0 = (double)r * xstep + 10.0;
+            const double e1 = (r + 1 == HX) ? 70.0 : (double)(r + 1) * xstep + 10.0;
+            xs[m] = (e0 + e1) / 2; ys[m] = mv; ++m;                      // :240-241
+        }
+    }
+    if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
+    else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
+}
+
+// ground ranges compacted in row order for the frames that need NumPy's float32 mean (k_pre_mean32), from the rows
+template <typename T>
+__global__ __launch_bounds__(PB) void k_lean_gather(PreArgs a)
+{
+    const int f = blockIdx.y;
+    if (!a.fr[f].need_mean32) return;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    const double *pl = a.plane + 4 * f;
+    const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
+    const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);
+    const T *rows = (const T *)a.rows;
+    __shared__ int wc[4][4];
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const unsigned long long lt = (1ull << (tid & 63)) - 1ull;
+    bool g[4];
+    int pre[4];
+    double gdv[4];
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + tid;
+        double gn, gc;
+        g[q] = false;
+        if (r < n) {
+            const T *p = rows + (base + r) * 5;
+            g[q] = lean_row<T>(a, w0, w1, w2, h, wn, p[0], p[1], p[2], p[3], gdv[q], gn, gc) && gn == gn;
+        }
+        const unsigned long long m = __ballot(g[q]);
+        pre[q] = __popcll(m & lt);
+        if ((tid & 63) == 0) wc[q][wv] = __popcll(m);
+    }
+    __syncthreads();
+    int run = (int)a.part[((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS + LP_PREFIX];
+    for (int q = 0; q < 4; ++q) {
+        int off = run;
+        for (int ww = 0; ww < wv; ++ww) off += wc[q][ww];
+        if (g[q]) a.cdist[base + off + pre[q]] = (float)gdv[q];
+        run += wc[q][0] + wc[q][1] + wc[q][2] + wc[q][3];
+    }
+}
+
+// the quadratic from the frame's sums and its noise line (columns scaled by their norms, as np.polyfit does)
+__global__ __launch_bounds__(64) void k_lean_solve(PreArgs a, double *thr_poly)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const PreFrame &fr = a.fr[f];
+    double *out = thr_poly + 3 * f;
+    const double nn = fr.n_ground;
+    if (nn < 3) { out[0] = out[1] = out[2] = 0.0; return; }
+    const double *q = fr.q;
+    const double nf = a.noise_floor, m0 = fr.pmin0, m1 = fr.pmin1;
+    // sum a y with y = (nf (pmin0 d + pmin1)) c  (augmentation.py:252-253, simulation.py:462): linear in the line
+    const double s5 = nf * (m0 * q[LQ_A2GC] + m1 * q[LQ_A2C]);
+    const double s6 = nf * (m0 * q[LQ_A1GC] + m1 * q[LQ_A1C]);
+    const double s7 = nf * (m0 * q[LQ_GC] + m1 * q[LQ_C]);
+    const double c2 = sqrt(q[LQ_A2A2]), c1 = sqrt(q[LQ_A1A1]), c0 = sqrt(nn);
+    double G[3][4] = {{q[LQ_A2A2] / (c2 * c2), q[LQ_A2A1] / (c2 * c1), q[LQ_A2] / (c2 * c0), s5 / c2},
+                      {q[LQ_A2A1] / (c1 * c2), q[LQ_A1A1] / (c1 * c1), q[LQ_A1] / (c1 * c0), s6 / c1},
+                      {q[LQ_A2] / (c0 * c2), q[LQ_A1] / (c0 * c1), nn / (c0 * c0), s7 / c0}};
+    for (int i = 0; i < 3; ++i) {                                        // Gaussian elimination, partial pivoting
+        int piv = i;
+        for (int r = i + 1; r < 3; ++r) if (fabs(G[r][i]) > fabs(G[piv][i])) piv = r;
+        if (piv != i) for (int k = 0; k < 4; ++k) { const double t = G[i][k]; G[i][k] = G[piv][k]; G[piv][k] = t; }
+        for (int r = i + 1; r < 3; ++r) {
+            const double m = G[r][i] / G[i][i];
+            for (int k = i; k < 4; ++k) G[r][k] -= m * G[i][k];
+        }
+    }
+    double x[3];
+    for (int i = 2; i >= 0; --i) {
+        double t = G[i][3];
+        for (int k = i + 1; k < 3; ++k) t -= G[i][k] * x[k];
+        x[i] = t / G[i][i];
+    }
+    out[0] = x[0] / c2; out[1] = x[1] / c1; out[2] = x[2] / c0;
+    a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
+}
+
 // ================================================================================================================
 // wet ground (augmentation.py:88-159; phy_equations.py:35-108)
 
@@ -791,11 +1100,58 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
     return 0;
 }
 
+// The snowfall prepass without per-row scratch: two passes over the rows (statistics; histogram), the rest per frame.
+static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
+                    int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status, hipStream_t st)
+{
+    PreArgs a{};
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
+    a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
+    const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
+    a.max_tiles = max_tiles;
+    const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)n_frames;
+    if (ensure(s, B_PART, nf * (size_t)max_tiles * LP_COLS * 8) || ensure(s, B_HIST, nf * HX * HY * 4) ||
+        ensure(s, B_ROWMIN, nf * HX * 8) || ensure(s, B_FRAME, nf * sizeof(PreFrame)) || (dtype == 0 && ensure(s, B_CDIST, n * 4)))
+        return -1;
+    a.part = (double *)s->buf[B_PART]; a.hist = (int32_t *)s->buf[B_HIST]; a.rowmin = (double *)s->buf[B_ROWMIN];
+    a.fr = (PreFrame *)s->buf[B_FRAME]; a.cdist = (float *)s->buf[B_CDIST];
+    hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_lean_stats<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_lean_means, dim3((unsigned)n_frames), dim3(64), 0, st, a, 3, 7 /* SNOWGPU_E_GROUND */);
+    LCHK();
+    if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_lean_hist<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_lean_lines, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, dtype == 0 ? 1 : 0);
+    LCHK();
+    if (dtype == 0) {
+        // only frames whose noise line fell back to p = linregress(range, I / cos) need NumPy's float32 mean of the ranges; the
+        // two kernels below leave at once for every other frame
+        const int max_leaves = (int)(max_frame / 64 + 8);
+        if (ensure(s, B_LEAF, nf * 3 * (size_t)max_leaves * 4)) return -1;
+        hipLaunchKernelGGL(k_lean_gather<float>, grid, dim3(PB), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        LCHK();
+    }
+    hipLaunchKernelGGL(k_lean_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, thr_poly);
+    LCHK();
+    return 0;
+}
+
 extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                               int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
                               int32_t *status, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    static const bool legacy = getenv("SNOWGPU_PREPASS_LEGACY") != nullptr;      // A/B: the three-scratch-array chain of rounds 1-3
+    if (!legacy) return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, st);
     PreArgs a{};
     a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
     a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;

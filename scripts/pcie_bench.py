@@ -54,16 +54,17 @@ def main():
     h_ids = np.asarray(ids, np.int32)
     planes = np.asarray([[0.0, 0.0, -1.0, -1.7]] * F)
 
-    def call(want_src):
-        return eng.ctx.augment_batch(pin_in, off, h_ids, bench.BEAM_DIV, plane=planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
+    def call(want_src, plane="injected"):
+        return eng.ctx.augment_batch(pin_in, off, h_ids, bench.BEAM_DIV, plane=planes if plane == "injected" else None, out_rows=pin_out,
+                                     out_src=pin_src, want_src=want_src)
 
-    def timed(want_src):
-        call(want_src)
+    def timed(want_src, plane="injected"):
+        call(want_src, plane)
         best = 1e9
         t0 = time.perf_counter()
         for _ in range(args.reps):
             c0 = time.perf_counter()
-            call(want_src)
+            call(want_src, plane)
             best = min(best, time.perf_counter() - c0)
         return (time.perf_counter() - t0) / args.reps, best
 
@@ -72,6 +73,31 @@ def main():
     digest = [int(counts.sum()), int(stats[:, 0].sum()), int(stats[:, 1].sum()), int(stats[:, 2].sum()),
               float(pin_out[:int(counts[0]), 3].sum()), int(pin_src[:int(counts[0])].astype(np.int64).sum())]
     s_nosrc, b_nosrc = timed(False)
+    # plane = NULL at the C ABI: calculate_plane (simulation.py:449) on the device inside the batch -- the reference's default call
+    s_ref, _ = timed(True, "device")                                     # method 'reference': the plane the reference returns today
+    eng.ctx.set_plane_method("lsq")
+    s_lsq, _ = timed(True, "device")                                     # method 'lsq': one more pass over the rows + one block per frame
+    eng.ctx.set_plane_method("reference")
+    # ... and through the Python entry the reference's callers use (augment_batch: per-frame order / table-id bookkeeping on the host)
+    from lidar_snow_sim_amd.tools.snowfall.simulation import FlatBatch, augment_batch
+    orders = []
+    for f in range(F):
+        random.seed(args.seed_base + f)
+        o = list(range(layers))
+        random.shuffle(o)
+        orders.append(o)
+    fb = FlatBatch(pin_in, off)
+
+    def py_batch(**kw):
+        augment_batch(fb, "unused", bench.BEAM_DIV, particles=tables, orders=orders, **kw)
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            augment_batch(fb, "unused", bench.BEAM_DIV, particles=tables, orders=orders, **kw)
+        return (time.perf_counter() - t0) / args.reps
+
+    py_inj = py_batch(planes=[([0.0, 0.0, -1.0], -1.7)] * F)
+    py_ref = py_batch()
+    py_lsq = py_batch(plane_method="lsq")
     # one sweep end to end through the C ABI (page-locked) and through the Python augment() (pageable input)
     one_off = np.array([0, n_per], np.int64)
 
@@ -99,10 +125,24 @@ def main():
         py_augment(pageable, "unused", bench.BEAM_DIV, only_camera_fov=False, plane=([0.0, 0.0, -1.0], -1.7), order=order0, particles=tables)
 
     py_ms, py_min = med(one_py)
+
+    def one_py_default():                                                # the literal reference call: no plane, no order
+        py_augment(pageable, "unused", bench.BEAM_DIV, only_camera_fov=False, particles=tables)
+
+    def one_py_lsq():
+        py_augment(pageable, "unused", bench.BEAM_DIV, only_camera_fov=False, particles=tables, plane_method="lsq")
+
+    pyd_ms, pyd_min = med(one_py_default)
+    pyl_ms, pyl_min = med(one_py_lsq)
     print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_best": n_total / b_src, "points_per_s_without_src": n_total / s_nosrc,
                       "points_per_s_without_src_best": n_total / b_nosrc, "frames": F, "reps": args.reps, "points_per_frame": n_per,
                       "digest": digest, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
-                      "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules}))
+                      "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules,
+                      "default_plane": {"c_abi_points_per_s_reference": n_total / s_ref, "c_abi_points_per_s_lsq": n_total / s_lsq,
+                                        "python_points_per_s_injected": n_total / py_inj, "python_points_per_s_reference": n_total / py_ref,
+                                        "python_points_per_s_lsq": n_total / py_lsq},
+                      "single_frame_python_default_ms": pyd_ms, "single_frame_python_default_min_ms": pyd_min,
+                      "single_frame_python_lsq_ms": pyl_ms, "single_frame_python_lsq_min_ms": pyl_min}))
 
 
 if __name__ == "__main__":

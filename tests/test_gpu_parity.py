@@ -319,6 +319,43 @@ def test_stream_driver_writes_reference_layout(eng, so, tables, tmp_path):
         assert np.array_equal(np.fromfile(stream.output_path(lidar, "gunn", combos[0][0], s), dtype=np.float32), first[s])
 
 
+def test_sharded_stream_writes_the_same_bytes_as_the_single_rank_run(eng, tables, tmp_path):
+    """stream.run with rank / world = 0/2 and 1/2 (one GPU, one after the other, each seeded like the single
+    rank) writes exactly the files of the world = 1 run -- every (mode, frame, combo) gets the permutation the reference's
+    sequential loop draws for it (precompute.py:70-92, simulation.py:482-486)."""
+    import random
+    import shutil
+    from lidar_snow_sim_amd import stream
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    lidar = tmp_path / "lidar_hdl64_strongest"
+    lidar.mkdir()
+    ids = [f"2018-02-03_{i:05d}" for i in range(7)]
+    full = synthetic_sweep(64, 2048, seed=13, intensity="lambert").reshape(64, 2048, 5)
+    for i, s in enumerate(ids):
+        np.ascontiguousarray(full[:, i::64, :].reshape(-1, 5)).tofile(lidar / f"{s}.bin")
+    combos = stream.rate_combos()[2:4]
+    tl = _tables64(tables)
+    kw = dict(modes=("gunn", "sekhon"), combos=combos, batch=3, particles_by_prefix={f"{m}_{rr}_{occ}": tl for m in ("gunn", "sekhon") for rr, occ in combos})
+    out_root = lidar.parent / "snowfall_simulation"
+
+    def snapshot():
+        files = {str(p.relative_to(out_root)): p.read_bytes() for p in sorted(out_root.rglob("*.bin"))}
+        shutil.rmtree(out_root)
+        return files
+
+    random.seed(21)
+    assert stream.run(lidar, ids, **kw) == len(ids) * 4
+    whole = snapshot()
+    existing = set()                                             # both ranks start against the same (empty) output tree
+    random.seed(21)
+    n0 = stream.run(lidar, ids, rank=0, world=2, existing=existing, **kw)
+    random.seed(21)
+    n1 = stream.run(lidar, ids, rank=1, world=2, existing=existing, **kw)
+    assert n0 + n1 == len(ids) * 4 and n0 == 4 * 4 and n1 == 3 * 4
+    sharded = snapshot()
+    assert sharded.keys() == whole.keys() and all(sharded[k] == whole[k] for k in whole)
+
+
 # ---- BASELINE.json configs as parity cases ------------------------------------------------------------------------
 def test_config_C1_dense_table_half_mm_per_hour(so, tables):
     """C1: 0.5 mm/h @ 2.0 m/s (40 112 flakes per line at R0 = 80 m): the capacity tiers start at 8 entries."""
