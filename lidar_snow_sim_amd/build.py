@@ -15,7 +15,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libsnowgpu.so"
-SOURCES = ["snowgpu_kernels.hip", "snowgpu_prepass.hip", "snowgpu_plane.hip", "snowgpu_sampler.hip", "snowgpu_tables.hip", "snowgpu_api.cpp"]
+SOURCES = ["snowgpu_kernels.hip", "snowgpu_rows.hip", "snowgpu_prepass.hip", "snowgpu_plane.hip", "snowgpu_sampler.hip", "snowgpu_tables.hip", "snowgpu_api.cpp"]
 # -ffp-contract=off: every decision of the reference is made on separately rounded float64/float32
 # operations (NumPy never fuses a multiply into an add); a contracted FMA would change them.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

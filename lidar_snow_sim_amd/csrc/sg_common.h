@@ -132,6 +132,10 @@ struct SgBeamArgs {
     const int32_t *tier_info;    // [0..3] entries per class, [4..7] start of each class in tier_list
     int32_t cls;
     int32_t work_lo, work_hi;
+    // row kernels (snowgpu_rows.hip): beams whose dict needs NumPy's pairwise sum (an owner with >= 8 slots) are deferred to a
+    // second instantiation through this list (laid out like tier_list: class k from tier_info[4 + k]) and its per-class counters
+    int32_t *redo_list;
+    int32_t *redo_cnt;
     // dict hand-over of a list-mode pass: entry i of the class -> slot i (planes of tq_cap entries)
     double *tq;
     uint16_t *tq_sc;
@@ -175,6 +179,10 @@ int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);
+// class args->cls of the tier lists (capacity lmax) as a row kernel: G lanes per beam, scan + dict + received power in one pass
+int sg_launch_rows(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+// the scan of a later tier alone as a row kernel: fills the tier's hand-over buffer like sg_launch_beams(.., direct 0, dict_only 1)
+int sg_launch_rows_scan(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
                        int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,

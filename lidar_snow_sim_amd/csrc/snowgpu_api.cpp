@@ -89,7 +89,7 @@ struct snowgpu_ctx {
     DevBuf<int2_t> pw_items;          // work items of k_power
     DevBuf<double> spill;             // spill slots of the 4-entry pass
     DevBuf<int32_t> pw_count;
-    DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base;
+    DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base, redo_list, redo_cnt;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
     DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
     DevBuf<double> h_lists;           // global-list tier: per-lane lists
@@ -102,6 +102,9 @@ struct snowgpu_ctx {
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
+    int row_scan = 0;                 // SNOWGPU_ROW_SCAN=1: the later tiers scan with G lanes per beam (snowgpu_rows.hip) instead of one beam per lane --
+                                      // measured: same rows, 2x the instructions, 4 % slower on C2 (the step is bound by VALU issue)
+    bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
@@ -269,6 +272,8 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_ROW_SCAN"); if (v) ctx->row_scan = std::atoi(v); }
     // In a process that has loaded PyTorch's HIP runtime layer the runtime moves device-to-host copies with a full-grid blit
     // kernel, which stalls whatever computes beside it: one lane and larger chunks lose least there (1.8 instead of 1.3 G
     // points/s in-process).  The environment overrides either way.
@@ -319,6 +324,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
     ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->spill.release();
+    ctx->redo_list.release(); ctx->redo_cnt.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -840,6 +846,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // Later capacity tiers = classes of the tier lists; the last class is the global-list tier, whose lists hold a whole
     // table if need be (capped at 8192 flakes in one beam).
     const int n_cls = n_tiers;
+    // The later tiers run as row kernels (snowgpu_rows.hip: G lanes per beam; scan, dict and received power in one pass, no
+    // hand-over buffers) unless the one-beam-per-lane chain of rounds 1-3 is asked for (A/B, spill slots, tier-cap tests).
+    const bool tier_rows = R->tier_rows && !R->use_spill && R->tier_cap_override <= 0 && R->per_lane_scan >= 0;
     const int h_lanes = 256;
     const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(R->max_flakes, 64u), 8192u);
     a.n_cls = n_cls;
@@ -848,8 +857,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->h_lists, (size_t)4 * (size_t)(h_cap + 1) * (size_t)h_lanes);
     a.h_lists = ctx->h_lists.p; a.h_cap = h_cap; a.h_lanes = h_lanes;
     a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p;
+    if (tier_rows) {
+        ENSURE(ctx, ctx->redo_list, n);
+        ENSURE(ctx, ctx->redo_cnt, SG_MAX_CLASSES);
+        HIPCHK(ctx, hipMemsetAsync(ctx->redo_cnt.p, 0, sizeof(int32_t) * SG_MAX_CLASSES, st));
+        a.redo_list = ctx->redo_list.p; a.redo_cnt = ctx->redo_cnt.p;
+    }
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
-    for (int k = 0; k + 1 < n_cls; ++k) {
+    for (int k = 0; k + 1 < n_cls && !tier_rows; ++k) {
         tq_caps[k] = tier_queue_cap(R, tiers[k + 1], b.n_total);
         ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * (3 * (size_t)tiers[k + 1] + 2));
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
@@ -949,6 +964,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             break;
         }
         const int lmax = tiers[k + 1];
+        if (tier_rows) {
+            a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
+            e = sg_launch_rows(&a, b.dtype, lmax, sk);
+            continue;
+        }
         if (k == 0 && use_spill) {                       // its lists are in the spill slots: received power only
             a.tq = nullptr; a.tq_sc = nullptr; a.tq_cap = 0; a.spill_list = 1;
             a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
@@ -958,7 +978,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         }
         a.tq = ctx->tq[k].p; a.tq_sc = ctx->tq_sc[k].p; a.tq_cap = (int32_t)tq_caps[k];
         a.work_lo = 0; a.work_hi = (int32_t)tq_caps[k];
-        e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);                       // scan + dict, hand-over
+        if (R->row_scan && R->per_lane_scan >= 0) e = sg_launch_rows_scan(&a, b.dtype, lmax, sk);   // scan, hand-over (G lanes per beam)
+        else e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);                   // the same, one beam per lane
         if (!e) e = sg_launch_power_list(&a, b.dtype, lmax, sk);
         if (!e && tq_caps[k] < b.n_total) {              // entries beyond the hand-over buffer: received power in place
             a.work_lo = (int32_t)tq_caps[k]; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "sg_beam.h"
+#include "sg_kutil.h"
 
 #define SG_BLOCK 256
 #ifndef SG_NB4
@@ -46,21 +47,6 @@
 #ifndef SG_LANES_63
 #define SG_LANES_63 16
 #endif
-
-__device__ __forceinline__ int sg_find_frame(const int64_t *__restrict__ off, int n_frames, int64_t g)
-{
-    int lo = 0, hi = n_frames - 1;   // largest f with off[f] <= g
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (off[mid] <= g) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ unsigned long long sg_lanemask_lt()
-{
-    return (1ull << (threadIdx.x & 63)) - 1ull;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Stable counting sort by channel, per frame.  grid = (tiles per frame, frames), 256 threads, a tile
@@ -171,37 +157,6 @@ template <int P>
 __device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 {
     return (slot >> 6) * (int64_t)(P * 64) + (int64_t)plane * 64 + (slot & 63);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Frame of a sorted position.
-__device__ __forceinline__ int sg_frame_of(const SgBeamArgs &a, int64_t g)
-{
-    if (a.uniform_rows > 0) {                    // equal-sized frames: no search (float estimate, integer fix-up)
-        const unsigned rows_u = (unsigned)a.uniform_rows, gu = (unsigned)g;
-        int fe = (int)((float)gu * a.inv_uniform_rows);
-        if (fe >= a.n_frames) fe = a.n_frames - 1;
-        while (fe > 0 && gu < (unsigned)fe * rows_u) --fe;
-        while (fe + 1 < a.n_frames && gu >= (unsigned)(fe + 1) * rows_u) ++fe;
-        return fe;
-    }
-    return sg_find_frame(a.frame_off, a.n_frames, g);
-}
-
-// intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam (same-address atomics
-// from every lane serialise in L2).  Every lane of the wave must call this.
-__device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool live, int f, long long d2)
-{
-    unsigned long long todo = __ballot(live && d2 != 0);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int fl = __shfl(f, leader);
-        const bool mine = live && f == fl;
-        long long part = mine ? d2 : 0;
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if ((int)(threadIdx.x & 63) == leader && part != 0) atomicAdd(&diff2[fl], (unsigned long long)part);
-        todo &= ~__ballot(mine);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
