@@ -56,6 +56,15 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 #define SG_RHO(j) s_rho[SG_IDX(j)]
 #define SG_RATIO(j) s_ratio[SG_IDX(j)]
 
+// Bin window of a scatterer, packed beside a work-list entry in one 8-byte list cell: high word = k0 | k1 << 16 (both below
+// 2^16: SG_RBINS = 1230), low word = a group start of the stage-A work list -- so that the work list can share the window
+// column (k_power keeps three list columns in LDS instead of four: one more block per CU for the long-list tiers).
+__device__ __forceinline__ int sg_kp_k0(double pk) { return __double2hiint(pk) & 0xffff; }
+__device__ __forceinline__ int sg_kp_k1(double pk) { return (int)((unsigned)__double2hiint(pk) >> 16); }
+__device__ __forceinline__ double sg_kp_make(int k0, int k1) { return __hiloint2double(k0 | (k1 << 16), 0); }
+__device__ __forceinline__ void sg_work_put(double *cell, int g) { reinterpret_cast<int *>(cell)[0] = g; }   // low word only (little endian)
+__device__ __forceinline__ int sg_work_get(const double *cell) { return reinterpret_cast<const int *>(cell)[0]; }
+
 // Phases 1-2 and 3a for one beam (per lane).  Leaves the scatterer list in this lane's list column:
 // s_a1[t] amplitude, s_a2[t] packed (k1, k0), s_rho[t] range, t = 0 .. n_flakes (hard target last).
 template <typename T, int LMAX, int STRIDE> __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_a2, double *s_rho, double *s_ratio, int tid, SgBeamOut &out, int rstride = 0);
@@ -217,10 +226,8 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
-                                            bool EXACT_TAN, double *spill = nullptr, int spill_cap = 0)
+                                            bool EXACT_TAN)
 {
-    // spill: slot of the block's column 0 (slots follow the columns), or null.  Flakes LMAX .. spill_cap - 1 of a beam go to
-    // its slot as they are met (the caller adds the first LMAX and the header if the beam ends up within spill_cap).
     out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.n_hits = 0;
     out.label = 0; out.new_i = 0; out.k_best = 0;
     const int lane = tid & 63, wbase = tid & ~63;
@@ -304,9 +311,6 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                 if (pos < LMAX) {
                     s_a1[pos * STRIDE + col] = na1; s_a2[pos * STRIDE + col] = na2; s_rho[pos * STRIDE + col] = f.rho;
                     s_key[pos * STRIDE + col] = p;
-                } else if (pos < spill_cap) {
-                    double *sp = spill + (size_t)col * SG_SPILL_STRIDE + 4 + 4 * pos;
-                    sp[0] = na1; sp[1] = na2; sp[2] = f.rho; sp[3] = __hiloint2double(0, p);
                 }
             }
         }
@@ -326,13 +330,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                 double na1, na2;
                 if (!sg_flake_hits(g, f, na1, na2)) continue;
                 ++hits;
-                if (L == LMAX) {
-                    if (hits <= spill_cap) {
-                        double *sp = spill + (size_t)tid * SG_SPILL_STRIDE + 4 + 4 * (hits - 1);
-                        sp[0] = na1; sp[1] = na2; sp[2] = f.rho; sp[3] = __hiloint2double(0, key);
-                    }
-                    continue;
-                }
+                if (L == LMAX) continue;
                 s_a1[L * STRIDE + tid] = na1; s_a2[L * STRIDE + tid] = na2; s_rho[L * STRIDE + tid] = f.rho; s_key[L * STRIDE + tid] = key;
                 ++L;
             }
@@ -363,12 +361,17 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
 // widths per owner.  Owner of the slot starting at endpoint e is the first (nearest) j with a1_j <= e < a2_j, so each
 // owner's sum can be produced by walking the endpoints inside its own interval -- no sorted endpoint array, no assignment
 // array.
-template <int LMAX, int STRIDE>
+// KEEP_RHO = false (k_power, list capacities up to 16): the flakes' ranges are NOT in the list columns -- s_rho is never touched;
+// instead *srcmap receives, 4 bits per dict entry t, the list index j the entry came from, and the caller fetches the ranges
+// itself afterwards (one list column less in LDS).  The debug tap is then the caller's too.
+template <int LMAX, int STRIDE, bool KEEP_RHO = true>
 __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, double *s_ratio, int tid, int dbg_cap, int32_t *dbg_count,
-                                            double *dbg_rj, double *dbg_ratio, int rstride = 0)
+                                            double *dbg_rj, double *dbg_ratio, int rstride = 0, unsigned long long *srcmap = nullptr)
 {
     constexpr bool HUGE_TIER = LMAX == 0;
+    static_assert(KEEP_RHO || (LMAX > 0 && LMAX <= 16), "the source map holds 16 four-bit entries");
+    unsigned long long smap = 0;
     // One pass over the list entries (a1_q, a2_q).  Short lists (capacity <= 8) are walked fully unrolled with every load
     // issued up front -- the walk is a chain of LDS round trips otherwise, one per entry -- the longer ones four at a time.
     auto for_entries = [&](auto &&body) {
@@ -478,18 +481,22 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         }
         double sum = 0.0 + SG_RATIO(j);
         if (redo) { bool made; sum = owner_walk(j, made); }
-        const double rho = SG_RHO(j);
-        SG_RHO(S) = rho;                                        // S <= j: in-place compaction
+        if constexpr (KEEP_RHO) {
+            const double rho = SG_RHO(j);
+            SG_RHO(S) = rho;                                    // S <= j: in-place compaction
+        } else smap |= (unsigned long long)j << (4 * S);
         SG_RATIO(S) = sg_clip01(sum / delta);                   // :288-290
         ++S;
     }
-    SG_RHO(S) = d;
+    if constexpr (KEEP_RHO) SG_RHO(S) = d;
     SG_RATIO(S) = sg_clip01(tgt_sum / delta);
     const int n_dict = S + 1;
-    if (dbg_count) {
-        *dbg_count = n_dict;
-        for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
-    }
+    if constexpr (KEEP_RHO) {
+        if (dbg_count) {
+            *dbg_count = n_dict;
+            for (int t = 0; t < n_dict && t < dbg_cap; ++t) { dbg_rj[t] = SG_RHO(t); dbg_ratio[t] = SG_RATIO(t); }
+        }
+    } else if (srcmap) *srcmap = smap;
     return S;
 }
 
@@ -549,7 +556,52 @@ __device__ __forceinline__ void sg_beam_amp(T d_t, int S, int channel, const SgL
         if (k1 > SG_RBINS) { out.range_error = 1; k1 = SG_RBINS; }      // reference: IndexError (:149)
         if (k0 < 0) k0 = 0;
         SG_A1(t) = amp;
-        SG_A2(t) = __hiloint2double(k1, k0);
+        SG_A2(t) = sg_kp_make(k0, k1);
+    }
+    out.n_flakes = S;
+    out.has_power = 1;
+}
+
+// The same for k_power's three-column layout: in: s_rr[t] = ratio of dict entry t (t = 0 .. S, the hard target last),
+// rho_of(t) = range of flake entry t < S (fetched by the caller: the hand-over queue); out: s_a1[t] amplitude, s_x[t] window
+// (sg_kp_make; the low word is the stage-A work list's), s_rr[t] = range -- the ratio's cell, overwritten once it has been used.
+template <typename T, int LMAX, int STRIDE, typename RhoOf>
+__device__ __forceinline__ void sg_beam_amp3(T d_t, int S, int channel, const SgLasers *__restrict__ las, double *s_a1, double *s_x,
+                                             double *s_rr, int tid, SgBeamOut &out, RhoOf rho_of)
+{
+    constexpr bool F32 = SgReal<T>::is_f32;
+    constexpr int rstride = 0;
+    const int max_i = las->max_i[channel];
+    const double c_tau = 299792458.0 * 1e-8;                    // c * tau_h
+    const double beta_0 = 1 * 1e-6 / SG_PI;                     // :108
+    const double i_snow = 0.9 * max_i;                          // :140
+    const double ca_p0 = i_snow / beta_0;                       // :141 (also used for the hard target, Q1)
+    for (int t = 0; t <= S; ++t) {
+        int k0, k1;
+        double amp, r_out;
+        const double ratio = s_rr[SG_IDX(t)];
+        if (F32 && t == S) {                                    // hard target keeps its float32 range
+            const float r = (float)d_t;
+            k0 = (int)ceilf(r * 10.0f);                         // :145
+            float ee = r + (float)c_tau;                        // :146 (float32 under NEP 50)
+            ee = ee * 10.0f;
+            ee = floorf(ee) + 1.0f;
+            k1 = (int)ee;
+            const float r2 = r * r;                             // r_j ** 2 in float32 (:549)
+            amp = (((ca_p0 * beta_0) * ratio) * sg_xsi(r)) / (double)r2;
+            r_out = (double)r;
+        } else {
+            const double r = t == S ? (double)d_t : rho_of(t);
+            k0 = (int)ceil(r * 10);                             // :145
+            k1 = (int)(floor((r + c_tau) * 10) + 1);            // :146
+            amp = (((ca_p0 * beta_0) * ratio) * sg_xsi(r)) / (r * r);   // :549
+            r_out = r;
+        }
+        if (k1 > SG_RBINS) { out.range_error = 1; k1 = SG_RBINS; }      // reference: IndexError (:149)
+        if (k0 < 0) k0 = 0;
+        s_a1[SG_IDX(t)] = amp;
+        s_x[SG_IDX(t)] = sg_kp_make(k0, k1);
+        s_rr[SG_IDX(t)] = r_out;
     }
     out.n_flakes = S;
     out.has_power = 1;
@@ -626,7 +678,7 @@ __device__ __forceinline__ void sg_eval_group(int k, int t_from, int S, const do
     }
     for (int t = t_from; t < S; ++t) {
         const double pk = s_a2[SG_IDX(t)];
-        const int q0 = __double2loint(pk), q1 = __double2hiint(pk);
+        const int q0 = sg_kp_k0(pk), q1 = sg_kp_k1(pk);
         if (q0 >= k + NB) break;                             // flake windows start in range order
         if (q1 <= k) continue;
         const double amp = s_a1[SG_IDX(t)], r = s_rho[SG_IDX(t)];
@@ -671,7 +723,7 @@ __device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ r
     const double c_tau = 299792458.0 * 1e-8;
     const double step = (120 + c_tau) / (SG_RBINS - 1);
     const double tpk = s_a2[SG_IDX(S)];
-    const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+    const int tk0 = sg_kp_k0(tpk), tk1 = sg_kp_k1(tpk);
     const double tamp = s_a1[SG_IDX(S)], td = s_rho[SG_IDX(S)];
     double amax = tamp;
     for (int t = 0; t < S; ++t) amax = fmax(amax, s_a1[SG_IDX(t)]);
@@ -679,7 +731,7 @@ __device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ r
     int nw = 0;
     auto flush = [&]() {
         for (int w = 0; w < nw; ++w)
-            sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
+            sg_eval_group<STRIDE, EXACT, NB>(sg_work_get(&s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0,
                                              tk1, tamp, td, best, k_best, rstride);
         nw = 0;
     };
@@ -688,7 +740,7 @@ __device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ r
         const double A = s_a1[SG_IDX(t)];
         if (!(A > 0.0)) continue;                 // adds nothing anywhere; the bins it covers belong to others' zones
         const double pk = s_a2[SG_IDX(t)];
-        const int k0 = __double2loint(pk), k1 = __double2hiint(pk);
+        const int k0 = sg_kp_k0(pk), k1 = sg_kp_k1(pk);
         // Each bin is the business of the strongest scatterer covering it (ties: the nearer one).  So this window
         // answers only for its bins outside stronger overlapping windows -- those trim it from the left (lo_trim) or
         // from the right (hi_trim); windows are in range order and of (almost) equal length -- and only the weaker
@@ -704,13 +756,13 @@ __device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ r
         };
         for (int j = t - 1; j >= 0; --j) {
             const double pj = s_a2[SG_IDX(j)];
-            if (__double2hiint(pj) <= k0) break;
-            visit(j, __double2loint(pj), __double2hiint(pj));
+            if (sg_kp_k1(pj) <= k0) break;
+            visit(j, sg_kp_k0(pj), sg_kp_k1(pj));
         }
         for (int j = t + 1; j <= S; ++j) {
             const double pj = s_a2[SG_IDX(j)];
-            if (__double2loint(pj) >= k1) break;
-            visit(j, __double2loint(pj), __double2hiint(pj));
+            if (sg_kp_k0(pj) >= k1) break;
+            visit(j, sg_kp_k0(pj), sg_kp_k1(pj));
         }
         const double need = fmax(best, floor_);
         if ((A + oth) * (1.0 + 1e-9) < need) continue;
@@ -730,7 +782,7 @@ __device__ __forceinline__ int sg_power_plan(int S, const double *__restrict__ r
         if (hi_trim - 1 < kb) kb = hi_trim - 1;
         for (int g = ka; g <= kb; g += NB) {
             if (nw == wcap) flush();
-            s_work[SG_IDX(nw)] = __hiloint2double(0, g);
+            sg_work_put(&s_work[SG_IDX(nw)], g);
             ++nw;
         }
     }
@@ -745,10 +797,10 @@ __device__ __forceinline__ void sg_lane_power(int S, const double *__restrict__ 
     const int nw = sg_power_plan<STRIDE, EXACT, NB, WCAP>(S, rgrid, s_a1, s_a2, s_rho, s_work, tid, best, k_best, rstride, rwcap);
     // ---- stage B ----
     const double tpk = s_a2[SG_IDX(S)];
-    const int tk0 = __double2loint(tpk), tk1 = __double2hiint(tpk);
+    const int tk0 = sg_kp_k0(tpk), tk1 = sg_kp_k1(tpk);
     const double tamp = s_a1[SG_IDX(S)], td = s_rho[SG_IDX(S)];
     for (int w = 0; w < nw; ++w)
-        sg_eval_group<STRIDE, EXACT, NB>(__double2loint(s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td,
+        sg_eval_group<STRIDE, EXACT, NB>(sg_work_get(&s_work[SG_IDX(w)]), 0, S, rgrid, s_a1, s_a2, s_rho, tid, tk0, tk1, tamp, td,
                                          best, k_best, rstride);
 }
 
@@ -787,9 +839,9 @@ __device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__rest
         if (valid) {
             const int tid = colbase + o;                        // the owner's column (SG_IDX)
             constexpr int rstride = 0;
-            const int g = __double2loint(s_work[SG_IDX(j)]);
+            const int g = sg_work_get(&s_work[SG_IDX(j)]);
             const double tpk = s_a2[SG_IDX(So)];
-            sg_eval_group<STRIDE, EXACT, NB>(g, 0, So, rgrid, s_a1, s_a2, s_rho, tid, __double2loint(tpk), __double2hiint(tpk),
+            sg_eval_group<STRIDE, EXACT, NB>(g, 0, So, rgrid, s_a1, s_a2, s_rho, tid, sg_kp_k0(tpk), sg_kp_k1(tpk),
                                              s_a1[SG_IDX(So)], s_rho[SG_IDX(So)], gbest, gk, 0);
         }
         for (int r = 0; r < maxn; ++r) {                        // (cross-lane reads outside divergent code)

@@ -27,9 +27,6 @@ struct SgEntry {
 #define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m */
 #define SG_QSTEP_M 8.0
 
-#define SG_SPILL_CAP 8
-#define SG_SPILL_STRIDE (4 + 4 * SG_SPILL_CAP)   /* doubles per spill slot: 3 header values + pad, 4 per flake */
-
 struct SgTable {
     const SgEntry *entries;     // bins concatenated, each bin sorted by rho ascending
     const uint32_t *bin_start;  // n_bins + 1 offsets into entries
@@ -140,12 +137,7 @@ struct SgBeamArgs {
     double *tq;
     uint16_t *tq_sc;
     int32_t tq_cap;
-    // Spill slots of the pass over all rows, one per sorted position (SG_SPILL_STRIDE doubles): a beam that meets more flakes
-    // than its LDS list holds, up to spill_cap, leaves ALL of them here -- range, azimuth, count | channel << 8, then
-    // (a1, a2, rho, scan order) per flake, unsorted -- and its tier's k_power reads them instead of scanning again.
-    double *spill;
-    int32_t spill_cap;           // 0: no spill slots (every over-full beam is scanned again by its tier)
-    int32_t spill_list;          // k_power<.., LISTQ>: the class's flake lists are the spill slots of its rows
+    int32_t tq_unsorted;         // the slots hold the flakes in scan order (k_tier_scan_direct): k_power sorts them by range as it loads them
     // global-list tier: per-lane lists in global memory, h_cap entries each, h_lanes lanes
     double *h_lists;
     int32_t h_cap, h_lanes;
@@ -179,6 +171,8 @@ int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);
+// the scan of a later tier without LDS lists: hits go to the tier's hand-over buffer in scan order (args->tq_unsorted must be 1 for its k_power)
+int sg_launch_tier_scan(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 // class args->cls of the tier lists (capacity lmax) as a row kernel: G lanes per beam, scan + dict + received power in one pass
 int sg_launch_rows(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 // the scan of a later tier alone as a row kernel: fills the tier's hand-over buffer like sg_launch_beams(.., direct 0, dict_only 1)

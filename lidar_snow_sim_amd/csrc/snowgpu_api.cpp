@@ -87,7 +87,6 @@ struct snowgpu_ctx {
     DevBuf<uint16_t> dq_sc;
     DevBuf<unsigned long long> qn;    // per region: front | back << 32
     DevBuf<int2_t> pw_items;          // work items of k_power
-    DevBuf<double> spill;             // spill slots of the 4-entry pass
     DevBuf<int32_t> pw_count;
     DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base, redo_list, redo_cnt;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
@@ -97,11 +96,11 @@ struct snowgpu_ctx {
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
     int lists_first = 0;              // SNOWGPU_LISTS_FIRST=1: tier lists (and so the tiers) before k_power and the prepass start
-    int use_spill = 0;                // SNOWGPU_SPILL=1: over-full beams of the 4-entry pass leave their lists in spill slots (off: see DESIGN.md)
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
+    int tier_scan_lds = 0;            // SNOWGPU_TIER_SCAN_LDS=1: the later tiers' scans keep their lists in LDS (rounds 1-3) -- A/B
     int row_scan = 0;                 // SNOWGPU_ROW_SCAN=1: the later tiers scan with G lanes per beam (snowgpu_rows.hip) instead of one beam per lane --
                                       // measured: same rows, 2x the instructions, 4 % slower on C2 (the step is bound by VALU issue)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
@@ -265,7 +264,6 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_SPILL"); ctx->use_spill = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_LISTS_FIRST"); ctx->lists_first = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
@@ -274,6 +272,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_ROW_SCAN"); if (v) ctx->row_scan = std::atoi(v); }
+    { const char *v = std::getenv("SNOWGPU_TIER_SCAN_LDS"); if (v) ctx->tier_scan_lds = std::atoi(v); }
     // In a process that has loaded PyTorch's HIP runtime layer the runtime moves device-to-host copies with a full-grid blit
     // kernel, which stalls whatever computes beside it: one lane and larger chunks lose least there (1.8 instead of 1.3 G
     // points/s in-process).  The environment overrides either way.
@@ -323,7 +322,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->spill.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
     ctx->redo_list.release(); ctx->redo_cnt.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
@@ -654,7 +653,9 @@ static int sync_tables(snowgpu_ctx *ctx)
 static void choose_tiers(const snowgpu_ctx *ctx, double beam_div_deg, int tiers[4], int *n_tiers)
 {
     const double expect = (double)ctx->max_flakes * (beam_div_deg * (SG_PI / 180.0)) / SG_TWO_PI;
-    int first = expect <= 12.0 ? 4 : (expect <= 24.0 ? 8 : (expect <= 40.0 ? 16 : SG_LCAP));
+    // (measured on the 40 k-flake tables of C1, expect = 19: a 4-entry first pass is 5 % faster than an 8-entry one, a 16-entry one
+    // half as fast -- the lists' LDS footprint decides the occupancy of the pass over ALL rows, the tiers only see the long ones)
+    int first = expect <= 24.0 ? 4 : (expect <= 48.0 ? 8 : (expect <= 96.0 ? 16 : SG_LCAP));
     if (ctx->first_tier_override == 4 || ctx->first_tier_override == 8 || ctx->first_tier_override == 16 ||
         ctx->first_tier_override == SG_LCAP)
         first = ctx->first_tier_override;
@@ -847,8 +848,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // table if need be (capped at 8192 flakes in one beam).
     const int n_cls = n_tiers;
     // The later tiers run as row kernels (snowgpu_rows.hip: G lanes per beam; scan, dict and received power in one pass, no
-    // hand-over buffers) unless the one-beam-per-lane chain of rounds 1-3 is asked for (A/B, spill slots, tier-cap tests).
-    const bool tier_rows = R->tier_rows && !R->use_spill && R->tier_cap_override <= 0 && R->per_lane_scan >= 0;
+    // hand-over buffers) -- an experiment, off by default (measured slower: DESIGN.md section 5).
+    const bool tier_rows = R->tier_rows && R->tier_cap_override <= 0 && R->per_lane_scan >= 0;
     const int h_lanes = 256;
     const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(R->max_flakes, 64u), 8192u);
     a.n_cls = n_cls;
@@ -890,16 +891,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
-    }
-    // Spill slots (SNOWGPU_SPILL=1): the beams the 4-entry pass finds over-full but within 8 flakes leave their lists behind,
-    // and the 8-entry tier starts from those instead of scanning again (288 bytes per sorted position, touched by a few per
-    // cent of them).  Off by default: the scattered stores cost the pass over all rows more (+0.10 ms on the 256-frame batch)
-    // than the tier's scan costs beside the other kernels of the tail; with every kernel alone on the chip it saves 0.27 ms.
-    const bool use_spill = R->use_spill && tiers[0] == 4 && n_cls >= 2 && tiers[1] == SG_SPILL_CAP && R->per_lane_scan <= 0 &&
-                           n * SG_SPILL_STRIDE * sizeof(double) <= ((size_t)32 << 30);
-    if (use_spill) {
-        ENSURE(ctx, ctx->spill, (n + 256) * SG_SPILL_STRIDE);
-        a.spill = ctx->spill.p; a.spill_cap = SG_SPILL_CAP;
     }
     if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
@@ -969,17 +960,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             e = sg_launch_rows(&a, b.dtype, lmax, sk);
             continue;
         }
-        if (k == 0 && use_spill) {                       // its lists are in the spill slots: received power only
-            a.tq = nullptr; a.tq_sc = nullptr; a.tq_cap = 0; a.spill_list = 1;
-            a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
-            e = sg_launch_power_list(&a, b.dtype, lmax, sk);
-            a.spill_list = 0;
-            continue;
-        }
         a.tq = ctx->tq[k].p; a.tq_sc = ctx->tq_sc[k].p; a.tq_cap = (int32_t)tq_caps[k];
         a.work_lo = 0; a.work_hi = (int32_t)tq_caps[k];
-        if (R->row_scan && R->per_lane_scan >= 0) e = sg_launch_rows_scan(&a, b.dtype, lmax, sk);   // scan, hand-over (G lanes per beam)
-        else e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);                   // the same, one beam per lane
+        a.tq_unsorted = 0;
+        if (R->row_scan && R->per_lane_scan >= 0) e = sg_launch_rows_scan(&a, b.dtype, lmax, sk);   // scan, hand-over (G lanes per beam: an experiment)
+        else if (R->tier_scan_lds || R->per_lane_scan < 0) e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);   // one beam per lane, lists sorted in LDS (rounds 1-3)
+        else { a.tq_unsorted = 1; e = sg_launch_tier_scan(&a, b.dtype, lmax, sk); }   // one beam per lane, no LDS: k_power sorts as it loads
         if (!e) e = sg_launch_power_list(&a, b.dtype, lmax, sk);
         if (!e && tq_caps[k] < b.n_total) {              // entries beyond the hand-over buffer: received power in place
             a.work_lo = (int32_t)tq_caps[k]; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);

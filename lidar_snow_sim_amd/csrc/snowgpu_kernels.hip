@@ -30,6 +30,15 @@
 #ifndef SG_NB_TIERS
 #define SG_NB_TIERS 8     /* ... and by the later tiers */
 #endif
+#ifndef SG_KP_THREE_MAX
+#define SG_KP_THREE_MAX 16    /* k_power keeps three list columns in LDS (not four) for capacities SG_KP_THREE_MIN .. SG_KP_THREE_MAX; 0: never */
+#endif
+#ifndef SG_KP_THREE_MIN
+#define SG_KP_THREE_MIN 8     /* (the 4-entry k_power gains no occupancy from it -- it takes half of each CU by design -- and pays for the ranges' second trip: 5.17 vs 4.90 ms per C2 step) */
+#endif
+#ifndef SG_KP_WAVES_TIERS
+#define SG_KP_WAVES_TIERS 1   /* waves per SIMD the 8- and 16-entry k_power are compiled for: 2 and 3 (<= 168 VGPRs, a few spilled) measured the same */
+#endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
@@ -274,19 +283,8 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
         if (LIST && a.per_lane_scan >= 0) {
             if (act) L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
         } else {
-            double *spill_blk = nullptr;              // spill slot of this block's column 0 (sorted positions follow the columns)
-            if constexpr (DICT == 2) spill_blk = a.spill + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_SPILL_STRIDE;
             L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
-                                             a.exact_math != 0, spill_blk, spill_blk ? a.spill_cap : 0);
-            if (spill_blk && act && o.overflow && o.n_hits <= a.spill_cap) {   // header and the flakes the LDS list holds
-                double *sp = spill_blk + (size_t)tid * SG_SPILL_STRIDE;
-                sp[0] = (double)d_t; sp[1] = theta_c; sp[2] = __hiloint2double(0, o.n_hits | (ch << 8));
-                for (int j = 0; j < LMAX; ++j) {
-                    double *e = sp + 4 + 4 * j;
-                    e[0] = s_a1[j * BLOCK + tid]; e[1] = s_a2[j * BLOCK + tid]; e[2] = s_rho[j * BLOCK + tid];
-                    e[3] = __hiloint2double(0, s_key[j * BLOCK + tid]);
-                }
-            }
+                                             a.exact_math != 0);
         }
         if constexpr (!LIST) {
             if (act && a.rng) ((T *)a.rng)[g] = d_t;  // simulation.py:89, for the noise-floor pass (:465-469, :518-520)
@@ -397,6 +395,74 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
 }
 
 // ------------------------------------------------------------------------------------------------
+// The scan of a later capacity tier WITHOUT lists in LDS: one beam per lane walks its bins (simulation.py:338-410) and writes
+// every intersecting flake straight into the beam's slot of the tier's hand-over buffer, in the order it meets them; the
+// near -> far order (simulation.py:413-417) is made by k_power<.., LISTQ> when it loads the slot into its own LDS lists
+// (insertion by range, scan order on equal ranges -- the order sg_beam_scan's insertion produces).  The scan is a chain of
+// dependent record loads (12 % VALU issue, 65 % waiting: profiles/r04a_*_pmc.txt); with three LMAX-entry lists per beam in LDS
+// it ran at 1.25 (16 entries) to 2.5 (8 entries) waves per SIMD, without them at what its registers allow.  Stores are
+// coalesced like the old hand-over's: lane = slot, so the lanes of a wave that meet their h-th flake together write neighbours.
+template <typename T, int LMAX>
+__global__ __launch_bounds__(256, 4) void k_tier_scan_direct(SgBeamArgs a)
+{
+    constexpr int P = SG_QPLANES(LMAX);
+    const int n_las = a.las->n;
+    int64_t work_n = a.tier_info[a.cls];
+    if (work_n > a.work_hi) work_n = a.work_hi;
+    const int64_t work_off = a.tier_info[4 + a.cls];
+    for (int64_t i = (int64_t)a.work_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < work_n; i += (int64_t)gridDim.x * 256) {
+        const int32_t g = a.tier_list[work_off + i];
+        const int f = sg_frame_of(a, g);
+        const T *row = (const T *)a.rows + (a.frame_off[f] + a.perm[g]) * 5;
+        const T px = row[0], py = row[1], pz = row[2];
+        const int ch = (int)row[4];                                       // a flagged beam was simulated: valid channel
+        const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];
+        const int64_t slot = i;                                           // entry i of the class -> slot i
+        if (tab.entries == nullptr) { atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */); a.tq_sc[slot] = 0xffff; a.rec[g] = 0u; continue; }
+        T d_t;
+        const SgBeamGeo geo = sg_beam_geometry<T>(px, py, pz, a.beam_div_deg, a.exact_math != 0, d_t);
+        const int nb = (int)tab.n_bins;
+        const int b_lo = sg_bin_of(geo.theta_r - SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        const int b_hi = sg_bin_of(geo.theta_l + SG_BEAM_MARGIN, tab.inv_bin_w, nb);
+        int span = b_hi - b_lo;
+        if (span < 0) span += nb;
+        int hits = 0, b = b_lo;
+        double *q = a.tq + (slot >> 6) * (int64_t)(P * 64) + (slot & 63);   // plane p of this slot: q[p * 64]
+        for (int s = 0; s <= span; ++s) {
+            const uint32_t e0 = tab.bin_start[b], e1 = tab.bin_start[b + 1];
+            SgEntry nxt = tab.entries[e0];                              // (one spare record at the end of the array: e + 1 is always readable)
+            for (uint32_t e = e0; e < e1; ++e) {
+                const SgEntry fl = nxt;
+                nxt = tab.entries[e + 1];
+                if (!(fl.rho < geo.d)) break;                           // :345 (bins are sorted by range)
+                if (s > 0 && !(fl.flags & 1u)) continue;                // already met in an earlier bin
+                double na1, na2;
+                if (!sg_flake_hits(geo, fl, na1, na2)) continue;
+                if (hits < LMAX) { q[(2 + 3 * hits) * 64] = na1; q[(3 + 3 * hits) * 64] = na2; q[(4 + 3 * hits) * 64] = fl.rho; }
+                ++hits;
+            }
+            if (++b == nb) b = 0;
+        }
+        if (hits > LMAX) {                                                // a listed beam fits its tier by construction
+            atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
+            atomicCAS(&a.status[1], -1, g);
+            a.tq_sc[slot] = 0xffff; a.rec[g] = 0u;
+        } else if (hits == 0) {
+            a.tq_sc[slot] = 0xffff;                                       // no flake list: the record is final
+            a.rec[g] = 0u;
+            if (a.dbg_count) {                                            // debug tap: the dict of a clear beam is its hard target alone
+                a.dbg_count[g] = 1;
+                a.dbg_rj[(int64_t)g * a.dbg_cap] = (double)d_t;
+                a.dbg_ratio[(int64_t)g * a.dbg_cap] = sg_clear_beam_ratio(geo.theta_c, a.beam_div_deg);
+            }
+        } else {
+            q[0] = (double)d_t; q[64] = geo.theta_c;
+            a.tq_sc[slot] = (uint16_t)(hits | (ch << 8));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Work items of k_power for the queue of a direct-mode pass: one item = up to `lanes` consecutive live slots of one
 // region (its front run, then its back run).  One thread per region; items are appended with one atomic per wave.
 // item = {first slot, count | (frame + 1) << 10}; the back run (beams with several flakes) in items of lanes_back slots.
@@ -442,23 +508,29 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
 // result record.  Nothing is read but the queue: range, azimuth and flake list of the beam; its channel rides in the slot.
 //   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots: 64 one-flake slots, or a
 //                  window of SG_KP_WIN x 64 multi-flake slots)
-//   LISTQ = true   a list-mode pass's hand-over buffer (or the spill slots of its rows): item i = window i of the class
+//   LISTQ = true   a list-mode pass's hand-over buffer: item i = window i of the class
 // PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
 // barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
 // that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
 // then bound by the latency of its first loads.  (Requesting the slot data of a wave's NEXT item before it computes the
 // current one was measured too: since phase 2 moved here the registers that costs outweigh the latency it hides.)
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 1) void k_power(SgBeamArgs a)
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : (LMAX <= 16 ? SG_KP_WAVES_TIERS : 1)) void k_power(SgBeamArgs a)
 {
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
     constexpr int WIN = BLOCK < 64 ? 1 : SG_KP_WIN;       // waves' worth of slots per work item
     constexpr int P = SG_QPLANES(LMAX);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_a1 = (double *)smem;
+    // Three list columns for capacities up to 16 (THREE): interval angles a1, a2 and the ratio / range column -- the flakes' ranges
+    // stay in the hand-over queue until the dict is done (sg_beam_dict<.., KEEP_RHO = false> returns which list entry each dict
+    // entry came from), then amplitude -> a1's cells, bin window + work list -> a2's, range -> the ratio's.  One column less is
+    // one more block per CU where the lists are long (16 entries: 26 KB instead of 35 KB per wave: six waves per CU, not four).
+    constexpr bool THREE = SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN;
     double *s_a2 = s_a1 + (LMAX + 1) * BLOCK;
-    double *s_rho = s_a2 + (LMAX + 1) * BLOCK;
-    double *s_ratio = s_rho + (LMAX + 1) * BLOCK;
+    double *s_rho = s_a2 + (LMAX + 1) * BLOCK;                            // THREE: the ratio column first, the ranges afterwards
+    double *s_ratio = THREE ? s_rho : s_rho + (LMAX + 1) * BLOCK;
+    double *s_work = THREE ? s_a2 : s_ratio;                              // stage-A work list: low words of the window column / own column
     const int tid = threadIdx.x, lane = tid & 63;
     const int ltid = BLOCK < 64 ? lane : tid;          // column of the LDS lists
     int64_t work_n = 0, work_off = 0;
@@ -505,9 +577,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                     const int idx = r * 64 + lane;
                     key[r] = 255;                             // past the end of the window: last
                     if (idx < cnt) {
-                        unsigned sc;
-                        if (LISTQ && a.spill_list) sc = (unsigned)__double2loint(a.spill[(size_t)a.tier_list[work_off + start + idx] * SG_SPILL_STRIDE + 2]);
-                        else sc = scs[(int64_t)start + idx];
+                        const unsigned sc = scs[(int64_t)start + idx];
                         key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
                     }
                     rank[r] = 0;
@@ -546,13 +616,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             unsigned sc = 0xffffu;
             int32_t g = 0;
             double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
-            const bool from_spill = LISTQ && a.spill_list;    // the class's lists are the spill slots of the pass over all rows
-            const double *sp = nullptr;
-            if (in && from_spill) {
-                g = a.tier_list[work_off + slot];
-                sp = a.spill + (size_t)g * SG_SPILL_STRIDE;
-                d = sp[0]; tc = sp[1]; sc = (unsigned)__double2loint(sp[2]);
-            } else if (in) {                                  // everything a beam surely has, in one round of loads
+            if (in) {                                         // everything a beam surely has, in one round of loads
                 sc = scs[slot];
                 g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
                 d = planes[sg_qaddr<P>(slot, 0)];             // the beam's range (simulation.py:89), widened from the row dtype
@@ -569,51 +633,78 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             double best = 0.0;
             if (live) {
                 f = item_f >= 0 ? item_f : sg_frame_of(a, g);
-                if (from_spill) {
-                    // the flakes as the scan met them: insertion sort by (range, scan order) while loading (simulation.py:413-417);
-                    // the scan order rides in the ratio column, which phase 2 overwrites
-                    for (int j = 0; j < L && j < LMAX; ++j) {
-                        const double x1 = sp[4 + 4 * j], x2 = sp[5 + 4 * j], r = sp[6 + 4 * j];
-                        const int k = __double2loint(sp[7 + 4 * j]);
-                        int q = j;
-                        while (q > 0 && (s_rho[(q - 1) * BLOCK + ltid] > r ||
-                                         (s_rho[(q - 1) * BLOCK + ltid] == r && __double2loint(s_ratio[(q - 1) * BLOCK + ltid]) > k))) {
+                // ord: 4 bits per list entry -- the hit (scan order) it came from; identity unless the scan left the flakes unsorted
+                unsigned long long ord = 0xfedcba9876543210ull;
+                if (LISTQ && a.tq_unsorted) {
+                    // the flakes as the scan met them: insertion by range, scan order on equal ranges (simulation.py:413-417).  The
+                    // ranges pass through the ratio / range column (free until the dict); THREE: they go back to being fetched from
+                    // the queue afterwards, through `ord`.
+                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
+                    if constexpr (THREE) ord = 0;
+                    for (int h = 1; h < L; ++h) {
+                        const double x1 = planes[sg_qaddr<P>(slot, 2 + 3 * h)], x2 = planes[sg_qaddr<P>(slot, 3 + 3 * h)];
+                        const double r = planes[sg_qaddr<P>(slot, 4 + 3 * h)];
+                        int q = h;
+                        while (q > 0 && s_rho[(q - 1) * BLOCK + ltid] > r) {
                             s_rho[q * BLOCK + ltid] = s_rho[(q - 1) * BLOCK + ltid]; s_a1[q * BLOCK + ltid] = s_a1[(q - 1) * BLOCK + ltid];
-                            s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid]; s_ratio[q * BLOCK + ltid] = s_ratio[(q - 1) * BLOCK + ltid];
+                            s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid];
                             --q;
                         }
                         s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2;
-                        s_ratio[q * BLOCK + ltid] = __hiloint2double(0, k);
+                        if constexpr (THREE) {
+                            const unsigned long long low = (1ull << (4 * q)) - 1ull;
+                            ord = (ord & low) | ((unsigned long long)h << (4 * q)) | ((ord & ~low) << 4);
+                        }
                     }
                 } else {
-                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
+                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2;
+                    if constexpr (!THREE) s_rho[ltid] = f_rho;
                     for (int j = 1; j < L; ++j) {
                         s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 2 + 3 * j)];
                         s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 3 + 3 * j)];
-                        s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
+                        if constexpr (!THREE) s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
                     }
                 }
+                auto queue_rho = [&](int j) -> double {       // range of list entry j (THREE: from the queue)
+                    const int h = (int)((ord >> (4 * j)) & 15ull);
+                    return h == 0 ? f_rho : planes[sg_qaddr<P>(slot, 4 + 3 * h)];
+                };
                 int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
                 double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
                 double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)g * a.dbg_cap : nullptr;
-                S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+                unsigned long long srcmap = 0;
+                if constexpr (THREE) S = sg_beam_dict<LMAX, BLOCK, false>(L, tc, d, a.beam_div_deg, s_a1, s_a2, nullptr, s_ratio, ltid, 0, nullptr, nullptr, nullptr, 0, &srcmap);
+                else S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+                if constexpr (THREE) {
+                    if (dc) {                                   // debug tap: ratios now, ranges from the queue
+                        *dc = S + 1;
+                        for (int t = 0; t <= S && t < a.dbg_cap; ++t) {
+                            const int j = (int)((srcmap >> (4 * t)) & 15ull);
+                            drj[t] = t == S ? d : queue_rho(j);
+                            dra[t] = s_ratio[t * BLOCK + ltid];
+                        }
+                    }
+                }
                 if (S > 0) {                                // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
                     const T d_t = (T)d;                     // exact
-                    sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
+                    if constexpr (THREE) {
+                        sg_beam_amp3<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, ltid, o,
+                                                     [&](int t) { return queue_rho((int)((srcmap >> (4 * t)) & 15ull)); });
+                    } else sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
                     if (o.range_error) {
                         atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
                         atomicCAS(&a.status[1], -1, g);
                     }
                     // stage A of the received-power profile, lane by lane: the few groups of bins that can hold its maximum
-                    if (a.exact_math) nw = sg_power_plan<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
-                    else nw = sg_power_plan<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, ltid, best, k_best);
+                    if (a.exact_math) nw = sg_power_plan<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
+                    else nw = sg_power_plan<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
                 } else S = 0;
             }
             // stage B, the whole wave over the groups of its 64 beams
             {
                 const int colbase = BLOCK < 64 ? 0 : (tid & ~63);
-                if (a.exact_math) sg_wave_eval<BLOCK, true, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, colbase, best, k_best);
-                else sg_wave_eval<BLOCK, false, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_ratio, colbase, best, k_best);
+                if (a.exact_math) sg_wave_eval<BLOCK, true, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
+                else sg_wave_eval<BLOCK, false, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
             }
             if (live) {
                 uint32_t rec = 0;
@@ -1220,7 +1311,6 @@ template <typename T, int LMAX, int BLOCK>
 static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStream_t st)
 {
     if (direct) {
-        if constexpr (LMAX == 4) { if (a->spill_cap > 0) return launch_beams_t<T, LMAX, BLOCK, false, 2>(a, st); }   // + spill slots
         return launch_beams_t<T, LMAX, BLOCK, false, 1>(a, st);
     }
     return dict_only ? launch_beams_t<T, LMAX, BLOCK, true, 1>(a, st) : launch_beams_t<T, LMAX, BLOCK, true, 0>(a, st);
@@ -1229,7 +1319,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
 static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
 {
-    const size_t lds = sizeof(double) * ((size_t)BLOCK * 4 * (LMAX + 1));
+    const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_power<T, LMAX, BLOCK, LISTQ>, lds, attr_set)) return e;
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, LANES = BLOCK < 64 ? BLOCK : 64;
@@ -1258,6 +1348,27 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
     return 0;
+}
+
+// the LDS-free scan of a later tier (class a->cls, capacity lmax = 8, 16 or 63): fills the tier's hand-over buffer, flakes in scan order
+template <typename T>
+static int launch_tier_scan_t(const SgBeamArgs *a, int lmax, hipStream_t st)
+{
+    const int64_t n = (int64_t)a->work_hi - a->work_lo;
+    if (n <= 0) return 0;
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)sg_cu_count(dev_id) * 8);
+    if (lmax == 8) hipLaunchKernelGGL((k_tier_scan_direct<T, 8>), dim3(blocks), dim3(256), 0, st, *a);
+    else if (lmax == 16) hipLaunchKernelGGL((k_tier_scan_direct<T, 16>), dim3(blocks), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL((k_tier_scan_direct<T, SG_LCAP>), dim3(blocks), dim3(256), 0, st, *a);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sg_launch_tier_scan(const SgBeamArgs *a, int dtype, int lmax, void *stream)
+{
+    return dtype == 0 ? launch_tier_scan_t<float>(a, lmax, (hipStream_t)stream) : launch_tier_scan_t<double>(a, lmax, (hipStream_t)stream);
 }
 
 // threads per block of the pass with list capacity lmax (the segment builder counts blocks of this size)

@@ -801,36 +801,6 @@ def test_tier_hand_over_buffer_overflow_runs_in_place(so, tables, monkeypatch):
     assert np.array_equal(s0[:n], r_src) and np.array_equal(o0[:n, 3:], r_aug[:, 3:])
 
 
-@pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_spill_slots_give_the_same_rows_as_the_second_scan(so, tables, monkeypatch, dtype):
-    """SNOWGPU_SPILL=1: beams the 4-entry pass finds over-full (5 .. 8 flakes) leave their flake lists in spill slots and the
-    8-entry tier computes from those instead of scanning again.  Same bytes as the default path, and both equal the oracle."""
-    from lidar_snow_sim_amd import engine
-    pc = _stretched_subsweep().astype(dtype)
-    tl = _tables64(tables)
-    bd = float(np.degrees(3e-3))
-    order = list(np.random.default_rng(8).permutation(64))
-    poly = [0.0, 0.01, 2.0]
-    results = []
-    for spill in ("0", "1"):
-        monkeypatch.setenv("SNOWGPU_SPILL", spill)
-        e = engine.Engine(0)
-        try:
-            tids = e.table_ids_from_arrays(tl, order)
-            results.append(e.ctx.augment_batch(pc, [0, pc.shape[0]], [tids], bd, thr_poly=[poly]))
-            st = e.ctx.last_status()
-        finally:
-            e.ctx.close()
-    assert st[2] > 0, st                                         # the 8-entry tier had beams
-    (o0, s0, c0, st0, _), (o1, s1, c1, st1, _) = results
-    n = int(c0[0])
-    assert np.array_equal(c0, c1) and np.array_equal(st0, st1) and np.array_equal(s0[:n], s1[:n])
-    assert o0[:n].tobytes() == o1[:n].tobytes()
-    r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
-    assert tuple(int(v) for v in st1[0]) == tuple(int(v) for v in r_stats)
-    assert np.array_equal(s1[:n], r_src) and np.array_equal(o1[:n, 3:], r_aug[:, 3:])
-
-
 @pytest.mark.parametrize("first", [4, 8, 16, 63])
 def test_every_first_tier_gives_the_same_rows(so, tables, monkeypatch, first):
     """SNOWGPU_FIRST_TIER picks the capacity the pass over all rows starts with (normally chosen from the table size):
