@@ -226,8 +226,10 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
 template <typename T, int LMAX, int STRIDE>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
-                                            bool EXACT_TAN)
+                                            bool EXACT_TAN, double *ov_blk = nullptr, int ov_cap = 0)
 {
+    // ov_blk: overflow slot of the block's column 0 (the slots follow the columns), or null.  Flakes LMAX .. ov_cap - 1 of a beam go
+    // to its slot as they are met (the caller adds the first LMAX and the header if the beam ends up within ov_cap).
     out.overflow = 0; out.range_error = 0; out.diff2 = 0.0; out.has_power = 0; out.n_flakes = 0; out.n_hits = 0;
     out.label = 0; out.new_i = 0; out.k_best = 0;
     const int lane = tid & 63, wbase = tid & ~63;
@@ -311,6 +313,9 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                 if (pos < LMAX) {
                     s_a1[pos * STRIDE + col] = na1; s_a2[pos * STRIDE + col] = na2; s_rho[pos * STRIDE + col] = f.rho;
                     s_key[pos * STRIDE + col] = p;
+                } else if (pos < ov_cap) {
+                    double *sp = ov_blk + (size_t)col * SG_OV_STRIDE + 2 + 3 * pos;
+                    sp[0] = na1; sp[1] = na2; sp[2] = f.rho;
                 }
             }
         }
@@ -330,7 +335,13 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                 double na1, na2;
                 if (!sg_flake_hits(g, f, na1, na2)) continue;
                 ++hits;
-                if (L == LMAX) continue;
+                if (L == LMAX) {
+                    if (hits <= ov_cap) {
+                        double *sp = ov_blk + (size_t)tid * SG_OV_STRIDE + 2 + 3 * (hits - 1);
+                        sp[0] = na1; sp[1] = na2; sp[2] = f.rho;
+                    }
+                    continue;
+                }
                 s_a1[L * STRIDE + tid] = na1; s_a2[L * STRIDE + tid] = na2; s_rho[L * STRIDE + tid] = f.rho; s_key[L * STRIDE + tid] = key;
                 ++L;
             }

@@ -24,6 +24,10 @@ struct SgEntry {
     uint32_t src;    // row in the uploaded table
 };
 
+#define SG_OV_CAP 16      /* flakes per overflow slot: a beam of the pass over all rows that meets more flakes than its LDS list holds, up to
+                             this many, leaves ALL of them in the slot of its sorted position and its tier runs no second scan */
+#define SG_OV_STRIDE (2 + 3 * SG_OV_CAP)   /* doubles per overflow slot: range, azimuth, then (a1, a2, rho) per flake -- the plane order of the
+                                              hand-over queues, stride 1 */
 #define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m */
 #define SG_QSTEP_M 8.0
 
@@ -137,7 +141,14 @@ struct SgBeamArgs {
     double *tq;
     uint16_t *tq_sc;
     int32_t tq_cap;
-    int32_t tq_unsorted;         // the slots hold the flakes in scan order (k_tier_scan_direct): k_power sorts them by range as it loads them
+    int32_t tq_unsorted;
+    // Overflow slots of the pass over all rows, one per sorted position (SG_OV_STRIDE doubles, touched only by beams that over-fill
+    // their LDS list): range, azimuth, (a1, a2, rho) of every flake met, in arrival order; ov_sc[g] = flakes | channel << 8.
+    // k_power<.., LISTQ> of a class reads them instead of a hand-over buffer when ov_list is set (and sorts by range as it loads).
+    double *ov;
+    uint16_t *ov_sc;
+    int32_t ov_cap;              // 0: no overflow slots (every over-full beam is scanned again by its tier)
+    int32_t ov_list;             // k_power<.., LISTQ>: this class's flake lists are the overflow slots of its rows         // the slots hold the flakes in scan order (k_tier_scan_direct): k_power sorts them by range as it loads them
     // global-list tier: per-lane lists in global memory, h_cap entries each, h_lanes lanes
     double *h_lists;
     int32_t h_cap, h_lanes;

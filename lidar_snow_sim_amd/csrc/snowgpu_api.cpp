@@ -88,6 +88,9 @@ struct snowgpu_ctx {
     DevBuf<unsigned long long> qn;    // per region: front | back << 32
     DevBuf<int2_t> pw_items;          // work items of k_power
     DevBuf<int32_t> pw_count;
+    DevBuf<double> ov;                // overflow slots of the pass over all rows (SG_OV_STRIDE doubles per sorted position)
+    DevBuf<uint16_t> ov_sc;
+    int use_ov = 1;                   // SNOWGPU_OVERFLOW_SLOTS=0: every over-full beam is scanned again by its tier (rounds 1-3)
     DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base, redo_list, redo_cnt;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
     DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
@@ -273,6 +276,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_ROW_SCAN"); if (v) ctx->row_scan = std::atoi(v); }
     { const char *v = std::getenv("SNOWGPU_TIER_SCAN_LDS"); if (v) ctx->tier_scan_lds = std::atoi(v); }
+    { const char *v = std::getenv("SNOWGPU_OVERFLOW_SLOTS"); if (v) ctx->use_ov = std::atoi(v); }
     // In a process that has loaded PyTorch's HIP runtime layer the runtime moves device-to-host copies with a full-grid blit
     // kernel, which stalls whatever computes beside it: one lane and larger chunks lose least there (1.8 instead of 1.3 G
     // points/s in-process).  The environment overrides either way.
@@ -322,7 +326,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->ov.release(); ctx->ov_sc.release();
     ctx->redo_list.release(); ctx->redo_cnt.release();
     ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
@@ -866,6 +870,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     }
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int k = 0; k + 1 < n_cls && !tier_rows; ++k) {
+        if (R->use_ov && tiers[0] < SG_OV_CAP && tiers[k + 1] <= SG_OV_CAP && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan &&
+            R->tier_cap_override <= 0 && n * SG_OV_STRIDE * sizeof(double) <= ((size_t)40 << 30))
+            continue;                                    // (this class reads the overflow slots: no hand-over buffer)
         tq_caps[k] = tier_queue_cap(R, tiers[k + 1], b.n_total);
         ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * (3 * (size_t)tiers[k + 1] + 2));
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
@@ -891,6 +898,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->pw_items, n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
+    }
+    // Overflow slots: a beam of the pass over all rows that over-fills its LDS list, up to SG_OV_CAP flakes, leaves all of them in
+    // the slot of its sorted position, and the tiers up to that capacity run no second scan (400 bytes per sorted position, touched
+    // by the few per cent of beams that overflow: 13 GB of address space for a 256-sweep batch, 0.6 GB per chunk of the pipeline).
+    const bool use_ov = R->use_ov && tiers[0] < SG_OV_CAP && n_cls >= 2 && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan && !tier_rows &&
+                        R->tier_cap_override <= 0 && n * SG_OV_STRIDE * sizeof(double) <= ((size_t)40 << 30);
+    if (use_ov) {
+        ENSURE(ctx, ctx->ov, (n + 256) * SG_OV_STRIDE);
+        ENSURE(ctx, ctx->ov_sc, n + 256);
+        a.ov = ctx->ov.p; a.ov_sc = ctx->ov_sc.p; a.ov_cap = SG_OV_CAP;
     }
     if (use_seg) {
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
@@ -955,6 +972,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             break;
         }
         const int lmax = tiers[k + 1];
+        if (use_ov && lmax <= SG_OV_CAP) {               // its lists are in the overflow slots: received power only, no second scan
+            a.tq = nullptr; a.tq_sc = nullptr; a.tq_cap = 0; a.ov_list = 1; a.tq_unsorted = 0;
+            a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
+            e = sg_launch_power_list(&a, b.dtype, lmax, sk);
+            a.ov_list = 0;
+            continue;
+        }
         if (tier_rows) {
             a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
             e = sg_launch_rows(&a, b.dtype, lmax, sk);

@@ -283,8 +283,21 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
         if (LIST && a.per_lane_scan >= 0) {
             if (act) L = sg_beam_scan<T, LMAX, BLOCK>(px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, tid, o, d_t, theta_c, a.exact_math != 0);
         } else {
+            // overflow slot of this block's column 0 (sorted positions follow the columns) -- the pass over all rows only
+            double *ov_blk = nullptr;
+            if constexpr (!LIST) {
+                if (a.ov_cap > 0) ov_blk = a.ov + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_OV_STRIDE;
+            }
             L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
-                                             a.exact_math != 0);
+                                             a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
+            if (ov_blk && act && o.overflow && o.n_hits <= a.ov_cap) {   // header and the flakes the LDS list holds: the slot is complete
+                double *sp = ov_blk + (size_t)tid * SG_OV_STRIDE;
+                sp[0] = (double)d_t; sp[1] = theta_c;
+                for (int j = 0; j < LMAX; ++j) {
+                    sp[2 + 3 * j] = s_a1[j * BLOCK + tid]; sp[3 + 3 * j] = s_a2[j * BLOCK + tid]; sp[4 + 3 * j] = s_rho[j * BLOCK + tid];
+                }
+                a.ov_sc[g] = (uint16_t)(o.n_hits | (ch << 8));
+            }
         }
         if constexpr (!LIST) {
             if (act && a.rng) ((T *)a.rng)[g] = d_t;  // simulation.py:89, for the noise-floor pass (:465-469, :518-520)
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                     const int idx = r * 64 + lane;
                     key[r] = 255;                             // past the end of the window: last
                     if (idx < cnt) {
-                        const unsigned sc = scs[(int64_t)start + idx];
+                        const unsigned sc = (LISTQ && a.ov_list) ? a.ov_sc[a.tier_list[work_off + start + idx]] : scs[(int64_t)start + idx];
                         key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
                     }
                     rank[r] = 0;
@@ -616,12 +629,17 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             unsigned sc = 0xffffu;
             int32_t g = 0;
             double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
+            // where the beam's hand-over data lies: plane p at qb[p * qs] -- a slot of a blocked-SoA queue (stride 64), or the
+            // overflow slot of its sorted position (stride 1)
+            const double *qb = planes;
+            int qs = 64;
             if (in) {                                         // everything a beam surely has, in one round of loads
-                sc = scs[slot];
                 g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
-                d = planes[sg_qaddr<P>(slot, 0)];             // the beam's range (simulation.py:89), widened from the row dtype
-                tc = planes[sg_qaddr<P>(slot, 1)];
-                f_a1 = planes[sg_qaddr<P>(slot, 2)]; f_a2 = planes[sg_qaddr<P>(slot, 3)]; f_rho = planes[sg_qaddr<P>(slot, 4)];
+                if (LISTQ && a.ov_list) { qb = a.ov + (size_t)g * SG_OV_STRIDE; qs = 1; sc = a.ov_sc[g]; }
+                else { qb = planes + sg_qaddr<P>(slot, 0); sc = scs[slot]; }
+                d = qb[0];                                    // the beam's range (simulation.py:89), widened from the row dtype
+                tc = qb[qs];
+                f_a1 = qb[2 * qs]; f_a2 = qb[3 * qs]; f_rho = qb[4 * qs];
             }
             const bool live = in && sc != 0xffffu;            // 0xffff: a listed beam without a flake (its record is final)
             const int L = (int)(sc & 255u), ch = (int)(sc >> 8);
@@ -635,22 +653,33 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                 f = item_f >= 0 ? item_f : sg_frame_of(a, g);
                 // ord: 4 bits per list entry -- the hit (scan order) it came from; identity unless the scan left the flakes unsorted
                 unsigned long long ord = 0xfedcba9876543210ull;
-                if (LISTQ && a.tq_unsorted) {
+                if (LISTQ && (a.tq_unsorted || a.ov_list)) {
                     // the flakes as the scan met them: insertion by range, scan order on equal ranges (simulation.py:413-417).  The
                     // ranges pass through the ratio / range column (free until the dict); THREE: they go back to being fetched from
                     // the queue afterwards, through `ord`.
                     s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
                     if constexpr (THREE) ord = 0;
+                    // first every flake into the columns as it lies in the queue -- independent loads, all in flight together --, then
+                    // the insertion sort on LDS alone (a load per step of the sort would put a memory latency into every step)
+#pragma unroll 4
                     for (int h = 1; h < L; ++h) {
-                        const double x1 = planes[sg_qaddr<P>(slot, 2 + 3 * h)], x2 = planes[sg_qaddr<P>(slot, 3 + 3 * h)];
-                        const double r = planes[sg_qaddr<P>(slot, 4 + 3 * h)];
+                        s_a1[h * BLOCK + ltid] = qb[(2 + 3 * h) * qs];
+                        s_a2[h * BLOCK + ltid] = qb[(3 + 3 * h) * qs];
+                        s_rho[h * BLOCK + ltid] = qb[(4 + 3 * h) * qs];
+                    }
+                    for (int h = 1; h < L; ++h) {
+                        const double x1 = s_a1[h * BLOCK + ltid], x2 = s_a2[h * BLOCK + ltid], r = s_rho[h * BLOCK + ltid];
                         int q = h;
-                        while (q > 0 && s_rho[(q - 1) * BLOCK + ltid] > r) {
+                        // (equal ranges of different flakes -- probability zero for sampled tables -- fall back on the interval angles, so
+                        // that the order never depends on the order in which the scan's lanes reached the slot)
+                        while (q > 0 && (s_rho[(q - 1) * BLOCK + ltid] > r ||
+                                         (s_rho[(q - 1) * BLOCK + ltid] == r && a.ov_list &&
+                                          (s_a1[(q - 1) * BLOCK + ltid] > x1 || (s_a1[(q - 1) * BLOCK + ltid] == x1 && s_a2[(q - 1) * BLOCK + ltid] > x2))))) {
                             s_rho[q * BLOCK + ltid] = s_rho[(q - 1) * BLOCK + ltid]; s_a1[q * BLOCK + ltid] = s_a1[(q - 1) * BLOCK + ltid];
                             s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid];
                             --q;
                         }
-                        s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2;
+                        if (q != h) { s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2; }
                         if constexpr (THREE) {
                             const unsigned long long low = (1ull << (4 * q)) - 1ull;
                             ord = (ord & low) | ((unsigned long long)h << (4 * q)) | ((ord & ~low) << 4);
@@ -660,14 +689,14 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
                     s_a1[ltid] = f_a1; s_a2[ltid] = f_a2;
                     if constexpr (!THREE) s_rho[ltid] = f_rho;
                     for (int j = 1; j < L; ++j) {
-                        s_a1[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 2 + 3 * j)];
-                        s_a2[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 3 + 3 * j)];
-                        if constexpr (!THREE) s_rho[j * BLOCK + ltid] = planes[sg_qaddr<P>(slot, 4 + 3 * j)];
+                        s_a1[j * BLOCK + ltid] = qb[(2 + 3 * j) * qs];
+                        s_a2[j * BLOCK + ltid] = qb[(3 + 3 * j) * qs];
+                        if constexpr (!THREE) s_rho[j * BLOCK + ltid] = qb[(4 + 3 * j) * qs];
                     }
                 }
                 auto queue_rho = [&](int j) -> double {       // range of list entry j (THREE: from the queue)
                     const int h = (int)((ord >> (4 * j)) & 15ull);
-                    return h == 0 ? f_rho : planes[sg_qaddr<P>(slot, 4 + 3 * h)];
+                    return h == 0 ? f_rho : qb[(4 + 3 * h) * qs];
                 };
                 int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
                 double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
