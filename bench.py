@@ -254,6 +254,9 @@ def main():
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["C5"], help="C2 (default) is BASELINE.json's metric config")
     ap.add_argument("--dry", action="store_true", help="launch logic only: gloo on CPU, no GPU work (tests)")
+    ap.add_argument("--tables", default="host", choices=("host", "device"),
+                    help="host: dart_throwing on the host (bit-exact mirror of sampling.py), uploaded once; device: sampled and filed on the GPU "
+                         "(snowgpu_sample_table, seed = f(prefix, line)): no table ever crosses the link; reports sampler throughput")
     args = ap.parse_args()
     if args.inner:
         args.no_cpu_baseline = args.no_pmc = args.no_pcie = True
@@ -322,8 +325,28 @@ def main():
     eng = engine.get_engine(local_rank)
     if layers != 64:                                       # SURVEY 8 d: 128-entry laser table = the 64-entry one tiled
         eng.set_lasers(engine.load_lasers() * (layers // 64))
-    tables = make_tables(layers, snowfall, velocity, distinct=min(layers, 64))
-    ktot = sum(t.shape[0] for t in tables)
+    sampler = None
+    if args.tables == "device":
+        from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+        occ, rate = smp.compute_occupancy(snowfall, velocity), smp.snowfall_rate_to_rainfall_rate(snowfall, velocity)
+        prefix = f"gunn_{rate}_{occ}"
+        eng.keep_sampled_rows = not args.no_cpu_baseline            # the CPU oracle needs the rows the device made
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        dev_ids = [eng.sampled_table_id(prefix, line) for line in range(1, min(layers, 64) + 1)]
+        torch.cuda.synchronize()
+        samp_s = time.perf_counter() - c0
+        flakes = [eng.sampled_flakes[(prefix, line)] for line in range(1, min(layers, 64) + 1)]
+        tables = [eng.sampled_rows[(prefix, line)] for line in range(1, min(layers, 64) + 1)] if eng.keep_sampled_rows else None
+        ktot = sum(flakes) * (layers // min(layers, 64))
+        sampler = {"tables": len(dev_ids), "tables_per_s": len(dev_ids) / samp_s, "flakes": int(sum(flakes)), "flakes_per_s": sum(flakes) / samp_s,
+                   "seconds": samp_s, "note": "snowgpu_sample_table: Philox dart throwing + filing (derive / bin / sort) on the device, "
+                                              "one call per table, nothing downloaded" + (" except the rows the CPU oracle checks against" if eng.keep_sampled_rows else "")}
+        if tables is not None:
+            tables = [tables[i % len(tables)] for i in range(layers)]
+    else:
+        tables = make_tables(layers, snowfall, velocity, distinct=min(layers, 64))
+        ktot = sum(t.shape[0] for t in tables)
     F = args.frames
     import random
     frames, orders, table_ids, planes, polys = [], [], [], [], []
@@ -336,7 +359,8 @@ def main():
         random.shuffle(order)
         frames.append(pc)
         orders.append(order)
-        table_ids.append(eng.table_ids_from_arrays(tables, order))
+        table_ids.append([dev_ids[order[c] % len(dev_ids)] for c in range(layers)] if args.tables == "device"
+                         else eng.table_ids_from_arrays(tables, order))
         planes.append([*plane[0], plane[1]])
         if args.host_prepass:
             polys.append(noise_threshold_poly(pc, plane[0], plane[1], 0.7))
@@ -408,7 +432,7 @@ def main():
     # with a full-grid blit kernel instead of the DMA engine (traced), which stalls every kernel beside it.  The in-process
     # figure is reported next to it.
     pcie, single = None, None
-    if not args.no_pcie and not fused_wet:
+    if not args.no_pcie and not fused_wet and args.tables == "host":
         child = None
         try:
             env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
@@ -458,6 +482,7 @@ def main():
                 "frac_of_link_bound_without_src": mine[1] / (PCIE_PEAK / 20.0 * world),
                 "in_process_with_pytorch": n_total / inproc_s,
                 "matches_device_entry": host_same and (child is None or child["digest"] == digest),
+                "q8_numpy": (child or {}).get("q8_numpy"),
                 "default_plane": dp or None, "default_plane_all_ranks": {"reference": mine[2], "lsq": mine[3]} if dp else None,
                 "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
                         "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
@@ -488,7 +513,7 @@ def main():
         avg_ms = beam_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
         traffic, traffic_src, valu = None, None, None
-        inner_argv = ["--steps", "2", "--warmup", "1", "--frames", str(F), "--workload", args.workload]
+        inner_argv = ["--steps", "2", "--warmup", "1", "--frames", str(F), "--workload", args.workload, "--tables", args.tables]
         if not args.no_pmc and world == 1:
             fetch = pmc_pass(["FETCH_SIZE"], inner_argv, 3)
             write = pmc_pass(["WRITE_SIZE"], inner_argv, 3) if fetch else None
@@ -574,6 +599,9 @@ def main():
             result["pcie_inclusive"] = pcie
         if single is not None:
             result["single_frame"] = single
+        if sampler is not None:
+            result["sampler"] = sampler
+            result["config"]["tables"] = "sampled and filed on the device (snowgpu_sample_table, seed = f(prefix, line))"
         if not args.no_cpu_baseline and world == 1:      # rank 0, N = 1 only
             from oracle import snow_oracle as so
             # (i) one host core on frame 0; (ii) ALL logical CPUs on frames 0..15 through the pthread driver of

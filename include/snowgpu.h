@@ -139,6 +139,7 @@ int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
  * snowgpu_augment_batch -- augment() (simulation.py:427-544, only_camera_fov=False) for a batch of
  * frames whose rows live in HOST memory.
  *
+ *   rows       the frames, concatenated -- or NULL right after snowgpu_prepass_stats on the same frames (their rows are still on the device)
  *   table_ids  n_frames x n_lasers: the table feeding channel c of frame f, i.e. the id the caller
  *              uploaded `<prefix>_<order[c]+1>.npy` under (simulation.py:70, :78, :482-486)
  *   beam_divergence_deg  as passed to augment() (degrees; simulation.py:96-97)
@@ -243,6 +244,26 @@ int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int64_t *frame
 int snowgpu_estimate_planes_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,
                                    const int64_t *d_frame_offsets, const void *d_rows, int dtype, double *d_out_planes,
                                    int32_t *d_out_info, void *stream);
+
+/*
+ * First half of the noise-threshold prepass (simulation.py:449-461; wet_ground/augmentation.py:195-235) for a caller that wants the
+ * reference's answer on ITS OWN machine: the reference takes the sparsest bin of every histogram row with np.argpartition(hist, 2)
+ * [:, 0] (:236), whose result depends on the NumPy build (quirk Q8).  The device makes the expensive part -- ground rows, I / cos,
+ * the regression line p, the 50 x 2555 histogram, the sums of the quadratic fit --, the caller takes the row minima with its own
+ * NumPy, fits the noise line and the quadratic from the sums, and passes the polynomials to snowgpu_augment_batch (thr_poly).
+ *   plane     n_frames x 4, or NULL (estimated on the device, snowgpu_set_plane_method)
+ *   out_hist  n_frames x 50 x 2555 int32 (histogram2d of (range, I / cos) over (10, 70) x (5, max), augmentation.py:232-233)
+ *   out_rec   n_frames x SNOWGPU_PREPASS_REC doubles: ground rows, mean range, np.mean of the float32 range column as NumPy
+ *             computes it, mean I / cos, max I / cos, p slope, p intercept (linregress, :216-219), then the sums over the ground
+ *             rows of a2 a2, a2 a1, a2, a1 a1, a1, a2 d c, a2 c, a1 d c, a1 c, d c, c  (a1 = d = range, a2 = range^2, c = cos of the
+ *             incident angle): the normal equations of np.polyfit(range, nf (m0 d + m1) c, 2) are linear in the noise line (m0, m1)
+ * Fewer than 3 ground rows in a frame: SNOWGPU_E_GROUND, as the batch entries report it.  Empty bins of out_hist already hold
+ * the frame's ground-row count (hist[hist == 0] = len(pointcloud_planes), :234-235).  The uploaded rows stay in the context: the
+ * next snowgpu_augment_batch of the SAME frames may pass rows = NULL and computes on them instead of uploading them again.
+ */
+#define SNOWGPU_PREPASS_REC 18
+int snowgpu_prepass_stats(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                          const double *plane, int32_t *out_hist, double *out_rec);
 
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats",
 ]
 
 PLANE_METHODS = {"reference": 0, "lsq": 1, "ransac": 2}
@@ -105,6 +105,8 @@ def lib():
             L.snowgpu_estimate_planes.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]
             L.snowgpu_estimate_planes_device.restype = ctypes.c_int
             L.snowgpu_estimate_planes_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, vp, vp]
+            L.snowgpu_prepass_stats.restype = ctypes.c_int
+            L.snowgpu_prepass_stats.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp]
             L.snowgpu_set_pipeline.restype = ctypes.c_int
             L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
@@ -217,11 +219,12 @@ class Context:
         return arr
 
     def augment_batch(self, rows, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None,
-                      noise_floor=0.7, perm=None, want_thr=False, out_rows=None, out_src=None, want_src=True):
+                      noise_floor=0.7, perm=None, want_thr=False, out_rows=None, out_src=None, want_src=True, rows_resident=False):
         """rows: N_total x 5 (float32/float64), frame_offsets: n_frames + 1, table_ids: n_frames x n_lasers.
         out_rows / out_src: optional caller-owned result buffers (at least N_total rows; pinned_empty() ones move at
         PCIe speed and are not page-faulted in on every call).  want_src=False: the source indices stay on the device
-        (out_src is returned as None).
+        (out_src is returned as None).  rows_resident: `rows` are the rows of the immediately preceding prepass_stats() call --
+        they are still on the device and are not uploaded again (rows = NULL at the C ABI).
 
         Returns (out_rows [N_total x 5, only the first counts[f] rows of each frame slot are valid],
                  out_src, counts, stats[n_frames x 3], thr_poly or None)."""
@@ -251,7 +254,7 @@ class Context:
         pm = None if perm is None else np.ascontiguousarray(perm, np.int32)
         out_thr = np.zeros((nf, 3)) if want_thr else None
         with self._call_lock:
-            rc = self._L.snowgpu_augment_batch(self._h, nf, _p(off), _p(rows), code, _p(tids), float(beam_divergence),
+            rc = self._L.snowgpu_augment_batch(self._h, nf, _p(off), None if rows_resident else _p(rows), code, _p(tids), float(beam_divergence),
                                                _p(thr), _p(pl), float(noise_floor), _p(pm), _p(out_rows), _p(out_src),
                                                _p(counts), _p(stats), _p(out_thr))
             self._check(rc)
@@ -317,6 +320,23 @@ class Context:
         with self._call_lock:
             self._check(self._L.snowgpu_estimate_planes(self._h, nf, _p(off), _p(rows), code, _p(planes), _p(info)))
         return planes, info
+
+    def prepass_stats(self, rows, frame_offsets, plane=None, hist_out=None):
+        """(hist n_frames x 50 x 2555 int32, rec n_frames x 18 float64): the device half of the noise-threshold prepass
+        (snowgpu_prepass_stats) for a caller that takes the histogram's row minima with its own NumPy (quirk Q8)."""
+        rows = np.ascontiguousarray(rows)
+        code = _dtype_code(rows.dtype)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf = len(off) - 1
+        pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        if hist_out is not None and hist_out.size >= nf * 50 * 2555 and hist_out.dtype == np.int32 and hist_out.flags.c_contiguous:
+            hist = hist_out.reshape(-1)[:nf * 50 * 2555].reshape(nf, 50, 2555)     # e.g. a page-locked buffer kept by the caller
+        else:
+            hist = np.empty((nf, 50, 2555), np.int32)
+        rec = np.empty((nf, 18), np.float64)
+        with self._call_lock:
+            self._check(self._L.snowgpu_prepass_stats(self._h, nf, _p(off), _p(rows), code, _p(pl), _p(hist), _p(rec)))
+        return hist, rec
 
     def sample_table(self, table_id, occupancy_ratio, diameter_scale_mm, r_0, seed, want_rows=True):
         """Sample a snowflake table on the device (and file it there under table_id >= 0).  Returns the K x 3 rows, or K

@@ -14,9 +14,13 @@ struct SgWetParams {
     const double *lines;        // optional DEVICE array n_frames x 4: the two fitted lines supplied by the caller (snowgpu_set_wet_lines)
 };
 
+#define SG_PRE_REC 18      /* doubles per frame of sg_prepass_stats_run's record */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
+                         int64_t max_frame, const double *plane, int32_t *d_hist, double *d_rec, int32_t *status, void *stream);
 // Returns 0, a positive hipError_t, or -1 on allocation failure.  plane: n_frames x 4 (wx, wy, wz, h).
 int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                    int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status,

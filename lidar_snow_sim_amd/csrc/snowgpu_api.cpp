@@ -124,6 +124,10 @@ struct snowgpu_ctx {
     SgPlaneParams plane_par{SG_PLANE_REFERENCE, 1024, 5, 0, -1.55};
     DevBuf<double> plane_est, wet_plane_est;
     DevBuf<int32_t> plane_info;
+    int64_t resident_rows = -1;       // rows snowgpu_prepass_stats left in rows_in (and their dtype): a following snowgpu_augment_batch with
+    int resident_dtype = -1;          // rows == NULL computes on them instead of uploading the same rows again
+    DevBuf<int32_t> stats_hist;       // snowgpu_prepass_stats: n_frames x 50 x 2555
+    DevBuf<double> stats_rec;
     // fused snow + wet (snowgpu_augment_wet_batch*): the snowfall result stays here
     DevBuf<uint8_t> snow_rows;
     DevBuf<int32_t> snow_src, wet_src, wet_flags;
@@ -340,7 +344,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->rows_crop.release(); ctx->crop_src.release(); ctx->crop_out_src.release(); ctx->crop_counts.release(); ctx->crop_off.release(); ctx->crop_stats.release();
     sg_prepass_release(&ctx->prepass);
     sg_plane_release(&ctx->plane_scr);
-    ctx->plane_est.release(); ctx->wet_plane_est.release(); ctx->plane_info.release();
+    ctx->plane_est.release(); ctx->wet_plane_est.release(); ctx->plane_info.release(); ctx->stats_hist.release(); ctx->stats_rec.release();
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
     for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3})
@@ -1160,7 +1164,7 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // ends with a synchronisation)
     for (int c = 0; c < n_chunks; ++c) {
         const int64_t r0 = frame_offsets[c_first[(size_t)c]], cn = frame_offsets[c_first[(size_t)c + 1]] - r0;
-        if (cn) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
+        if (cn && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c], ctx->s_h2d));
         if (trace) HIPCHK(ctx, hipEventRecord(tev[1 + 4 * (size_t)c], ctx->s_h2d));
     }
@@ -1290,11 +1294,15 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     }
     const int64_t n_total = frame_offsets[n_frames];
     if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
-    if (n_total > 0 && (!rows || !out_rows)) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    if (n_total > 0 && !out_rows) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
+    if (n_total > 0 && !rows && (ctx->resident_rows != n_total || ctx->resident_dtype != dtype))
+        return fail(ctx, SNOWGPU_E_INVALID, "rows == NULL needs the rows of the last snowgpu_prepass_stats call (same size and dtype)");
+    if (rows) ctx->resident_rows = -1;                 // (a fresh upload replaces whatever was resident)
     if (!out_counts || !out_stats) return fail(ctx, SNOWGPU_E_INVALID, "null count/stat buffers");
     if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const bool wants_precrop = ctx->fov.enabled && ctx->fov_pre && !dbg_count && n_total > 0;
+    if (wants_precrop && !rows) return fail(ctx, SNOWGPU_E_INVALID, "rows == NULL cannot be combined with the pre-augment crop");
     if (!dbg_count && !perm_out && !wants_precrop && ctx->pipe_rows > 0 && n_frames > 1 && n_total > ctx->pipe_rows + ctx->pipe_rows / 2)
         return host_batch_pipelined(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_div_deg, thr_poly, plane, noise_floor, perm,
                                     out_rows, out_src, out_counts, out_stats, out_thr_poly);
@@ -1318,7 +1326,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     else if (plane) std::memcpy(ctx->mail_up_h + up_par, plane, 32 * nfz);          // neither: the plane is estimated on the device
     std::memcpy(ctx->mail_up_h + up_ids, table_ids, 4 * nfz * nlz);
     HIPCHK(ctx, hipMemcpyAsync(ctx->mail_up_d.p, ctx->mail_up_h, up_bytes, hipMemcpyHostToDevice, st));
-    if (row_bytes) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
+    if (row_bytes && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_frame_off = (const int64_t *)(ctx->mail_up_d.p + up_off);
     const int32_t *d_table_ids = (const int32_t *)(ctx->mail_up_d.p + up_ids);
     const double *d_thr = thr_poly ? (const double *)(ctx->mail_up_d.p + up_par) : nullptr;
@@ -1675,6 +1683,7 @@ extern "C" int snowgpu_augment_wet_batch(snowgpu_ctx *ctx, int n_frames, const i
     ENSURE(ctx, ctx->table_ids, nf * nl);
     ENSURE(ctx, ctx->plane, nf * 4);
     ENSURE(ctx, ctx->wet_plane, nf * 4);
+    ctx->resident_rows = -1;
     if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->table_ids.p, table_ids, sizeof(int32_t) * nf * nl, hipMemcpyHostToDevice, st));
@@ -1772,6 +1781,7 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     ENSURE(ctx, ctx->out_counts, (size_t)n_frames);
     ENSURE(ctx, ctx->plane, (size_t)n_frames * 4);
     ENSURE(ctx, ctx->dbg_count, (size_t)n_frames);   // reused as the per-frame "returned unchanged" flags
+    ctx->resident_rows = -1;
     if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, n * 5 * esz, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * ((size_t)n_frames + 1), hipMemcpyHostToDevice, st));
     if (plane) HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * (size_t)n_frames, hipMemcpyHostToDevice, st));
@@ -1859,7 +1869,8 @@ extern "C" int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int
     ENSURE(ctx, ctx->plane_info, nf * 4);
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
     if (ctx->plane_par.method != SG_PLANE_REFERENCE && n_total > 0) {       // (the reference-today plane reads no row)
-        ENSURE(ctx, ctx->rows_in, (size_t)n_total * 5 * esz);
+        ctx->resident_rows = -1;
+    ENSURE(ctx, ctx->rows_in, (size_t)n_total * 5 * esz);
         HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, (size_t)n_total * 5 * esz, hipMemcpyHostToDevice, st));
     }
     int e = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame,
@@ -1869,4 +1880,54 @@ extern "C" int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int
     if (out_info) HIPCHK(ctx, hipMemcpyAsync(out_info, ctx->plane_info.p, sizeof(int32_t) * 4 * nf, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return SNOWGPU_OK;
+}
+
+
+// ---- noise-threshold prepass, first half (simulation.py:449-461; wet_ground/augmentation.py:195-235) -------------------------
+// For a caller that wants the reference's answer on ITS machine (quirk Q8): the 50 x 2555 histogram of (range, I / cos) over the
+// ground rows and the per-frame sums, from the device; the caller takes np.argpartition(hist, 2)[:, 0] itself, fits the noise
+// line and the quadratic from the sums, and hands the polynomials to snowgpu_augment_batch (thr_poly).
+extern "C" int snowgpu_prepass_stats(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
+                                     const double *plane, int32_t *out_hist, double *out_rec)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (n_frames <= 0 || !frame_offsets || !out_hist || !out_rec || (dtype != 0 && dtype != 1))
+        return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_prepass_stats: null pointer or bad dtype");
+    if (frame_offsets[0] != 0) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets[0] must be 0");
+    int64_t max_frame = 0;
+    for (int f = 0; f < n_frames; ++f) {
+        if (frame_offsets[f + 1] < frame_offsets[f]) return fail(ctx, SNOWGPU_E_INVALID, "frame_offsets must be non-decreasing");
+        max_frame = std::max(max_frame, frame_offsets[f + 1] - frame_offsets[f]);
+    }
+    const int64_t n_total = frame_offsets[n_frames];
+    if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
+    if (n_total > 0 && !rows) return fail(ctx, SNOWGPU_E_INVALID, "null row buffer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t esz = dtype == 0 ? 4 : 8, nf = (size_t)n_frames, hist_n = nf * 50 * 2555;
+    hipStream_t st = ctx->stream;
+    ENSURE(ctx, ctx->frame_off, nf + 1);
+    ENSURE(ctx, ctx->plane, nf * 4);
+    ENSURE(ctx, ctx->plane_info, nf * 4);
+    ENSURE(ctx, ctx->rows_in, std::max<size_t>((size_t)n_total * 5 * esz, 8));
+    ENSURE(ctx, ctx->stats_hist, hist_n);
+    ENSURE(ctx, ctx->stats_rec, nf * SG_PRE_REC);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
+    if (n_total) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, (size_t)n_total * 5 * esz, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(int32_t) * 8, st));
+    if (plane) HIPCHK(ctx, hipMemcpyAsync(ctx->plane.p, plane, sizeof(double) * 4 * nf, hipMemcpyHostToDevice, st));
+    else {
+        int pe = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame,
+                              ctx->plane.p, ctx->plane_info.p, st);
+        if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+    }
+    int e = sg_prepass_stats_run(&ctx->prepass, ctx->rows_in.p, dtype, ctx->frame_off.p, n_frames, n_total, max_frame, ctx->plane.p,
+                                 ctx->stats_hist.p, ctx->stats_rec.p, ctx->d_status, st);
+    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
+    int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(out_hist, ctx->stats_hist.p, sizeof(int32_t) * hist_n, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(out_rec, ctx->stats_rec.p, sizeof(double) * nf * SG_PRE_REC, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->resident_rows = n_total; ctx->resident_dtype = dtype;
+    return status_to_error(ctx, status);
 }

@@ -1145,6 +1145,86 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     return 0;
 }
 
+// Per-frame record of the lean prepass for a caller that finishes the fit itself (snowgpu_prepass_stats): SG_PRE_REC doubles.
+__global__ void k_lean_export(PreArgs a, double *out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const PreFrame &fr = a.fr[f];
+    double *o = out + (int64_t)f * SG_PRE_REC;
+    o[0] = fr.n_ground; o[1] = fr.xmean; o[2] = fr.xmean32; o[3] = fr.ymean; o[4] = fr.ymax; o[5] = fr.p0; o[6] = fr.p1;
+    for (int k = 0; k < 11; ++k) o[7 + k] = fr.q[k];
+}
+
+// hist[hist == 0] = len(pointcloud_planes) (augmentation.py:234-235) where the histogram is made: the caller converts and selects only
+__global__ __launch_bounds__(PB) void k_lean_fill_empty(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int ng = (int)a.fr[f].n_ground;
+    int32_t *h = a.hist + (int64_t)f * HX * HY;
+    for (int i = blockIdx.x * PB + threadIdx.x; i < HX * HY; i += gridDim.x * PB)
+        if (h[i] == 0) h[i] = ng;
+}
+
+__global__ void k_lean_force_mean32(PreArgs a)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < a.n_frames) a.fr[f].need_mean32 = 1;
+}
+
+// The lean prepass up to the histogram and the regression line p, for a caller that takes the per-row minima of the histogram
+// with its own code (quirk Q8: np.argpartition): d_hist receives n_frames x 50 x 2555 int32, d_rec n_frames x SG_PRE_REC doubles
+// (n_ground, mean range, NumPy's float32 mean of the ranges, mean I / cos, max I / cos, p slope, p intercept, the 11 sums of the
+// quadratic fit in LQ_* order).
+extern "C" int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
+                                    int64_t n_total, int64_t max_frame, const double *plane, int32_t *d_hist, double *d_rec,
+                                    int32_t *status, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    PreArgs a{};
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
+    a.noise_floor = 0.7; a.power_factor = 15.0; a.status = status;
+    const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
+    a.max_tiles = max_tiles;
+    const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)n_frames;
+    if (ensure(s, B_PART, nf * (size_t)max_tiles * LP_COLS * 8) || ensure(s, B_ROWMIN, nf * HX * 8) || ensure(s, B_FRAME, nf * sizeof(PreFrame)) ||
+        (dtype == 0 && ensure(s, B_CDIST, n * 4)))
+        return -1;
+    a.part = (double *)s->buf[B_PART]; a.hist = d_hist; a.rowmin = (double *)s->buf[B_ROWMIN];
+    a.fr = (PreFrame *)s->buf[B_FRAME]; a.cdist = (float *)s->buf[B_CDIST];
+    hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    const unsigned fb = (unsigned)((n_frames + 63) / 64);
+    if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_lean_stats<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_lean_means, dim3((unsigned)n_frames), dim3(64), 0, st, a, 3, 7 /* SNOWGPU_E_GROUND */);
+    LCHK();
+    if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
+    else hipLaunchKernelGGL(k_lean_hist<double>, grid, dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
+    LCHK();
+    hipLaunchKernelGGL(k_lean_lines, dim3(fb), dim3(64), 0, st, a, dtype == 0 ? 1 : 0);
+    LCHK();
+    if (dtype == 0) {        // NumPy's float32 mean of the ranges for EVERY frame: the caller's line may fall back to p (augmentation.py:250-251)
+        const int max_leaves = (int)(max_frame / 64 + 8);
+        if (ensure(s, B_LEAF, nf * 3 * (size_t)max_leaves * 4)) return -1;
+        hipLaunchKernelGGL(k_lean_force_mean32, dim3(fb), dim3(64), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_lean_gather<float>, grid, dim3(PB), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        LCHK();
+    }
+    hipLaunchKernelGGL(k_lean_export, dim3(fb), dim3(64), 0, st, a, d_rec);
+    LCHK();
+    hipLaunchKernelGGL(k_lean_fill_empty, dim3(32, (unsigned)n_frames), dim3(PB), 0, st, a);     // (after the row minima: they read the raw counts)
+    LCHK();
+    return 0;
+}
+
 extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                               int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
                               int32_t *status, void *stream)

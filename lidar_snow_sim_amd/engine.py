@@ -70,6 +70,15 @@ class Engine:
             self._pin_in = buf = self.ctx.pinned_empty(max(need, 1 << 20) * 5 // 4, np.uint8)
         return buf[:need].view(dtype).reshape(int(n_rows), 5)
 
+    def hist_buffer(self, n_frames):
+        """Reused page-locked int32 buffer for the histograms of Context.prepass_stats (130 MB for 256 frames: a fresh pageable
+        array would be page-faulted in on every call)."""
+        need = int(n_frames) * 50 * 2555
+        buf = getattr(self, "_pin_hist", None)
+        if buf is None or buf.size < need:
+            self._pin_hist = buf = self.ctx.pinned_empty(need + need // 4, np.int32)
+        return buf
+
     def result_buffers(self, n_rows, dtype):
         """(out_rows n x 5, out_src n) in page-locked memory from the pool, or pageable arrays past PIN_LIMIT."""
         import ctypes
@@ -154,11 +163,43 @@ class Engine:
         with self._lock:
             return self._new_id()
 
-    def file_table_id(self, particle_file_prefix, line, root_path=None):
-        """Device table id of <prefix>_<line>.npy under the reference's directories (simulation.py:324-329)."""
+    def file_table_id(self, particle_file_prefix, line, root_path=None, sample_missing=False):
+        """Device table id of <prefix>_<line>.npy under the reference's directories (simulation.py:324-329).
+        sample_missing: a table whose file does not exist is sampled on the device instead (sampled_table_id)."""
         base = (Path(root_path) / "training" / "snowflakes" / "npy") if root_path else particle_dir()
         path = base / f"{particle_file_prefix}_{line}.npy"
+        if sample_missing and not path.is_file():
+            return self.sampled_table_id(particle_file_prefix, line)
         return self.table_id(("file", str(path)), lambda p=path: np.load(str(p)))
+
+    # ---- tables made where they are used (SURVEY 8 f-2) -----------------------------------------------------------------
+    R_0 = 80.0                   # sampling.py:362: the reference's tables cover 80 m
+    keep_sampled_rows = False    # tests: keep a host copy of every table sampled on the device (sampled_rows)
+
+    def sampled_table_id(self, particle_file_prefix, line):
+        """Device table id of the table the reference would load from <prefix>_<line>.npy, sampled and filed ON THE DEVICE
+        (snowgpu_sample_table: the dart-throwing process of sampling.py:90-194 from a Philox stream) -- no file, no download.
+        prefix = f'{mode}_{rain_rate}_{occupancy}' as precompute.py:101 / pointcloud_viewer.py:2802 build it; the seed is a
+        function of (prefix, line), so every engine, rank and run makes the same table for the same name."""
+        key = ("device", particle_file_prefix, int(line))
+        with self._lock:
+            tid = self._tables.get(key)
+            if tid is not None:
+                return tid
+            mode, rain_rate, occupancy = parse_prefix(particle_file_prefix)
+            from .tools.snowfall.sampling import gunn_marshall, sekhon_srivastava
+            rate_parameter = gunn_marshall(rain_rate) if mode == "gunn" else sekhon_srivastava(rain_rate)
+            tid = self._new_id()
+            res = self.ctx.sample_table(tid, occupancy, (1 / rate_parameter) * 10, self.R_0, table_seed(particle_file_prefix, line),
+                                        want_rows=self.keep_sampled_rows)
+            if self.keep_sampled_rows:
+                self.__dict__.setdefault("sampled_rows", {})[(particle_file_prefix, int(line))] = res
+                n = res.shape[0]
+            else:
+                n = int(res)
+            self._tables[key] = tid
+            self.__dict__.setdefault("sampled_flakes", {})[(particle_file_prefix, int(line))] = n
+            return tid
 
     def table_ids_from_files(self, particle_file_prefix, order, root_path=None):
         """The reference's lookup (simulation.py:78, :324-329): channel c reads <prefix>_<order[c]+1>.npy."""
@@ -170,6 +211,24 @@ class Engine:
         for ch in range(self.n_lasers):
             ids.append(self.array_table_id(particles[order[ch]]))
         return ids
+
+
+def parse_prefix(particle_file_prefix):
+    """(mode, rain_rate, occupancy) of f'{mode}_{rain_rate}_{occupancy}' (precompute.py:101, pointcloud_viewer.py:2802)."""
+    parts = str(particle_file_prefix).split("_")
+    if len(parts) != 3 or parts[0] not in ("gunn", "sekhon"):
+        raise ValueError(f"cannot sample tables for prefix {particle_file_prefix!r}: expected 'gunn_<rain rate>_<occupancy>' or "
+                         "'sekhon_<rain rate>_<occupancy>'")
+    try:
+        return parts[0], float(parts[1]), float(parts[2])
+    except ValueError:
+        raise ValueError(f"cannot sample tables for prefix {particle_file_prefix!r}: rain rate and occupancy must be numbers") from None
+
+
+def table_seed(particle_file_prefix, line):
+    """64-bit seed of the device-sampled table <prefix>_<line>: a stable hash (not Python's salted hash())."""
+    import hashlib
+    return int.from_bytes(hashlib.blake2b(f"{particle_file_prefix}|{int(line)}".encode(), digest_size=8).digest(), "little")
 
 
 _particle_dir = None

@@ -132,13 +132,15 @@ def plan(lidar_folder: Path, ids: Sequence[str], modes, combos, batch: int, n_la
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
         batch: int = 32, calib=None, device: int = 0, rank: int = 0, world: int = 1, particles_by_prefix=None,
         planes=None, workers: int = 2, readers: int = 4, writers: int = 4, depth: int = 4, keep_outputs: bool = True,
-        report: dict = None, plane_method: str = 'reference', plane_seed: int = 0, existing=None) -> int:
+        report: dict = None, plane_method: str = 'reference', plane_seed: int = 0, existing=None, sample_missing: bool = False) -> int:
     """Process this rank's share of `sample_ids`; returns the number of files written.
 
     workers   GPU worker threads, each with its own engine context on `device`
     readers / writers   file I/O threads; depth: batches the readers may run ahead, results the writers may lag behind
     planes    None (calculate_plane per frame on the device, by `plane_method`: 'reference' = the plane the reference returns today,
               'lsq', 'ransac' seeded with `plane_seed`) or one (w, h) used for every frame
+    sample_missing  particle tables whose <prefix>_<line>.npy does not exist are sampled on the device (augment_batch(particles=
+              'missing')): an empty particle directory is enough to run
     existing  set of output paths to treat as present (default: a listing of the output folders taken before anything is
               written).  Ranks of a sharded run must agree on it: start them against a quiescent output tree (they each list it
               before writing; a launcher-started run lists behind a barrier, see main()), or pass the same set to all
@@ -245,7 +247,8 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
                     t0 = time.perf_counter()
                     try:
                         results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
-                                                particles=None if particles_by_prefix is None else particles_by_prefix[job[2]],
+                                                particles=(particles_by_prefix[job[2]] if particles_by_prefix is not None
+                                                           else ('missing' if sample_missing else None)),
                                                 planes=None if planes is None else [planes] * len(frames),
                                                 orders=job[4], device=device, slot=slot, calib=calib, pre_crop=calib is not None,
                                                 plane_method=plane_method, plane_seed=plane_seed)
@@ -297,6 +300,7 @@ def main(argv=None):
     ap.add_argument('--writers', type=int, default=4)
     ap.add_argument('--seed', type=int, default=None, help='random.seed() before the permutations are drawn (same on every rank)')
     ap.add_argument('--plane-method', default='reference', choices=('reference', 'lsq', 'ransac'))
+    ap.add_argument('--sample-missing', action='store_true', help='sample particle tables that have no .npy file on the device')
     args = ap.parse_args(argv)
     rank, local_rank, world = sdist.env_rank_world()
     calib = None
@@ -316,7 +320,7 @@ def main(argv=None):
         random.seed(args.seed)                                  # the same seed on every rank: the reference's sequential draw order
     n = run(args.lidar, read_split(args.split), particle_root=args.particles, batch=args.batch, calib=calib,
             device=local_rank, rank=rank, world=world, workers=args.workers, readers=args.readers, writers=args.writers, report=rep,
-            existing=existing, plane_method=args.plane_method)
+            existing=existing, plane_method=args.plane_method, sample_missing=args.sample_missing)
     print(f'rank {rank}/{world}: wrote {n} files in {rep.get("wall_s", 0.0):.1f} s')
 
 

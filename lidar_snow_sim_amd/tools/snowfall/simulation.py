@@ -23,7 +23,7 @@ import numpy as np
 
 from ... import _native
 from ... import engine as _engine
-from ..wet_ground.augmentation import noise_threshold_poly
+from ..wet_ground.augmentation import noise_polys_from_device_stats, noise_threshold_poly
 
 PI = np.pi
 
@@ -64,14 +64,17 @@ class _LineIds:
 
 
 class _LazyFileIds(_LineIds):
-    """<prefix>_<line>.npy, loaded on first use only (a frame touches the lines its permutation names)."""
+    """<prefix>_<line>.npy, loaded on first use only (a frame touches the lines its permutation names).  sample: 'missing' --
+    a table without a file is sampled on the device; 'all' -- every table is, the directory is never looked at."""
 
-    def __init__(self, eng, prefix, root_path):
+    def __init__(self, eng, prefix, root_path, sample=None):
         super().__init__(eng)
-        self.prefix, self.root_path = prefix, root_path
+        self.prefix, self.root_path, self.sample = prefix, root_path, sample
 
     def resolve(self, k):
-        return self.eng.file_table_id(self.prefix, k + 1, self.root_path)
+        if self.sample == 'all':
+            return self.eng.sampled_table_id(self.prefix, k + 1)
+        return self.eng.file_table_id(self.prefix, k + 1, self.root_path, sample_missing=self.sample == 'missing')
 
 
 class _ArrayIds(_LineIds):
@@ -152,7 +155,10 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 the plane comes from the cropped cloud, as in precompute.py:96-104
     orders      optional per-frame channel permutations; default: range(64), shuffled with the global
                 `random` module when shuffle=True, one draw per frame in frame order
-    particles   optional sequence of K x 3 tables (index = line - 1) instead of <prefix>_<line>.npy files
+    particles   optional sequence of K x 3 tables (index = line - 1) instead of <prefix>_<line>.npy files; or 'device': every table
+                is sampled and filed ON THE DEVICE from the prefix alone (mode, rain rate, occupancy; R_0 = 80 m; seed = hash of
+                (prefix, line)) -- statistically the reference's tables (sampling.py:90-194), not bit for bit, no file read;
+                or 'missing': files where they exist, the device sampler where they do not
     thr_polys   optional per-frame (p0, p1, p2) noise-threshold polynomials (skips the prepass)
     calib       optional calibration (V2C, R0, P2): the camera-FOV crop of simulation.py:532-540 is then applied inside the
                 compaction kernels, (1024, 1920) image; num_removed counts the cropped rows (:538)
@@ -178,13 +184,17 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         raise TypeError("all frames of a batch must share one dtype")
     if q8 not in ('first', 'numpy'):
         raise ValueError("q8 must be 'first' or 'numpy'")
+    # q8='numpy': the histogram's row minima must come from THIS process' NumPy.  The device still makes everything that is
+    # expensive (ground rows, I / cos, regression line, histogram, the sums of the quadratic fit: Context.prepass_stats) unless the
+    # caller asked for the host prepass or the batch needs the device pre-crop (whose cropped rows never visit the host).
+    q8_device = q8 == 'numpy' and device_prepass and thr_polys is None and not (calib is not None and pre_crop)
     if q8 == 'numpy':
         device_prepass = False
     if plane_method not in _native.PLANE_METHODS:
         raise ValueError("plane_method must be 'reference', 'lsq' or 'ransac'")
     nl = eng.n_lasers
     ncols = rows[0].shape[1]
-    host_fit = thr_polys is None and not device_prepass          # the polynomial is fitted here (q8='numpy', device_prepass=False)
+    host_fit = thr_polys is None and not device_prepass and not q8_device      # the polynomial is fitted here, from the rows
     fit_rows = rows
     if host_fit and calib is not None and pre_crop:
         # precompute.py:96-104 hands augment() the CROPPED cloud: plane and polynomial are fitted on it
@@ -202,7 +212,12 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             if shuffle:
                 random.shuffle(order)                                       # simulation.py:485-486
         if ids_by_line is None:
-            ids_by_line = _ArrayIds(eng, particles) if particles is not None else _LazyFileIds(eng, particle_file_prefix, root_path)
+            if isinstance(particles, str):
+                if particles not in ('device', 'missing'):
+                    raise ValueError("particles must be a sequence of tables, 'device' or 'missing'")
+                ids_by_line = _LazyFileIds(eng, particle_file_prefix, root_path, sample='all' if particles == 'device' else 'missing')
+            else:
+                ids_by_line = _ArrayIds(eng, particles) if particles is not None else _LazyFileIds(eng, particle_file_prefix, root_path)
         table_ids.append(ids_by_line[order[:nl]])                           # channel c reads line order[c] + 1 (simulation.py:78)
         if thr_polys is not None:
             polys.append(np.asarray(thr_polys[i], np.float64))
@@ -224,6 +239,20 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 np.concatenate([r[:, :5] for r in rows], out=flat)
             else:
                 flat[...] = rows[0][:, :5]
+        resident = False
+        if q8_device:
+            if planes is None:
+                eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=ncols)
+            try:
+                hist, rec = eng.ctx.prepass_stats(flat, offsets, plane=np.asarray(plane_rows) if plane_rows else None,
+                                                  hist_out=eng.hist_buffer(len(rows)))
+            except _native.SnowGPUError as err:
+                _raise_like_reference(err)
+            finally:
+                if planes is None and plane_method != 'reference':
+                    eng.ctx.set_plane_method('reference')
+            polys = list(noise_polys_from_device_stats(hist, rec, noise_floor))
+            resident = True                                                      # the rows are on the device already
         out_rows, out_src = eng.result_buffers(int(offsets[-1]), dt)
         # The device counting sort handles integer channel values 0..255 and reports anything else
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
@@ -240,7 +269,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                     out, src, counts, stats, _ = eng.ctx.augment_batch(
                         flat, offsets, table_ids, beam_divergence, thr_poly=np.asarray(polys) if polys else None,
                         plane=None if (polys or device_plane) else np.asarray(plane_rows), noise_floor=noise_floor, perm=perm,
-                        out_rows=out_rows, out_src=out_src, want_src=want_src)
+                        out_rows=out_rows, out_src=out_src, want_src=want_src, rows_resident=resident and attempt == 0 and crop_idx is None)
                     break
                 except _native.SnowGPUError as err:
                     if attempt == 0 and err.code == _native.E_CHANNELS:

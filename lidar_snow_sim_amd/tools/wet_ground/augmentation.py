@@ -56,6 +56,84 @@ def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, powe
     return relative_output_intensity, adaptive_noise_threshold, p, stat_values
 
 
+_tls = None
+
+
+def _scratch_f64(n):
+    """A float64 scratch array of n elements, kept per thread."""
+    global _tls
+    import threading
+    if _tls is None:
+        _tls = threading.local()
+    buf = getattr(_tls, "buf", None)
+    if buf is None or buf.size < n:
+        _tls.buf = buf = np.empty(n + n // 8, np.float64)
+    return buf[:n]
+
+
+_pool = None
+
+
+def _thread_pool(workers):
+    """One pool for the life of the process: its threads keep their scratch arrays."""
+    global _pool
+    from concurrent.futures import ThreadPoolExecutor
+    if _pool is None or _pool._max_workers != workers:
+        _pool = ThreadPoolExecutor(max_workers=workers)
+    return _pool
+
+
+def noise_polys_from_device_stats(hist, rec, noise_floor=0.7, threads=None):
+    """Threshold polynomials (n_frames x 3) for q8='numpy' from the device half of the prepass (Context.prepass_stats): the
+    histogram's row minima are taken HERE, with this process' NumPy -- np.argpartition(hist, 2)[:, 0] on float64 rows of 2555
+    bins whose empty bins hold the ground-row count, exactly the reference's expression (augmentation.py:232-236) -- and the
+    rest of estimate_laser_parameters (:237-253) and the quadratic fit (simulation.py:462-467) follow from the device's sums.
+    The row selections of a batch run on a thread pool (NumPy releases the GIL inside argpartition)."""
+    import os
+    nf = hist.shape[0]
+    xedges = np.linspace(10, 70, 51)                                                # np.histogram2d's edges (:232-233)
+    xmid = (xedges[:-1] + xedges[1:]) / 2                                           # :240-241
+
+    def select(lo, hi):
+        # :234-236 for frames lo .. hi - 1: the device has already put the ground-row count into the empty bins; the histogram
+        # becomes the float64 array np.histogram2d returns (one casting copy) and the selection is the reference's expression --
+        # row by row, so a (frames * 50) x 2555 array gives what fifty-row arrays give.  Both release the GIL.
+        h = _scratch_f64((hi - lo) * 50 * 2555).reshape(-1, 2555)                  # (reused per thread: no page faults after the first call)
+        np.copyto(h, hist[lo:hi].reshape(-1, 2555))
+        return np.argpartition(h, 2)[:, 0].reshape(hi - lo, 50)
+
+    workers = threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if nf <= 2 or workers <= 1:
+        ymins = select(0, nf)
+    else:
+        per = max(1, -(-nf // workers))
+        ymins = np.concatenate(list(_thread_pool(workers).map(lambda lo: select(lo, min(lo + per, nf)), range(0, nf, per))))
+    # the rest for all frames at once (augmentation.py:237-253, simulation.py:462-467)
+    n_ground, ymax, p0, p1 = rec[:, 0], rec[:, 4], rec[:, 5], rec[:, 6]
+    step = (np.abs(ymax) - 5.0) / 2555.0
+    min_vals = ymins * step[:, None] + 5.0                                          # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
+    use = min_vals > 5                                                              # :238
+    cnt = use.sum(axis=1)
+    ok = cnt > 3                                                                    # :248
+    cs = np.maximum(cnt, 1)
+    xm = (use * xmid).sum(axis=1) / cs
+    ym = (use * min_vals).sum(axis=1) / cs
+    dx, dy = (xmid - xm[:, None]) * use, (min_vals - ym[:, None]) * use
+    sxx = (dx * dx).sum(axis=1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        slope = (dx * dy).sum(axis=1) / sxx                                         # scipy linregress: ssxym / ssxm (:249)
+    m0 = np.where(ok, slope, p0)                                                    # :250-251: too few rows -> the regression line p
+    m1 = np.where(ok, ym - slope * xm, p1)
+    q = rec[:, 7:18]
+    a22, a21, a2, a11, a1, a2gc, a2c, a1gc, a1c, gc, c = (q[:, k] for k in range(11))
+    # normal equations of np.polyfit(d, nf (m0 d + m1) c, 2), columns scaled by their norms as polyfit scales them
+    rhs = noise_floor * np.stack([m0 * a2gc + m1 * a2c, m0 * a1gc + m1 * a1c, m0 * gc + m1 * c], axis=1)
+    G = np.stack([np.stack([a22, a21, a2], axis=1), np.stack([a21, a11, a1], axis=1), np.stack([a2, a1, n_ground], axis=1)], axis=1)
+    sc = np.sqrt(np.stack([a22, a11, n_ground], axis=1))
+    sol = np.linalg.solve(G / (sc[:, :, None] * sc[:, None, :]), (rhs / sc)[:, :, None])[:, :, 0]
+    return sol / sc
+
+
 def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7, q8='first'):
     """Quadratic (p0, p1, p2) of the per-point noise threshold over range -- simulation.py:450-467 (host)."""
     w = np.asarray(w)

@@ -98,6 +98,9 @@ def main():
     py_inj = py_batch(planes=[([0.0, 0.0, -1.0], -1.7)] * F)
     py_ref = py_batch()
     py_lsq = py_batch(plane_method="lsq")
+    # q8='numpy': the histogram's row minima from THIS process' NumPy (quirk Q8); the device makes histogram and sums (prepass_stats),
+    # the rows cross the link twice
+    py_q8 = py_batch(planes=[([0.0, 0.0, -1.0], -1.7)] * F, q8="numpy")
     # one sweep end to end through the C ABI (page-locked) and through the Python augment() (pageable input)
     one_off = np.array([0, n_per], np.int64)
 
@@ -141,6 +144,9 @@ def main():
                       "default_plane": {"c_abi_points_per_s_reference": n_total / s_ref, "c_abi_points_per_s_lsq": n_total / s_lsq,
                                         "python_points_per_s_injected": n_total / py_inj, "python_points_per_s_reference": n_total / py_ref,
                                         "python_points_per_s_lsq": n_total / py_lsq},
+                      "q8_numpy": {"python_points_per_s": n_total / py_q8, "share_of_q8_first": py_inj / py_q8,
+                                   "note": "augment_batch(..., q8='numpy') vs the same call with q8='first' (python_points_per_s_injected): "
+                                           "device half of the prepass + np.argpartition of 50 x 2555 float64 rows per frame on a thread pool"},
                       "single_frame_python_default_ms": pyd_ms, "single_frame_python_default_min_ms": pyd_min,
                       "single_frame_python_lsq_ms": pyl_ms, "single_frame_python_lsq_min_ms": pyl_min}))
 

@@ -124,3 +124,57 @@ def test_filed_per_flake_quantities_match_the_reference_geometry(golden):
     with pytest.raises(Exception):                                   # a disk over the origin is refused by the device path too
         bad = torch.tensor([[0.001, 0.001, 0.01]], dtype=torch.float64, device="cuda:0")
         eng.ctx.file_table_device(eng.user_table_id(), bad.data_ptr(), 1)
+
+
+def test_stream_driver_with_an_empty_particle_directory_samples_on_the_device(smp, tmp_path):
+    """no <prefix>_<line>.npy anywhere -- the stream driver (precompute.py:74-106) samples the 64 tables of every
+    prefix on the device (seed = f(prefix, line)), caches the ids, and every output equals the CPU oracle run on the read-back
+    tables; augment(particles='device') reaches the same tables by name."""
+    import random
+    from lidar_snow_sim_amd import engine, stream
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment
+    from oracle import snow_oracle as so
+    eng = engine.get_engine(0)
+    eng.keep_sampled_rows = True
+    try:
+        lidar = tmp_path / "lidar_hdl64_strongest"
+        lidar.mkdir()
+        (tmp_path / "training" / "snowflakes" / "npy").mkdir(parents=True)       # the reference's directory, empty
+        ids = ["2018-02-03_00001", "2018-02-03_00002"]
+        full = synthetic_sweep(64, 2048, seed=17, intensity="lambert").reshape(64, 2048, 5)
+        frames = {}
+        for i, s in enumerate(ids):
+            frames[s] = np.ascontiguousarray(full[:, i::64, :].reshape(-1, 5))
+            frames[s].tofile(lidar / f"{s}.bin")
+        combos = stream.rate_combos()[3:4]                                        # 2.5 mm/h @ 1.6 m/s
+        prefix = f"gunn_{combos[0][0]}_{combos[0][1]}"
+        with pytest.raises(FileNotFoundError):                                    # the reference's behaviour without the switch (simulation.py:329)
+            stream.run(lidar, ids, particle_root=str(tmp_path), modes=("gunn",), combos=combos, batch=2)
+        random.seed(8)
+        n = stream.run(lidar, ids, particle_root=str(tmp_path), modes=("gunn",), combos=combos, batch=2, sample_missing=True)
+        assert n == 2
+        tabs = [eng.sampled_rows[(prefix, line)] for line in range(1, 65)]        # the tables as the device made them
+        assert all(t.shape[0] > 10000 for t in tabs) and eng.sampled_flakes[(prefix, 1)] == tabs[0].shape[0]
+        assert len({t.shape[0] for t in tabs}) > 8                                # 64 different tables, not one table 64 times
+        random.seed(8)
+        bd = float(np.degrees(3e-3))
+        for s in ids:
+            order = list(range(64))
+            random.shuffle(order)
+            got = np.fromfile(stream.output_path(lidar, "gunn", combos[0][0], s), dtype=np.float32).reshape(-1, 5)
+            _, exp, _ = so.augment(frames[s], tabs, bd, order, plane=None)
+            assert got.shape == exp.shape and np.array_equal(got[:, 3:], exp[:, 3:])
+        n_tables = eng.ctx._L.snowgpu_table_count(eng.ctx.handle)
+        # the same names through augment(): cached ids, no new table
+        random.seed(8)
+        order = list(range(64))
+        random.shuffle(order)
+        stats, aug = augment(frames[ids[0]], prefix, bd, only_camera_fov=False, particles="device", order=order)
+        s0, a0, _ = so.augment(frames[ids[0]], tabs, bd, order, plane=None)
+        assert tuple(int(v) for v in stats) == tuple(int(v) for v in s0) and np.array_equal(aug[:, 3:], a0[:, 3:])
+        assert eng.ctx._L.snowgpu_table_count(eng.ctx.handle) == n_tables
+        with pytest.raises(ValueError):
+            augment(frames[ids[0]], "mytables", bd, only_camera_fov=False, particles="device")     # a prefix that names no (mode, rate, occupancy)
+    finally:
+        eng.keep_sampled_rows = False
