@@ -191,7 +191,7 @@ int sg_launch_rows_scan(const SgBeamArgs *args, int dtype, int lmax, void *strea
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
                        int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
-                       int32_t *chunk_blk, void *stream);
+                       int32_t *chunk_blk, const SgTable *tables, SgTable *resolved /* n_frames x n_las, or null */, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *tier_info,
                          int32_t *status_counts, int32_t cap, int n_cls, void *stream);

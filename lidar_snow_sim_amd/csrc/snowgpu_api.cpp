@@ -106,6 +106,7 @@ struct snowgpu_ctx {
     int tier_scan_lds = 0;            // SNOWGPU_TIER_SCAN_LDS=1: the later tiers' scans keep their lists in LDS (rounds 1-3) -- A/B
     int row_scan = 0;                 // SNOWGPU_ROW_SCAN=1: the later tiers scan with G lanes per beam (snowgpu_rows.hip) instead of one beam per lane --
                                       // measured: same rows, 2x the instructions, 4 % slower on C2 (the step is bound by VALU issue)
+    bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
     bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
@@ -277,7 +278,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
-    { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; ctx->tier_rows_auto = !v; }
     { const char *v = std::getenv("SNOWGPU_ROW_SCAN"); if (v) ctx->row_scan = std::atoi(v); }
     { const char *v = std::getenv("SNOWGPU_TIER_SCAN_LDS"); if (v) ctx->tier_scan_lds = std::atoi(v); }
     { const char *v = std::getenv("SNOWGPU_OVERFLOW_SLOTS"); if (v) ctx->use_ov = std::atoi(v); }
@@ -813,12 +814,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
     HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
     {
-        int e = sg_launch_resolve_tables(R->d_tables, (int)R->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
+        int e = 0;
+        if (!use_seg) e = sg_launch_resolve_tables(R->d_tables, (int)R->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
-        if (use_seg) {
+        if (use_seg) {                                // (its first kernel resolves the table descriptors on the way)
             e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, R->h_las.n, (int)R->tables.size(), first_block,
                                    ctx->seg_tbl_cnt.p, ctx->seg_tbl_base.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p,
-                                   ctx->seg_n.p, ctx->seg_of_blk.p, n_chunks, ctx->chunk_blk.p, s_aux);
+                                   ctx->seg_n.p, ctx->seg_of_blk.p, n_chunks, ctx->chunk_blk.p, R->d_tables, ctx->frame_tables.p, s_aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
     }
@@ -857,7 +859,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const int n_cls = n_tiers;
     // The later tiers run as row kernels (snowgpu_rows.hip: G lanes per beam; scan, dict and received power in one pass, no
     // hand-over buffers) -- an experiment, off by default (measured slower: DESIGN.md section 5).
-    const bool tier_rows = R->tier_rows && R->tier_cap_override <= 0 && R->per_lane_scan >= 0;
+    // Small batches (up to four sweeps): a tier holds a few hundred beams -- one or two waves' worth for one beam per lane, a chain of
+    // dependent latencies 100 us long -- and the row kernels, G lanes per beam, finish them in a third of that (0.334 -> 0.306 ms per
+    // single sweep); from 16 sweeps on they lose (2-3x the instructions).  SNOWGPU_TIER_ROWS=1 / 0 forces either.
+    const bool rows_small = R->tier_rows_auto && b.n_total <= ((int64_t)1 << 19);
+    const bool tier_rows = (R->tier_rows || rows_small) && R->tier_cap_override <= 0 && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan;
     const int h_lanes = 256;
     const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(R->max_flakes, 64u), 8192u);
     a.n_cls = n_cls;

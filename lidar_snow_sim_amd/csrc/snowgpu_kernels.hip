@@ -841,10 +841,18 @@ __device__ __forceinline__ SgPair sg_pair(int p, const int64_t *__restrict__ fra
 
 __global__ __launch_bounds__(256) void k_seg_count(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
-                                                   unsigned long long *__restrict__ tbl_cnt)
+                                                   unsigned long long *__restrict__ tbl_cnt, const SgTable *__restrict__ tables,
+                                                   SgTable *__restrict__ resolved)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n_frames * 256) return;
+    if (resolved && (p & 255) < n_las) {              // table descriptor of (frame, channel): what k_resolve_tables does, one launch less
+        const int64_t i = (int64_t)(p >> 8) * n_las + (p & 255);
+        const int t = table_ids[i];
+        SgTable d{};
+        if (t >= 0 && t < n_tables) d = tables[t];
+        resolved[i] = d;
+    }
     const SgPair r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
     if (r.rows > 0) atomicAdd(&tbl_cnt[r.key], (1ull << 32) | (unsigned long long)((r.rows + blk - 1) / blk));
 }
@@ -852,7 +860,7 @@ __global__ __launch_bounds__(256) void k_seg_count(const int64_t *__restrict__ f
 // exclusive scan of the packed per-table counts (both halves at once: neither overflows 32 bits); leaves the counts zero
 // so that k_seg_place can use them as cursors
 __global__ __launch_bounds__(1024) void k_seg_scan(unsigned long long *__restrict__ tbl_cnt, unsigned long long *__restrict__ tbl_base, int n,
-                                                   int32_t *__restrict__ seg_n)
+                                                   int32_t *__restrict__ seg_n, int32_t *__restrict__ one_chunk_blk)
 {
     __shared__ unsigned long long sc[1024];
     const int t = threadIdx.x;
@@ -864,7 +872,10 @@ __global__ __launch_bounds__(1024) void k_seg_scan(unsigned long long *__restric
     for (int d = 1; d < 1024; d <<= 1) { const unsigned long long add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
     unsigned long long run = sc[t] - sum;
     for (int k = b0; k < b1; ++k) { const unsigned long long c = tbl_cnt[k]; tbl_base[k] = run; run += c; tbl_cnt[k] = 0; }
-    if (t == 1023) { seg_n[0] = (int32_t)(sc[1023] >> 32); seg_n[1] = (int32_t)(sc[1023] & 0xffffffffull); }
+    if (t == 1023) {
+        seg_n[0] = (int32_t)(sc[1023] >> 32); seg_n[1] = (int32_t)(sc[1023] & 0xffffffffull);
+        if (one_chunk_blk) { one_chunk_blk[0] = 0; one_chunk_blk[1] = (int32_t)(sc[1023] & 0xffffffffull); }   // the pass as ONE launch: all blocks
+    }
 }
 
 __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
@@ -1070,34 +1081,41 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
             k = noise_ok;
             if (fov.enabled && k) k = sg_in_fov(fov, (double)o.x, (double)o.y, (double)o.z);   // :532-540
         }
-        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0) | ((noise_ok && is_att) ? 4 : 0));   // bit 2: counts in num_attenuated
+        keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0));
         c += k;
+        c += (noise_ok && is_att) ? (1 << 16) : 0;                          // high half: rows that count in num_attenuated (:525, before the crop)
     }
     __shared__ int s[4];
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    if (threadIdx.x == 0) tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];   // kept | attenuated << 16 (a tile has 1024 rows)
 }
 
+// per frame: tile offsets of the kept rows and the statistics (simulation.py:522-530).  diff2 (per frame: twice the intensity-
+// difference sum of the attenuated beams, final once the per-beam kernels are through) may be null: the pre-augment crop has none.
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
                                                            const int32_t *__restrict__ tile_cnt,
                                                            int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
-                                                           int64_t *__restrict__ out_stats, int64_t max_tiles)
+                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles)
 {
     const int f = blockIdx.x;
     const int64_t n = frame_off[f + 1] - frame_off[f];
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     if (threadIdx.x == 0) {                      // <= a few hundred tiles per frame: a serial scan is fine
         int run = 0;
+        int64_t att = 0;
         for (int64_t t = 0; t < tiles; ++t) {
+            const int c = tile_cnt[(int64_t)f * max_tiles + t];
             tile_base[(int64_t)f * max_tiles + t] = run;
-            run += tile_cnt[(int64_t)f * max_tiles + t];
+            run += c & 0xffff;
+            att += c >> 16;
         }
         out_counts[f] = run;
-        out_stats[f * 3 + 0] = 0;                // num_attenuated: filled by k_compact_scatter
+        out_stats[f * 3 + 0] = att;              // num_attenuated (:525)
         out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522, + the camera crop :538)
-        out_stats[f * 3 + 2] = 0;
+        const double diff_sum = diff2 ? (double)(long long)diff2[f] / 2.0 : 0.0;
+        out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // :527-530 int()
     }
 }
 
@@ -1116,12 +1134,11 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     __shared__ int wave_cnt[4][4];               // [round][wave]
     const int tid = threadIdx.x, w = tid >> 6;
     bool k[4];
-    int pre[4], att = 0;
+    int pre[4];
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + tid;
         const int kb = r < n ? (int)keep[base + r] : 0;
         k[q] = kb & 1;
-        if (kb & 4) ++att;                                                         // simulation.py:525
         const unsigned long long m = __ballot(k[q]);
         pre[q] = __popcll(m & sg_lanemask_lt());
         if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
@@ -1144,8 +1161,6 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
         }
         run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
     }
-    for (int o = 32; o > 0; o >>= 1) att += __shfl_down(att, o);
-    if ((tid & 63) == 0 && att) atomicAdd((unsigned long long *)&out_stats[f * 3 + 0], (unsigned long long)att);
 }
 
 // ---- pre-augment camera crop (precompute.py:96-99): pc = pc[get_fov_flag(lidar_to_rect(pc[:, 0:3]), (1024, 1920))] -----
@@ -1211,15 +1226,6 @@ __global__ __launch_bounds__(SG_BLOCK) void k_crop_scatter(const T *__restrict__
         }
         run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
     }
-}
-
-__global__ void k_stats_final(int n_frames, int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2)
-{
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_frames) return;
-    const int64_t att = out_stats[f * 3 + 0];
-    const double diff_sum = (double)(long long)diff2[f] / 2.0;
-    out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // simulation.py:527-530 int()
 }
 
 // Chunk boundaries of the segment order: chunk c of n_chunks = blocks [chunk_blk[c], chunk_blk[c + 1]), cut at segment
@@ -1464,20 +1470,23 @@ extern "C" int sg_launch_huge(const SgBeamArgs *a, int dtype, void *stream)
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
                                   int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
-                                  int32_t *chunk_blk, void *stream)
+                                  int32_t *chunk_blk, const SgTable *tables, SgTable *resolved, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)n_frames;         // 256 pairs per frame, one thread each
     if (hipMemsetAsync(tbl_cnt, 0, sizeof(unsigned long long) * ((size_t)n_tables + 1), st) != hipSuccess) return (int)hipGetLastError();
-    hipLaunchKernelGGL(k_seg_count, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block, tbl_cnt);
+    hipLaunchKernelGGL(k_seg_count, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block, tbl_cnt,
+                       tables, resolved);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, tbl_cnt, tbl_base, n_tables + 1, seg_n);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, tbl_cnt, tbl_base, n_tables + 1, seg_n, n_chunks == 1 ? chunk_blk : (int32_t *)nullptr);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_seg_place, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block,
                        tbl_base, tbl_cnt, seg_start, seg_cnt, seg_frame, seg_blk, seg_of_blk);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_seg_chunks, dim3(1), dim3(64), 0, st, seg_n, seg_blk, n_chunks, chunk_blk);
-    SG_CHECK_LAUNCH();
+    if (n_chunks > 1) {
+        hipLaunchKernelGGL(k_seg_chunks, dim3(1), dim3(64), 0, st, seg_n, seg_blk, n_chunks, chunk_blk);
+        SG_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1510,14 +1519,12 @@ extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *re
     if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, (const float *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, (const double *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, max_tiles);
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles);
     SG_CHECK_LAUNCH();
     if (dtype == 0)
         hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
     else
         hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
-    SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_stats_final, dim3((n_frames + 63) / 64), dim3(64), 0, st, n_frames, out_stats, diff2);
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -1532,7 +1539,7 @@ extern "C" int sg_launch_crop_count(const void *rows, int dtype, const int64_t *
     if (dtype == 0) hipLaunchKernelGGL(k_crop_flag<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     else hipLaunchKernelGGL(k_crop_flag<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, max_tiles);
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, (const unsigned long long *)nullptr, max_tiles);
     SG_CHECK_LAUNCH();
     return 0;
 }

@@ -264,7 +264,9 @@ __device__ __forceinline__ float np_leaf_sum_f32(const float *v, int n)     // n
     return res;
 }
 
-__global__ __launch_bounds__(PB) void k_pre_mean32(PreArgs a, int *leaf_buf, int max_leaves)
+__device__ void lean_solve_frame_fwd(const PreArgs &a, int f, double *thr_poly);
+
+__global__ __launch_bounds__(PB) void k_pre_mean32(PreArgs a, int *leaf_buf, int max_leaves, double *thr_poly_or_null)
 {
     const int f = blockIdx.x;
     const int n = (int)a.fr[f].n_ground;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(PB) void k_pre_mean32(PreArgs a, int *leaf_buf, int
         fr.xmean32 = (double)(total / (float)n);                             // _mean: float32 true_divide
         fr.p1 = fr.ymean - fr.p0 * fr.xmean32;                               // linregress intercept (augmentation.py:216)
         fr.pmin1 = fr.p1;                                                    // pmin = p (:250-251)
+        if (thr_poly_or_null) lean_solve_frame_fwd(a, f, thr_poly_or_null);  // the lean chain: the quadratic waited for this intercept
     }
 }
 
@@ -563,6 +566,7 @@ __global__ __launch_bounds__(64) void k_pre_poly_solve(PreArgs a, double *thr_po
 }
 
 
+
 // ================================================================================================================
 // Lean snowfall prepass (round 4).  The chain above moves every ground row through three float64 scratch arrays (range,
 // I / cos, cos: written once, read twice -- 2.8 GB per 256-sweep step, more than the per-beam kernels fetch).  The snowfall
@@ -755,11 +759,9 @@ __global__ __launch_bounds__(PB) void k_lean_hist(PreArgs a)
         if (t_key[i] >= 0) atomicAdd(&hist[t_key[i]], t_cnt[i]);
 }
 
-// the two lines from the frame's centred moments (k_lean_means) and the histogram's row minima
-__global__ __launch_bounds__(64) void k_lean_lines(PreArgs a, int xmean_f32)
+// the two lines from the frame's centred moments (k_lean_means) and the histogram's row minima (one thread per frame)
+__device__ __forceinline__ void lean_lines_frame(const PreArgs &a, int f, int xmean_f32)
 {
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= a.n_frames) return;
     PreFrame &fr = a.fr[f];
     const double ng = fr.n_ground;
     double slope = 0, icpt = 0;
@@ -782,6 +784,12 @@ __global__ __launch_bounds__(64) void k_lean_lines(PreArgs a, int xmean_f32)
     }
     if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
     else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
+}
+
+__global__ __launch_bounds__(64) void k_lean_lines(PreArgs a, int xmean_f32)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f < a.n_frames) lean_lines_frame(a, f, xmean_f32);
 }
 
 // ground ranges compacted in row order for the frames that need NumPy's float32 mean (k_pre_mean32), from the rows
@@ -825,11 +833,11 @@ __global__ __launch_bounds__(PB) void k_lean_gather(PreArgs a)
     }
 }
 
-// the quadratic from the frame's sums and its noise line (columns scaled by their norms, as np.polyfit does)
-__global__ __launch_bounds__(64) void k_lean_solve(PreArgs a, double *thr_poly)
+// the quadratic from the frame's sums and its noise line (columns scaled by their norms, as np.polyfit does); one thread per frame
+__device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double *thr_poly);
+__device__ void lean_solve_frame_fwd(const PreArgs &a, int f, double *thr_poly) { lean_solve_frame(a, f, thr_poly); }
+__device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double *thr_poly)
 {
-    const int f = blockIdx.x * 64 + threadIdx.x;
-    if (f >= a.n_frames) return;
     const PreFrame &fr = a.fr[f];
     double *out = thr_poly + 3 * f;
     const double nn = fr.n_ground;
@@ -861,6 +869,38 @@ __global__ __launch_bounds__(64) void k_lean_solve(PreArgs a, double *thr_poly)
     }
     out[0] = x[0] / c2; out[1] = x[1] / c1; out[2] = x[2] / c0;
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
+}
+
+// Row minima of the frame's histogram, the two lines, and -- unless the frame needs NumPy's float32 mean first (k_lean_gather,
+// k_lean_mean32_solve) -- the quadratic: one block per frame instead of three launches (rowmin / lines / solve) in the chain of
+// dependent launches a small batch is bound by.  16 waves: wave w takes histogram rows w, w + 16, ...
+__global__ __launch_bounds__(1024) void k_lean_finish(PreArgs a, int xmean_f32, double *thr_poly)
+{
+    const int f = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const PreFrame &fr = a.fr[f];
+    const int ng = (int)fr.n_ground;
+    const double step = (fr.ymax - 5.0) / HY;
+    for (int row = wv; row < HX; row += 16) {
+        const int32_t *h = a.hist + ((int64_t)f * HX + row) * HY;
+        int best = 0x7fffffff, bidx = 0x7fffffff;
+        for (int b = lane; b < HY; b += 64) {
+            int c = h[b];
+            if (c == 0) c = ng;                                              // hist[hist == 0] = len(ground) (augmentation.py:234-235)
+            if (c < best) { best = c; bidx = b; }                            // ascending b per lane: first minimum
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const int ob = __shfl_xor(best, o), oi = __shfl_xor(bidx, o);
+            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        if (lane == 0) a.rowmin[(int64_t)f * HX + row] = (bidx == HY) ? fr.ymax : (double)bidx * step + 5.0;   // yedges[ymins] (:237)
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lean_lines_frame(a, f, xmean_f32);
+        if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
+    }
 }
 
 // ================================================================================================================
@@ -1094,7 +1134,7 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
         if (ensure(s, B_LEAF, nf * 3 * (size_t)max_leaves * 4)) return -1;
         hipLaunchKernelGGL(k_pre_gather, grid, dim3(PB), 0, st, a);
         LCHK();
-        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)a.n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)a.n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves, (double *)nullptr);
         LCHK();
     }
     return 0;
@@ -1126,22 +1166,18 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
     else hipLaunchKernelGGL(k_lean_hist<double>, grid, dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
-    LCHK();
-    hipLaunchKernelGGL(k_lean_lines, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, dtype == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_lean_finish, dim3((unsigned)n_frames), dim3(1024), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
     LCHK();
     if (dtype == 0) {
-        // only frames whose noise line fell back to p = linregress(range, I / cos) need NumPy's float32 mean of the ranges; the
-        // two kernels below leave at once for every other frame
+        // only frames whose noise line fell back to p = linregress(range, I / cos) need NumPy's float32 mean of the ranges (and
+        // their quadratic waits for it); the two kernels below leave at once for every other frame
         const int max_leaves = (int)(max_frame / 64 + 8);
         if (ensure(s, B_LEAF, nf * 3 * (size_t)max_leaves * 4)) return -1;
         hipLaunchKernelGGL(k_lean_gather<float>, grid, dim3(PB), 0, st, a);
         LCHK();
-        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves, thr_poly);
         LCHK();
     }
-    hipLaunchKernelGGL(k_lean_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, thr_poly);
-    LCHK();
     return 0;
 }
 
@@ -1215,7 +1251,7 @@ extern "C" int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int d
         LCHK();
         hipLaunchKernelGGL(k_lean_gather<float>, grid, dim3(PB), 0, st, a);
         LCHK();
-        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves);
+        hipLaunchKernelGGL(k_pre_mean32, dim3((unsigned)n_frames), dim3(PB), 0, st, a, (int *)s->buf[B_LEAF], max_leaves, (double *)nullptr);
         LCHK();
     }
     hipLaunchKernelGGL(k_lean_export, dim3(fb), dim3(64), 0, st, a, d_rec);

@@ -9,9 +9,10 @@
 //           land in lane order; a rank sort by (range, scan order) puts them near -> far (simulation.py:413-417);
 //   dict    every elementary slot costs one ballot (owner = first covering lane, simulation.py:284) and one row-minimum (the next
 //           endpoint) instead of a walk over the list; each lane keeps the running sum of the slots it owns, which IS NumPy's
-//           sum for fewer than 8 addends -- a beam where somebody collects 8 or more is put on a (nearly always empty) redo
-//           list and finished by the PAIRWISE instantiation of the same kernel, which streams NumPy's blocked pairwise sum
-//           (SgNpSum: 64 more registers, which the common case should not pay for), so the ratios stay bit-identical to
+//           sum for fewer than 8 addends -- a beam where a flake collects 8 or more is put on a (nearly always empty) redo list
+//           and finished by the PAIRWISE instantiation of the same kernel, which streams NumPy's blocked pairwise sum (SgNpSum:
+//           32 more registers, which the common case should not pay for); the hard target's slots, often more than 8, are summed
+//           NumPy's way by eight lanes of the row in every case -- so the ratios stay bit-identical to
 //           diffs[assignment == j].sum() (:289-293);
 //   power   amplitudes lane-parallel (one division per scatterer, all at once), the pruning bounds of sg_power_plan with the
 //           other scatterers read from a 2 KB LDS scratch, and the surviving (scatterer, bin) pairs of the whole wave
@@ -67,17 +68,26 @@ struct Row {
 };
 
 // One walk over the elementary slots of a row's beam (simulation.py:266-293): lane j holds the interval [a1, a2) of flake j
-// (+inf, +inf beyond the list).  PAIRWISE = false: running sums (exact for fewer than 8 addends per owner); true: NumPy's
-// blocked pairwise sum for any number (the rare repeat).  Returns the lane's own sum, the hard target's sum (replicated over the
-// row) and how many slots each collected.
+// (+inf, +inf beyond the list).  Returns the lane's own sum and the hard target's sum (replicated over the row) and how many slots
+// each collected.
+//   own sums   PAIRWISE = false: running sums -- exact for fewer than 8 addends per owner (np.add.reduce adds them left to right);
+//              true: NumPy's blocked pairwise sum for any number (SgNpSum: the rare repeat for an owner with 8 or more slots).
+//   target     ALWAYS NumPy's sum, whatever the count -- the gaps between the flakes of a long list easily make 8 or more
+//              unowned slots.  Lane-parallel: addend i of the target goes to lane i mod 8 of the row (its `pend`); when a block of
+//              eight is complete the eight lanes commit it to their accumulators r (NumPy's eight interleaved partial sums); at the
+//              end the accumulators are combined pairwise and the 0 .. 7 pending addends follow left to right -- operation for
+//              operation what loops_utils.h.src's pairwise_sum does for n <= 128 (a beam has at most 2 * 63 + 2 endpoints).
 template <int G, bool PAIRWISE>
 __device__ __forceinline__ void rw_slot_walk(bool row_on, double a1, double a2, double ra, double la, double e_min, double e_max,
                                              double &own_sum, int &own_cnt, double &tgt_sum, int &tgt_cnt)
 {
     using R = Row<G>;
-    SgNpSum acc_o, acc_t;
-    if constexpr (PAIRWISE) { acc_o.reset(); acc_t.reset(); }
-    own_sum = 0.0; own_cnt = 0; tgt_sum = 0.0; tgt_cnt = 0;
+    static_assert(G >= 8, "the target's pairwise sum uses eight lanes of the row");
+    SgNpSum acc_o;
+    if constexpr (PAIRWISE) acc_o.reset();
+    own_sum = 0.0; own_cnt = 0; tgt_cnt = 0;
+    double t_r = 0.0, t_pend = 0.0;                                   // lanes 0 .. 7 of the row: accumulator and pending addend
+    int t_blocks = 0;
     double e = e_min;
     const int me = R::lj();
     while (__any(row_on && e < e_max)) {
@@ -94,7 +104,12 @@ __device__ __forceinline__ void rw_slot_walk(bool row_on, double a1, double a2, 
             const double w = nxt - e;                                 // :266 diffs
             const int own = cm ? __ffsll((long long)cm) - 1 : -1;
             if (own < 0) {                                            // nobody claimed it: hard target (:292-293)
-                if constexpr (PAIRWISE) acc_t.push(w); else tgt_sum = tgt_cnt ? tgt_sum + w : w;
+                const int slot8 = tgt_cnt & 7;
+                if (me == slot8) t_pend = w;
+                if (slot8 == 7) {                                     // a block of eight is complete
+                    if (me < 8) t_r = t_blocks ? t_r + t_pend : t_pend;
+                    ++t_blocks;
+                }
                 ++tgt_cnt;
             } else if (own == me) {
                 if constexpr (PAIRWISE) acc_o.push(w); else own_sum = own_cnt ? own_sum + w : w;
@@ -103,8 +118,19 @@ __device__ __forceinline__ void rw_slot_walk(bool row_on, double a1, double a2, 
             e = nxt;
         }
     }
-    if constexpr (PAIRWISE) { own_sum = acc_o.result(); tgt_sum = acc_t.result(); }
-    else { own_sum = 0.0 + own_sum; tgt_sum = tgt_cnt ? 0.0 + (-0.0 + tgt_sum) : 0.0; }
+    if constexpr (PAIRWISE) own_sum = acc_o.result(); else own_sum = 0.0 + own_sum;
+    // the target: ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), then the pending addends oldest first, then 0.0 + .
+    {
+        const int rb = R::base();
+        double r[8], p[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { r[j] = __shfl(t_r, rb + j); p[j] = __shfl(t_pend, rb + j); }
+        double res = t_blocks ? ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])) : -0.0;
+        const int c = tgt_cnt & 7;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) if (j < c) res += p[j];
+        tgt_sum = 0.0 + res;
+    }
 }
 
 // The pruning bounds of sg_power_plan for ONE scatterer (amplitude A, window [k0, k1), range r, index t in dict order) against
@@ -297,8 +323,8 @@ __global__ __launch_bounds__(RW_BLOCK, PAIRWISE ? 2 : RW_WAVES) void k_rows(SgBe
         rw_slot_walk<G, PAIRWISE>(row_on, a1, a2, ra, la, e_min, e_max, own_sum, own_cnt, tgt_sum, tgt_cnt);
         bool deferred = false;                                            // row-uniform
         if constexpr (!PAIRWISE) {
-            const int worst = R::rmaxi(own_cnt > tgt_cnt ? own_cnt : tgt_cnt);
-            deferred = row_on && worst >= 8;                              // somebody sums 8 or more slots: NumPy's pairwise blocks
+            const int worst = R::rmaxi(own_cnt);
+            deferred = row_on && worst >= 8;                              // a flake owns 8 or more slots: NumPy's pairwise blocks (rare)
             if (deferred && lj == 0) a.redo_list[work_off + atomicAdd(&a.redo_cnt[a.cls], 1)] = g;
         }
         const bool has = row_on && !deferred && lj < L && own_cnt > 0;    // the flake owns a slot: it enters the dict (:288)
@@ -538,7 +564,7 @@ static int launch_rows_t(const SgBeamArgs *a, hipStream_t st)
     else hipLaunchKernelGGL((k_rows<T, G, false, false>), dim3(blocks), dim3(RW_BLOCK), 0, st, *a);
     RW_CHECK_LAUNCH();
     // the beams it deferred (an owner with 8 or more elementary slots): nearly always none -- a small grid that leaves at once
-    const unsigned redo_blocks = blocks;         // (the hard target of a long list often collects 8 or more slots: not that rare)
+    const unsigned redo_blocks = std::min(blocks, 64u);
     if (a->exact_math) hipLaunchKernelGGL((k_rows<T, G, true, true>), dim3(redo_blocks), dim3(RW_BLOCK), 0, st, *a);
     else hipLaunchKernelGGL((k_rows<T, G, false, true>), dim3(redo_blocks), dim3(RW_BLOCK), 0, st, *a);
     RW_CHECK_LAUNCH();
