@@ -215,11 +215,11 @@ extern "C" const char *snowgpu_last_error(const snowgpu_ctx *ctx) { return ctx ?
 static int init_streams(snowgpu_ctx *ctx)
 {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    {   // The prepass streams the rows once (bandwidth-bound, small blocks) beside kernels that fill the CUs with long-lived
-        // LDS-heavy blocks; at equal priority its blocks wait for slots and the 0.9 ms chain stretches past everything
-        // else.  It gets the highest stream priority; the others stay at the default.  (SNOWGPU_PRIO=<bits>: 1 aux,
-        // 2 aux2, 4 aux3 -- measured: none 5.04 ms per step, prepass only 4.93, prepass + k_power 4.90, all three 4.96.)
-        int least = 0, greatest = 0, mask = 2;
+    {   // Stream priorities of the side streams (SNOWGPU_PRIO=<bits>: 1 aux, 2 aux2, 4 aux3).  Rounds 1-3 ran the prepass (aux2) at the
+        // highest priority: its three scratch-array passes were starved by the long-lived LDS-heavy blocks beside them (5.04 vs 4.93 ms
+        // per step).  The lean prepass of round 4 reads the rows twice and nothing else; at equal priority the step is 1 % faster
+        // (4.62 vs 4.68 ms), so all streams are equal now.
+        int least = 0, greatest = 0, mask = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));
