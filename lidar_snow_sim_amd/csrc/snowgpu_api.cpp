@@ -215,11 +215,12 @@ extern "C" const char *snowgpu_last_error(const snowgpu_ctx *ctx) { return ctx ?
 static int init_streams(snowgpu_ctx *ctx)
 {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    {   // Stream priorities of the side streams (SNOWGPU_PRIO=<bits>: 1 aux, 2 aux2, 4 aux3).  Rounds 1-3 ran the prepass (aux2) at the
-        // highest priority: its three scratch-array passes were starved by the long-lived LDS-heavy blocks beside them (5.04 vs 4.93 ms
-        // per step).  The lean prepass of round 4 reads the rows twice and nothing else; at equal priority the step is 1 % faster
-        // (4.62 vs 4.68 ms), so all streams are equal now.
-        int least = 0, greatest = 0, mask = 0;
+    {   // Stream priorities of the side streams (SNOWGPU_PRIO=<bits>: 1 aux, 2 aux2, 4 aux3; default 2).  The prepass stream (aux2) sits
+        // in the HIGH-priority pool.  Rounds 1-3 needed that for scheduling (its scratch-array passes were starved by the long-lived
+        // LDS-heavy blocks beside them: 5.04 vs 4.93 ms per step); for the lean prepass of round 4 it no longer matters on the device
+        // entry (4.62 vs 4.68 ms the other way round) -- but the runtime hands out hardware queues per priority pool, and with aux2 in
+        // the normal pool the host pipeline's streams share queues: 1.47 instead of 1.85 G points/s through the host entry (measured).
+        int least = 0, greatest = 0, mask = 2;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed-base", type=int, default=1000)
+    ap.add_argument("--fast", action="store_true", help="the two headline figures only (A/B runs)")
     args = ap.parse_args()
     import bench                      # helpers only: bench.py imports torch lazily, inside main()
     assert "torch" not in sys.modules
@@ -73,6 +74,9 @@ def main():
     digest = [int(counts.sum()), int(stats[:, 0].sum()), int(stats[:, 1].sum()), int(stats[:, 2].sum()),
               float(pin_out[:int(counts[0]), 3].sum()), int(pin_src[:int(counts[0])].astype(np.int64).sum())]
     s_nosrc, b_nosrc = timed(False)
+    if args.fast:
+        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc}))
+        return
     # plane = NULL at the C ABI: calculate_plane (simulation.py:449) on the device inside the batch -- the reference's default call
     s_ref, _ = timed(True, "device")                                     # method 'reference': the plane the reference returns today
     eng.ctx.set_plane_method("lsq")
