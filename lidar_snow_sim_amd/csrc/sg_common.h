@@ -175,7 +175,7 @@ extern "C" {
 #endif
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
-                   int64_t max_tiles_per_frame, void *stream);
+                   int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, void *stream);
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);

@@ -746,10 +746,30 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // kernels: bandwidth-bound reductions beside latency-bound scans.
     const double *thr = b.thr_poly;
     bool pre_forked = false;
+    // The prepass' per-tile statistics ride on the channel sort's first pass over the rows when the plane is known by then: a
+    // caller's plane, or the reference-today plane (a constant).  Estimated planes (least squares, RANSAC) come later, on the
+    // prepass stream, and the statistics keep their own pass.
+    static const bool no_fuse = std::getenv("SNOWGPU_NO_SORT_STATS") != nullptr;        // A/B
+    const bool fuse_stats = !b.thr_poly && !b.perm && !no_fuse && !sg_prepass_legacy() && !R->prepass_early &&
+                            (b.plane != nullptr || R->plane_par.method == SG_PLANE_REFERENCE);
+    const double *early_plane = b.plane;
+    double *lean_part = nullptr;
+    if (fuse_stats) {
+        if (!early_plane) {
+            ENSURE(ctx, ctx->plane_est, (size_t)b.n_frames * 4);
+            ENSURE(ctx, ctx->plane_info, (size_t)b.n_frames * 4);
+            int pe = sg_plane_run(&ctx->plane_scr, &R->plane_par, b.rows, b.dtype, b.frame_off, nullptr, b.n_frames, b.n_total, b.max_frame,
+                                  ctx->plane_est.p, ctx->plane_info.p, st);
+            if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+            early_plane = ctx->plane_est.p;
+        }
+        lean_part = sg_prepass_reserve_tiles(&ctx->prepass, b.n_frames, b.max_frame);
+        if (!lean_part) return fail(ctx, SNOWGPU_E_HIP, "prepass: allocation");
+    }
     auto launch_prepass = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
         HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
-        const double *pl = b.plane;
+        const double *pl = fuse_stats ? early_plane : b.plane;
         if (!pl) {                                  // simulation.py:449 calculate_plane(pc): on the device, by the context's method
             ENSURE(ctx, ctx->plane_est, (size_t)b.n_frames * 4);
             ENSURE(ctx, ctx->plane_info, (size_t)b.n_frames * 4);
@@ -759,7 +779,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             pl = ctx->plane_est.p;
         }
         int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, pl,
-                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2);
+                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2, fuse_stats ? 1 : 0);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         if (b.out_thr_poly)
             HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, ctx->thr_poly.p, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, s_aux2));
@@ -783,7 +803,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->perm, n);
         ENSURE(ctx, ctx->keep, n);                // channel bytes between the two sort passes; flag / keep bytes afterwards
         int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
-                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, st);
+                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, fuse_stats ? early_plane : nullptr, lean_part, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;
     }

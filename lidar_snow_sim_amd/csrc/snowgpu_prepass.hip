@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include "sg_common.h"
 #include "sg_prepass.h"
+#include "sg_lean.h"
 
 #define PB 256
 #define HX 50     /* range rows of the histogram (augmentation.py:232) */
@@ -35,10 +36,7 @@ struct PreFrame {          // per-frame state shared by the kernels
     double sxx, sxy;
     double q[11];          // LQ_* below
 };
-// q: sums over the ground rows with a1 = range, a2 = range^2 (a float32 product for float32 rows, as np.polyfit has it), c = cos(angle)
-enum { LQ_A2A2 = 0, LQ_A2A1, LQ_A2, LQ_A1A1, LQ_A1, LQ_A2GC, LQ_A2C, LQ_A1GC, LQ_A1C, LQ_GC, LQ_C };
-#define LP_COLS 20         /* doubles per tile of the lean path's partials */
-enum { LP_N = 0, LP_SX, LP_SY, LP_YMAX, LP_MXX, LP_MXY, LP_PREFIX, LP_Q0 = 8 /* .. LP_Q0 + 10 */ };
+// (LQ_* : the sums of the quadratic fit, LP_* : the per-tile partials -- sg_lean.h)
 
 struct PreArgs {
     const void *rows;
@@ -578,80 +576,25 @@ __global__ __launch_bounds__(64) void k_pre_poly_solve(PreArgs a, double *thr_po
 // instead of loading them.  Tiles are combined per frame in a fixed order (Chan's pairwise update for the centred
 // moments), so a batch is reproducible run to run.  No per-row scratch at all.
 template <typename T>
-__device__ __forceinline__ bool lean_row(const PreArgs &a, double w0, double w1, double w2, double h, double wn, T x, T y, T z, T inten,
-                                         double &gd, double &gn, double &gc)
-{
-    const double dot = ((double)x * w0 + (double)y * w1) + (double)z * w2;   // np.matmul(pc[:, :3], w)
-    const double hog = dot + h;
-    if (!(hog < a.delta && hog > -a.delta)) return false;                    // simulation.py:450-451
-    double nrm;
-    if (sizeof(T) == 4) nrm = (double)sqrtf((float)((x * x + y * y) + z * z));   // float32 norm (simulation.py:455)
-    else { const double xd = (double)x, yd = (double)y, zd = (double)z; nrm = sqrt((xd * xd + yd * yd) + zd * zd); }
-    const double c = dot / (nrm * wn);                                       // simulation.py:454-455; cos(arccos(c)) taken as c
-    gc = fabs(c) <= 1.0 ? c : NAN;                                           // arccos outside [-1, 1] is NaN in the reference too
-    gn = (double)inten / gc;                                                 // augmentation.py:207
-    gd = nrm;                                                                // augmentation.py:208
-    return true;
-}
-
-template <typename T>
 __global__ __launch_bounds__(PB) void k_lean_stats(PreArgs a)
 {
     const int f = blockIdx.y;
     const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
-    const double *pl = a.plane + 4 * f;
-    const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
-    const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);              // np.linalg.norm(w)
     const T *rows = (const T *)a.rows;
     T rx[4], ry[4], rz[4], ri[4];                // all loads of the tile in flight before the first use
+    bool valid[4];
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
-        const T *p = rows + (base + (r < n ? r : 0)) * 5;
+        valid[q] = r < n;
+        const T *p = rows + (base + (valid[q] ? r : 0)) * 5;
         rx[q] = p[0]; ry[q] = p[1]; rz[q] = p[2]; ri[q] = p[3];
     }
-    bool g[4];
-    double gd[4], gn[4], gc[4];
-    double v[3] = {0.0, 0.0, 0.0};
-    double ymax = -INFINITY;
-    for (int q = 0; q < 4; ++q) {
-        const int64_t r = tile0 + q * PB + threadIdx.x;
-        g[q] = r < n && lean_row<T>(a, w0, w1, w2, h, wn, rx[q], ry[q], rz[q], ri[q], gd[q], gn[q], gc[q]);
-        if (g[q]) { v[0] += 1.0; v[1] += gd[q]; v[2] += gn[q]; ymax = fmax(ymax, gn[q]); }
-    }
-    __shared__ double sm[4 * 13];
-    __shared__ double smax[4];
-    __shared__ double s_mean[2];
-    block_sum<3>(v, sm);
-    ymax = wave_max(ymax);
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = ymax;
-    if (threadIdx.x == 0) { s_mean[0] = v[0] > 0 ? v[1] / v[0] : 0.0; s_mean[1] = v[0] > 0 ? v[2] / v[0] : 0.0; }
-    __syncthreads();
-    const double mx = s_mean[0], my = s_mean[1];
-    const double cnt = v[0], sx = v[1], sy = v[2];      // (valid in thread 0 only)
-    double u[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = 0; q < 4; ++q) {
-        if (!g[q] || gn[q] != gn[q]) continue;
-        const double dx = gd[q] - mx, dy = gn[q] - my;
-        u[0] += dx * dx; u[1] += dx * dy;
-        // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
-        double a2;
-        if constexpr (sizeof(T) == 4) { const float xf = (float)gd[q]; a2 = (double)(xf * xf); }
-        else a2 = gd[q] * gd[q];
-        const double a1 = gd[q], c = gc[q], dc = gd[q] * c;
-        u[2 + LQ_A2A2] += a2 * a2; u[2 + LQ_A2A1] += a2 * a1; u[2 + LQ_A2] += a2; u[2 + LQ_A1A1] += a1 * a1; u[2 + LQ_A1] += a1;
-        u[2 + LQ_A2GC] += a2 * dc; u[2 + LQ_A2C] += a2 * c; u[2 + LQ_A1GC] += a1 * dc; u[2 + LQ_A1C] += a1 * c;
-        u[2 + LQ_GC] += dc; u[2 + LQ_C] += c;
-    }
-    block_sum<13>(u, sm);
-    if (threadIdx.x == 0) {
-        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS;
-        o[LP_N] = cnt; o[LP_SX] = sx; o[LP_SY] = sy;
-        o[LP_YMAX] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
-        o[LP_MXX] = u[0]; o[LP_MXY] = u[1];
-        for (int k = 0; k < 11; ++k) o[LP_Q0 + k] = u[2 + k];
-    }
+    __shared__ double sm[58];
+    SgLeanTile lt;
+    lt.plane = a.plane; lt.delta = a.delta; lt.part = a.part; lt.max_tiles = a.max_tiles;
+    lean_tile_stats<T>(lt, f, blockIdx.x, rx, ry, rz, ri, valid, sm);
 }
 
 // one wave per frame: exclusive prefix of the tile counts, means, maximum, centred moments and the fit's sums
@@ -734,7 +677,7 @@ __global__ __launch_bounds__(PB) void k_lean_hist(PreArgs a)
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
         double gd, gn, gc;
-        if (r < n && lean_row<T>(a, w0, w1, w2, h, wn, rx[q], ry[q], rz[q], ri[q], gd, gn, gc) && gn == gn) {
+        if (r < n && lean_row<T>(a.delta, w0, w1, w2, h, wn, rx[q], ry[q], rz[q], ri[q], gd, gn, gc) && gn == gn) {
             const int bx = hist_bin(gd, 10.0, 70.0, HX);                 // augmentation.py:232-233
             const int by = hist_bin(gn, 5.0, ymaxv, HY);
             if (bx >= 0 && by >= 0) key[q] = bx * HY + by;
@@ -817,7 +760,7 @@ __global__ __launch_bounds__(PB) void k_lean_gather(PreArgs a)
         g[q] = false;
         if (r < n) {
             const T *p = rows + (base + r) * 5;
-            g[q] = lean_row<T>(a, w0, w1, w2, h, wn, p[0], p[1], p[2], p[3], gdv[q], gn, gc) && gn == gn;
+            g[q] = lean_row<T>(a.delta, w0, w1, w2, h, wn, p[0], p[1], p[2], p[3], gdv[q], gn, gc) && gn == gn;
         }
         const unsigned long long m = __ballot(g[q]);
         pre[q] = __popcll(m & lt);
@@ -1141,8 +1084,17 @@ static int estimate(SgPrepassScratch *s, PreArgs &a, int dtype, int64_t n_total,
 }
 
 // The snowfall prepass without per-row scratch: two passes over the rows (statistics; histogram), the rest per frame.
+// (the tile partials' buffer, for a caller whose own row-streaming kernel fills it: sg_launch_sort with statistics)
+extern "C" double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, int64_t max_frame)
+{
+    const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
+    if (ensure(s, B_PART, (size_t)n_frames * (size_t)max_tiles * LP_COLS * 8)) return nullptr;
+    return (double *)s->buf[B_PART];
+}
+
 static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
-                    int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status, hipStream_t st)
+                    int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status, hipStream_t st,
+                    bool tiles_done)
 {
     PreArgs a{};
     a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
@@ -1158,9 +1110,11 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
-    if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, st, a);
-    else hipLaunchKernelGGL(k_lean_stats<double>, grid, dim3(PB), 0, st, a);
-    LCHK();
+    if (!tiles_done) {                               // (else the channel sort's first kernel left the tile partials on its way over the rows)
+        if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, st, a);
+        else hipLaunchKernelGGL(k_lean_stats<double>, grid, dim3(PB), 0, st, a);
+        LCHK();
+    }
     hipLaunchKernelGGL(k_lean_means, dim3((unsigned)n_frames), dim3(64), 0, st, a, 3, 7 /* SNOWGPU_E_GROUND */);
     LCHK();
     if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
@@ -1261,13 +1215,18 @@ extern "C" int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int d
     return 0;
 }
 
+extern "C" int sg_prepass_legacy(void)
+{
+    static const bool legacy = getenv("SNOWGPU_PREPASS_LEGACY") != nullptr;      // A/B: the three-scratch-array chain of rounds 1-3
+    return legacy ? 1 : 0;
+}
+
 extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                               int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
-                              int32_t *status, void *stream)
+                              int32_t *status, void *stream, int tiles_done)
 {
     hipStream_t st = (hipStream_t)stream;
-    static const bool legacy = getenv("SNOWGPU_PREPASS_LEGACY") != nullptr;      // A/B: the three-scratch-array chain of rounds 1-3
-    if (!legacy) return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, st);
+    if (!sg_prepass_legacy()) return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, st, tiles_done != 0);
     PreArgs a{};
     a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
     a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
