@@ -814,6 +814,15 @@ __device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
 }
 
+// lines and (unless the frame needs NumPy's float32 mean first) the quadratic, one thread per frame, after k_pre_rowmin
+__global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f32, double *thr_poly)
+{
+    const int f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= a.n_frames) return;
+    lean_lines_frame(a, f, xmean_f32);
+    if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
+}
+
 // Row minima of the frame's histogram, the two lines, and -- unless the frame needs NumPy's float32 mean first (k_lean_gather,
 // k_lean_mean32_solve) -- the quadratic: one block per frame instead of three launches (rowmin / lines / solve) in the chain of
 // dependent launches a small batch is bound by.  16 waves: wave w takes histogram rows w, w + 16, ...
@@ -1120,8 +1129,15 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
     else hipLaunchKernelGGL(k_lean_hist<double>, grid, dim3(PB), 0, st, a);
     LCHK();
-    hipLaunchKernelGGL(k_lean_finish, dim3((unsigned)n_frames), dim3(1024), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
-    LCHK();
+    if (n_frames <= 16) {        // small batches are bound by their chain of dependent launches: row minima, lines and quadratic in one
+        hipLaunchKernelGGL(k_lean_finish, dim3((unsigned)n_frames), dim3(1024), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
+        LCHK();
+    } else {                     // large ones by throughput: 50 blocks per frame read the histogram (one block per frame took 0.9 ms of a 256-sweep step)
+        hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_lean_lines_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
+        LCHK();
+    }
     if (dtype == 0) {
         // only frames whose noise line fell back to p = linregress(range, I / cos) need NumPy's float32 mean of the ranges (and
         // their quadratic waits for it); the two kernels below leave at once for every other frame
