@@ -18,7 +18,7 @@ def short(name):
 
 # ---- bench lines --------------------------------------------------------------------------------------------------
 lines = {}
-for w in ("C2", "C2far", "C1", "C4", "C3"):
+for w in ("C2", "C2far", "C1", "C4", "C3", "C2_device_tables"):
     f = ev / f"bench_{w}.json"
     if f.exists():
         got = [l for l in f.read_text().splitlines() if l.startswith("{")]
@@ -42,7 +42,7 @@ if bench and bench.get("roofline", {}).get("traffic"):
            "bytes_per_launch": rl["traffic"], "detail": rl.get("traffic_detail"),
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate child passes of `bench.py --steps 2 --warmup 1`, summed over the kernels "
                    "of the timed region, averaged over the 3 steps, counters x 1024 B x calibration factor (FETCH_SIZE x 2.0 on gfx950: "
-                   f"{tag}_pmc_calibration.json, kernels of known byte counts)"}
+                   f"r03_pmc_calibration.json, kernels of known byte counts)"}
     (prof / "hbm_traffic.json").write_text(json.dumps(rec, indent=1))
 for w in ("C5",):
     f = ev / f"bench_{w}.json"
@@ -56,7 +56,7 @@ sq = subprocess.run([sys.executable, str(root / "scripts" / "pmc_summary.py"), s
 keep, cur = [], []
 for ln in sq.splitlines() + [""]:
     if not ln.startswith(" "):
-        if cur and cur[0].startswith(("void k_beams", "void k_power")):
+        if cur and cur[0].startswith(("void k_beams", "void k_power", "void k_rows", "void k_tier_scan_direct")):
             keep += cur
         cur = [ln]
     else:
