@@ -88,7 +88,6 @@ struct SgBeamArgs {
     uint32_t *rec_q;             // per queue slot of the direct-mode pass: result record of the beam queued there
     void *rng;                   // per sorted position: the beam's range in the row dtype (simulation.py:89), written by the pass over
                                  // all rows for every simulated beam: the noise-floor pass reads 4 bytes instead of gathering the row
-    uint8_t *flag;               // per sorted position: 0, or 3 + k for a beam that needs later capacity tier k
     int32_t *status;             // [0] error code, [1] first offending sorted row
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
     int32_t exact_math;          // 1: libm sin / tan + true division (validation mode)
@@ -129,12 +128,18 @@ struct SgBeamArgs {
     int32_t kp_lds_quarters;     // host: share of a CU's capacity k_power takes for the main queue (1..4 quarters; 0 = all)
     int64_t dq_n;                // plane stride (= n_total)
     // list mode: this launch handles entries [work_lo, min(work_hi, count)) of class `cls` of the tier lists
-    const int32_t *tier_list;    // the class lists, concatenated
-    const int32_t *tier_info;    // [0..3] entries per class, [4..7] start of each class in tier_list
+    // The pass over all rows puts an over-full beam on the list of the tier that holds all its flakes: into its region's slice of
+    // tier_sparse (class k at k * tier_stride; tn[region][k] entries from the region's first sorted position on), which k_power_plan
+    // (bases) and k_tier_gather close up into tier_list.  Any order: a tier's results do not depend on it.
+    int32_t *tier_list;          // the class lists, tier_stride (= n_total) entries apart
+    int32_t *tier_info;          // [0..3] entries per class
+    int64_t tier_stride;
+    int32_t *tier_sparse;        // the same before closing up
+    int32_t *tn, *tbase;         // per region x SG_MAX_CLASSES: entries, start in the closed-up list
     int32_t cls;
     int32_t work_lo, work_hi;
     // row kernels (snowgpu_rows.hip): beams whose dict needs NumPy's pairwise sum (an owner with >= 8 slots) are deferred to a
-    // second instantiation through this list (laid out like tier_list: class k from tier_info[4 + k]) and its per-class counters
+    // second instantiation through this list (laid out like tier_list: class k at k * tier_stride) and its per-class counters
     int32_t *redo_list;
     int32_t *redo_cnt;
     // dict hand-over of a list-mode pass: entry i of the class -> slot i (planes of tq_cap entries)
@@ -179,7 +184,8 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
-int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream);
+int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, void *ev_plan /* hipEvent_t recorded behind the plan kernel, or null */);
+int sg_launch_tier_gather(const SgBeamArgs *args, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);
 // the scan of a later tier without LDS lists: hits go to the tier's hand-over buffer in scan order (args->tq_unsorted must be 1 for its k_power)
@@ -193,8 +199,6 @@ int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *ti
                        int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
                        int32_t *chunk_blk, const SgTable *tables, SgTable *resolved /* n_frames x n_las, or null */, void *stream);
 int sg_beams_block(int lmax);
-int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list, int32_t *tier_info,
-                         int32_t *status_counts, int32_t cap, int n_cls, void *stream);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,

@@ -59,6 +59,7 @@ struct snowgpu_ctx {
     hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;   // prepass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // resolve / segments
     hipEvent_t ev_fp[SG_MAX_CHUNKS] = {}, ev_join2 = nullptr;   // chunk of the first pass done -> its k_power
+    hipEvent_t ev_plan[SG_MAX_CHUNKS] = {};                      // ... its k_power_plan done -> the tier lists can be closed up
     hipEvent_t ev_lists = nullptr, ev_join3 = nullptr;   // tier lists built -> later tiers
     std::string err;
     std::vector<DeviceTable> tables;
@@ -91,14 +92,13 @@ struct snowgpu_ctx {
     DevBuf<double> ov;                // overflow slots of the pass over all rows (SG_OV_STRIDE doubles per sorted position)
     DevBuf<uint16_t> ov_sc;
     int use_ov = 1;                   // SNOWGPU_OVERFLOW_SLOTS=0: every over-full beam is scanned again by its tier (rounds 1-3)
-    DevBuf<int32_t> tier_list, tier_info, ttile_cnt, ttile_base, redo_list, redo_cnt;
+    DevBuf<int32_t> tier_list, tier_sparse, tier_info, tbase, redo_list, redo_cnt;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
     DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
     DevBuf<double> h_lists;           // global-list tier: per-lane lists
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
-    int lists_first = 0;              // SNOWGPU_LISTS_FIRST=1: tier lists (and so the tiers) before k_power and the prepass start
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
@@ -230,6 +230,7 @@ static int init_streams(snowgpu_ctx *ctx)
     for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
     for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
+    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_plan[c], hipEventDisableTiming));
     return SNOWGPU_OK;
 }
 
@@ -256,6 +257,7 @@ static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks, int n_lanes)
         for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3})
             HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
         for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_fp[c], hipEventDisableTiming));
+        for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_plan[c], hipEventDisableTiming));
     }
     return SNOWGPU_OK;
 }
@@ -273,7 +275,6 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_LISTS_FIRST"); ctx->lists_first = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
@@ -334,7 +335,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
     ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->ov.release(); ctx->ov_sc.release();
     ctx->redo_list.release(); ctx->redo_cnt.release();
-    ctx->tier_list.release(); ctx->tier_info.release(); ctx->ttile_cnt.release(); ctx->ttile_base.release(); ctx->h_lists.release();
+    ctx->tier_list.release(); ctx->tier_sparse.release(); ctx->tbase.release(); ctx->tier_info.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_out.release();
@@ -352,6 +353,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3})
         if (e) (void)hipEventDestroy(e);
     for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_fp[c]) (void)hipEventDestroy(ctx->ev_fp[c]);
+    for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_plan[c]) (void)hipEventDestroy(ctx->ev_plan[c]);
     for (hipStream_t st : {ctx->aux3, ctx->aux2, ctx->aux, ctx->stream})
         if (st) (void)hipStreamDestroy(st);
     delete ctx;
@@ -852,15 +854,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->rng, n * (b.dtype == 0 ? 4 : 8));
     ENSURE(ctx, ctx->keep, n);
     ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
-    ENSURE(ctx, ctx->tier_list, n);
+    ENSURE(ctx, ctx->tier_list, n * (size_t)n_tiers);      // one list per later tier, each as long as the batch (address space) ...
+    ENSURE(ctx, ctx->tier_sparse, n * (size_t)n_tiers);    // ... and the same as the scan leaves them: region by region
     ENSURE(ctx, ctx->tier_info, 2 * SG_MAX_CLASSES);
-    const size_t ttiles = (n + SG_TILE - 1) / SG_TILE + 1;
-    ENSURE(ctx, ctx->ttile_cnt, SG_MAX_CLASSES * ttiles);
-    ENSURE(ctx, ctx->ttile_base, SG_MAX_CLASSES * ttiles);
     ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);
     ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
-    // flag bytes of the first pass (3 + k: the beam needs later capacity tier k): nothing stale may be left in them
-    HIPCHK(ctx, hipMemsetAsync(ctx->keep.p, 0, n, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->tier_info.p, 0, sizeof(int32_t) * 2 * SG_MAX_CLASSES, st));
     SgBeamArgs a{};
@@ -869,7 +867,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.las = R->d_las; a.frame_tables = ctx->frame_tables.p;
     a.rgrid = R->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
-    a.flag = ctx->keep.p; a.status = b.status; a.diff2 = ctx->diff2.p;
+    a.status = b.status; a.diff2 = ctx->diff2.p;
     static const bool no_rng = std::getenv("SNOWGPU_NO_RNG") != nullptr;      // A/B: the noise-floor pass gathers every row again
     a.rng = no_rng ? nullptr : ctx->rng.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
@@ -892,9 +890,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.cls_cap[n_cls - 1] = h_cap;
     ENSURE(ctx, ctx->h_lists, (size_t)4 * (size_t)(h_cap + 1) * (size_t)h_lanes);
     a.h_lists = ctx->h_lists.p; a.h_cap = h_cap; a.h_lanes = h_lanes;
-    a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p;
+    a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p; a.tier_stride = b.n_total; a.tier_sparse = ctx->tier_sparse.p;
     if (tier_rows) {
-        ENSURE(ctx, ctx->redo_list, n);
+        ENSURE(ctx, ctx->redo_list, n * (size_t)n_tiers);
         ENSURE(ctx, ctx->redo_cnt, SG_MAX_CLASSES);
         HIPCHK(ctx, hipMemsetAsync(ctx->redo_cnt.p, 0, sizeof(int32_t) * SG_MAX_CLASSES, st));
         a.redo_list = ctx->redo_list.p; a.redo_cnt = ctx->redo_cnt.p;
@@ -919,8 +917,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->dq, (n + 64) * planes);          // blocked SoA: groups of 64 slots
         ENSURE(ctx, ctx->dq_g, n);
         ENSURE(ctx, ctx->dq_sc, n);
-        ENSURE(ctx, ctx->qn, regions);
-        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * regions, st));
+        // per region: the queue counter, then (same allocation, one memset) the SG_MAX_CLASSES tier-list counters
+        static_assert(SG_MAX_CLASSES * sizeof(int32_t) == 2 * sizeof(unsigned long long), "tn follows qn");
+        ENSURE(ctx, ctx->qn, 3 * regions);
+        ENSURE(ctx, ctx->tbase, SG_MAX_CLASSES * regions);
+        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * 3 * regions, st));
+        a.tn = (int32_t *)(ctx->qn.p + regions); a.tbase = ctx->tbase.p;
         a.dq = ctx->dq.p; a.dq_g = ctx->dq_g.p; a.dq_sc = ctx->dq_sc.p; a.qn = ctx->qn.p; a.dq_n = b.n_total;
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
@@ -949,7 +951,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = 0;
-    const bool lists_first = n_chunks == 1 && R->lists_first;
     {
         // linear order: regions are runs of 8 blocks, chunk boundaries fall on them
         const int64_t lin_blocks = (b.n_total + first_block - 1) / first_block;
@@ -964,21 +965,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             }
             e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
             if (e) break;
-            // SNOWGPU_LISTS_FIRST=1: the tier lists -- three short kernels that the chain lists -> tier scan -> tier power
-            // starts with -- before k_power and the prepass are released.  Whoever reaches the CUs first keeps them: with many
-            // beams in the tiers (C2far: 16 %) the step gains 6 %, with few (C2: 3.5 %) k_power starts behind the tier scans
-            // and the step loses 18 %.  The host does not know the counts when it launches, so the default stays "beside".
-            if (lists_first) {
-                e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
-                                         b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
-                if (e) break;
-            }
             // The pass queued the beams that met a flake: their received-power phase runs on a side stream, next to the
             // following chunks and to the (latency-bound, mostly empty) later capacity tiers.
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp[c], 0));
             HIPCHK(ctx, hipMemsetAsync(ctx->pw_count.p, 0, sizeof(int32_t), s_aux));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, ctx->ev_plan[c]);
+            if (e) break;
+            // the tier lists closed up: behind the plan kernel, on the caller's stream, where the tiers start
+            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_plan[c], 0));
+            e = sg_launch_tier_gather(&a, st);
         }
     }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
@@ -986,12 +982,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // The noise-threshold prepass streams the rows (bandwidth-bound, no LDS): it runs beside the received-power phase and
     // the later tiers (latency-bound, LDS-bound) rather than beside the sort and the scan, which it would slow down.
     if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
-    // Tier lists from the flag bytes (the scan counted on past a full list, so every flagged beam knows its tier), then
-    // the tiers side by side: class 0 on the caller's stream, the others on two side streams.
-    if (!lists_first)
-        e = sg_launch_tier_lists(ctx->keep.p, b.n_total, ctx->ttile_cnt.p, ctx->ttile_base.p, ctx->tier_list.p, ctx->tier_info.p,
-                                 b.status + 2, (int32_t)std::min<size_t>(n, (size_t)INT32_MAX), n_cls, st);
-    if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier list launch: ") + hipGetErrorString((hipError_t)e));
+    // The scan put every over-full beam on the list of its tier (it counted on past a full list, so the beam knows which): the tiers
+    // start as soon as it has ended, side by side -- class 0 on the caller's stream, the others on a side stream.
     const bool side3 = n_cls >= 2;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
     for (int k = 0; k < n_cls && !e; ++k) {

@@ -3,9 +3,9 @@
 //   k_sort_*     stable counting sort of every frame's rows by channel                      (simulation.py:447)
 //   k_seg_*      launch order of the first pass: (table, frame, channel) segments
 //   k_beams      one thread per beam: candidate scan + occlusion dict; beams with flakes hand their dict to k_power
-//                through a compact queue, beams with more flakes than the list holds are flagged with the capacity
+//                through a compact queue, beams with more flakes than the list holds go on the list of the capacity
 //                tier that takes them                                                       (simulation.py:50-424)
-//   k_tier_*     ordered tier lists from the flag bytes
+//   k_tier_scan_direct  the scan of a later tier whose lists the first pass could not keep
 //   k_power      received power on the 10 cm grid, first maximum, attenuate-or-scatter        (simulation.py:135-188)
 //   k_beams_huge the global-list tier (more than 63 flakes in one beam)
 //   k_compact_*  output rows from original rows + 4-byte result records, noise-floor filter, camera-FOV crop, stable
@@ -185,7 +185,7 @@ __device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 // The per-beam kernel.  Dynamic LDS: four per-thread lists of LMAX + 1 float64 entries, strided by the block size.
 //   LIST = false  direct mode, the pass over all rows: phases 1-2 (scan, occlusion dict).  A beam without flakes is
 //                 finished (record written); a beam with flakes hands its dict to k_power through its region's slice
-//                 of the dict queue; a beam with more flakes than the list holds is flagged with the capacity tier that
+//                 of the dict queue; a beam with more flakes than the list holds is appended to the list of the capacity tier that
 //                 takes all of them (the scan counts on, so the count is exact).
 //   LIST = true   a later capacity tier over its class of the tier lists; DICT = true: dict hand-over to
 //                 k_power<.., LISTQ> (entry i of the class -> slot i), DICT = false: phases 1-3 in place (the entries
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
     if (LIST) {
         work_n = a.tier_info[a.cls];
         if (work_n > a.work_hi) work_n = a.work_hi;
-        work_off = a.tier_info[4 + a.cls];
+        work_off = (int64_t)a.cls * a.tier_stride;
     }
     const int64_t stride = (int64_t)gridDim.x * BLOCK;
     int seg_f = -1, seg_ch = -1;                      // segment-ordered direct mode: the block's frame and channel
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
     double theta_c = 0.0;
     SgTable tab{};
     bool act = false;                                 // this lane simulates a beam
+    [[maybe_unused]] int tier_k = -1;                 // the pass over all rows: the later tier this beam goes to
     if (simulated) {
         tab = a.frame_tables[(int64_t)f * n_las + ch];   // resolved per (frame, channel) by k_resolve_tables
         if (tab.entries == nullptr) atomicCAS(&a.status[0], 0, 1 /* SNOWGPU_E_INVALID */);
@@ -339,12 +340,29 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
                 atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
                 atomicCAS(&a.status[1], -1, (int32_t)g);
             } else {
-                a.flag[g] = (uint8_t)(3 + k);         // k_tier_* build the tier lists from the flags, in sorted-row order
+                tier_k = k;                           // appended to that tier's list below
                 pending = true;
             }
         } else if (o.range_error) {
             atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
             atomicCAS(&a.status[1], -1, (int32_t)g);
+        }
+    }
+    if constexpr (!LIST) {
+        // ---- tier lists: an over-full beam goes on its REGION's slice of its tier's list -- one atomic per wave and class on the
+        // region's counter (thousands of addresses; one counter per class for the whole batch was measured: 300 000 atomics on one
+        // address, device scope, made this pass 40 % slower).  k_power_plan / k_tier_gather close the slices up afterwards.
+        // Nothing to do for the 96 % of the waves without an over-full beam.
+        if (__ballot(tier_k >= 0)) {
+            for (int k = 0; k < a.n_cls; ++k) {
+                const unsigned long long m = __ballot(tier_k == k);
+                if (!m) continue;
+                const int leader = __ffsll((long long)m) - 1;
+                int base = 0;
+                if ((tid & 63) == leader) base = atomicAdd(&a.tn[(int64_t)__builtin_amdgcn_readfirstlane(region) * SG_MAX_CLASSES + k], (int)__popcll(m));
+                base = __shfl(base, leader);
+                if (tier_k == k) a.tier_sparse[(int64_t)k * a.tier_stride + q_base + base + (int)__popcll(m & sg_lanemask_lt())] = (int32_t)g;
+            }
         }
     }
     if constexpr (DICT) {
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(256, 4) void k_tier_scan_direct(SgBeamArgs a)
     const int n_las = a.las->n;
     int64_t work_n = a.tier_info[a.cls];
     if (work_n > a.work_hi) work_n = a.work_hi;
-    const int64_t work_off = a.tier_info[4 + a.cls];
+    const int64_t work_off = (int64_t)a.cls * a.tier_stride;
     for (int64_t i = (int64_t)a.work_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < work_n; i += (int64_t)gridDim.x * 256) {
         const int32_t g = a.tier_list[work_off + i];
         const int f = sg_frame_of(a, g);
@@ -492,13 +510,12 @@ __global__ __launch_bounds__(256, 4) void k_tier_scan_direct(SgBeamArgs a)
 // Work items of k_power for the queue of a direct-mode pass: one item = up to `lanes` consecutive live slots of one
 // region (its front run, then its back run).  One thread per region; items are appended with one atomic per wave.
 // item = {first slot, count | (frame + 1) << 10}; the back run (beams with several flakes) in items of lanes_back slots.
-__global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int lanes_back, int n_regions_ub)
+// region r of this launch's block range: its slice [q_base, q_base + q_size) of the sorted positions, its frame + 1 (segments)
+__device__ __forceinline__ bool sg_region(const SgBeamArgs &a, int r, int n_regions_ub, int64_t &q_base, int &q_size, int &f1)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    int n_items = 0, nf = 0, nb = 0, q_size = 0, f1 = 0;
-    int64_t q_base = 0;
     const int64_t lo = a.chunk_blk ? a.chunk_blk[a.chunk] : a.blk_lo, hi = a.chunk_blk ? a.chunk_blk[a.chunk + 1] : a.blk_hi;
     bool mine = false;
+    q_base = 0; q_size = 0; f1 = 0;
     if (a.seg_blk) {
         if (r < a.seg_n[0]) {
             const int64_t b0 = a.seg_blk[r];
@@ -510,6 +527,26 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
         const int64_t b0 = q_base / a.blk_rows;
         mine = q_base < a.n_total && b0 >= lo && b0 < hi;
         if (mine) q_size = (int)(a.n_total - q_base < a.q_chunk ? a.n_total - q_base : a.q_chunk);
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int lanes_back, int n_regions_ub)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int n_items = 0, nf = 0, nb = 0, q_size = 0, f1 = 0;
+    int64_t q_base = 0;
+    const bool mine = sg_region(a, r, n_regions_ub, q_base, q_size, f1);
+    // the later tiers' lists: where this region's slice of each goes in the closed-up list (tier_info[k] ends up as the length)
+    for (int k = 0; k < a.n_cls; ++k) {
+        const int c = mine ? a.tn[(int64_t)r * SG_MAX_CLASSES + k] : 0;
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+        const int total = __shfl(inc, 63);
+        int base = 0;
+        if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(&a.tier_info[k], total);
+        base = __shfl(base, 63) + inc - c;
+        if (mine) a.tbase[(int64_t)r * SG_MAX_CLASSES + k] = base;
     }
     if (mine) {
         const unsigned long long c = a.qn[r];
@@ -526,6 +563,23 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
         a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 10));
     for (int k = 0; k < nb; k += lanes_back)
         a.pw_items[base++] = make_int2((int)(q_base + q_size - nb + k), (nb - k < lanes_back ? nb - k : lanes_back) | (f1 << 10));
+}
+
+// The regions' slices of the tier lists, closed up: one wave per region (bases from k_power_plan); reports the list lengths.
+__global__ __launch_bounds__(256) void k_tier_gather(SgBeamArgs a, int n_regions_ub)
+{
+    const int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    if (blockIdx.x == 0 && threadIdx.x < SG_MAX_CLASSES) a.status[2 + threadIdx.x] = a.tier_info[threadIdx.x];   // beams per later tier
+    int q_size = 0, f1 = 0;
+    int64_t q_base = 0;
+    if (!sg_region(a, r, n_regions_ub, q_base, q_size, f1)) return;
+    for (int k = 0; k < a.n_cls; ++k) {
+        const int c = a.tn[(int64_t)r * SG_MAX_CLASSES + k];
+        if (c == 0) continue;
+        const int32_t *src = a.tier_sparse + (int64_t)k * a.tier_stride + q_base;
+        int32_t *dst = a.tier_list + (int64_t)k * a.tier_stride + a.tbase[(int64_t)r * SG_MAX_CLASSES + k];
+        for (int i = lane; i < c; i += 64) dst[i] = src[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -568,7 +622,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     if (LISTQ) {
         work_n = a.tier_info[a.cls];
         if (work_n > a.work_hi) work_n = a.work_hi;
-        work_off = a.tier_info[4 + a.cls];
+        work_off = (int64_t)a.cls * a.tier_stride;
         if (WIN > 1 && work_n <= (int64_t)step * LANES) item_slots = LANES;
         n_items = (int)((work_n + item_slots - 1) / item_slots);
     } else {
@@ -776,7 +830,7 @@ __global__ __launch_bounds__(64) void k_beams_huge(SgBeamArgs a)
     double *s_a1 = a.h_lists, *s_a2 = s_a1 + col, *s_rho = s_a2 + col, *s_ratio = s_rho + col;
     const int n_las = a.las->n;
     int64_t work_n = a.tier_info[a.cls];
-    const int64_t work_off = a.tier_info[4 + a.cls];
+    const int64_t work_off = (int64_t)a.cls * a.tier_stride;
     int64_t chunk = (int64_t)blockIdx.x * 64;
     if (chunk >= work_n) return;
     do {
@@ -907,104 +961,6 @@ __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ f
     const int b0 = (int)(base & 0xffffffffull) + (int)(c & 0xffffffffull);
     seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = b0;
     for (int q = 0; q < nb; ++q) seg_of_blk[b0 + q] = slot;      // block -> segment: one load per block in k_beams
-}
-
-// ------------------------------------------------------------------------------------------------
-// Tier lists, built from the flag bytes of the direct-mode pass: class k = positions g with flag[g] == 3 + k, ascending
-// (sorted-row order keeps the lanes of a tier's waves neighbours in channel and azimuth -- one table, nearby bins; an
-// atomic queue would hand a wave 64 beams of as many channels, i.e. tables: every load a miss).  The classes are
-// concatenated in one list; tier_info = {entries per class [4], start of each class [4]}.  Three kernels over tiles
-// of SG_TILE positions: count, one-block scan, scatter.  (Folding the scan into the last block of the count kernel was
-// tried: the device-scope fence it needs writes back the L2 of the block's XCD, and 16 000 of those cost more than the
-// launch they save.)
-__global__ __launch_bounds__(SG_BLOCK) void k_tier_count(const uint8_t *__restrict__ flag, int64_t n_total, int32_t *__restrict__ tile_cnt)
-{
-    const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
-    uint32_t v = 0;
-    if (g0 + 3 < n_total) v = *(const uint32_t *)(flag + g0);
-    else for (int q = 0; q < 4; ++q) if (g0 + q < n_total) v |= (uint32_t)flag[g0 + q] << (8 * q);
-    int c[SG_MAX_CLASSES] = {0, 0, 0, 0};
-    if (v) {                                                        // most words carry no flag at all
-        for (int q = 0; q < 4; ++q) {
-            const int b = (int)((v >> (8 * q)) & 0xff) - 3;
-            for (int k = 0; k < SG_MAX_CLASSES; ++k) c[k] += (b == k);
-        }
-    }
-    __shared__ int sm[SG_BLOCK / 64][SG_MAX_CLASSES];
-    for (int k = 0; k < SG_MAX_CLASSES; ++k) {
-        int x = c[k];
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-        if ((tid & 63) == 0) sm[tid >> 6][k] = x;
-    }
-    __syncthreads();
-    if (tid < SG_MAX_CLASSES) {
-        int t = 0;
-        for (int w = 0; w < SG_BLOCK / 64; ++w) t += sm[w][tid];
-        tile_cnt[SG_MAX_CLASSES * (int64_t)blockIdx.x + tid] = t;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_tier_scan(const int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_base, int tiles,
-                                                    int32_t *__restrict__ tier_info, int32_t *__restrict__ status_counts)
-{
-    __shared__ int s[SG_MAX_CLASSES][1024];
-    const int tid = threadIdx.x;
-    const int per = (tiles + 1023) / 1024, b0 = tid * per, b1 = b0 + per < tiles ? b0 + per : tiles;
-    int sum[SG_MAX_CLASSES] = {0, 0, 0, 0};
-    for (int i = b0; i < b1; ++i)
-        for (int k = 0; k < SG_MAX_CLASSES; ++k) sum[k] += tile_cnt[SG_MAX_CLASSES * i + k];
-    for (int k = 0; k < SG_MAX_CLASSES; ++k) s[k][tid] = sum[k];
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        int add[SG_MAX_CLASSES];
-        for (int k = 0; k < SG_MAX_CLASSES; ++k) add[k] = tid >= d ? s[k][tid - d] : 0;
-        __syncthreads();
-        for (int k = 0; k < SG_MAX_CLASSES; ++k) s[k][tid] += add[k];
-        __syncthreads();
-    }
-    int run[SG_MAX_CLASSES], start = 0;
-    for (int k = 0; k < SG_MAX_CLASSES; ++k) {                      // class k follows class k - 1 in the list
-        run[k] = start + s[k][tid] - sum[k];
-        if (tid == 0) { tier_info[k] = s[k][1023]; tier_info[SG_MAX_CLASSES + k] = start; status_counts[k] = s[k][1023]; }
-        start += s[k][1023];
-    }
-    for (int i = b0; i < b1; ++i)
-        for (int k = 0; k < SG_MAX_CLASSES; ++k) {
-            tile_base[SG_MAX_CLASSES * i + k] = run[k];
-            run[k] += tile_cnt[SG_MAX_CLASSES * i + k];
-        }
-}
-
-__global__ __launch_bounds__(SG_BLOCK) void k_tier_scatter(const uint8_t *__restrict__ flag, int64_t n_total, const int32_t *__restrict__ tile_cnt,
-                                                           const int32_t *__restrict__ tile_base, int32_t *__restrict__ list, int32_t cap)
-{
-    const int tid = threadIdx.x;
-    const int32_t *tc = tile_cnt + SG_MAX_CLASSES * (int64_t)blockIdx.x;
-    if ((tc[0] | tc[1] | tc[2] | tc[3]) == 0) return;               // most tiles hold no flagged beam
-    const int64_t g0 = (int64_t)blockIdx.x * SG_TILE + (int64_t)tid * 4;
-    int cls[4];
-    int c[SG_MAX_CLASSES] = {0, 0, 0, 0};
-    for (int q = 0; q < 4; ++q) {
-        const int b = g0 + q < n_total ? (int)flag[g0 + q] - 3 : -1;
-        cls[q] = (b >= 0 && b < SG_MAX_CLASSES) ? b : -1;
-        for (int k = 0; k < SG_MAX_CLASSES; ++k) c[k] += (cls[q] == k);
-    }
-    __shared__ int sm[SG_BLOCK / 64][SG_MAX_CLASSES];
-    int slot[SG_MAX_CLASSES];
-    for (int k = 0; k < SG_MAX_CLASSES; ++k) {                      // exclusive prefix of c[k] over the block
-        int inc = c[k];
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((tid & 63) >= o) inc += v; }
-        if ((tid & 63) == 63) sm[tid >> 6][k] = inc;
-        slot[k] = inc - c[k];
-    }
-    __syncthreads();
-    for (int k = 0; k < SG_MAX_CLASSES; ++k) {
-        slot[k] += tile_base[SG_MAX_CLASSES * (int64_t)blockIdx.x + k];
-        for (int w = 0; w < (tid >> 6); ++w) slot[k] += sm[w][k];
-    }
-    for (int q = 0; q < 4; ++q)
-        if (cls[q] >= 0) { const int sl = slot[cls[q]]++; if (sl < cap) list[sl] = (int32_t)(g0 + q); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1374,7 +1330,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
@@ -1401,6 +1357,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st)
         const int lanes_back = (BLOCK < 64 || back_est <= (int64_t)blocks * (THREADS / 64) * LANES * 5 / 2) ? LANES : LANES * SG_KP_WIN;
         hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
         SG_CHECK_LAUNCH();
+        if (ev_plan && hipEventRecord(ev_plan, st) != hipSuccess) return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
@@ -1449,19 +1406,29 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
-extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream)
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan)
 {
     hipStream_t st = (hipStream_t)stream;
+    hipEvent_t ev = (hipEvent_t)ev_plan;              // recorded behind k_power_plan (the tier lists' bases are known then)
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st);
-        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st);
-        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st);
-        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st);
-    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st);
-    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st);
-    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev);
+}
+
+extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)
+{
+    const unsigned g = (unsigned)((a->n_regions_ub + 3) / 4);
+    if (g == 0) return 0;
+    hipLaunchKernelGGL(k_tier_gather, dim3(g), dim3(256), 0, (hipStream_t)stream, *a, (int)a->n_regions_ub);
+    SG_CHECK_LAUNCH();
+    return 0;
 }
 
 // ... and for the hand-over buffer of a list-mode pass
@@ -1509,22 +1476,6 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
         hipLaunchKernelGGL(k_seg_chunks, dim3(1), dim3(64), 0, st, seg_n, seg_blk, n_chunks, chunk_blk);
         SG_CHECK_LAUNCH();
     }
-    return 0;
-}
-
-extern "C" int sg_launch_tier_lists(const uint8_t *flag, int64_t n_total, int32_t *tile_cnt, int32_t *tile_base, int32_t *list,
-                                    int32_t *tier_info, int32_t *status_counts, int32_t cap, int n_cls, void *stream)
-{
-    (void)n_cls;
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t tiles = (n_total + SG_TILE - 1) / SG_TILE;
-    if (tiles == 0) return 0;
-    hipLaunchKernelGGL(k_tier_count, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, flag, n_total, tile_cnt);
-    SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_tier_scan, dim3(1), dim3(1024), 0, st, tile_cnt, tile_base, (int)tiles, tier_info, status_counts);
-    SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_tier_scatter, dim3((unsigned)tiles), dim3(SG_BLOCK), 0, st, flag, n_total, tile_cnt, tile_base, list, cap);
-    SG_CHECK_LAUNCH();
     return 0;
 }
 

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(RW_BLOCK, PAIRWISE ? 2 : RW_WAVES) void k_rows(SgBe
     const int n_las = a.las->n;
     int64_t work_n = PAIRWISE ? a.redo_cnt[a.cls] : a.tier_info[a.cls];      // PAIRWISE: the beams the first instantiation deferred
     if (work_n > a.work_hi) work_n = a.work_hi;
-    const int64_t work_off = a.tier_info[4 + a.cls];
+    const int64_t work_off = (int64_t)a.cls * a.tier_stride;
     const int32_t *work_list = PAIRWISE ? a.redo_list : a.tier_list;
     const int waves = (int)gridDim.x * (RW_BLOCK / 64);
     const int wave = (int)blockIdx.x * (RW_BLOCK / 64) + (tid >> 6);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(RW_BLOCK, 4) void k_rows_scan(SgBeamArgs a)
     const int n_las = a.las->n;
     int64_t work_n = a.tier_info[a.cls];
     if (work_n > a.work_hi) work_n = a.work_hi;
-    const int64_t work_off = a.tier_info[4 + a.cls];
+    const int64_t work_off = (int64_t)a.cls * a.tier_stride;
     const int waves = (int)gridDim.x * (RW_BLOCK / 64);
     const int wave = (int)blockIdx.x * (RW_BLOCK / 64) + (tid >> 6);
     for (int64_t chunk = (int64_t)a.work_lo + (int64_t)wave * RPW; chunk < work_n; chunk += (int64_t)waves * RPW) {
