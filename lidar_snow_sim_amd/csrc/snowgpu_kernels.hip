@@ -548,19 +548,31 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
         base = __shfl(base, 63) + inc - c;
         if (mine) a.tbase[(int64_t)r * SG_MAX_CLASSES + k] = base;
     }
+    int n_one = 0;                                    // items of k_power1 (one-flake beams: the front of the region's slice)
     if (mine) {
         const unsigned long long c = a.qn[r];
         nf = (int)(c & 0xffffffffull); nb = (int)(c >> 32);
-        n_items = (nf + lanes - 1) / lanes + (nb + lanes_back - 1) / lanes_back;
+        n_one = (nf + lanes - 1) / lanes;
+        n_items = (nb + lanes_back - 1) / lanes_back;
+        if (!a.pw_items1) { n_items += n_one; n_one = 0; }
     }
-    int inc = n_items;                                // inclusive scan over the wave, one atomic for its total
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
-    const int total = __shfl(inc, 63);
-    int base = 0;
-    if ((threadIdx.x & 63) == 63 && total > 0) base = atomicAdd(a.pw_count, total);
-    base = __shfl(base, 63) + inc - n_items;
-    for (int k = 0; k < nf; k += lanes)
-        a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 10));
+    auto reserve = [&](int n, int32_t *counter) {    // inclusive scan over the wave, one atomic for its total
+        int inc = n;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if ((int)(threadIdx.x & 63) >= o) inc += v; }
+        const int total = __shfl(inc, 63);
+        int b = 0;
+        if ((threadIdx.x & 63) == 63 && total > 0) b = atomicAdd(counter, total);
+        return __shfl(b, 63) + inc - n;
+    };
+    int base = reserve(n_items, a.pw_count);
+    if (a.pw_items1) {
+        int base1 = reserve(n_one, a.pw_count + 1);
+        for (int k = 0; k < nf; k += lanes)
+            a.pw_items1[base1++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 10));
+    } else {
+        for (int k = 0; k < nf; k += lanes)
+            a.pw_items[base++] = make_int2((int)(q_base + k), (nf - k < lanes ? nf - k : lanes) | (f1 << 10));
+    }
     for (int k = 0; k < nb; k += lanes_back)
         a.pw_items[base++] = make_int2((int)(q_base + q_size - nb + k), (nb - k < lanes_back ? nb - k : lanes_back) | (f1 << 10));
 }
@@ -813,6 +825,119 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             }
             sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The beams of the pass over all rows that met exactly ONE flake (six of ten beams that met any, at 2.5 mm/h): their own kernel
+// (sg_one_prep / sg_one_zone / sg_one_bin) -- no flake lists, two thirds of k_power's registers, twice its waves per SIMD.
+// Items from k_power_plan: up to 64 neighbouring queue slots of one region each; persistent waves stride over them.  A beam has
+// one or two bins to evaluate when its two windows are apart and up to a dozen when they overlap, so the wave numbers the
+// (beam, bin) pairs of its 64 beams by a prefix sum and takes them 64 at a time, whichever beam they belong to (the owner's
+// scatterers through LDS); a segmented reduction over the lanes folds each beam's bins (first maximum, simulation.py:151).
+template <typename T>
+__global__ __launch_bounds__(256, 4) void k_power1(SgBeamArgs a, int qplanes)
+{
+    __shared__ double s_famp[256], s_tamp[256], s_rho[256], s_d[256], s_best[256];
+    __shared__ int2 s_win[256];                       // fk0 | fk1 << 16, tk0 | tk1 << 16
+    __shared__ int s_k[256];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    const int n_items = a.pw_count[1];
+    const int step = (int)gridDim.x * 4;
+    for (int i = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6); i < n_items; i += step) {
+        const int2 it = a.pw_items1[i];
+        const int start = __builtin_amdgcn_readfirstlane(it.x), dy = __builtin_amdgcn_readfirstlane(it.y);
+        const int cnt = dy & 1023, item_f = (dy >> 10) - 1;
+        const bool live = lane < cnt;
+        const int64_t slot = (int64_t)start + lane;
+        SgBeamOut o;
+        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+        int f = 0, ch = 0, S = 0, g = 0;
+        SgOne P{};
+        if (live) {
+            const double *q = a.dq + (slot >> 6) * (int64_t)(qplanes * 64) + (slot & 63);
+            const double d = q[0], tc = q[64], a1 = q[128], a2 = q[192], rho = q[256];
+            ch = (int)(a.dq_sc[slot] >> 8);
+            g = a.dq_g[slot];
+            f = item_f >= 0 ? item_f : sg_frame_of(a, g);
+            S = sg_one_prep<T>(d, tc, a1, a2, rho, ch, a.las, a.beam_div_deg, P, o);
+        }
+        // stage A for the stronger scatterer of every beam: it answers for every bin of its window
+        const bool tgt_first = sg_one_target_stronger(P);
+        int ka = 0, kb = -1;
+        if (S) sg_one_zone(P, tgt_first, 0.0, ka, kb);
+        const int n = kb >= ka ? kb - ka + 1 : 0;
+        s_famp[tid] = P.famp; s_tamp[tid] = P.tamp; s_rho[tid] = P.rho; s_d[tid] = P.d;
+        s_win[tid] = make_int2(P.fk0 | (P.fk1 << 16), P.tk0 | (P.tk1 << 16));
+        s_best[tid] = 0.0; s_k[tid] = 0;
+        asm volatile("" ::: "memory");                // written and read by the lanes of one wave: LDS keeps a wave's operations in order
+        int incl = n;
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        const int excl = incl - n;
+        const int total = __shfl(incl, 63);
+        for (int base = 0; base < total; base += 64) {
+            const int p = base + lane;
+            const bool valid = p < total;
+            int lo = 0, hi = 63;                      // owner = first lane whose inclusive count exceeds p
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(incl, mid);
+                if (v > p) hi = mid; else lo = mid + 1;
+            }
+            const int ow = lo & 63;
+            const int k = __shfl(ka, ow) + (p - __shfl(excl, ow));
+            double sm = -1.0;
+            int kk = 0x7fffffff, oo = 64 + lane;      // (a lane without a pair: a run of its own)
+            if (valid) {
+                const int col = wbase + ow;
+                const int2 w = s_win[col];
+                const double fa = s_famp[col], ta = s_tamp[col], rh = s_rho[col], dd = s_d[col];
+                sm = a.exact_math ? sg_one_bin<true>(fa, ta, rh, dd, w.x & 0xffff, (int)((unsigned)w.x >> 16), w.y & 0xffff, (int)((unsigned)w.y >> 16), k, a.rgrid)
+                                  : sg_one_bin<false>(fa, ta, rh, dd, w.x & 0xffff, (int)((unsigned)w.x >> 16), w.y & 0xffff, (int)((unsigned)w.y >> 16), k, a.rgrid);
+                kk = k; oo = ow;
+            }
+            // the pairs of one beam are neighbours: fold them towards the last lane of the run (larger sum; equal sums: smaller bin)
+            for (int off = 1; off < 64; off <<= 1) {
+                const double s2 = __shfl_up(sm, off);
+                const int k2 = __shfl_up(kk, off), o2 = __shfl_up(oo, off);
+                if (lane >= off && o2 == oo && (s2 > sm || (s2 == sm && k2 < kk))) { sm = s2; kk = k2; }
+            }
+            const int on = __shfl_down(oo, 1);
+            if (valid && (lane == 63 || on != oo)) {  // ... which folds it into the beam's cell (its bins may come in two rounds)
+                volatile double *vb = s_best;
+                volatile int *vk = s_k;
+                const int col = wbase + oo;
+                const double b0 = vb[col];
+                const int k0 = vk[col];
+                if (sm > b0 || (sm == b0 && kk < k0)) { vb[col] = sm; vk[col] = kk; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (live) {
+            uint32_t rec = 0;
+            if (S) {
+                double best = ((volatile double *)s_best)[tid];
+                int k_best = ((volatile int *)s_k)[tid];
+                // the weaker scatterer answers for its bins outside the stronger one's window: they count only if its amplitude
+                // comes within 0.34 % of the maximum found (a handful of beams per million)
+                int wa, wb;
+                sg_one_zone(P, !tgt_first, best, wa, wb);
+                for (int k = wa; k <= wb; ++k) {
+                    const double sm = a.exact_math ? sg_one_bin<true>(P.famp, P.tamp, P.rho, P.d, P.fk0, P.fk1, P.tk0, P.tk1, k, a.rgrid)
+                                                   : sg_one_bin<false>(P.famp, P.tamp, P.rho, P.d, P.fk0, P.fk1, P.tk0, P.tk1, k, a.rgrid);
+                    if (sm > best || (sm == best && k < k_best)) { best = sm; k_best = k; }
+                }
+                if (o.range_error) {
+                    atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+                    atomicCAS(&a.status[1], -1, g);
+                }
+                sg_beam_decide(P.d, ch, a.las, best, k_best, o);
+                rec = sg_pack_record(o);
+            }
+            a.rec_q[slot] = rec;
+        }
+        sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the next item overwrites the cells
     }
 }
 
@@ -1330,7 +1455,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr)
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr, hipStream_t st1 = nullptr)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
@@ -1358,6 +1483,13 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_pla
         hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
         SG_CHECK_LAUNCH();
         if (ev_plan && hipEventRecord(ev_plan, st) != hipSuccess) return (int)hipGetLastError();
+        if (a->pw_items1) {                           // the one-flake beams: beside k_power (another stream) or ahead of it
+            hipStream_t s1 = (st1 && ev_plan) ? st1 : st;
+            if (s1 != st && hipStreamWaitEvent(s1, ev_plan, 0) != hipSuccess) return (int)hipGetLastError();
+            const unsigned g1 = (unsigned)std::min<int64_t>((int64_t)sg_cu_count(dev_id) * 4, (a->n_total / LANES + a->n_regions_ub + 3) / 4);
+            if (g1 > 0) hipLaunchKernelGGL(k_power1<T>, dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
+            SG_CHECK_LAUNCH();
+        }
     }
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
@@ -1406,20 +1538,20 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
-extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan)
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan, void *stream1)
 {
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream, s1 = (hipStream_t)stream1;
     hipEvent_t ev = (hipEvent_t)ev_plan;              // recorded behind k_power_plan (the tier lists' bases are known then)
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev);
-        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev);
-        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev);
-        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev, s1);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev, s1);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev, s1);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev, s1);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev);
-    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev);
-    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev);
-    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev, s1);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev, s1);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev, s1);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev, s1);
 }
 
 extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)
