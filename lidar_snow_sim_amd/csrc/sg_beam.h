@@ -864,138 +864,6 @@ __device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__rest
     }
 }
 
-// ---- a beam that met ONE flake (k_power1) -----------------------------------------------------------------------------
-// Phases 2, 3a and 3b of the general path (sg_beam_dict, sg_beam_amp, sg_power_plan + sg_eval_group) written out for the list
-// {one flake, the hard target}: the same expressions in the same order, so every intermediate is the value the general path
-// computes.  The occlusion walk meets at most three elementary slots.  Stage A: each bin is the business of the strongest
-// scatterer covering it, so of the two windows the STRONGER one (ties: the flake) answers for all its bins -- the weaker one can
-// only add to them -- and the weaker one for its bins outside, which matter only if its amplitude reaches 0.9966 of the other's:
-// sg_one_zone gives the bins of either that can hold or tie the maximum, sg_one_bin a bin's exact sum (flake first, then the
-// hard target: the order of the reference's loop).  The kernel spreads the (beam, bin) pairs of a wave's beams over its lanes.
-struct SgOne {
-    double famp, tamp;        // amplitudes: flake, hard target
-    double rho, d;            // their ranges
-    int fk0, fk1, tk0, tk1;   // their bin windows [k0, k1)
-};
-
-// returns S (0: no elementary slot owned by the flake -> the beam keeps label 0)
-template <typename T>
-__device__ __forceinline__ int sg_one_prep(double d, double theta_c, double a1, double a2, double rho, int channel,
-                                           const SgLasers *__restrict__ las, double beam_div_deg, SgOne &p, SgBeamOut &out)
-{
-    constexpr bool F32 = SgReal<T>::is_f32;
-    // -- phase 2: compute_occlusion_dict (simulation.py:252-295), one interval
-    double theta_r, theta_l;
-    sg_beam_limits(theta_c, beam_div_deg, theta_r, theta_l);
-    double ra = theta_r, la = theta_l;
-    if (ra > la) {                                              // :260-263
-        ra = ra - SG_TWO_PI;
-        if (a1 > a2) a1 = a1 - SG_TWO_PI;
-    }
-    const double delta = beam_div_deg * (SG_PI / 180.0);        // :289
-    double e_min = ra < la ? ra : la, e_max = ra < la ? la : ra;
-    if (a1 < e_min) e_min = a1;
-    if (a2 < e_min) e_min = a2;
-    if (a1 > e_max) e_max = a1;
-    if (a2 > e_max) e_max = a2;
-    double fsum = 0.0, tsum = -0.0;                             // the flake's slots, the target's (np.sum of fewer than 8 addends)
-    bool fown = false;
-    for (double e = e_min; e < e_max;) {
-        const bool own = a1 <= e && e < a2;                     // :284
-        double nxt = e_max;
-        if (a1 > e && a1 < nxt) nxt = a1;
-        if (a2 > e && a2 < nxt) nxt = a2;
-        if (ra > e && ra < nxt) nxt = ra;
-        if (la > e && la < nxt) nxt = la;
-        const double w = nxt - e;
-        if (own) { fsum = fown ? fsum + w : w; fown = true; }
-        else tsum += w;
-        e = nxt;
-    }
-    if (!fown) return 0;
-    const double ratio_f = sg_clip01((0.0 + fsum) / delta), ratio_t = sg_clip01((0.0 + tsum) / delta);   // :288-293
-    // -- phase 3a: amplitudes and bin windows (simulation.py:137-146)
-    const int max_i = las->max_i[channel];
-    const double c_tau = 299792458.0 * 1e-8;
-    const double beta_0 = 1 * 1e-6 / SG_PI;
-    const double i_snow = 0.9 * max_i;
-    const double ca_p0 = i_snow / beta_0;
-    p.rho = rho; p.d = d;
-    p.fk0 = (int)ceil(rho * 10);
-    p.fk1 = (int)(floor((rho + c_tau) * 10) + 1);
-    p.famp = (((ca_p0 * beta_0) * ratio_f) * sg_xsi(rho)) / (rho * rho);
-    if constexpr (F32) {                                        // the hard target keeps its float32 range
-        const float r = (float)(T)d;
-        p.tk0 = (int)ceilf(r * 10.0f);
-        float ee = r + (float)c_tau;
-        ee = ee * 10.0f;
-        ee = floorf(ee) + 1.0f;
-        p.tk1 = (int)ee;
-        const float r2 = r * r;
-        p.tamp = (((ca_p0 * beta_0) * ratio_t) * sg_xsi(r)) / (double)r2;
-    } else {
-        p.tk0 = (int)ceil(d * 10);
-        p.tk1 = (int)(floor((d + c_tau) * 10) + 1);
-        p.tamp = (((ca_p0 * beta_0) * ratio_t) * sg_xsi(d)) / (d * d);
-    }
-    if (p.fk1 > SG_RBINS) { out.range_error = 1; p.fk1 = SG_RBINS; }
-    if (p.tk1 > SG_RBINS) { out.range_error = 1; p.tk1 = SG_RBINS; }
-    if (p.fk0 < 0) p.fk0 = 0;
-    if (p.tk0 < 0) p.tk0 = 0;
-    out.n_flakes = 1;
-    out.has_power = 1;
-    return 1;
-}
-
-__device__ __forceinline__ bool sg_one_target_stronger(const SgOne &p) { return p.tamp > p.famp; }   // ties: the nearer one, the flake
-
-// stage A for one of the two scatterers (the hard target if `target`), given the best sum so far: its bins [ka, kb] that can hold
-// or tie the maximum (kb < ka: none)
-__device__ __forceinline__ void sg_one_zone(const SgOne &p, bool target, double best, int &ka, int &kb)
-{
-    const double c_tau = 299792458.0 * 1e-8;
-    const double step = (120 + c_tau) / (SG_RBINS - 1);
-    const double A = target ? p.tamp : p.famp, Ao = target ? p.famp : p.tamp, r = target ? p.d : p.rho;
-    const int k0 = target ? p.tk0 : p.fk0, k1 = target ? p.tk1 : p.fk1, q0 = target ? p.fk0 : p.tk0, q1 = target ? p.fk1 : p.tk1;
-    ka = 0; kb = -1;
-    if (!(A > 0.0)) return;
-    double oth = 0.0;
-    int lo_trim = k0, hi_trim = k1;
-    if (p.tk0 < p.fk1) {                                        // the windows share a bin (they start in range order)
-        if (Ao > A || (Ao == A && target)) {                    // the other one is the stronger (ties: the one listed first, the flake)
-            if (q0 <= k0) { if (q1 > lo_trim) lo_trim = q1; }
-            else if (q1 >= k1) { if (q0 < hi_trim) hi_trim = q0; }
-        } else oth += Ao;
-    }
-    const double need = fmax(best, 0.9966 * fmax(p.tamp, p.famp));
-    if ((A + oth) * (1.0 + 1e-9) < need) return;
-    const double q = (need * (1.0 - 1e-9) - oth * (1.0 + 1e-9)) / A;
-    ka = k0; kb = k1 - 1;
-    if (q >= 0.5) {
-        const double om = q < 1.0 ? 1.0 - q : 0.0;
-        const double dl = (double)sqrtf((float)(1.26 * om)) * (1.0 + 1e-6) + 1e-6;
-        const double Rc = r + c_tau / 2;
-        const double D = dl * (c_tau / SG_PI) + 0.006;
-        const int za = (int)ceil((Rc - D) * (1.0 / step)), zb = (int)floor((Rc + D) * (1.0 / step));
-        if (za > ka) ka = za;
-        if (zb < kb) kb = zb;
-    }
-    if (lo_trim > ka) ka = lo_trim;
-    if (hi_trim - 1 < kb) kb = hi_trim - 1;
-}
-
-// the received power of bin k (simulation.py:135, :149): the flake's term, then the hard target's
-template <bool EXACT>
-__device__ __forceinline__ double sg_one_bin(double famp, double tamp, double rho, double d, int fk0, int fk1, int tk0, int tk1, int k,
-                                             const double *__restrict__ rgrid)
-{
-    const double Rk = EXACT ? rgrid[k < SG_RBINS ? k : SG_RBINS - 1] : sg_range_bin(k);
-    double sm = 0.0;
-    if (k >= fk0 && k < fk1) sm += sg_power_term<EXACT>(famp, Rk, rho);
-    if (k >= tk0 && k < tk1) sm += sg_power_term<EXACT>(tamp, Rk, d);
-    return sm;
-}
-
 // ---- phase 3c (per lane): focal term, clipping, attenuate-or-scatter decision (simulation.py:152-188) -------
 // d = the beam's range as float64 (the value of the row dtype).  A scattered point (label 2) moves to
 // d_max = k_best / 10 - c tau / 2 on its ray; the row is rebuilt from the record by sg_scatter_scale below.

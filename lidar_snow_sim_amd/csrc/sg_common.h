@@ -122,8 +122,9 @@ struct SgBeamArgs {
     uint16_t *dq_sc;             // per slot: flakes in the list | channel << 8
     unsigned long long *qn;      // per region
     int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 10}
-    int32_t *pw_count;           // [0] items planned, [1] items of the one-flake kernel (reset per chunk)
-    int2_t *pw_items1;           // work items of k_power1 (the one-flake beams of every region), or null: k_power takes them too
+    int32_t *pw_count;           // [0] items planned, [1] items of k_power_few (reset per chunk)
+    int2_t *pw_items1;           // work items of k_power_few (the front of every region's slice), or null: k_power takes them too
+    int32_t front_max;           // beams with up to this many flakes fill a region's slice from the front (1 .. 3 with pw_items1; else 1)
     int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
     int32_t blk_rows;            // rows per block of the direct-mode pass
     int32_t kp_lds_quarters;     // host: share of a CU's capacity k_power takes for the main queue (1..4 quarters; 0 = all)
@@ -185,8 +186,7 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
-int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, void *ev_plan /* hipEvent_t recorded behind the plan kernel, or null */,
-                    void *stream1 /* where the one-flake kernel runs (behind ev_plan), or null: on `stream` ahead of k_power */);
+int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, void *ev_plan /* hipEvent_t recorded behind the plan kernel, or null */);
 int sg_launch_tier_gather(const SgBeamArgs *args, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);

@@ -101,7 +101,7 @@ struct snowgpu_ctx {
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
     int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
                                       // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
-    int one_flake = 1;                // SNOWGPU_ONE_FLAKE=0: the one-flake beams go through k_power like the others
+    int few = 2;                      // SNOWGPU_FEW=0..3: beams with up to this many flakes go through k_power_few (0: all through k_power)
     int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
     int tier_scan_lds = 0;            // SNOWGPU_TIER_SCAN_LDS=1: the later tiers' scans keep their lists in LDS (rounds 1-3) -- A/B
@@ -278,7 +278,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
     { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_ONE_FLAKE"); ctx->one_flake = v ? std::atoi(v) : 1; }
+    { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
@@ -934,8 +934,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->pw_items, 2 * items_cap);
         ENSURE(ctx, ctx->pw_count, 4);
         a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
-        // beams with ONE flake take their own kernel (k_power1: registers only) -- unless the occlusion tap wants their dicts
-        a.pw_items1 = (R->one_flake && !b.dbg_count && lanes == 64) ? ctx->pw_items.p + items_cap : nullptr;
+        // beams with up to `few` flakes take their own kernel (k_power_few: registers only) -- unless the occlusion tap wants their dicts
+        a.pw_items1 = (R->few > 0 && !b.dbg_count && lanes == 64) ? ctx->pw_items.p + items_cap : nullptr;
+        a.front_max = a.pw_items1 ? std::min(R->few, std::min(3, tiers[0])) : 1;
     }
     // Overflow slots: a beam of the pass over all rows that over-fills its LDS list, up to SG_OV_CAP flakes, leaves all of them in
     // the slot of its sorted position, and the tiers up to that capacity run no second scan (400 bytes per sorted position, touched
@@ -951,8 +952,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
-    // SNOWGPU_ONE_FLAKE=2: k_power1 on the tiers' side stream, beside k_power, instead of ahead of it on k_power's stream
-    const bool one_side = a.pw_items1 && R->one_flake == 2 && !serial;
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     // measurement hooks: one event pair around the whole per-beam region
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
@@ -977,7 +976,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp[c], 0));
             HIPCHK(ctx, hipMemsetAsync(ctx->pw_count.p, 0, 2 * sizeof(int32_t), s_aux));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, ctx->ev_plan[c], one_side ? s_aux3 : nullptr);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, ctx->ev_plan[c]);
             if (e) break;
             // the tier lists closed up: behind the plan kernel, on the caller's stream, where the tiers start
             HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_plan[c], 0));
@@ -1027,7 +1026,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         }
     }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier launch: ") + hipGetErrorString((hipError_t)e));
-    if (side3 || one_side) { HIPCHK(ctx, hipEventRecord(ctx->ev_join3, s_aux3)); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0)); }
+    if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_join3, s_aux3)); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0)); }
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
     // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats

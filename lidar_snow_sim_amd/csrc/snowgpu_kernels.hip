@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include "sg_beam.h"
+#include "sg_few.h"
 #include "sg_kutil.h"
 #include "sg_lean.h"
 
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
         if constexpr (!LIST) {
             // The region's slice of the queue: beams with one flake from the front, the others from the back -- one
             // packed 64-bit atomic per wave on the region's counter (thousands of distinct addresses: no serialisation).
-            const bool front = o.has_power && L == 1, back = o.has_power && L > 1;
+            const bool front = o.has_power && L <= a.front_max, back = o.has_power && L > a.front_max;
             const unsigned long long mf = __ballot(front), mb = __ballot(back);
             if (mf | mb) {
                 const int leader = __ffsll((long long)(mf | mb)) - 1;
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
         base = __shfl(base, 63) + inc - c;
         if (mine) a.tbase[(int64_t)r * SG_MAX_CLASSES + k] = base;
     }
-    int n_one = 0;                                    // items of k_power1 (one-flake beams: the front of the region's slice)
+    int n_one = 0;                                    // items of k_power_few (beams with few flakes: the front of the region's slice)
     if (mine) {
         const unsigned long long c = a.qn[r];
         nf = (int)(c & 0xffffffffull); nb = (int)(c >> 32);
@@ -829,18 +830,20 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The beams of the pass over all rows that met exactly ONE flake (six of ten beams that met any, at 2.5 mm/h): their own kernel
-// (sg_one_prep / sg_one_zone / sg_one_bin) -- no flake lists, two thirds of k_power's registers, twice its waves per SIMD.
-// Items from k_power_plan: up to 64 neighbouring queue slots of one region each; persistent waves stride over them.  A beam has
-// one or two bins to evaluate when its two windows are apart and up to a dozen when they overlap, so the wave numbers the
+// The beams of the pass over all rows that met only a FEW flakes -- up to N; six of ten beams that met any met one, eight of ten
+// one or two, at 2.5 mm/h -- in their own kernel (sg_few.h): no flake lists in LDS, two thirds of k_power's registers, twice its
+// waves per SIMD.  They fill the front of every region's slice of the queue, and k_power is left with the beams that met more.
+// Items from k_power_plan: up to 64 neighbouring queue slots of one region each; persistent waves stride over them.  A beam has one
+// or two bins to evaluate when its scatterers' windows are apart and up to a dozen when they overlap, so the wave numbers the
 // (beam, bin) pairs of its 64 beams by a prefix sum and takes them 64 at a time, whichever beam they belong to (the owner's
 // scatterers through LDS); a segmented reduction over the lanes folds each beam's bins (first maximum, simulation.py:151).
-template <typename T>
-__global__ __launch_bounds__(256, 4) void k_power1(SgBeamArgs a, int qplanes)
+// Measured (256 sweeps, same box): N = 2: C2 4.53 -> 4.34 ms, C4 10.6 -> 10.2 ms, C2far 9.05 -> 9.22 ms; N = 1: 4.53, 10.6, 9.05 (and
+// 9.58 / 11.03 without any such kernel); N = 3 (143 registers, three waves per SIMD): 4.70, 10.5, 9.02.
+template <typename T, int N>
+__global__ __launch_bounds__(256, N <= 2 ? 4 : 3) void k_power_few(SgBeamArgs a, int qplanes)
 {
-    __shared__ double s_famp[256], s_tamp[256], s_rho[256], s_d[256], s_best[256];
-    __shared__ int2 s_win[256];                       // fk0 | fk1 << 16, tk0 | tk1 << 16
-    __shared__ int s_k[256];
+    __shared__ double s_amp[N + 1][256], s_rho[N + 1][256], s_best[256];      // scatterer N: the hard target
+    __shared__ int s_win[N + 1][256], s_zone[N + 1][256], s_k[256];           // k0 | k1 << 16;  first bin | bins << 16
     const int tid = (int)threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int n_items = a.pw_count[1];
     const int step = (int)gridDim.x * 4;
@@ -853,22 +856,38 @@ __global__ __launch_bounds__(256, 4) void k_power1(SgBeamArgs a, int qplanes)
         SgBeamOut o;
         o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
         int f = 0, ch = 0, S = 0, g = 0;
-        SgOne P{};
+        SgFew<N> P{};
+        int zone[N + 1], n = 0;
+#pragma unroll
+        for (int z = 0; z <= N; ++z) zone[z] = 0;
         if (live) {
             const double *q = a.dq + (slot >> 6) * (int64_t)(qplanes * 64) + (slot & 63);
-            const double d = q[0], tc = q[64], a1 = q[128], a2 = q[192], rho = q[256];
-            ch = (int)(a.dq_sc[slot] >> 8);
+            const unsigned sc = a.dq_sc[slot];
+            const double d = q[0], tc = q[64];
+            double a1[N], a2[N], rho[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {             // every plane of the slot exists, filled or not: all loads in one flight
+                a1[j] = q[(2 + 3 * j) * 64]; a2[j] = q[(3 + 3 * j) * 64]; rho[j] = q[(4 + 3 * j) * 64];
+            }
+            ch = (int)(sc >> 8);
             g = a.dq_g[slot];
             f = item_f >= 0 ? item_f : sg_frame_of(a, g);
-            S = sg_one_prep<T>(d, tc, a1, a2, rho, ch, a.las, a.beam_div_deg, P, o);
+            S = sg_few_prep<T, N>(d, tc, (int)(sc & 255u), a1, a2, rho, ch, a.las, a.beam_div_deg, P, o);
+            if (S) {                                  // stage A: the bins of every scatterer's window that can hold the maximum
+                int ka, kb;
+                sg_few_zone<N, 0>(P, 0.0, ka, kb);
+                if (kb >= ka) { zone[0] = ka | ((kb - ka + 1) << 16); n += kb - ka + 1; }
+                if constexpr (N >= 2) { sg_few_zone<N, 1>(P, 0.0, ka, kb); if (kb >= ka) { zone[1] = ka | ((kb - ka + 1) << 16); n += kb - ka + 1; } }
+                if constexpr (N >= 3) { sg_few_zone<N, 2>(P, 0.0, ka, kb); if (kb >= ka) { zone[2] = ka | ((kb - ka + 1) << 16); n += kb - ka + 1; } }
+                sg_few_zone<N, N>(P, 0.0, ka, kb);
+                if (kb >= ka) { zone[N] = ka | ((kb - ka + 1) << 16); n += kb - ka + 1; }
+            }
         }
-        // stage A for the stronger scatterer of every beam: it answers for every bin of its window
-        const bool tgt_first = sg_one_target_stronger(P);
-        int ka = 0, kb = -1;
-        if (S) sg_one_zone(P, tgt_first, 0.0, ka, kb);
-        const int n = kb >= ka ? kb - ka + 1 : 0;
-        s_famp[tid] = P.famp; s_tamp[tid] = P.tamp; s_rho[tid] = P.rho; s_d[tid] = P.d;
-        s_win[tid] = make_int2(P.fk0 | (P.fk1 << 16), P.tk0 | (P.tk1 << 16));
+#pragma unroll
+        for (int t = 0; t < N; ++t) { s_amp[t][tid] = P.amp[t]; s_rho[t][tid] = P.rho[t]; s_win[t][tid] = P.k0[t] | (P.k1[t] << 16); }
+        s_amp[N][tid] = P.tamp; s_rho[N][tid] = P.d; s_win[N][tid] = P.tk0 | (P.tk1 << 16);
+#pragma unroll
+        for (int z = 0; z <= N; ++z) s_zone[z][tid] = zone[z];
         s_best[tid] = 0.0; s_k[tid] = 0;
         asm volatile("" ::: "memory");                // written and read by the lanes of one wave: LDS keeps a wave's operations in order
         int incl = n;
@@ -885,15 +904,29 @@ __global__ __launch_bounds__(256, 4) void k_power1(SgBeamArgs a, int qplanes)
                 if (v > p) hi = mid; else lo = mid + 1;
             }
             const int ow = lo & 63;
-            const int k = __shfl(ka, ow) + (p - __shfl(excl, ow));
+            int j = p - __shfl(excl, ow);
             double sm = -1.0;
             int kk = 0x7fffffff, oo = 64 + lane;      // (a lane without a pair: a run of its own)
             if (valid) {
                 const int col = wbase + ow;
-                const int2 w = s_win[col];
-                const double fa = s_famp[col], ta = s_tamp[col], rh = s_rho[col], dd = s_d[col];
-                sm = a.exact_math ? sg_one_bin<true>(fa, ta, rh, dd, w.x & 0xffff, (int)((unsigned)w.x >> 16), w.y & 0xffff, (int)((unsigned)w.y >> 16), k, a.rgrid)
-                                  : sg_one_bin<false>(fa, ta, rh, dd, w.x & 0xffff, (int)((unsigned)w.x >> 16), w.y & 0xffff, (int)((unsigned)w.y >> 16), k, a.rgrid);
+                int k = 0;
+                bool found = false;
+#pragma unroll
+                for (int z = 0; z <= N; ++z) {        // which zone of its beam the pair falls in
+                    const int zc = s_zone[z][col], zn = (int)((unsigned)zc >> 16);
+                    if (!found) { if (j < zn) { k = (zc & 0xffff) + j; found = true; } else j -= zn; }
+                }
+                double amp[N], rho[N];
+                int k0[N], k1[N];
+#pragma unroll
+                for (int t = 0; t < N; ++t) {
+                    amp[t] = s_amp[t][col]; rho[t] = s_rho[t][col];
+                    const int w = s_win[t][col];
+                    k0[t] = w & 0xffff; k1[t] = (int)((unsigned)w >> 16);
+                }
+                const int tw = s_win[N][col];
+                sm = a.exact_math ? sg_few_bin<true, N>(amp, rho, k0, k1, s_amp[N][col], s_rho[N][col], tw & 0xffff, (int)((unsigned)tw >> 16), k, a.rgrid)
+                                  : sg_few_bin<false, N>(amp, rho, k0, k1, s_amp[N][col], s_rho[N][col], tw & 0xffff, (int)((unsigned)tw >> 16), k, a.rgrid);
                 kk = k; oo = ow;
             }
             // the pairs of one beam are neighbours: fold them towards the last lane of the run (larger sum; equal sums: smaller bin)
@@ -908,25 +941,16 @@ __global__ __launch_bounds__(256, 4) void k_power1(SgBeamArgs a, int qplanes)
                 volatile int *vk = s_k;
                 const int col = wbase + oo;
                 const double b0 = vb[col];
-                const int k0 = vk[col];
-                if (sm > b0 || (sm == b0 && kk < k0)) { vb[col] = sm; vk[col] = kk; }
+                const int kc = vk[col];
+                if (sm > b0 || (sm == b0 && kk < kc)) { vb[col] = sm; vk[col] = kk; }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (live) {
             uint32_t rec = 0;
             if (S) {
-                double best = ((volatile double *)s_best)[tid];
-                int k_best = ((volatile int *)s_k)[tid];
-                // the weaker scatterer answers for its bins outside the stronger one's window: they count only if its amplitude
-                // comes within 0.34 % of the maximum found (a handful of beams per million)
-                int wa, wb;
-                sg_one_zone(P, !tgt_first, best, wa, wb);
-                for (int k = wa; k <= wb; ++k) {
-                    const double sm = a.exact_math ? sg_one_bin<true>(P.famp, P.tamp, P.rho, P.d, P.fk0, P.fk1, P.tk0, P.tk1, k, a.rgrid)
-                                                   : sg_one_bin<false>(P.famp, P.tamp, P.rho, P.d, P.fk0, P.fk1, P.tk0, P.tk1, k, a.rgrid);
-                    if (sm > best || (sm == best && k < k_best)) { best = sm; k_best = k; }
-                }
+                const double best = ((volatile double *)s_best)[tid];
+                const int k_best = ((volatile int *)s_k)[tid];
                 if (o.range_error) {
                     atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
                     atomicCAS(&a.status[1], -1, g);
@@ -1455,7 +1479,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr, hipStream_t st1 = nullptr)
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
@@ -1483,11 +1507,14 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_pla
         hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
         SG_CHECK_LAUNCH();
         if (ev_plan && hipEventRecord(ev_plan, st) != hipSuccess) return (int)hipGetLastError();
-        if (a->pw_items1) {                           // the one-flake beams: beside k_power (another stream) or ahead of it
-            hipStream_t s1 = (st1 && ev_plan) ? st1 : st;
-            if (s1 != st && hipStreamWaitEvent(s1, ev_plan, 0) != hipSuccess) return (int)hipGetLastError();
+        if (a->pw_items1) {                           // the beams with few flakes: ahead of k_power on its stream (beside it, on the
+            hipStream_t s1 = st;                      // tiers' stream, was measured: 4.67 instead of 4.59 ms)
             const unsigned g1 = (unsigned)std::min<int64_t>((int64_t)sg_cu_count(dev_id) * 4, (a->n_total / LANES + a->n_regions_ub + 3) / 4);
-            if (g1 > 0) hipLaunchKernelGGL(k_power1<T>, dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
+            if (g1 > 0) {
+                if (a->front_max == 1) hipLaunchKernelGGL((k_power_few<T, 1>), dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
+                else if (a->front_max == 2) hipLaunchKernelGGL((k_power_few<T, 2>), dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
+                else hipLaunchKernelGGL((k_power_few<T, 3>), dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
+            }
             SG_CHECK_LAUNCH();
         }
     }
@@ -1538,20 +1565,20 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
-extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan, void *stream1)
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan)
 {
-    hipStream_t st = (hipStream_t)stream, s1 = (hipStream_t)stream1;
+    hipStream_t st = (hipStream_t)stream;
     hipEvent_t ev = (hipEvent_t)ev_plan;              // recorded behind k_power_plan (the tier lists' bases are known then)
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev, s1);
-        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev, s1);
-        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev, s1);
-        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev, s1);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev, s1);
-    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev, s1);
-    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev, s1);
-    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev, s1);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev);
 }
 
 extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)
