@@ -186,7 +186,8 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
-int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, void *ev_plan /* hipEvent_t recorded behind the plan kernel, or null */);
+int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, int plan_only /* 1: k_power_plan alone; 0: the kernels it feeds */,
+                    void *ev_few /* hipEvent_t recorded behind k_power_few, or null */);
 int sg_launch_tier_gather(const SgBeamArgs *args, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);

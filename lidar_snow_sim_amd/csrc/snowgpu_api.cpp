@@ -59,7 +59,7 @@ struct snowgpu_ctx {
     hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;   // prepass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // resolve / segments
     hipEvent_t ev_fp[SG_MAX_CHUNKS] = {}, ev_join2 = nullptr;   // chunk of the first pass done -> its k_power
-    hipEvent_t ev_plan[SG_MAX_CHUNKS] = {};                      // ... its k_power_plan done -> the tier lists can be closed up
+    hipEvent_t ev_few = nullptr;                          // k_power_few done -> (large batches) the tiers and the prepass
     hipEvent_t ev_lists = nullptr, ev_join3 = nullptr;   // tier lists built -> later tiers
     std::string err;
     std::vector<DeviceTable> tables;
@@ -88,11 +88,10 @@ struct snowgpu_ctx {
     DevBuf<uint16_t> dq_sc;
     DevBuf<unsigned long long> qn;    // per region: front | back << 32
     DevBuf<int2_t> pw_items;          // work items of k_power
-    DevBuf<int32_t> pw_count;
     DevBuf<double> ov;                // overflow slots of the pass over all rows (SG_OV_STRIDE doubles per sorted position)
     DevBuf<uint16_t> ov_sc;
     int use_ov = 1;                   // SNOWGPU_OVERFLOW_SLOTS=0: every over-full beam is scanned again by its tier (rounds 1-3)
-    DevBuf<int32_t> tier_list, tier_sparse, tier_info, tbase, redo_list, redo_cnt;
+    DevBuf<int32_t> tier_list, tier_sparse, tbase, redo_list;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
     DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
     DevBuf<double> h_lists;           // global-list tier: per-lane lists
@@ -118,7 +117,6 @@ struct snowgpu_ctx {
     DevBuf<double> thr_poly, plane, dbg_rj, dbg_ratio, user_thr, out_thr;
     DevBuf<int32_t> user_perm;
     DevBuf<int32_t> dbg_count;
-    DevBuf<unsigned long long> diff2;
     DevBuf<SgTable> frame_tables;
     SgPrepassScratch prepass{};
     // ground plane estimated on the device when a batch brings neither a plane nor a polynomial (planes.py:12-50)
@@ -228,10 +226,9 @@ static int init_streams(snowgpu_ctx *ctx)
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, (mask & 2) ? greatest : 0));
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, (mask & 4) ? greatest : 0));
     }
-    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3})
+    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3, &ctx->ev_few})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
     for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
-    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_plan[c], hipEventDisableTiming));
     return SNOWGPU_OK;
 }
 
@@ -255,10 +252,9 @@ static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks, int n_lanes)
         ln->root = ctx;
         ctx->lanes.push_back(ln);
         if (hipStreamCreateWithPriority(&ln->stream, hipStreamNonBlocking, least) != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, "lane stream");
-        for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3})
+        for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3, &ln->ev_few})
             HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
         for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_fp[c], hipEventDisableTiming));
-        for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_plan[c], hipEventDisableTiming));
     }
     return SNOWGPU_OK;
 }
@@ -335,15 +331,15 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
-    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->pw_count.release(); ctx->ov.release(); ctx->ov_sc.release();
-    ctx->redo_list.release(); ctx->redo_cnt.release();
-    ctx->tier_list.release(); ctx->tier_sparse.release(); ctx->tbase.release(); ctx->tier_info.release(); ctx->h_lists.release();
+    ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->ov.release(); ctx->ov_sc.release();
+    ctx->redo_list.release();
+    ctx->tier_list.release(); ctx->tier_sparse.release(); ctx->tbase.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
     ctx->rank.release(); ctx->keep.release(); ctx->rows_in.release(); ctx->rows_out.release();
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
-    ctx->dbg_count.release(); ctx->diff2.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
+    ctx->dbg_count.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
     ctx->snow_rows.release(); ctx->snow_src.release(); ctx->wet_src.release(); ctx->wet_flags.release(); ctx->snow_counts.release();
     ctx->wet_counts.release(); ctx->wet_rows.release(); ctx->wet_plane.release();
     ctx->rows_crop.release(); ctx->crop_src.release(); ctx->crop_out_src.release(); ctx->crop_counts.release(); ctx->crop_off.release(); ctx->crop_stats.release();
@@ -352,10 +348,9 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->plane_est.release(); ctx->wet_plane_est.release(); ctx->plane_info.release(); ctx->stats_hist.release(); ctx->stats_rec.release();
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3})
+    for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3, ctx->ev_few})
         if (e) (void)hipEventDestroy(e);
     for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_fp[c]) (void)hipEventDestroy(ctx->ev_fp[c]);
-    for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_plan[c]) (void)hipEventDestroy(ctx->ev_plan[c]);
     for (hipStream_t st : {ctx->aux3, ctx->aux2, ctx->aux, ctx->stream})
         if (st) (void)hipStreamDestroy(st);
     delete ctx;
@@ -855,21 +850,17 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->rec_q, n);
     ENSURE(ctx, ctx->rng, n * (b.dtype == 0 ? 4 : 8));
     ENSURE(ctx, ctx->keep, n);
-    ENSURE(ctx, ctx->diff2, (size_t)b.n_frames);
     ENSURE(ctx, ctx->tier_list, n * (size_t)n_tiers);      // one list per later tier, each as long as the batch (address space) ...
     ENSURE(ctx, ctx->tier_sparse, n * (size_t)n_tiers);    // ... and the same as the scan leaves them: region by region
-    ENSURE(ctx, ctx->tier_info, 2 * SG_MAX_CLASSES);
     ENSURE(ctx, ctx->ctile_cnt, (size_t)b.n_frames * (size_t)max_tiles + 1);
     ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
-    HIPCHK(ctx, hipMemsetAsync(ctx->diff2.p, 0, sizeof(unsigned long long) * (size_t)b.n_frames, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->tier_info.p, 0, sizeof(int32_t) * 2 * SG_MAX_CLASSES, st));
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.las = R->d_las; a.frame_tables = ctx->frame_tables.p;
     a.rgrid = R->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
-    a.status = b.status; a.diff2 = ctx->diff2.p;
+    a.status = b.status;
     static const bool no_rng = std::getenv("SNOWGPU_NO_RNG") != nullptr;      // A/B: the noise-floor pass gathers every row again
     a.rng = no_rng ? nullptr : ctx->rng.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
@@ -892,12 +883,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     a.cls_cap[n_cls - 1] = h_cap;
     ENSURE(ctx, ctx->h_lists, (size_t)4 * (size_t)(h_cap + 1) * (size_t)h_lanes);
     a.h_lists = ctx->h_lists.p; a.h_cap = h_cap; a.h_lanes = h_lanes;
-    a.tier_list = ctx->tier_list.p; a.tier_info = ctx->tier_info.p; a.tier_stride = b.n_total; a.tier_sparse = ctx->tier_sparse.p;
+    a.tier_list = ctx->tier_list.p; a.tier_stride = b.n_total; a.tier_sparse = ctx->tier_sparse.p;
     if (tier_rows) {
         ENSURE(ctx, ctx->redo_list, n * (size_t)n_tiers);
-        ENSURE(ctx, ctx->redo_cnt, SG_MAX_CLASSES);
-        HIPCHK(ctx, hipMemsetAsync(ctx->redo_cnt.p, 0, sizeof(int32_t) * SG_MAX_CLASSES, st));
-        a.redo_list = ctx->redo_list.p; a.redo_cnt = ctx->redo_cnt.p;
+        a.redo_list = ctx->redo_list.p;
     }
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int k = 0; k + 1 < n_cls && !tier_rows; ++k) {
@@ -919,12 +908,18 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->dq, (n + 64) * planes);          // blocked SoA: groups of 64 slots
         ENSURE(ctx, ctx->dq_g, n);
         ENSURE(ctx, ctx->dq_sc, n);
-        // per region: the queue counter, then (same allocation, one memset) the SG_MAX_CLASSES tier-list counters
-        static_assert(SG_MAX_CLASSES * sizeof(int32_t) == 2 * sizeof(unsigned long long), "tn follows qn");
-        ENSURE(ctx, ctx->qn, 3 * regions);
+        // Everything this step counts up from zero lies in ONE block, cleared by one fill (each fill is a launch on the chain between
+        // the sort and the scan): per region the queue counter and the SG_MAX_CLASSES tier-list counters; per frame the intensity
+        // statistics; the tier lists' lengths, the work-item counters, the row kernels' redo counters.
+        static_assert(SG_MAX_CLASSES * sizeof(int32_t) == 2 * sizeof(unsigned long long), "a region's tier counters are two 64-bit words");
+        const size_t zero_words = 3 * regions + (size_t)b.n_frames + 8;
+        ENSURE(ctx, ctx->qn, zero_words);
         ENSURE(ctx, ctx->tbase, SG_MAX_CLASSES * regions);
-        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * 3 * regions, st));
+        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * zero_words, st));
         a.tn = (int32_t *)(ctx->qn.p + regions); a.tbase = ctx->tbase.p;
+        a.diff2 = ctx->qn.p + 3 * regions;
+        int32_t *small = (int32_t *)(ctx->qn.p + 3 * regions + (size_t)b.n_frames);      // 16 ints
+        a.tier_info = small; a.pw_count = small + 8; a.redo_cnt = small + 12;
         a.dq = ctx->dq.p; a.dq_g = ctx->dq_g.p; a.dq_sc = ctx->dq_sc.p; a.qn = ctx->qn.p; a.dq_n = b.n_total;
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
@@ -932,8 +927,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.kp_lds_quarters = R->kp_quarters;
         const size_t items_cap = n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64;
         ENSURE(ctx, ctx->pw_items, 2 * items_cap);
-        ENSURE(ctx, ctx->pw_count, 4);
-        a.pw_items = ctx->pw_items.p; a.pw_count = ctx->pw_count.p;
+        a.pw_items = ctx->pw_items.p;
         // beams with up to `few` flakes take their own kernel (k_power_few: registers only) -- unless the occlusion tap wants their dicts
         a.pw_items1 = (R->few > 0 && !b.dbg_count && lanes == 64) ? ctx->pw_items.p + items_cap : nullptr;
         a.front_max = a.pw_items1 ? std::min(R->few, std::min(3, tiers[0])) : 1;
@@ -952,6 +946,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.seg_blk = ctx->seg_blk.p; a.seg_start = ctx->seg_start.p; a.seg_cnt = ctx->seg_cnt.p; a.seg_frame = ctx->seg_frame.p;
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
+    const bool few_first = a.pw_items1 && !serial && b.n_total > ((int64_t)1 << 19);
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     // measurement hooks: one event pair around the whole per-beam region
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
@@ -971,15 +966,20 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             }
             e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
             if (e) break;
-            // The pass queued the beams that met a flake: their received-power phase runs on a side stream, next to the
-            // following chunks and to the (latency-bound, mostly empty) later capacity tiers.
+            // The plan of what the pass queued (work items of k_power_few / k_power; where each region's slice of the tier lists goes)
+            // runs behind it on the same stream -- the tiers then start with one short kernel (k_tier_gather) and no hop between streams --
+            // and the received-power kernels it feeds on a side stream, next to the following chunks and the later capacity tiers.
+            if (c > 0) HIPCHK(ctx, hipMemsetAsync(a.pw_count, 0, 2 * sizeof(int32_t), st));     // (chunk 0: cleared with the rest)
+            e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr);
+            if (e) break;
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp[c], 0));
-            HIPCHK(ctx, hipMemsetAsync(ctx->pw_count.p, 0, 2 * sizeof(int32_t), s_aux));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, ctx->ev_plan[c]);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr);
             if (e) break;
-            // the tier lists closed up: behind the plan kernel, on the caller's stream, where the tiers start
-            HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_plan[c], 0));
+            // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
+            // the tiers, the prepass and k_power do better behind it than beside it (measured: 4.37 against 4.69 ms per 256 sweeps when
+            // they all start together; the other way round for a single sweep, where nothing fills anything).
+            if (few_first) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
             e = sg_launch_tier_gather(&a, st);
         }
     }
@@ -1034,7 +1034,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
     e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          ctx->diff2.p, b.no_fov ? nullptr : &R->fov, max_tiles, st);
+                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
 }

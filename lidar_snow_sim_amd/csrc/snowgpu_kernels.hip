@@ -838,9 +838,11 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
 // (beam, bin) pairs of its 64 beams by a prefix sum and takes them 64 at a time, whichever beam they belong to (the owner's
 // scatterers through LDS); a segmented reduction over the lanes folds each beam's bins (first maximum, simulation.py:151).
 // Measured (256 sweeps, same box): N = 2: C2 4.53 -> 4.34 ms, C4 10.6 -> 10.2 ms, C2far 9.05 -> 9.22 ms; N = 1: 4.53, 10.6, 9.05 (and
-// 9.58 / 11.03 without any such kernel); N = 3 (143 registers, three waves per SIMD): 4.70, 10.5, 9.02.
+// 9.58 / 11.03 without any such kernel); N = 3: 4.32, 9.77, 9.48 (and C1: 8.98 without, 8.58 with N = 2, 8.78 with N = 3).
+// Tried and dropped: the kernel beside k_power on another stream, two or three blocks per CU instead of four (all 1 - 10 % slower:
+// the persistent kernels of this phase do best when each has the chip to itself for its turn).
 template <typename T, int N>
-__global__ __launch_bounds__(256, N <= 2 ? 4 : 3) void k_power_few(SgBeamArgs a, int qplanes)
+__global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)   // (N = 3: 127 registers and eight spilled; at three waves per SIMD, 143 registers, it was slower on every workload)
 {
     __shared__ double s_amp[N + 1][256], s_rho[N + 1][256], s_best[256];      // scatterer N: the hard target
     __shared__ int s_win[N + 1][256], s_zone[N + 1][256], s_k[256];           // k0 | k1 << 16;  first bin | bins << 16
@@ -1479,7 +1481,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_plan = nullptr)
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = false, hipEvent_t ev_few = nullptr)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
@@ -1504,9 +1506,11 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_pla
         // (small batches: a wave walking a window would serialise what the idle rest of the chip could do at once)
         const int64_t back_est = a->n_total / 10;
         const int lanes_back = (BLOCK < 64 || back_est <= (int64_t)blocks * (THREADS / 64) * LANES * 5 / 2) ? LANES : LANES * SG_KP_WIN;
-        hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
-        SG_CHECK_LAUNCH();
-        if (ev_plan && hipEventRecord(ev_plan, st) != hipSuccess) return (int)hipGetLastError();
+        if (plan_only) {                              // (its own call: the plan runs on the scan's stream, the kernels it feeds beside the tiers)
+            hipLaunchKernelGGL(k_power_plan, dim3(pg), dim3(256), 0, st, *a, LANES, lanes_back, (int)a->n_regions_ub);
+            SG_CHECK_LAUNCH();
+            return 0;
+        }
         if (a->pw_items1) {                           // the beams with few flakes: ahead of k_power on its stream (beside it, on the
             hipStream_t s1 = st;                      // tiers' stream, was measured: 4.67 instead of 4.59 ms)
             const unsigned g1 = (unsigned)std::min<int64_t>((int64_t)sg_cu_count(dev_id) * 4, (a->n_total / LANES + a->n_regions_ub + 3) / 4);
@@ -1516,6 +1520,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, hipEvent_t ev_pla
                 else hipLaunchKernelGGL((k_power_few<T, 3>), dim3(g1), dim3(256), 0, s1, *a, SG_QPLANES(LMAX));
             }
             SG_CHECK_LAUNCH();
+            if (ev_few && hipEventRecord(ev_few, st) != hipSuccess) return (int)hipGetLastError();
         }
     }
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
@@ -1565,20 +1570,22 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
 }
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
-extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, void *ev_plan)
+// plan_only = 1: k_power_plan alone (work items of k_power / k_power_few, places of the tier lists' slices); 0: k_power_few and k_power
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, int plan_only, void *ev_few)
 {
     hipStream_t st = (hipStream_t)stream;
-    hipEvent_t ev = (hipEvent_t)ev_plan;              // recorded behind k_power_plan (the tier lists' bases are known then)
+    const bool po = plan_only != 0;
+    hipEvent_t ef = (hipEvent_t)ev_few;
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, ev);
-        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, ev);
-        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, ev);
-        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, ev);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, po, ef);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, po, ef);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, po, ef);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, po, ef);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, ev);
-    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, ev);
-    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, ev);
-    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, ev);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, po, ef);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, po, ef);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, po, ef);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, po, ef);
 }
 
 extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)

@@ -19,6 +19,7 @@ python scripts/trace_timeline.py $O/stats > $O/timeline.txt
 SNOWGPU_BENCH_PMC_DUMP=$O/pmc_fetch_write_per_kernel.csv timeout 400 python bench.py > $O/bench_C2.json 2> $O/bench_C2.err
 # 5. the other workloads of BASELINE.json
 for w in ${WORKLOADS:-C4 C3}; do timeout 200 python bench.py --workload $w --no-pmc --no-cpu-baseline $( [ $w = C4 ] && echo --frames 128 ) > $O/bench_$w.json 2> $O/bench_$w.err; done
+timeout 200 python bench.py --tables device --no-pmc --no-pcie > $O/bench_C2_device_tables.json 2> $O/bench_C2_device_tables.err
 timeout 300 python bench.py --workload C5 --frames ${C5_FRAMES:-10000} > $O/bench_C5.json 2> $O/bench_C5.err
 # 6. the pipeline's own event trace (upload / compute / download per chunk)
 SNOWGPU_PIPE_TRACE=1 timeout 120 python scripts/pcie_bench.py --reps 1 2>&1 | grep "^pipe" | tail -25 > $O/pipeline_trace.txt

@@ -152,7 +152,8 @@ def test_stream_driver_with_an_empty_particle_directory_samples_on_the_device(sm
         with pytest.raises(FileNotFoundError):                                    # the reference's behaviour without the switch (simulation.py:329)
             stream.run(lidar, ids, particle_root=str(tmp_path), modes=("gunn",), combos=combos, batch=2)
         random.seed(8)
-        n = stream.run(lidar, ids, particle_root=str(tmp_path), modes=("gunn",), combos=combos, batch=2, sample_missing=True)
+        # one GPU worker: the batch then runs on the engine this test reads the sampled rows back from (slot 0)
+        n = stream.run(lidar, ids, particle_root=str(tmp_path), modes=("gunn",), combos=combos, batch=2, sample_missing=True, workers=1)
         assert n == 2
         tabs = [eng.sampled_rows[(prefix, line)] for line in range(1, 65)]        # the tables as the device made them
         assert all(t.shape[0] > 10000 for t in tabs) and eng.sampled_flakes[(prefix, 1)] == tabs[0].shape[0]
