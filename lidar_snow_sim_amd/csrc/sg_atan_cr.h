@@ -4,8 +4,9 @@
 // atan2 / atan are correctly rounded in practice (its IBM Accurate Mathematical Library code falls back to a second,
 // ~100-bit stage whenever the first cannot decide the rounding).  The device math library's versions differ from it in the
 // last bit for some inputs; this one evaluates atan in double-double arithmetic (~2^-100 relative) and rounds once, so it
-// returns the same double as glibc wherever glibc is correctly rounded -- checked against it on 2 * 10^8 inputs in the build
-// container (tests/test_host_logic.py::test_correctly_rounded_atan2_equals_glibc, scripts/probe/atan_cr_check.cpp).
+// returns the same double as glibc wherever glibc is correctly rounded -- scripts/probe/atan_cr_check.cpp compares the two (2 * 10^8
+// inputs once in the build container; 4 * 10^6 on every run of tests/test_host_logic.py::
+// test_correctly_rounded_atan2_equals_glibc_where_glibc_is, which settles each mismatch with 70-digit arithmetic).
 //
 //   atan2(y, x): t = min(|y|, |x|) / max(|y|, |x|) in double-double; c = round(64 t) / 64; u = (t - c) / (1 + t c), |u| <= 2^-7;
 //   atan(t) = atan(c) [table, double-double] + u (1 - u^2/3 + u^4/5 - u^6/7 [double-double] + u^8/9 - .. + u^16/17 [double]);

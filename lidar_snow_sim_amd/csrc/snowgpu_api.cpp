@@ -1112,8 +1112,9 @@ static void *device_view(const void *host, size_t bytes)
 //   * the chunks compute into a batch-sized result buffer, each as ONE chain of launches on one stream, alternating between
 //     two lanes (the context itself and a sub-context with its own stream, events and scratch in the low-priority pool): a
 //     chunk starts the moment its upload lands, and the launch latency of one chain hides behind the other;
-//   * the downloads run on one more stream (low-priority pool: a hardware queue of its own) as a small-grid kernel of ours
-//     that writes page-locked memory directly (sg_launch_copy_link), each after its chunk's event.
+//   * the downloads run on one more stream (low-priority pool: a hardware queue of its own), each after its chunk's event: the
+//     runtime's copy, i.e. the DMA engine (SNOWGPU_LINK_BLOCKS=n: a small-grid kernel of ours that writes page-locked memory
+//     directly, sg_launch_copy_link -- measured slower: every kernel boundary then waits for outstanding host writes).
 // The host enqueues everything and waits once at the end.  Small per-frame arrays (table ids, planes / polynomials, counts,
 // statistics) cross once for the whole batch; a chunk sees its slice of them.
 static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
