@@ -2,7 +2,8 @@
 
 The reference takes this from the un-vendored OpenPCDet fork (pcdet.utils.calibration_kitti.Calibration)
 and a data file that is not in its tree (lib/OpenPCDet/data/dense/calib_hdl64.txt), so parity for this
-step is UNPINNED: what is here is the textbook KITTI projection (P2, R0_rect, Tr_velo_to_cam).
+step is UNPINNED: what is here restates that module's published lidar_to_rect / rect_to_img (P2, R0_rect, Tr_velo_to_cam;
+image coordinates divided by the rectified z, depth = third homogeneous coordinate - P2[2, 3]).
 """
 from pathlib import Path
 
@@ -36,7 +37,7 @@ class Calibration:
     def rect_to_img(self, pts_rect):
         hom = np.hstack((pts_rect, np.ones((pts_rect.shape[0], 1), dtype=np.float32)))
         pts_2d = np.dot(hom, self.P2.T)
-        pts_img = (pts_2d[:, 0:2].T / hom.dot(self.P2.T)[:, 2]).T
+        pts_img = (pts_2d[:, 0:2].T / hom[:, 2]).T            # OpenPCDet: by the rectified point's z (not the projected one: P2[2, 3] != 0 in KITTI files)
         depth = pts_2d[:, 2] - self.P2.T[3, 2]
         return pts_img, depth
 

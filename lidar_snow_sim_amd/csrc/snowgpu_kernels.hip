@@ -1144,15 +1144,18 @@ __device__ __forceinline__ SgRow<T> sg_rebuild_row(const T *__restrict__ row, ui
     return r;
 }
 
-// get_fov_flag(calib.lidar_to_rect(xyz), (h, w), calib) (simulation.py:39-47, :535-536) in float64, fixed operation order
-// (the reference's own arithmetic lives in an un-vendored module: parity unpinned, SURVEY 8 c)
+// get_fov_flag(calib.lidar_to_rect(xyz), (h, w), calib) (simulation.py:39-47, :535-536) in float64, fixed operation order.
+// The projection is OpenPCDet's (pcdet/utils/calibration_kitti.py, the reference's un-vendored submodule lib/OpenPCDet:
+// parity unpinned, SURVEY 8 c): rect_to_img divides the image coordinates by the RECTIFIED point's z, not by the third
+// homogeneous coordinate -- the two differ by P2[2][3], which real KITTI files carry (~ 3e-3) --, and the depth is that
+// coordinate minus P2[2][3].
 __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, double z)
 {
     double r[3];
     for (int j = 0; j < 3; ++j) r[j] = ((x * v.m[j] + y * v.m[3 + j]) + z * v.m[6 + j]) + v.m[9 + j];
     double h[3];
     for (int j = 0; j < 3; ++j) h[j] = ((r[0] * v.p[4 * j] + r[1] * v.p[4 * j + 1]) + r[2] * v.p[4 * j + 2]) + v.p[4 * j + 3];
-    const double u = h[0] / h[2], w = h[1] / h[2];
+    const double u = h[0] / r[2], w = h[1] / r[2];
     const double depth = h[2] - v.p[11];
     return u >= 0 && u < v.img_w && w >= 0 && w < v.img_h && depth >= 0;
 }

@@ -430,7 +430,7 @@ def fov_flag(xyz, v2c, r0, p2, img_shape=(1024, 1920)):
     rect = [((x * m[0, j] + y * m[1, j]) + z * m[2, j]) + m[3, j] for j in range(3)]
     hom = [((rect[0] * p2[j, 0] + rect[1] * p2[j, 1]) + rect[2] * p2[j, 2]) + p2[j, 3] for j in range(3)]   # rect_to_img
     with np.errstate(divide="ignore", invalid="ignore"):
-        u, w = hom[0] / hom[2], hom[1] / hom[2]
+        u, w = hom[0] / rect[2], hom[1] / rect[2]                       # OpenPCDet calibration_kitti.rect_to_img: by the rectified z
     depth = hom[2] - p2[2, 3]
     return (u >= 0) & (u < img_shape[1]) & (w >= 0) & (w < img_shape[0]) & (depth >= 0)        # sim:42-45
 

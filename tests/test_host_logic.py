@@ -813,3 +813,28 @@ def test_stream_reader_rejects_a_truncated_bin(tmp_path):
     from lidar_snow_sim_amd import stream
     src = open(stream.__file__).read()
     assert "nbytes % 20" in src and "not a whole number of float32 N x 5 rows" in src
+
+
+def test_fov_projection_divides_by_the_rectified_z_like_openpcdet():
+    """The camera-FOV test (simulation.py:39-47) goes through OpenPCDet's Calibration.rect_to_img (the reference's un-vendored
+    submodule): image coordinates = (rect_hom . P2^T)[:, :2] / RECTIFIED z, depth = third homogeneous coordinate - P2[2, 3].  With a
+    KITTI P2 (P2[2, 3] = 2.7e-3) that is not the division by the third homogeneous coordinate; host mirror and oracle restatement
+    must both be the former, and agree with each other point for point."""
+    from lidar_snow_sim_amd.calibration import Calibration, get_fov_flag
+    from oracle import snow_oracle as so
+    P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]])
+    R0 = np.array([[0.9999239, 0.00983776, -0.007445048], [-0.009869795, 0.9999421, -0.004278459], [0.007402527, 0.004351614, 0.9999631]])
+    V2C = np.array([[7.533745e-03, -9.999714e-01, -6.166020e-04, -4.069766e-03], [1.480249e-02, 7.280733e-04, -9.998902e-01, -7.631618e-02],
+                    [9.998621e-01, 7.523790e-03, 1.480755e-02, -2.717806e-01]])
+    cal = Calibration(P2=P2, R0=R0, V2C=V2C)
+    rng = np.random.default_rng(5)
+    pts = np.column_stack([rng.uniform(-5, 80, 20000), rng.uniform(-40, 40, 20000), rng.uniform(-3, 3, 20000)])
+    rect = cal.lidar_to_rect(pts)
+    img, depth = cal.rect_to_img(rect)
+    hom = np.hstack([rect, np.ones((len(rect), 1))]) @ P2.T
+    assert np.array_equal(img, (hom[:, :2].T / rect[:, 2]).T) and np.array_equal(depth, hom[:, 2] - P2[2, 3])
+    other = (hom[:, :2].T / hom[:, 2]).T                                   # what rounds 1 - 3 divided by
+    assert np.abs(img - other).max() > 1e-3                                # ... is a different picture coordinate
+    a = get_fov_flag(rect, (1024, 1920), cal)
+    b = so.fov_flag(pts, V2C, R0, P2, (1024, 1920))
+    assert np.array_equal(a, b) and 500 < a.sum() < 19500
