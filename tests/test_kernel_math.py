@@ -25,3 +25,43 @@ def test_few_flake_path_equals_the_general_path_bit_for_bit(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("few<")]
     assert len(lines) == 3 and all(" 0 mismatches" in ln for ln in lines), r.stdout
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
+def test_device_occlusion_dict_equals_the_oracle_bit_for_bit(tmp_path):
+    """sg_beam_dict (csrc/sg_beam.h: phase 2 of every per-beam kernel), compiled for the host, against the oracle's
+    compute_occlusion_dict (oracle/snow_oracle.c, pinned to the reference's L2 golden vectors) on random interval lists for the list
+    capacities 4, 8, 16 and 63: same entries, same ranges, same ratios to the last bit."""
+    so = tmp_path / "snow_oracle.o"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-c", str(ROOT / "oracle" / "snow_oracle.c"), "-o", str(so)])
+    obj, exe = tmp_path / "dict_vs_oracle.o", tmp_path / "dict_vs_oracle"
+    r = subprocess.run([HIPCC, "--cuda-host-only", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-w",
+                        "-I", str(ROOT / "lidar_snow_sim_amd" / "csrc"), "-I", str(ROOT / "include"),
+                        str(ROOT / "tests" / "host_harness" / "dict_vs_oracle.cpp"), "-c", "-o", str(obj)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    subprocess.check_call([HIPCC, str(obj), str(so), "-o", str(exe), "-lm", "-lpthread"])
+    r = subprocess.run([str(exe), "60000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("dict<")]
+    assert len(lines) == 4 and all(" 0 mismatches" in ln for ln in lines), r.stdout
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
+def test_device_per_beam_chain_equals_the_oracle_byte_for_byte(tmp_path):
+    """The whole per-beam chain of the kernels on the host: a random table filed by the product's host filing (csrc/sg_table_host.h),
+    random float32 beams through sg_beam (geometry, candidate scan, occlusion dict, amplitudes), sg_lane_power (received power with the
+    exact pruning, first maximum), sg_beam_decide and sg_scatter_scale -- against the oracle's process_single_channel
+    (oracle/snow_oracle.c, pinned to the reference's golden vectors): identical output rows and intensity-difference sums, in the
+    kernels' default arithmetic (own sine / tangent polynomials, computed range grid) and in the exact-math mode (libm)."""
+    so = tmp_path / "snow_oracle.o"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-c", str(ROOT / "oracle" / "snow_oracle.c"), "-o", str(so)])
+    obj, exe = tmp_path / "beam_vs_oracle.o", tmp_path / "beam_vs_oracle"
+    r = subprocess.run([HIPCC, "--cuda-host-only", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-w",
+                        "-I", str(ROOT / "lidar_snow_sim_amd" / "csrc"), "-I", str(ROOT / "include"),
+                        str(ROOT / "tests" / "host_harness" / "beam_vs_oracle.cpp"), "-c", "-o", str(obj)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    subprocess.check_call([HIPCC, str(obj), str(so), "-o", str(exe), "-lm", "-lpthread"])
+    r = subprocess.run([str(exe), "12000"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("beams<")]
+    assert len(lines) == 3 and all(" 0 mismatches" in ln for ln in lines), r.stdout
