@@ -2,7 +2,7 @@
 // filing (sg_table_host.h), occlusion dict, amplitudes, received power with its exact pruning, first maximum, attenuate-or-scatter
 // decision and the moved coordinates (sg_beam.h: sg_beam, sg_lane_power, sg_beam_decide, sg_scatter_scale) -- compiled for the host
 // and run beam by beam against the oracle's process_single_channel (oracle/snow_oracle.c: so_process_channel_f32, pinned to the
-// reference's golden vectors) on random float32 sweeps: the output rows must be the same bytes.  Both arithmetic modes: the kernels'
+// reference's golden vectors) on random float32 and float64 sweeps: the output rows must be the same bytes.  Both arithmetic modes: the kernels'
 // own sine / tangent polynomials (default) and libm + the tabulated range grid (snowgpu_set_exact_math).
 // usage: beam_vs_oracle [beams]; exit status 1 on any mismatch.  Built and run by tests/test_kernel_math.py.
 #include <hip/hip_runtime.h>
@@ -42,8 +42,17 @@ typedef struct { int32_t channel, min_intensity, max_intensity; double focal_slo
 extern "C" int so_process_channel_f32(const float *pts_in, int64_t M, const double *table_xyr, int64_t K, double beam_div_deg, const so_laser *las,
                                       const double *R, float *pts_out, double *diff_sum, int64_t *dump_count, int64_t *dump_key, double *dump_rj,
                                       double *dump_ratio, int64_t dump_cap, int64_t *dump_used);
+extern "C" int so_process_channel_f64(const double *pts_in, int64_t M, const double *table_xyr, int64_t K, double beam_div_deg, const so_laser *las,
+                                      const double *R, double *pts_out, double *diff_sum, int64_t *dump_count, int64_t *dump_key, double *dump_rj,
+                                      double *dump_ratio, int64_t dump_cap, int64_t *dump_used);
+static int oracle_channel(const float *in, int64_t M, const double *xyr, int64_t K, double div, const so_laser *l, const double *R, float *out, double *diff)
+{ return so_process_channel_f32(in, M, xyr, K, div, l, R, out, diff, nullptr, nullptr, nullptr, nullptr, 0, nullptr); }
+static int oracle_channel(const double *in, int64_t M, const double *xyr, int64_t K, double div, const so_laser *l, const double *R, double *out, double *diff)
+{ return so_process_channel_f64(in, M, xyr, K, div, l, R, out, diff, nullptr, nullptr, nullptr, nullptr, 0, nullptr); }
+static float row_norm(float x, float y, float z) { return sqrtf((x * x + y * y) + z * z); }
+static double row_norm(double x, double y, double z) { return sqrt((x * x + y * y) + z * z); }
 
-template <bool EXACT>
+template <typename T, bool EXACT>
 static long run_beams(long M, unsigned long long seed, double flake_r, int K)
 {
     std::mt19937_64 rng(seed);
@@ -71,52 +80,52 @@ static long run_beams(long M, unsigned long long seed, double flake_r, int K)
     so_laser ol{ch, las.min_i[ch], las.max_i[ch], las.focal_slope[ch], las.focal_offset[ch]};
     std::vector<double> R(SG_RBINS);
     for (int k = 0; k < SG_RBINS; ++k) R[k] = sg_range_bin(k);
-    std::vector<float> in((size_t)M * 5), ref((size_t)M * 5), got((size_t)M * 5);
+    std::vector<T> in((size_t)M * 5), ref((size_t)M * 5), got((size_t)M * 5);
     for (long j = 0; j < M; ++j) {
         const double d = 3.0 + 72.0 * U(rng), az = U(rng) * SG_TWO_PI, el = (U(rng) - 0.7) * 0.4;
-        in[5 * j] = (float)(d * std::cos(el) * std::cos(az)); in[5 * j + 1] = (float)(d * std::cos(el) * std::sin(az)); in[5 * j + 2] = (float)(d * std::sin(el));
-        in[5 * j + 3] = (float)(int)(U(rng) * 255); in[5 * j + 4] = (float)ch;
+        in[5 * j] = (T)(d * std::cos(el) * std::cos(az)); in[5 * j + 1] = (T)(d * std::cos(el) * std::sin(az)); in[5 * j + 2] = (T)(d * std::sin(el));
+        in[5 * j + 3] = (T)(int)(U(rng) * 255); in[5 * j + 4] = (T)ch;
     }
     double diff = 0;
-    const int orc = so_process_channel_f32(in.data(), M, xyr.data(), K, div, &ol, R.data(), ref.data(), &diff, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    const int orc = oracle_channel(in.data(), M, xyr.data(), K, div, &ol, R.data(), ref.data(), &diff);
     if (orc) { printf("oracle returned %d\n", orc); return 1; }
     constexpr int LC = 63;
     static double s_a1[LC + 2], s_a2[LC + 2], s_rho[LC + 2], s_ratio[LC + 2];
     long badn = 0, labels[3] = {0, 0, 0}, over = 0;
     long long diff2 = 0;
     for (long j = 0; j < M; ++j) {
-        const float px = in[5 * j], py = in[5 * j + 1], pz = in[5 * j + 2];
-        float *o = &got[5 * j];
-        memcpy(o, &in[5 * j], 5 * sizeof(float));
+        const T px = in[5 * j], py = in[5 * j + 1], pz = in[5 * j + 2];
+        T *o = &got[5 * j];
+        memcpy(o, &in[5 * j], 5 * sizeof(T));
         SgBeamOut bo{};
-        sg_beam<float, LC, 1>(px, py, pz, ch, tab, &las, div, s_a1, s_a2, s_rho, s_ratio, 0, bo, 0, nullptr, nullptr, nullptr, EXACT);
-        if (bo.overflow) { ++over; memcpy(o, &ref[5 * j], 5 * sizeof(float)); continue; }      // (more than 63 flakes: the global-list tier's business)
+        sg_beam<T, LC, 1>(px, py, pz, ch, tab, &las, div, s_a1, s_a2, s_rho, s_ratio, 0, bo, 0, nullptr, nullptr, nullptr, EXACT);
+        if (bo.overflow) { ++over; memcpy(o, &ref[5 * j], 5 * sizeof(T)); continue; }      // (more than 63 flakes: the global-list tier's business)
         int label = 0;
         if (bo.has_power) {
             double best = 0.0;
             int k_best = 0;
             sg_lane_power<1, EXACT, 4, LC>(bo.n_flakes, R.data(), s_a1, s_a2, s_rho, s_ratio, 0, best, k_best);
-            const float d_t = sqrtf((px * px + py * py) + pz * pz);
+            const T d_t = row_norm(px, py, pz);
             sg_beam_decide((double)d_t, ch, &las, best, k_best, bo);
             label = bo.label;
-            if (label == 2) {
+            if (label == 2) {                             // simulation.py:178-180: a column of the row dtype times a float64 scalar
                 const double sc = sg_scatter_scale(bo.k_best, (double)d_t);
-                o[0] = (float)((double)px * sc); o[1] = (float)((double)py * sc); o[2] = (float)((double)pz * sc);
+                o[0] = (T)((double)px * sc); o[1] = (T)((double)py * sc); o[2] = (T)((double)pz * sc);
             }
-            o[3] = (float)bo.new_i;
+            o[3] = (T)bo.new_i;
             diff2 += (long long)bo.diff2;
         }
-        o[4] = (float)label;
+        o[4] = (T)label;
         ++labels[label];
-        if (memcmp(o, &ref[5 * j], 5 * sizeof(float))) {
-            if (badn < 10) printf("MISMATCH beam %ld: got (%.9g %.9g %.9g %g %g) oracle (%.9g %.9g %.9g %g %g)\n", j, o[0], o[1], o[2], o[3], o[4],
-                                  ref[5 * j], ref[5 * j + 1], ref[5 * j + 2], ref[5 * j + 3], ref[5 * j + 4]);
+        if (memcmp(o, &ref[5 * j], 5 * sizeof(T))) {
+            if (badn < 10) printf("MISMATCH beam %ld: got (%.17g %.17g %.17g %g %g) oracle (%.17g %.17g %.17g %g %g)\n", j, (double)o[0], (double)o[1], (double)o[2],
+                                  (double)o[3], (double)o[4], (double)ref[5 * j], (double)ref[5 * j + 1], (double)ref[5 * j + 2], (double)ref[5 * j + 3], (double)ref[5 * j + 4]);
             ++badn;
         }
     }
     if ((double)diff2 != 2.0 * diff) { printf("intensity-difference sum: %lld / 2 vs oracle %.17g\n", diff2, diff); ++badn; }
-    printf("beams<%s> r=%.3f K=%d: %ld beams, %ld mismatches; labels %ld %ld %ld, %ld beyond 63 flakes\n", EXACT ? "exact" : "default", flake_r, K, M, badn,
-           labels[0], labels[1], labels[2], over);
+    printf("beams<%s, %s> r=%.3f K=%d: %ld beams, %ld mismatches; labels %ld %ld %ld, %ld beyond 63 flakes\n", sizeof(T) == 4 ? "float32" : "float64",
+           EXACT ? "exact" : "default", flake_r, K, M, badn, labels[0], labels[1], labels[2], over);
     return badn;
 }
 
@@ -124,8 +133,10 @@ int main(int argc, char **argv)
 {
     const long n = argc > 1 ? atol(argv[1]) : 100000;
     long bad = 0;
-    bad += run_beams<false>(n, 7, 0.004, 18000);      // the density of the 2.5 mm/h tables
-    bad += run_beams<false>(n, 8, 0.02, 18000);       // many flakes per beam
-    bad += run_beams<true>(n / 2, 9, 0.01, 18000);
+    bad += run_beams<float, false>(n, 7, 0.004, 18000);       // the density of the 2.5 mm/h tables
+    bad += run_beams<float, false>(n, 8, 0.02, 18000);        // many flakes per beam
+    bad += run_beams<float, true>(n / 2, 9, 0.01, 18000);
+    bad += run_beams<double, false>(n, 10, 0.01, 18000);      // float64 rows: the correctly rounded atan2 of the beam azimuth (sg_atan_cr.h)
+    bad += run_beams<double, true>(n / 2, 11, 0.01, 18000);
     return bad != 0;
 }
