@@ -897,16 +897,20 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         }
     }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join2, s_aux));
     // The noise-threshold prepass streams the rows (bandwidth-bound, no LDS): it runs beside the received-power phase and
     // the later tiers (latency-bound, LDS-bound) rather than beside the sort and the scan, which it would slow down.
     if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
     // The scan put every over-full beam on the list of its tier (it counted on past a full list, so the beam knows which): the tiers
     // start as soon as it has ended, side by side -- class 0 on the caller's stream, the others on a side stream.
     const bool side3 = n_cls >= 2;
+    // classes from the third on (the 63-entry and the global-list tier: few beams, long dependent chains) behind k_power on ITS stream,
+    // which is free long before the 8- and 16-entry tiers are through, instead of behind the second class
+    static const bool tail_on_aux = []{ const char *v = std::getenv("SNOWGPU_TIER_TAIL_AUX"); return v ? v[0] == '1' : true; }();
+    const bool tail_aux = tail_on_aux && n_cls >= 3 && !serial;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
+    if (tail_aux) HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_lists, 0));
     for (int k = 0; k < n_cls && !e; ++k) {
-        hipStream_t sk = k == 0 ? st : s_aux3;
+        hipStream_t sk = k == 0 ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
         a.seg_blk = nullptr;
         a.cls = k;
         if (k == n_cls - 1) {                            // the global-list tier
@@ -940,6 +944,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("tier launch: ") + hipGetErrorString((hipError_t)e));
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_join3, s_aux3)); HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join3, 0)); }
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join2, s_aux));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
     // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats
