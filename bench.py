@@ -56,7 +56,10 @@ WORKLOADS = {   # name: (layers, azimuths, snowfall mm/h, terminal velocity m/s,
     "C1": (64, 2048, 0.5, 2.0, 1.0),       # configs[0]'s table density (40 k flakes per line)
     "C4": (128, 4096, 10.0, 1.6, 1.0),     # configs[3]: 128 x 4096 dense sweep, heavy snowfall, tiled laser table
     "C3": (64, 2048, 2.5, 1.6, 1.0),       # configs[2]: the C2 sweeps through snowfall + wet ground, fused on the device
+    "C2fire": (64, 2048, 2.5, 1.6, 1.0),   # the C2 sweeps with their rows in FIRING order (azimuth-major, the 64 channels interleaved), as the
+                                           # sensor writes an STF .bin (precompute.py:78): the channel sort is no longer the identity
 }
+FIRING_ORDER = {"C2fire"}
 REGION_KERNELS = ("k_beams", "k_power", "k_tier")    # the per-beam region of roofline.avg_launch_ms
 # rocprofv3's FETCH_SIZE x 1024 B is HALF the bytes a kernel reads on gfx950, for every access shape the engine uses (4- and
 # 8-byte streams, 20-byte rows field by field, 64-byte records: ratio 0.5000 each), WRITE_SIZE x 1024 B is exact for streams:
@@ -94,14 +97,14 @@ def make_tables(n_lines=64, snowfall=SNOWFALL, velocity=VELOCITY, distinct=None)
     return [tabs[i % distinct] for i in range(n_lines)]
 
 
-def make_frame(layers, azimuths, seed, scale):
-    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+def make_frame(layers, azimuths, seed, scale, firing=False):
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep, firing_order
     pc = synthetic_sweep(layers, azimuths, seed=seed, intensity="lambert")
     if scale != 1.0:
         r = np.linalg.norm(pc[:, :3].astype(np.float64), axis=1)
         f = np.minimum(r * scale, 119.0) / r
         pc[:, :3] = (pc[:, :3] * f[:, None]).astype(np.float32)
-    return pc
+    return firing_order(pc, layers, azimuths) if firing else pc
 
 
 def cpu_model():
@@ -353,7 +356,7 @@ def main():
     plane = ([0.0, 0.0, -1.0], -1.7)
     for f in range(F):
         seed = 1000 + rank * F + f
-        pc = make_frame(layers, azimuths, seed, rscale)
+        pc = make_frame(layers, azimuths, seed, rscale, args.workload in FIRING_ORDER)
         random.seed(seed)
         order = list(range(layers))
         random.shuffle(order)

@@ -79,7 +79,12 @@ struct SgBeamArgs {
     int64_t n_total;
     int64_t uniform_rows;        // > 0: every frame has this many rows (frame = position / uniform_rows)
     float inv_uniform_rows;
-    const int32_t *perm;         // channel-sorted position (global) -> frame-local source row
+    const int32_t *perm;         // channel-sorted position (global) -> frame-local source row (written for UNSORTED frames only)
+    // Rows in channel-sorted order without a gather: a frame whose input rows already are channel-sorted (frame_unsorted[f] == 0:
+    // channel-major sweeps) is read in place -- sorted position g IS row g of `rows` --, any other frame (firing order: an STF .bin
+    // interleaves the channels, precompute.py:78) from the sorted copy the channel sort's scatter pass makes (row g of `srows`).
+    const void *srows;           // n_total rows, valid where frame_unsorted[f] != 0
+    const int32_t *frame_unsorted;   // n_frames
     const SgTable *frame_tables; // n_frames x n_lasers resolved descriptors (entries == nullptr: unknown table id)
     const SgLasers *las;
     const double *rgrid;         // SG_RBINS
@@ -182,7 +187,11 @@ extern "C" {
 #endif
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
-                   int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, void *stream);
+                   int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, int32_t *tile_unsorted,
+                   int32_t *frame_unsorted, void *srows, int identity_perm /* 1: perm also for sorted frames (debug tap) */, void *stream);
+// a caller-supplied permutation: the sorted copy by a plain gather, every frame flagged unsorted
+int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total, int64_t max_frame,
+                          const int32_t *perm, void *srows, int32_t *frame_unsorted, void *stream);
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
@@ -195,23 +204,19 @@ int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);
 int sg_launch_tier_scan(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 // class args->cls of the tier lists (capacity lmax) as a row kernel: G lanes per beam, scan + dict + received power in one pass
 int sg_launch_rows(const SgBeamArgs *args, int dtype, int lmax, void *stream);
-// the scan of a later tier alone as a row kernel: fills the tier's hand-over buffer like sg_launch_beams(.., direct 0, dict_only 1)
-int sg_launch_rows_scan(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                        int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
-                       int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
+                       int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk,
                        int32_t *chunk_blk, const SgTable *tables, SgTable *resolved /* n_frames x n_las, or null */, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
-int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_unsorted, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,
                       void *stream);
 int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
                          int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles, void *stream);
-// device -> page-locked host memory (or any two device-visible ranges) by a small-grid kernel; bytes % 4 == 0
-int sg_launch_copy_link(void *dst, const void *src, size_t bytes, int blocks, void *stream);
 int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,
                            int n_frames, const int32_t *tile_base, void *out_rows, int32_t *crop_src, int64_t max_tiles, void *stream);
 #ifdef __cplusplus

@@ -33,6 +33,13 @@ __device__ __forceinline__ int sg_frame_of(const SgBeamArgs &a, int64_t g)
     return sg_find_frame(a.frame_off, a.n_frames, g);
 }
 
+// Row of sorted position g of frame f: the input row itself when the frame came channel-sorted, else the sorted copy.
+template <typename T>
+__device__ __forceinline__ const T *sg_row(const SgBeamArgs &a, int f, int64_t g)
+{
+    return (const T *)(a.frame_unsorted[f] ? a.srows : a.rows) + g * 5;
+}
+
 // intensity_diff_sum (simulation.py:170, :512): one atomic per wave and frame, not one per beam (same-address atomics
 // from every lane serialise in L2).  Every lane of the wave must call this.
 __device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool live, int f, long long d2)

@@ -23,11 +23,11 @@ int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int dtype, const
                          int64_t max_frame, const double *plane, int32_t *d_hist, double *d_rec, int32_t *status, void *stream);
 // Returns 0, a positive hipError_t, or -1 on allocation failure.  plane: n_frames x 4 (wx, wy, wz, h).
 // tiles_done: the per-tile statistics were already left in sg_prepass_reserve_tiles()'s buffer by the channel sort (sg_launch_sort)
+// srows / frame_unsorted: optional -- the channel sort's sorted copy and the per-frame flags that say where it is valid
 int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                    int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status,
-                   void *stream, int tiles_done);
+                   void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted);
 double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, int64_t max_frame);
-int sg_prepass_legacy(void);
 int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
                const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,
                int64_t *out_counts, int32_t *out_flags, int32_t *status, void *stream);

@@ -19,8 +19,6 @@
 #include "sg_prepass.h"
 #include "sg_plane.h"
 
-#define SG_MAX_CHUNKS 16
-
 namespace {
 
 struct DeviceTable {
@@ -59,7 +57,7 @@ struct snowgpu_ctx {
     hipStream_t aux3 = nullptr;           // later capacity tiers beyond the first of them
     hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;   // prepass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // resolve / segments
-    hipEvent_t ev_fp[SG_MAX_CHUNKS] = {}, ev_join2 = nullptr;   // chunk of the first pass done -> its k_power
+    hipEvent_t ev_fp = nullptr, ev_join2 = nullptr;       // the pass over all rows (and its plan) done -> k_power_few / k_power
     hipEvent_t ev_few = nullptr;                          // k_power_few done -> (large batches) the tiers and the prepass
     hipEvent_t ev_lists = nullptr, ev_join3 = nullptr;   // tier lists built -> later tiers
     std::string err;
@@ -79,6 +77,8 @@ struct snowgpu_ctx {
     DevBuf<int64_t> crop_counts, crop_off, crop_stats;
     // scratch shared by every batch
     DevBuf<int32_t> tile_hist, tile_base, perm, ctile_cnt, ctile_base, table_ids, out_src;
+    DevBuf<uint8_t> srows;            // channel-sorted copy of the frames whose rows did not come channel-sorted (firing order)
+    DevBuf<int32_t> tile_unsorted, frame_unsorted;
     DevBuf<unsigned long long> seg_tbl_cnt, seg_tbl_base;
     DevBuf<int32_t> seg_blk, seg_cnt, seg_frame, seg_n, seg_of_blk;
     DevBuf<int64_t> seg_start;
@@ -91,7 +91,6 @@ struct snowgpu_ctx {
     DevBuf<int2_t> pw_items;          // work items of k_power
     DevBuf<double> ov;                // overflow slots of the pass over all rows (SG_OV_STRIDE doubles per sorted position)
     DevBuf<uint16_t> ov_sc;
-    int use_ov = 1;                   // SNOWGPU_OVERFLOW_SLOTS=0: every over-full beam is scanned again by its tier (rounds 1-3)
     DevBuf<int32_t> tier_list, tier_sparse, tbase, redo_list;
     DevBuf<double> tq[SG_MAX_CLASSES];        // dict hand-over buffers of the list-mode tiers
     DevBuf<uint16_t> tq_sc[SG_MAX_CLASSES];
@@ -99,17 +98,10 @@ struct snowgpu_ctx {
     bool linear_order = false;   // experiments: SNOWGPU_LINEAR_ORDER=1 keeps the first pass in sorted-row order
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
-    int kp_quarters = 2;              // quarters of a CU k_power takes for the main queue (SNOWGPU_KP_QUARTERS; 0 / 4 = all): its
-                                      // persistent blocks would otherwise hold every CU's LDS, and the later tiers + prepass run beside it
     int few = 2;                      // SNOWGPU_FEW=0..3: beams with up to this many flakes go through k_power_few (0: all through k_power)
-    int chunks_override = 0;          // experiments: SNOWGPU_CHUNKS=<launches the first pass is cut into>
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
-    int tier_scan_lds = 0;            // SNOWGPU_TIER_SCAN_LDS=1: the later tiers' scans keep their lists in LDS (rounds 1-3) -- A/B
-    int row_scan = 0;                 // SNOWGPU_ROW_SCAN=1: the later tiers scan with G lanes per beam (snowgpu_rows.hip) instead of one beam per lane --
-                                      // measured: same rows, 2x the instructions, 4 % slower on C2 (the step is bound by VALU issue)
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
-    bool prepass_early = false;       // experiments: SNOWGPU_PREPASS_EARLY=1 starts the prepass beside the sort instead of after the first pass
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
     DevBuf<uint16_t> rank;
@@ -141,15 +133,12 @@ struct snowgpu_ctx {
     hipStream_t prof_stream = nullptr;
     int exact_math = 0;
     // Host-pointer batches run as a pipeline of chunks (whole frames, about pipe_rows rows each); see host_batch_pipelined.
-    bool pipe_serial = true;
     snowgpu_ctx *root = nullptr;          // set in a lane: the context whose tables, lasers and settings it computes with
     std::vector<snowgpu_ctx *> lanes;     // further compute lanes of the host pipeline (own stream, events and scratch), made on first use
-    int pipe_lanes = 2;                   // SNOWGPU_PIPE_LANES: chunks computing side by side (lane 0 is the context itself)
-    int link_blocks = 0;                  // SNOWGPU_LINK_BLOCKS: 0 = downloads by the runtime's copy (the DMA engine, unless the process has
-                                          // initialised PyTorch: then a full-grid blit kernel); n > 0 = by a kernel of ours with n workgroups.
-                                          // Measured (scripts/probe/chain_probe.hip): while ANY kernel writes host memory, every kernel boundary
-                                          // on the device waits for its outstanding writes -- 3 us per dependent launch become 17 us beside a
-                                          // 16-workgroup copy, 41 us beside 64 -- whereas DMA traffic in either direction costs nothing
+    int pipe_lanes = 2;                   // SNOWGPU_PIPE_LANES: chunks computing side by side (lane 0 is the context itself).  Downloads are the
+                                          // runtime's copy, i.e. the DMA engine: a copy kernel of ours was measured (scripts/probe/chain_probe.hip) --
+                                          // while ANY kernel writes host memory every kernel boundary on the device waits for its outstanding
+                                          // writes (3 us per dependent launch become 17 - 41 us) -- and dropped
     // The small arrays of a host-pointer batch cross the link as ONE block each way, through page-locked mailboxes: frame
     // offsets | table ids | planes or polynomials going up, status | counts | statistics | polynomials coming back (a
     // single sweep otherwise spends a quarter of its time on seven tiny dependent copies).
@@ -160,7 +149,7 @@ struct snowgpu_ctx {
     std::vector<hipEvent_t> pipe_ev;      // [2 c] chunk c has been uploaded, [2 c + 1] computed
     DevBuf<int64_t> pipe_off;         // chunk-local frame offsets of every chunk, concatenated
     DevBuf<int32_t> pipe_status;      // 8 status words per chunk
-    int64_t pipe_rows = (int64_t)3 << 19;   // SNOWGPU_PIPE_ROWS / snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
+    int64_t pipe_rows = (int64_t)3 << 19;   // snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
     std::vector<double> wet_lines;    // snowgpu_set_wet_lines: consumed by the next snowgpu_wet_ground_batch
     DevBuf<double> d_wet_lines;
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
@@ -215,21 +204,19 @@ extern "C" const char *snowgpu_last_error(const snowgpu_ctx *ctx) { return ctx ?
 static int init_streams(snowgpu_ctx *ctx)
 {
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    {   // Stream priorities of the side streams (SNOWGPU_PRIO=<bits>: 1 aux, 2 aux2, 4 aux3; default 2).  The prepass stream (aux2) sits
-        // in the HIGH-priority pool.  Rounds 1-3 needed that for scheduling (its scratch-array passes were starved by the long-lived
-        // LDS-heavy blocks beside them: 5.04 vs 4.93 ms per step); for the lean prepass of round 4 it no longer matters on the device
-        // entry (4.62 vs 4.68 ms the other way round) -- but the runtime hands out hardware queues per priority pool, and with aux2 in
-        // the normal pool the host pipeline's streams share queues: 1.47 instead of 1.85 G points/s through the host entry (measured).
-        int least = 0, greatest = 0, mask = 2;
+    {   // The prepass stream (aux2) sits in the HIGH-priority pool.  Rounds 1-3 needed that for scheduling (its scratch-array passes
+        // were starved by the long-lived LDS-heavy blocks beside them: 5.04 vs 4.93 ms per step); for the lean prepass it no longer
+        // matters on the device entry (4.62 vs 4.68 ms the other way round) -- but the runtime hands out hardware queues per priority
+        // pool, and with aux2 in the normal pool the host pipeline's streams share queues: 1.47 instead of 1.85 G points/s through the
+        // host entry (measured).
+        int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (const char *v = std::getenv("SNOWGPU_PRIO")) mask = std::atoi(v);
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, (mask & 1) ? greatest : 0));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, (mask & 2) ? greatest : 0));
-        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, (mask & 4) ? greatest : 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, 0));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux2, hipStreamNonBlocking, greatest));
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->aux3, hipStreamNonBlocking, 0));
     }
-    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3, &ctx->ev_few})
+    for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3, &ctx->ev_few, &ctx->ev_fp})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
-    for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fp[c], hipEventDisableTiming));
     return SNOWGPU_OK;
 }
 
@@ -239,7 +226,6 @@ static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks, int n_lanes)
 {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (const char *v = std::getenv("SNOWGPU_PIPE_PRIO")) { if (v[0] == '0') least = greatest = 0; }     // A/B: everything in the normal pool
     if (!ctx->s_h2d) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_h2d, hipStreamNonBlocking, greatest));
     if (!ctx->s_d2h) HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->s_d2h, hipStreamNonBlocking, least));
     while ((int)ctx->pipe_ev.size() < 2 * n_chunks) {
@@ -253,9 +239,8 @@ static int ensure_pipeline(snowgpu_ctx *ctx, int n_chunks, int n_lanes)
         ln->root = ctx;
         ctx->lanes.push_back(ln);
         if (hipStreamCreateWithPriority(&ln->stream, hipStreamNonBlocking, least) != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, "lane stream");
-        for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3, &ln->ev_few})
+        for (hipEvent_t *ep : {&ln->ev_fork0, &ln->ev_join0, &ln->ev_fork, &ln->ev_join, &ln->ev_join2, &ln->ev_lists, &ln->ev_join3, &ln->ev_few, &ln->ev_fp})
             HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
-        for (int c = 0; c < SG_MAX_CHUNKS; ++c) HIPCHK(ctx, hipEventCreateWithFlags(&ln->ev_fp[c], hipEventDisableTiming));
     }
     return SNOWGPU_OK;
 }
@@ -273,28 +258,19 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     HIPCHK(ctx, hipSetDevice(device));
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_KP_QUARTERS"); ctx->kp_quarters = v ? std::atoi(v) : 2; }
-    { const char *v = std::getenv("SNOWGPU_CHUNKS"); ctx->chunks_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
-    { const char *v = std::getenv("SNOWGPU_PREPASS_EARLY"); ctx->prepass_early = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; ctx->tier_rows_auto = !v; }
-    { const char *v = std::getenv("SNOWGPU_ROW_SCAN"); if (v) ctx->row_scan = std::atoi(v); }
-    { const char *v = std::getenv("SNOWGPU_TIER_SCAN_LDS"); if (v) ctx->tier_scan_lds = std::atoi(v); }
-    { const char *v = std::getenv("SNOWGPU_OVERFLOW_SLOTS"); if (v) ctx->use_ov = std::atoi(v); }
     // In a process that has loaded PyTorch's HIP runtime layer the runtime moves device-to-host copies with a full-grid blit
     // kernel, which stalls whatever computes beside it: one lane and larger chunks lose least there (1.8 instead of 1.3 G
-    // points/s in-process).  The environment overrides either way.
+    // points/s in-process).  SNOWGPU_PIPE_LANES / snowgpu_set_pipeline override either way.
     if (void *h = dlopen("libc10_hip.so", RTLD_NOLOAD | RTLD_LAZY)) {
         dlclose(h);
         ctx->pipe_lanes = 1;
         ctx->pipe_rows = (int64_t)3 << 20;
     }
-    { const char *v = std::getenv("SNOWGPU_PIPE_ROWS"); if (v) ctx->pipe_rows = std::max<int64_t>(std::atoll(v), 0); }
-    { const char *v = std::getenv("SNOWGPU_PIPE_SERIAL"); if (v) ctx->pipe_serial = v[0] != '0'; }
     { const char *v = std::getenv("SNOWGPU_PIPE_LANES"); if (v) ctx->pipe_lanes = std::min(std::max(std::atoi(v), 1), 4); }
-    { const char *v = std::getenv("SNOWGPU_LINK_BLOCKS"); if (v) ctx->link_blocks = std::min(std::max(std::atoi(v), 0), 4096); }
     int rc = init_streams(ctx);
     if (rc) return rc;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_las, sizeof(SgLasers)));
@@ -329,7 +305,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->d_las) (void)hipFree(ctx->d_las);
     if (ctx->d_rgrid) (void)hipFree(ctx->d_rgrid);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
-    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release();
+    ctx->tile_hist.release(); ctx->tile_base.release(); ctx->perm.release(); ctx->srows.release(); ctx->tile_unsorted.release(); ctx->frame_unsorted.release();
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
     ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->ov.release(); ctx->ov_sc.release();
@@ -349,9 +325,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->plane_est.release(); ctx->wet_plane_est.release(); ctx->plane_info.release(); ctx->stats_hist.release(); ctx->stats_rec.release();
     for (auto e : ctx->ev_start) (void)hipEventDestroy(e);
     for (auto e : ctx->ev_stop) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3, ctx->ev_few})
+    for (hipEvent_t e : {ctx->ev_fork0, ctx->ev_join0, ctx->ev_fork, ctx->ev_join, ctx->ev_join2, ctx->ev_lists, ctx->ev_join3, ctx->ev_few, ctx->ev_fp})
         if (e) (void)hipEventDestroy(e);
-    for (int c = 0; c < SG_MAX_CHUNKS; ++c) if (ctx->ev_fp[c]) (void)hipEventDestroy(ctx->ev_fp[c]);
     for (hipStream_t st : {ctx->aux3, ctx->aux2, ctx->aux, ctx->stream})
         if (st) (void)hipStreamDestroy(st);
     delete ctx;
@@ -404,7 +379,7 @@ static int register_table(snowgpu_ctx *ctx, int table_id, SgEntry *entries, uint
     dt.bin_q = q;
     dt.desc.entries = entries;
     dt.desc.bin_start = bin_start;
-    dt.desc.bin_q = getenv("SNOWGPU_NO_QINDEX") ? nullptr : q;      // (A/B switch: full binary search per bin)
+    dt.desc.bin_q = q;
     dt.desc.n_bins = (uint32_t)SG_NBINS;
     dt.desc.n_entries = n_entries;
     dt.desc.inv_bin_w = SG_NBINS / SG_TWO_PI;
@@ -630,6 +605,7 @@ struct BatchDev {
     int dbg_cap = 0;
     int32_t *perm_out = nullptr;   // where the permutation actually used lives (device)
     bool no_fov = false;           // debug tap: never crop
+    bool want_perm = false;        // the caller reads perm_out back: the sort writes the permutation of channel-sorted frames too
     bool serial = false;           // every kernel on `stream`: no fork / join events (chunks of the host pipeline)
 };
 
@@ -643,6 +619,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (rc) { if (R != ctx) ctx->err = R->err; return rc; }
     const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
     const size_t n = (size_t)b.n_total;
+    const size_t esz = b.dtype == 0 ? 4 : 8;
     hipStream_t st = b.stream;
     const bool serial = R->serial || b.serial;
     hipStream_t s_aux = serial ? st : ctx->aux, s_aux2 = serial ? st : ctx->aux2, s_aux3 = serial ? st : ctx->aux3;
@@ -654,16 +631,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         return SNOWGPU_OK;
     }
     // 0. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial.  Only the compaction
-    // (the noise-floor decision) needs its result, so it runs on its own stream next to the sort and the per-beam
-    // kernels: bandwidth-bound reductions beside latency-bound scans.
+    // (the noise-floor decision) needs its result, so it runs on its own stream next to the received-power kernels:
+    // bandwidth-bound reductions beside latency-bound persistent waves.
     const double *thr = b.thr_poly;
     bool pre_forked = false;
     // The prepass' per-tile statistics ride on the channel sort's first pass over the rows when the plane is known by then: a
     // caller's plane, or the reference-today plane (a constant).  Estimated planes (least squares, RANSAC) come later, on the
     // prepass stream, and the statistics keep their own pass.
-    static const bool no_fuse = std::getenv("SNOWGPU_NO_SORT_STATS") != nullptr;        // A/B
-    const bool fuse_stats = !b.thr_poly && !b.perm && !no_fuse && !sg_prepass_legacy() && !R->prepass_early &&
-                            (b.plane != nullptr || R->plane_par.method == SG_PLANE_REFERENCE);
+    const bool fuse_stats = !b.thr_poly && !b.perm && (b.plane != nullptr || R->plane_par.method == SG_PLANE_REFERENCE);
     const double *early_plane = b.plane;
     double *lean_part = nullptr;
     if (fuse_stats) {
@@ -691,7 +666,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             pl = ctx->plane_est.p;
         }
         int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, pl,
-                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2, fuse_stats ? 1 : 0);
+                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2, fuse_stats ? 1 : 0, ctx->srows.p, ctx->frame_unsorted.p);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         if (b.out_thr_poly)
             HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, ctx->thr_poly.p, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, s_aux2));
@@ -702,27 +677,35 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (!thr) {
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
-        if (R->prepass_early) { int prc = launch_prepass(); if (prc) return prc; }
     } else if (b.out_thr_poly) {
         HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
     }
-    // 1. channel sort (simulation.py:447)
+    // 1. channel sort (simulation.py:447).  A frame whose rows come channel-sorted (channel-major sweeps) keeps the identity and is read
+    // in place; any other frame (firing order, as in an STF .bin) gets a sorted copy from the sort's second pass.  Either way sorted
+    // position g is "row g" of one of the two arrays for everything downstream: no gather through the permutation.
     const int32_t *perm = b.perm;
+    ENSURE(ctx, ctx->srows, n * 5 * esz);
+    ENSURE(ctx, ctx->frame_unsorted, (size_t)b.n_frames);
     if (!perm) {
         ENSURE(ctx, ctx->tile_hist, (size_t)b.n_frames * (size_t)max_tiles * 256);
         ENSURE(ctx, ctx->tile_base, (size_t)b.n_frames * (size_t)max_tiles * 256);
+        ENSURE(ctx, ctx->tile_unsorted, (size_t)b.n_frames * (size_t)max_tiles);
         ENSURE(ctx, ctx->rank, n);
         ENSURE(ctx, ctx->perm, n);
         ENSURE(ctx, ctx->keep, n);                // channel bytes between the two sort passes; flag / keep bytes afterwards
         int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
-                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, fuse_stats ? early_plane : nullptr, lean_part, st);
+                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, fuse_stats ? early_plane : nullptr, lean_part,
+                               ctx->tile_unsorted.p, ctx->frame_unsorted.p, ctx->srows.p, b.want_perm ? 1 : 0, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;
+    } else {
+        int e = sg_launch_gather_rows(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, perm, ctx->srows.p, ctx->frame_unsorted.p, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("gather launch: ") + hipGetErrorString((hipError_t)e));
     }
     b.perm_out = const_cast<int32_t *>(perm);
-    // 1b. on the side stream, next to the prepass: table descriptors per (frame, channel) and the launch order of the
-    // first pass -- by flake table (segments of the device sort) unless the caller brought the
-    // permutation (no channel histogram then) or table ids are too sparse for the segment builder.
+    // 1b. on the side stream: table descriptors per (frame, channel) and the launch order of the pass over all rows -- by flake
+    // table (segments of the device sort) unless the caller brought the permutation (no channel histogram
+    // then) or table ids are too sparse for the segment builder.
     const int64_t n_ft = (int64_t)b.n_frames * R->h_las.n;
     ENSURE(ctx, ctx->frame_tables, (size_t)n_ft);
     int tiers[4], n_tiers = 0;
@@ -736,14 +719,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
         ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
-        ENSURE(ctx, ctx->chunk_blk, SG_MAX_CHUNKS + 1);
+        ENSURE(ctx, ctx->chunk_blk, 2);
     }
-    // The first pass can run as n_chunks launches over consecutive block ranges, k_power of one range beside the scan of the
-    // next.  Measured: no gain -- both kernels are bound by the LDS their lists need (four 256-thread blocks per CU between
-    // them), so sharing a CU only trades waves -- hence one launch by default; SNOWGPU_CHUNKS keeps the experiment at hand.
+    // (The pass over all rows is ONE launch.  Cut into several, with k_power of one range beside the scan of the next, it gained
+    // nothing: both are bound by the LDS their lists need, so sharing a CU only trades waves.)
     const int64_t total_blocks_ub = (b.n_total + first_block - 1) / first_block + (use_seg ? (int64_t)b.n_frames * 256 : 0);
-    int n_chunks = 1;
-    if (R->chunks_override > 0) n_chunks = std::min(R->chunks_override, SG_MAX_CHUNKS);
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
     HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
     {
@@ -753,7 +733,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (use_seg) {                                // (its first kernel resolves the table descriptors on the way)
             e = sg_launch_segments(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, R->h_las.n, (int)R->tables.size(), first_block,
                                    ctx->seg_tbl_cnt.p, ctx->seg_tbl_base.p, ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p,
-                                   ctx->seg_n.p, ctx->seg_of_blk.p, n_chunks, ctx->chunk_blk.p, R->d_tables, ctx->frame_tables.p, s_aux);
+                                   ctx->seg_n.p, ctx->seg_of_blk.p, ctx->chunk_blk.p, R->d_tables, ctx->frame_tables.p, s_aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
     }
@@ -761,7 +741,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 3. beams
     ENSURE(ctx, ctx->rec, n);
     ENSURE(ctx, ctx->rec_q, n);
-    ENSURE(ctx, ctx->rng, n * (b.dtype == 0 ? 4 : 8));
+    ENSURE(ctx, ctx->rng, n * esz);
     ENSURE(ctx, ctx->keep, n);
     ENSURE(ctx, ctx->tier_list, n * (size_t)n_tiers);      // one list per later tier, each as long as the batch (address space) ...
     ENSURE(ctx, ctx->tier_sparse, n * (size_t)n_tiers);    // ... and the same as the scan leaves them: region by region
@@ -769,26 +749,25 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     ENSURE(ctx, ctx->ctile_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
     SgBeamArgs a{};
     a.rows = b.rows; a.frame_off = b.frame_off; a.n_frames = b.n_frames; a.n_total = b.n_total; a.perm = perm;
+    a.srows = ctx->srows.p; a.frame_unsorted = ctx->frame_unsorted.p;
     a.uniform_rows = (b.uniform_rows > 0 && b.n_total < ((int64_t)1 << 31)) ? b.uniform_rows : 0;
     a.inv_uniform_rows = a.uniform_rows > 0 ? 1.0f / (float)a.uniform_rows : 0.0f;
     a.las = R->d_las; a.frame_tables = ctx->frame_tables.p;
     a.rgrid = R->d_rgrid; a.beam_div_deg = b.beam_div_deg; a.rec = ctx->rec.p; a.rec_q = ctx->rec_q.p;
     a.status = b.status;
-    static const bool no_rng = std::getenv("SNOWGPU_NO_RNG") != nullptr;      // A/B: the noise-floor pass gathers every row again
-    a.rng = no_rng ? nullptr : ctx->rng.p;
+    a.rng = ctx->rng.p;
     a.dbg_count = b.dbg_count; a.dbg_rj = b.dbg_rj; a.dbg_ratio = b.dbg_ratio; a.dbg_cap = b.dbg_cap;
     a.exact_math = R->exact_math;
     a.per_lane_scan = R->per_lane_scan;
     // Later capacity tiers = classes of the tier lists; the last class is the global-list tier, whose lists hold a whole
     // table if need be (capped at 8192 flakes in one beam).
     const int n_cls = n_tiers;
-    // The later tiers run as row kernels (snowgpu_rows.hip: G lanes per beam; scan, dict and received power in one pass, no
-    // hand-over buffers) -- an experiment, off by default (measured slower: DESIGN.md section 5).
     // Small batches (up to four sweeps): a tier holds a few hundred beams -- one or two waves' worth for one beam per lane, a chain of
-    // dependent latencies 100 us long -- and the row kernels, G lanes per beam, finish them in a third of that (0.334 -> 0.306 ms per
-    // single sweep); from 16 sweeps on they lose (2-3x the instructions).  SNOWGPU_TIER_ROWS=1 / 0 forces either.
+    // dependent latencies 100 us long -- and the row kernels (snowgpu_rows.hip: G lanes per beam; scan, dict and received power in one
+    // pass, no hand-over buffers) finish them in a third of that (0.334 -> 0.306 ms per single sweep); from 16 sweeps on they lose
+    // (2-3x the instructions).  SNOWGPU_TIER_ROWS=1 / 0 forces either (tests/test_gpu_parity.py::test_tier_rows_switch).
     const bool rows_small = R->tier_rows_auto && b.n_total <= ((int64_t)1 << 19);
-    const bool tier_rows = (R->tier_rows || rows_small) && R->tier_cap_override <= 0 && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan;
+    const bool tier_rows = (R->tier_rows || rows_small) && R->tier_cap_override <= 0 && R->per_lane_scan >= 0;
     const int h_lanes = 256;
     const int h_cap = (int)std::min<uint32_t>(std::max<uint32_t>(R->max_flakes, 64u), 8192u);
     a.n_cls = n_cls;
@@ -801,11 +780,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->redo_list, n * (size_t)n_tiers);
         a.redo_list = ctx->redo_list.p;
     }
+    // Overflow slots: a beam of the pass over all rows that over-fills its LDS list, up to SG_OV_CAP flakes, leaves all of them in
+    // the slot of its sorted position, and the tiers up to that capacity run no second scan (400 bytes per sorted position, touched
+    // by the few per cent of beams that overflow: 13 GB of address space for a 256-sweep batch, 0.6 GB per chunk of the pipeline).
+    const bool use_ov = tiers[0] < SG_OV_CAP && n_cls >= 2 && R->per_lane_scan >= 0 && !tier_rows &&
+                        R->tier_cap_override <= 0 && n * SG_OV_STRIDE * sizeof(double) <= ((size_t)40 << 30);
     int64_t tq_caps[SG_MAX_CLASSES] = {0, 0, 0, 0};
     for (int k = 0; k + 1 < n_cls && !tier_rows; ++k) {
-        if (R->use_ov && tiers[0] < SG_OV_CAP && tiers[k + 1] <= SG_OV_CAP && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan &&
-            R->tier_cap_override <= 0 && n * SG_OV_STRIDE * sizeof(double) <= ((size_t)40 << 30))
-            continue;                                    // (this class reads the overflow slots: no hand-over buffer)
+        if (use_ov && tiers[k + 1] <= SG_OV_CAP) continue;     // (this class reads the overflow slots: no hand-over buffer)
         tq_caps[k] = tier_queue_cap(R, tiers[k + 1], b.n_total);
         ENSURE(ctx, ctx->tq[k], ((size_t)tq_caps[k] + 64) * (3 * (size_t)tiers[k + 1] + 2));
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
@@ -837,7 +819,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
         a.blk_rows = first_block;
-        a.kp_lds_quarters = R->kp_quarters;
+        a.kp_lds_quarters = 2;     // k_power's persistent blocks take half of each CU: the later tiers and the prepass run beside it
         const size_t items_cap = n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64;
         ENSURE(ctx, ctx->pw_items, 2 * items_cap);
         a.pw_items = ctx->pw_items.p;
@@ -845,11 +827,6 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.pw_items1 = (R->few > 0 && !b.dbg_count && lanes == 64) ? ctx->pw_items.p + items_cap : nullptr;
         a.front_max = a.pw_items1 ? std::min(R->few, std::min(3, tiers[0])) : 1;
     }
-    // Overflow slots: a beam of the pass over all rows that over-fills its LDS list, up to SG_OV_CAP flakes, leaves all of them in
-    // the slot of its sorted position, and the tiers up to that capacity run no second scan (400 bytes per sorted position, touched
-    // by the few per cent of beams that overflow: 13 GB of address space for a 256-sweep batch, 0.6 GB per chunk of the pipeline).
-    const bool use_ov = R->use_ov && tiers[0] < SG_OV_CAP && n_cls >= 2 && R->per_lane_scan >= 0 && !R->tier_scan_lds && !R->row_scan && !tier_rows &&
-                        R->tier_cap_override <= 0 && n * SG_OV_STRIDE * sizeof(double) <= ((size_t)40 << 30);
     if (use_ov) {
         ENSURE(ctx, ctx->ov, (n + 256) * SG_OV_STRIDE);
         ENSURE(ctx, ctx->ov_sc, n + 256);
@@ -866,29 +843,25 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
     int e = 0;
     {
-        // linear order: regions are runs of 8 blocks, chunk boundaries fall on them
         const int64_t lin_blocks = (b.n_total + first_block - 1) / first_block;
-        const int64_t lin_step = ((lin_blocks + n_chunks - 1) / n_chunks + 7) / 8 * 8;
-        for (int c = 0; c < n_chunks && !e; ++c) {
-            if (use_seg) {
-                a.chunk = c;                                 // every non-empty pair wastes less than one block; a chunk is cut at a segment start
-                a.grid_blocks = total_blocks_ub / n_chunks + b.max_frame / first_block + 2;
-            } else {
-                a.blk_lo = std::min<int64_t>((int64_t)c * lin_step, lin_blocks); a.blk_hi = std::min<int64_t>(a.blk_lo + lin_step, lin_blocks);
-                a.grid_blocks = a.blk_hi - a.blk_lo;
-            }
-            e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
-            if (e) break;
-            // The plan of what the pass queued (work items of k_power_few / k_power; where each region's slice of the tier lists goes)
-            // runs behind it on the same stream -- the tiers then start with one short kernel (k_tier_gather) and no hop between streams --
-            // and the received-power kernels it feeds on a side stream, next to the following chunks and the later capacity tiers.
-            if (c > 0) HIPCHK(ctx, hipMemsetAsync(a.pw_count, 0, 2 * sizeof(int32_t), st));     // (chunk 0: cleared with the rest)
-            e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr);
-            if (e) break;
-            HIPCHK(ctx, hipEventRecord(ctx->ev_fp[c], st));
-            HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp[c], 0));
+        if (use_seg) {
+            a.chunk = 0;                                 // every non-empty (frame, channel) pair wastes less than one block
+            a.grid_blocks = total_blocks_ub + b.max_frame / first_block + 2;
+        } else {
+            a.blk_lo = 0; a.blk_hi = lin_blocks;
+            a.grid_blocks = lin_blocks;
+        }
+        e = sg_launch_beams(&a, b.dtype, tiers[0], 1, 1, st);
+        // The plan of what the pass queued (work items of k_power_few / k_power; where each region's slice of the tier lists goes)
+        // runs behind it on the same stream -- the tiers then start with one short kernel (k_tier_gather) and no hop between streams --
+        // and the received-power kernels it feeds on a side stream, next to the later capacity tiers.
+        if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr);
+        if (!e) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fp, st));
+            HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp, 0));
             e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr);
-            if (e) break;
+        }
+        if (!e) {
             // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
             // the tiers, the prepass and k_power do better behind it than beside it (measured: 4.37 against 4.69 ms per 256 sweeps when
             // they all start together; the other way round for a single sweep, where nothing fills anything).
@@ -901,12 +874,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // the later tiers (latency-bound, LDS-bound) rather than beside the sort and the scan, which it would slow down.
     if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
     // The scan put every over-full beam on the list of its tier (it counted on past a full list, so the beam knows which): the tiers
-    // start as soon as it has ended, side by side -- class 0 on the caller's stream, the others on a side stream.
+    // start as soon as it has ended, side by side -- class 0 on the caller's stream, class 1 on a side stream, and the classes from
+    // the third on (the 63-entry and the global-list tier: few beams, long dependent chains) behind k_power on ITS stream, which is
+    // free long before the 8- and 16-entry tiers are through (C2 4.41 -> 4.30 ms, C2far 9.20 -> 8.64 ms against "behind class 1").
     const bool side3 = n_cls >= 2;
-    // classes from the third on (the 63-entry and the global-list tier: few beams, long dependent chains) behind k_power on ITS stream,
-    // which is free long before the 8- and 16-entry tiers are through, instead of behind the second class
-    static const bool tail_on_aux = []{ const char *v = std::getenv("SNOWGPU_TIER_TAIL_AUX"); return v ? v[0] == '1' : true; }();
-    const bool tail_aux = tail_on_aux && n_cls >= 3 && !serial;
+    const bool tail_aux = n_cls >= 3 && !serial;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
     if (tail_aux) HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_lists, 0));
     for (int k = 0; k < n_cls && !e; ++k) {
@@ -933,8 +905,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.tq = ctx->tq[k].p; a.tq_sc = ctx->tq_sc[k].p; a.tq_cap = (int32_t)tq_caps[k];
         a.work_lo = 0; a.work_hi = (int32_t)tq_caps[k];
         a.tq_unsorted = 0;
-        if (R->row_scan && R->per_lane_scan >= 0) e = sg_launch_rows_scan(&a, b.dtype, lmax, sk);   // scan, hand-over (G lanes per beam: an experiment)
-        else if (R->tier_scan_lds || R->per_lane_scan < 0) e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);   // one beam per lane, lists sorted in LDS (rounds 1-3)
+        if (R->per_lane_scan < 0) e = sg_launch_beams(&a, b.dtype, lmax, 0, 1, sk);   // the wave scan in the tiers too: lists sorted in LDS (validation)
         else { a.tq_unsorted = 1; e = sg_launch_tier_scan(&a, b.dtype, lmax, sk); }   // one beam per lane, no LDS: k_power sorts as it loads
         if (!e) e = sg_launch_power_list(&a, b.dtype, lmax, sk);
         if (!e && tq_caps[k] < b.n_total) {              // entries beyond the hand-over buffer: received power in place
@@ -947,10 +918,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     HIPCHK(ctx, hipEventRecord(ctx->ev_join2, s_aux));
     HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join2, 0));
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_stop[(size_t)ctx->ev_used], st)); ctx->ev_used++; }
-    // 4. output rows from original rows + records, round, noise-floor filter, camera crop, compaction, stats
+    // 4. output rows from (sorted) rows + records, round, noise-floor filter, camera crop, compaction, stats
     // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
-    e = sg_launch_compact(b.rows, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+    e = sg_launch_compact(b.rows, ctx->srows.p, ctx->frame_unsorted.p, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
                           a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
@@ -1007,19 +978,6 @@ extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int6
     return run_batch(ctx, b);
 }
 
-// The device-visible address of a page-locked host range (hipHostMalloc / hipHostRegister), or null for pageable memory.
-static void *device_view(const void *host, size_t bytes)
-{
-    if (!host || !bytes) return nullptr;
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
-    hipPointerAttribute_t end{};
-    if (hipPointerGetAttributes(&end, (const char *)host + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (end.type != hipMemoryTypeHost || !end.devicePointer) return nullptr;
-    return at.devicePointer;
-}
-
 // A host-pointer batch as a pipeline of chunks of whole frames.  What the traces of the first versions taught:
 // the runtime keeps a pool of (by default four) hardware queues PER stream priority, and streams beyond that share a queue
 // with another stream -- whose packets they then wait behind, events and copies included; its device-to-host copy is a
@@ -1031,8 +989,8 @@ static void *device_view(const void *host, size_t bytes)
 //     two lanes (the context itself and a sub-context with its own stream, events and scratch in the low-priority pool): a
 //     chunk starts the moment its upload lands, and the launch latency of one chain hides behind the other;
 //   * the downloads run on one more stream (low-priority pool: a hardware queue of its own), each after its chunk's event: the
-//     runtime's copy, i.e. the DMA engine (SNOWGPU_LINK_BLOCKS=n: a small-grid kernel of ours that writes page-locked memory
-//     directly, sg_launch_copy_link -- measured slower: every kernel boundary then waits for outstanding host writes).
+//     runtime's copy, i.e. the DMA engine (a small-grid kernel of ours writing page-locked memory directly was measured slower:
+//     every kernel boundary on the device then waits for the outstanding host writes).
 // The host enqueues everything and waits once at the end.  Small per-frame arrays (table ids, planes / polynomials, counts,
 // statistics) cross once for the whole batch; a chunk sees its slice of them.
 static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
@@ -1091,10 +1049,6 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         HIPCHK(ctx, hipMemcpyAsync(ctx->user_perm.p, perm, sizeof(int32_t) * (size_t)n_total, hipMemcpyHostToDevice, up));
     }
     if (out_thr_poly) ENSURE(ctx, ctx->out_thr, nf * 3);
-    // Page-locked result buffers are written by our small-grid kernel; anything else goes through hipMemcpyAsync.
-    // SNOWGPU_LINK_BLOCKS=0 keeps the runtime's copy for page-locked memory too.
-    char *d_out_rows = ctx->link_blocks > 0 ? (char *)device_view(out_rows, (size_t)n_total * rb) : nullptr;
-    char *d_out_src = (ctx->link_blocks > 0 && out_src) ? (char *)device_view(out_src, (size_t)n_total * 4) : nullptr;
     auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     std::vector<hipEvent_t> tev;                  // SNOWGPU_PIPE_TRACE: timed events -- base, then per chunk: uploaded, compute begins, computed, downloaded
@@ -1143,20 +1097,16 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = cs;
         // Beside a saturated link every cross-stream event costs more (the queues' completion signals live in host memory), so a
         // chunk keeps its kernels on one stream: 1.80 instead of 1.76 G points/s (2.09 / 1.96 without source indices), although
-        // the same chunk alone is faster with its side streams.  SNOWGPU_PIPE_SERIAL=0: side streams.
-        b.serial = ctx->pipe_serial || L > 1;              // a further lane has one stream only
+        // the same chunk alone is faster with its side streams.
+        b.serial = true;
         rc = run_batch(lc, b);
         if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
         PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
         if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
         PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
         if (cn) {
-            int e = 0;
-            if (d_out_rows) e = sg_launch_copy_link(d_out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, ctx->link_blocks, ctx->s_d2h);
-            else PIPECHK(hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
-            if (!e && out_src && d_out_src) e = sg_launch_copy_link(d_out_src + (size_t)r0 * 4, b.out_src, (size_t)cn * 4, ctx->link_blocks, ctx->s_d2h);
-            else if (!e && out_src) PIPECHK(hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
-            if (e) { rc = fail(ctx, SNOWGPU_E_HIP, std::string("download launch: ") + hipGetErrorString((hipError_t)e)); break; }
+            PIPECHK(hipMemcpyAsync((char *)out_rows + (size_t)r0 * rb, b.out_rows, (size_t)cn * rb, hipMemcpyDeviceToHost, ctx->s_d2h));
+            if (out_src) PIPECHK(hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
         }
         if (trace) PIPECHK(hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
     }
@@ -1334,6 +1284,7 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     b.out_rows = ctx->rows_out.p; b.out_src = ctx->out_src.p; b.out_counts = d_counts; b.out_stats = d_stats;
     b.out_thr_poly = out_thr_poly ? d_thr_out : nullptr; b.status = d_status; b.stream = st;
     b.no_fov = dbg_count != nullptr;
+    b.want_perm = perm_out != nullptr;
     if (dbg_count) {
         ENSURE(ctx, ctx->dbg_count, std::max<size_t>(n, 1));
         ENSURE(ctx, ctx->dbg_rj, std::max<size_t>(n * (size_t)dbg_cap, 1));

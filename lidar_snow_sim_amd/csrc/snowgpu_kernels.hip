@@ -65,10 +65,17 @@
 // that "earlier row" == "earlier (wave, round, lane)".
 // STATS: the tile's rows are here anyway -- the per-tile statistics of the noise-threshold prepass (sg_lean.h; needs the ground plane,
 // i.e. a plane that is known when the sort starts) ride along: one pass over the rows less per step (0.67 GB of 256 sweeps).
+// Ranks: every lane finds the lanes of its wave that hold the same channel by eight ballots, one per bit of the channel byte -- the
+// same cost whether the 64 rows are of one channel (a channel-major sweep) or of 64 (firing order: an STF .bin interleaves the
+// channels, precompute.py:78).  A loop with one round per DISTINCT channel of the wave took 1.23 ms of a 256-sweep step on firing-order
+// rows against 0.35 ms on channel-major ones (profiles/r05_C2fire_*).
+// tile_unsorted: 1 if a row of this tile has a smaller channel than the row before it (k_sort_scan folds the tiles of a frame: a
+// frame without such a row is channel-sorted as it stands, its permutation is the identity and nobody makes or reads a copy of it).
 template <typename T, bool STATS>
 __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ rows, const int64_t *__restrict__ frame_off,
                                                         int32_t *__restrict__ tile_hist, uint16_t *__restrict__ rank,
-                                                        uint8_t *__restrict__ ch8, int32_t *__restrict__ status, int64_t max_tiles, SgLeanTile lean)
+                                                        uint8_t *__restrict__ ch8, int32_t *__restrict__ status, int64_t max_tiles, SgLeanTile lean,
+                                                        int32_t *__restrict__ tile_unsorted)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
@@ -81,6 +88,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
     int my_bucket[4], my_rank[4];
     [[maybe_unused]] T sx[4], sy[4], sz[4], si[4];
     [[maybe_unused]] bool sv[4];
+    int descends = 0;
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + w * 256 + q * 64 + lane;
         const bool valid = r < n;
@@ -89,27 +97,36 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
             const T *p = rows + (base + (valid ? r : 0)) * 5;
             sx[q] = p[0]; sy[q] = p[1]; sz[q] = p[2]; si[q] = p[3]; sv[q] = valid;
         }
+        T c_prev = 0;                                 // lane 0: the channel of the row before this round's first (earlier round, wave or tile)
         if (valid) {
             const T c = rows[(base + r) * 5 + 4];
+            if (lane == 0 && r > 0) c_prev = rows[(base + r - 1) * 5 + 4];
             const int ci = (int)c;
             if ((T)ci == c && ci >= 0 && ci < 256) bucket = ci;
             else { atomicCAS(&status[0], 0, 5 /* SNOWGPU_E_CHANNELS */); bucket = 255; }
         }
+        {
+            int before_b = __shfl_up(bucket, 1);
+            if (lane == 0) before_b = r > 0 ? (int)c_prev : bucket;
+            if (valid && bucket < before_b) descends = 1;
+        }
         my_bucket[q] = bucket;
         my_rank[q] = 0;
         if (valid) ch8[base + r] = (uint8_t)bucket;     // the scatter pass reads 1 byte per row instead of the row again
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int v = __shfl(bucket, leader);
-            const unsigned long long m = __ballot(valid && bucket == v);
-            const int before = cnt[w][v];
-            if (valid && bucket == v) my_rank[q] = before + __popcll(m & sg_lanemask_lt());
-            if (lane == leader) cnt[w][v] = before + __popcll(m);
-            todo &= ~m;
+        unsigned long long same = __ballot(valid);      // lanes of this wave with my channel
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool set = (bucket >> bit) & 1;
+            const unsigned long long bb = __ballot(set);
+            same &= set ? bb : ~bb;
+        }
+        if (valid) {
+            const int before = cnt[w][bucket];          // (a wave's LDS operations keep their order: every read precedes the leaders' writes)
+            my_rank[q] = before + __popcll(same & sg_lanemask_lt());
+            if ((same & sg_lanemask_lt()) == 0) cnt[w][bucket] = before + __popcll(same);
         }
     }
-    __syncthreads();
+    const int any_descends = __syncthreads_or(descends);
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + w * 256 + q * 64 + lane;
         if (r < n) {
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
     }
     int32_t *h = tile_hist + ((int64_t)f * max_tiles + blockIdx.x) * 256;
     h[tid] = cnt[0][tid] + cnt[1][tid] + cnt[2][tid] + cnt[3][tid];
+    if (tid == 0) tile_unsorted[(int64_t)f * max_tiles + blockIdx.x] = any_descends ? 1 : 0;
     if constexpr (STATS) {
         __shared__ double sm[58];
         lean_tile_stats<T>(lean, f, blockIdx.x, sx, sy, sz, si, sv, sm);
@@ -127,22 +145,25 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
 }
 
 // One block per frame, thread v owns bucket v: tile_base[t][v] = (rows of smaller buckets) + (rows of
-// bucket v in earlier tiles).
+// bucket v in earlier tiles); frame_unsorted[f] = some tile of the frame saw a descending channel.
 __global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restrict__ frame_off,
                                                         const int32_t *__restrict__ tile_hist,
-                                                        int32_t *__restrict__ tile_base, int64_t max_tiles)
+                                                        int32_t *__restrict__ tile_base, int64_t max_tiles,
+                                                        const int32_t *__restrict__ tile_unsorted, int32_t *__restrict__ frame_unsorted)
 {
     const int f = blockIdx.x, v = threadIdx.x;
     const int64_t n = frame_off[f + 1] - frame_off[f];
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     const int32_t *h = tile_hist + (int64_t)f * max_tiles * 256;
     int32_t *b = tile_base + (int64_t)f * max_tiles * 256;
-    int total = 0;
+    int total = 0, uns = 0;
+    for (int64_t t = v; t < tiles; t += SG_BLOCK) uns |= tile_unsorted[(int64_t)f * max_tiles + t];
 #pragma unroll 8                                  // eight loads in flight: the loop is a chain of global-load latencies otherwise
     for (int64_t t = 0; t < tiles; ++t) total += h[t * 256 + v];
     __shared__ int s[256];
     s[v] = total;
-    __syncthreads();
+    uns = __syncthreads_or(uns);
+    if (v == 0) frame_unsorted[f] = uns ? 1 : 0;
     for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan over the 256 buckets
         int add = v >= d ? s[v - d] : 0;
         __syncthreads();
@@ -154,19 +175,84 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scan(const int64_t *__restric
     for (int64_t t = 0; t < tiles; ++t) { b[t * 256 + v] = run; run += h[t * 256 + v]; }
 }
 
-__global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const uint8_t *__restrict__ ch8, const int64_t *__restrict__ frame_off,
-                                                           const int32_t *__restrict__ tile_base,
-                                                           const uint16_t *__restrict__ rank, int32_t *__restrict__ perm,
-                                                           int64_t max_tiles)
+// Second pass of the sort, for the frames that need it (frame_unsorted[f]; a channel-sorted frame is read in place): the tile's rows
+// go to their places in the SORTED COPY of the frame, and perm gets their source rows.  The tile is staged through LDS in sorted
+// order first, so that the stores walk whole runs -- in firing order a tile holds 16 rows of each of 64 channels, i.e. 64 runs of
+// 320 contiguous bytes -- instead of scattering 20-byte rows lane by lane.  The per-beam kernels and the compaction then read sorted
+// position g as row g of the copy: no gather through perm anywhere (measured on firing-order rows before this: the scan 1.83 instead of
+// 1.60 ms, the compaction's scatter 0.69 instead of 0.36 ms, this pass -- 4-byte stores scattered over 64 channel runs -- 0.32 ms).
+// identity_perm: the debug tap wants the permutation of every frame, sorted ones too.
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__ rows, const uint8_t *__restrict__ ch8, const int64_t *__restrict__ frame_off,
+                                                           const int32_t *__restrict__ tile_hist, const int32_t *__restrict__ tile_base,
+                                                           const uint16_t *__restrict__ rank, int32_t *__restrict__ perm, T *__restrict__ srows,
+                                                           const int32_t *__restrict__ frame_unsorted, int identity_perm, int64_t max_tiles)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
+    const int tid = threadIdx.x;
+    if (!frame_unsorted[f]) {
+        if (identity_perm)
+            for (int q = 0; q < 4; ++q) { const int64_t r = tile0 + q * SG_BLOCK + tid; if (r < n) perm[base + r] = (int32_t)r; }
+        return;
+    }
+    __shared__ T stage[SG_TILE * 5];
+    __shared__ int s_dest[SG_TILE];
+    __shared__ uint16_t s_src[SG_TILE];
+    __shared__ int s_start[256];
     const int32_t *b = tile_base + ((int64_t)f * max_tiles + blockIdx.x) * 256;
+    {   // where each channel's run starts inside the tile's sorted image: exclusive scan of the tile's histogram
+        const int c = tile_hist[((int64_t)f * max_tiles + blockIdx.x) * 256 + tid];
+        s_start[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int add = tid >= d ? s_start[tid - d] : 0;
+            __syncthreads();
+            s_start[tid] += add;
+            __syncthreads();
+        }
+        const int excl = s_start[tid] - c;
+        __syncthreads();
+        s_start[tid] = excl;
+        __syncthreads();
+    }
+    const int m = (int)(n - tile0 < SG_TILE ? n - tile0 : SG_TILE);      // rows of this tile
     for (int q = 0; q < 4; ++q) {
-        const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
-        if (r < n) perm[base + b[ch8[base + r]] + rank[base + r]] = (int32_t)r;
+        const int i = q * SG_BLOCK + tid;
+        if (i < m) {
+            const int64_t r = tile0 + i;
+            const int ch = ch8[base + r], rk = rank[base + r];
+            const int sp = s_start[ch] + rk;                                 // position in the tile's sorted image
+            const T *p = rows + (base + r) * 5;
+            const T v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3], v4 = p[4];
+            T *d = stage + sp * 5;
+            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3; d[4] = v4;
+            s_dest[sp] = b[ch] + rk;                                         // frame-local sorted position
+            s_src[sp] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < m * 5; idx += SG_BLOCK) {
+        const int sp = idx / 5, j = idx - sp * 5;
+        srows[(base + s_dest[sp]) * 5 + j] = stage[idx];
+    }
+    for (int sp = tid; sp < m; sp += SG_BLOCK) perm[base + s_dest[sp]] = (int32_t)(tile0 + s_src[sp]);
+}
+
+// The sorted copy for a caller-supplied permutation (no device sort): a plain gather; every frame counts as unsorted.
+template <typename T>
+__global__ __launch_bounds__(SG_BLOCK) void k_gather_rows(const T *__restrict__ rows, const int64_t *__restrict__ frame_off, const int32_t *__restrict__ perm,
+                                                          T *__restrict__ srows, int32_t *__restrict__ frame_unsorted)
+{
+    const int f = blockIdx.y;
+    const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
+    if (blockIdx.x == 0 && threadIdx.x == 0) frame_unsorted[f] = 1;
+    for (int64_t r = (int64_t)blockIdx.x * SG_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * SG_BLOCK) {
+        const T *p = rows + (base + perm[base + r]) * 5;
+        T *d = srows + (base + r) * 5;
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3]; d[4] = p[4];
     }
 }
 
@@ -263,8 +349,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
     bool simulated = false;
     if (live) {
         f = (!LIST && seg_f >= 0) ? seg_f : sg_frame_of(a, g);
-        const int64_t src = a.frame_off[f] + a.perm[g];
-        const T *row = (const T *)a.rows + src * 5;
+        const T *row = sg_row<T>(a, f, g);
         px = row[0]; py = row[1]; pz = row[2];
         if constexpr (!LIST && DICT) pint = row[3];   // the pass over all rows leaves range + intensity for the noise-floor pass
         if (!LIST && seg_f >= 0) {                    // the device sort only builds segments of integer channels
@@ -458,7 +543,7 @@ __global__ __launch_bounds__(256, 4) void k_tier_scan_direct(SgBeamArgs a)
     for (int64_t i = (int64_t)a.work_lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < work_n; i += (int64_t)gridDim.x * 256) {
         const int32_t g = a.tier_list[work_off + i];
         const int f = sg_frame_of(a, g);
-        const T *row = (const T *)a.rows + (a.frame_off[f] + a.perm[g]) * 5;
+        const T *row = sg_row<T>(a, f, g);
         const T px = row[0], py = row[1], pz = row[2];
         const int ch = (int)row[4];                                       // a flagged beam was simulated: valid channel
         const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];
@@ -993,8 +1078,7 @@ __global__ __launch_bounds__(64) void k_beams_huge(SgBeamArgs a)
     if (live) {
         g = a.tier_list[work_off + chunk + threadIdx.x];
         f = sg_frame_of(a, g);
-        const int64_t src = a.frame_off[f] + a.perm[g];
-        const T *row = (const T *)a.rows + src * 5;
+        const T *row = sg_row<T>(a, f, g);
         const T px = row[0], py = row[1], pz = row[2];
         const int ch = (int)row[4];                                    // a flagged beam was simulated: valid channel
         const SgTable tab = a.frame_tables[(int64_t)f * n_las + ch];
@@ -1163,8 +1247,9 @@ __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, do
 // Stable compaction of kept rows, per frame.  keep byte: bit 0 = row is in the output, bit 1 = row passed the noise filter
 // (num_attenuated counts those, before the camera crop: simulation.py:525 precedes :532-540).
 template <typename T>
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
-                                                            const uint32_t *__restrict__ rec_q, const T *__restrict__ rng, const int32_t *__restrict__ perm, const double *__restrict__ thr_poly,
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict__ rows_in, const T *__restrict__ srows, const int32_t *__restrict__ frame_unsorted,
+                                                            const uint32_t *__restrict__ rec,
+                                                            const uint32_t *__restrict__ rec_q, const T *__restrict__ rng, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
                                                             int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
 {
@@ -1172,6 +1257,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
+    const T *rows = frame_unsorted[f] ? srows : rows_in;            // sorted position g = row g (see k_sort_scatter)
     const double p0 = thr_poly[(int64_t)f * 3], p1 = thr_poly[(int64_t)f * 3 + 1], p2 = thr_poly[(int64_t)f * 3 + 2];
     int c = 0;
     for (int q = 0; q < 4; ++q) {
@@ -1196,7 +1282,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
             is_att = lab_i == 1;
             k = noise_ok;
         } else {
-            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + perm[base + r]) * 5, rc);
+            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + r) * 5, rc);
             const T dd2 = o.dd * o.dd;
             const double thr = (p0 * (double)dd2 + p1 * (double)o.dd) + p2;
             noise_ok = (o.lab == (T)2) || ((double)o.i > thr);
@@ -1243,7 +1329,8 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__rest
 }
 
 template <typename T>
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ rows, const uint32_t *__restrict__ rec,
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ rows_in, const T *__restrict__ srows, const int32_t *__restrict__ frame_unsorted,
+                                                              const uint32_t *__restrict__ rec,
                                                               const uint32_t *__restrict__ rec_q, const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
                                                               const int64_t *__restrict__ frame_off,
                                                               const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
@@ -1254,6 +1341,8 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
+    const bool uns = frame_unsorted[f] != 0;
+    const T *rows = uns ? srows : rows_in;
     __shared__ int wave_cnt[4][4];               // [round][wave]
     const int tid = threadIdx.x, w = tid >> 6;
     bool k[4];
@@ -1274,10 +1363,10 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
         if (k[q]) {
             const int64_t r = base + tile0 + q * SG_BLOCK + tid;
             const int64_t dst = base + off + pre[q];
-            const int32_t src = perm[r];
+            const int32_t src = uns ? perm[r] : (int32_t)(r - base);
             uint32_t rc = rec[r];
             if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
-            const SgRow<T> o = sg_rebuild_row<T>(rows + (base + src) * 5, rc);
+            const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rc);
             T *d = out_rows + dst * 5;
             d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
             out_src[dst] = src;
@@ -1351,24 +1440,6 @@ __global__ __launch_bounds__(SG_BLOCK) void k_crop_scatter(const T *__restrict__
     }
 }
 
-// Chunk boundaries of the segment order: chunk c of n_chunks = blocks [chunk_blk[c], chunk_blk[c + 1]), cut at segment
-// starts (a segment's slice of the dict queue is complete only when all of its blocks have run), as even as that allows.
-__global__ void k_seg_chunks(const int32_t *__restrict__ seg_n, const int32_t *__restrict__ seg_blk, int n_chunks,
-                             int32_t *__restrict__ chunk_blk)
-{
-    const int c = threadIdx.x;
-    if (c > n_chunks) return;
-    const int n_seg = seg_n[0], total = seg_n[1];
-    if (c == n_chunks) { chunk_blk[c] = total; return; }
-    const int target = (int)(((int64_t)total * c) / n_chunks);
-    int lo = 0, hi = n_seg;                          // first segment whose first block is >= target (seg_blk ascends with the slot)
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (seg_blk[mid] < target) lo = mid + 1; else hi = mid;
-    }
-    chunk_blk[c] = lo < n_seg ? seg_blk[lo] : total;
-}
-
 // table_ids[frame][channel] -> the table descriptor itself, so that a beam needs one load instead of two dependent ones
 __global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_tables, const int32_t *__restrict__ table_ids,
                                  int64_t n, SgTable *__restrict__ out)
@@ -1404,7 +1475,8 @@ extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, con
 // (sg_prepass_reserve_tiles): the first kernel then leaves the prepass' per-tile statistics on its way over the rows
 extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                               int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
-                              int64_t max_tiles, const double *lean_plane, double *lean_part, void *stream)
+                              int64_t max_tiles, const double *lean_plane, double *lean_part, int32_t *tile_unsorted, int32_t *frame_unsorted,
+                              void *srows, int identity_perm, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
@@ -1412,16 +1484,30 @@ extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_
     SgLeanTile lt{};
     lt.plane = lean_plane; lt.delta = 0.5; lt.part = lean_part; lt.max_tiles = max_tiles;
     if (lean_plane && lean_part) {
-        if (dtype == 0) hipLaunchKernelGGL((k_sort_hist<float, true>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt);
-        else hipLaunchKernelGGL((k_sort_hist<double, true>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt);
+        if (dtype == 0) hipLaunchKernelGGL((k_sort_hist<float, true>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
+        else hipLaunchKernelGGL((k_sort_hist<double, true>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
     } else {
-        if (dtype == 0) hipLaunchKernelGGL((k_sort_hist<float, false>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt);
-        else hipLaunchKernelGGL((k_sort_hist<double, false>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt);
+        if (dtype == 0) hipLaunchKernelGGL((k_sort_hist<float, false>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
+        else hipLaunchKernelGGL((k_sort_hist<double, false>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
     }
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_hist, tile_base, max_tiles);
+    hipLaunchKernelGGL(k_sort_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_hist, tile_base, max_tiles, tile_unsorted, frame_unsorted);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_sort_scatter, grid, dim3(SG_BLOCK), 0, st, ch8, frame_off, tile_base, rank, perm, max_tiles);
+    if (dtype == 0) hipLaunchKernelGGL(k_sort_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, ch8, frame_off, tile_hist, tile_base, rank, perm, (float *)srows, frame_unsorted, identity_perm, max_tiles);
+    else hipLaunchKernelGGL(k_sort_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, ch8, frame_off, tile_hist, tile_base, rank, perm, (double *)srows, frame_unsorted, identity_perm, max_tiles);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total, int64_t max_frame,
+                                     const int32_t *perm, void *srows, int32_t *frame_unsorted, void *stream)
+{
+    (void)n_total;
+    if (n_frames <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_frame + SG_BLOCK - 1) / SG_BLOCK, 256)), (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_gather_rows<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, perm, (float *)srows, frame_unsorted);
+    else hipLaunchKernelGGL(k_gather_rows<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, perm, (double *)srows, frame_unsorted);
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -1627,7 +1713,7 @@ extern "C" int sg_launch_huge(const SgBeamArgs *a, int dtype, void *stream)
 
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
-                                  int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk, int n_chunks,
+                                  int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk,
                                   int32_t *chunk_blk, const SgTable *tables, SgTable *resolved, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1636,19 +1722,15 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
     hipLaunchKernelGGL(k_seg_count, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block, tbl_cnt,
                        tables, resolved);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, tbl_cnt, tbl_base, n_tables + 1, seg_n, n_chunks == 1 ? chunk_blk : (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_seg_scan, dim3(1), dim3(1024), 0, st, tbl_cnt, tbl_base, n_tables + 1, seg_n, chunk_blk);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_seg_place, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block,
                        tbl_base, tbl_cnt, seg_start, seg_cnt, seg_frame, seg_blk, seg_of_blk);
     SG_CHECK_LAUNCH();
-    if (n_chunks > 1) {
-        hipLaunchKernelGGL(k_seg_chunks, dim3(1), dim3(64), 0, st, seg_n, seg_blk, n_chunks, chunk_blk);
-        SG_CHECK_LAUNCH();
-    }
     return 0;
 }
 
-extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
+extern "C" int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_unsorted, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                                  int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, void *stream)
@@ -1658,15 +1740,15 @@ extern "C" int sg_launch_compact(const void *rows, int dtype, const uint32_t *re
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     SgFov fv{};
     if (fov) fv = *fov;
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, (const float *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, (const double *)rng, perm, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, (const float *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, (const double *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles);
     SG_CHECK_LAUNCH();
     if (dtype == 0)
-        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
     else
-        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
+        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -1694,44 +1776,6 @@ extern "C" int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     if (dtype == 0) hipLaunchKernelGGL(k_crop_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, keep, frame_off, new_off, tile_base, (float *)out_rows, crop_src, max_tiles);
     else hipLaunchKernelGGL(k_crop_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, keep, frame_off, new_off, tile_base, (double *)out_rows, crop_src, max_tiles);
-    SG_CHECK_LAUNCH();
-    return 0;
-}
-
-
-// ---- results to page-locked host memory -----------------------------------------------------------------------------
-// The download of a pipelined host batch is a kernel of OURS with a small grid: the runtime's own device-to-host copy is a
-// blit kernel that fills every CU with waves waiting on the link, and whatever is launched beside it (the next chunk's
-// kernels) waits until it is done (traced: 0.38 ms per million rows).  A few workgroups keep enough stores in flight to
-// saturate the link -- posted writes, nothing to wait for -- and leave the rest of the chip to the compute lanes.
-__global__ void __launch_bounds__(256) k_copy_link16(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
-{
-    const size_t stride = (size_t)gridDim.x * 256;
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {        // four independent 16-byte transfers per lane in flight
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
-}
-
-__global__ void __launch_bounds__(256) k_copy_link4(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, size_t n4)
-{
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
-}
-
-// bytes: a multiple of 4 (rows of 4- or 8-byte fields, int32 source indices).  dst / src: device-visible addresses.
-extern "C" int sg_launch_copy_link(void *dst, const void *src, size_t bytes, int blocks, void *stream)
-{
-    if (bytes == 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const bool wide = (((uintptr_t)dst | (uintptr_t)src) & 15) == 0;
-    const size_t body = wide ? bytes / 16 * 16 : 0;
-    if (body) hipLaunchKernelGGL(k_copy_link16, dim3((unsigned)blocks), dim3(256), 0, st, (uint4 *)dst, (const uint4 *)src, body / 16);
-    if (bytes > body)
-        hipLaunchKernelGGL(k_copy_link4, dim3((unsigned)(wide ? 1 : blocks)), dim3(256), 0, st, (uint32_t *)((char *)dst + body),
-                           (const uint32_t *)((const char *)src + body), (bytes - body) / 4);
     SG_CHECK_LAUNCH();
     return 0;
 }

@@ -40,6 +40,8 @@ struct PreFrame {          // per-frame state shared by the kernels
 
 struct PreArgs {
     const void *rows;
+    const void *srows;          // optional (snowfall prepass): the channel sort's sorted copy of the frames that came unsorted ...
+    const int32_t *frame_unsorted;   // ... and which frames those are (sg_common.h: SgBeamArgs)
     const int64_t *frame_off;
     const int64_t *frame_cnt;   // optional: rows actually present in frame f (compacted input); else off[f+1] - off[f]
     int n_frames;
@@ -485,90 +487,10 @@ __global__ void k_pre_override_lines(PreArgs a)
     fr.need_mean32 = 0;
 }
 
-// ---- P6: normal-equation partials of polyfit(ground_dist, thr * cos(angle), 2) (simulation.py:462-467) ----------
-template <typename T>
-__global__ __launch_bounds__(PB) void k_pre_poly_part(PreArgs a)
-{
-    const int f = blockIdx.y;
-    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
-    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
-    if (tile0 >= n) return;
-    const PreFrame fr = a.fr[f];
-    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double gnv[4], gdv[4], gav[4];               // all loads of the tile in flight before the first use
-    for (int q = 0; q < 4; ++q) {
-        const int64_t r = tile0 + q * PB + threadIdx.x;
-        gnv[q] = r < n ? a.g_norm[base + r] : NAN;
-    }
-    for (int q = 0; q < 4; ++q) {
-        const int64_t r = tile0 + q * PB + threadIdx.x;
-        const bool g = gnv[q] == gnv[q];
-        gdv[q] = g ? a.g_dist[base + r] : 0.0;
-        gav[q] = g ? a.g_ang[base + r] : 0.0;
-    }
-    for (int q = 0; q < 4; ++q) {
-        const double gn = gnv[q];
-        if (gn != gn) continue;
-        const double gd = gdv[q];
-        const double y = (a.noise_floor * (fr.pmin0 * gd + fr.pmin1)) * (a.cos_only ? gav[q] : cos(gav[q]));   // augmentation.py:252-253, simulation.py:462
-        // np.polyfit keeps the float32 dtype of x for the Vandermonde columns: x^2 is a float32 product
-        double a2;
-        if constexpr (sizeof(T) == 4) { const float xf = (float)gd; a2 = (double)(xf * xf); }
-        else a2 = gd * gd;
-        const double a1 = gd;
-        v[0] += a2 * a2; v[1] += a2 * a1; v[2] += a2; v[3] += a1 * a1; v[4] += a1;
-        v[5] += a2 * y; v[6] += a1 * y; v[7] += y; v[8] += 1.0;
-    }
-    __shared__ double sm[36];
-    block_sum<9>(v, sm);
-    if (threadIdx.x == 0) {
-        double *o = a.part + ((int64_t)f * a.max_tiles + blockIdx.x) * 12;
-        for (int k = 0; k < 9; ++k) o[k] = v[k];
-    }
-}
-
-// ---- P7: solve the 3 x 3 system (columns scaled by their norms, as np.polyfit does) ------------------------------
-__global__ __launch_bounds__(64) void k_pre_poly_solve(PreArgs a, double *thr_poly)
-{
-    const int f = blockIdx.x;
-    if (f >= a.n_frames) return;
-    const int64_t n = pre_rows(a, f);
-    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    const int cols[9] = {0, 1, 2, 3, 4, 5, 6, 7, 8};
-    double s[9];
-    frame_sums<9>(a.part + (int64_t)f * a.max_tiles * 12, tiles, cols, s);
-    if (threadIdx.x != 0) return;
-    double *out = thr_poly + 3 * f;
-    if (s[8] < 3) { out[0] = out[1] = out[2] = 0.0; return; }
-    const double c2 = sqrt(s[0]), c1 = sqrt(s[3]), c0 = sqrt(s[8]);
-    double G[3][4] = {{s[0] / (c2 * c2), s[1] / (c2 * c1), s[2] / (c2 * c0), s[5] / c2},
-                      {s[1] / (c1 * c2), s[3] / (c1 * c1), s[4] / (c1 * c0), s[6] / c1},
-                      {s[2] / (c0 * c2), s[4] / (c0 * c1), s[8] / (c0 * c0), s[7] / c0}};
-    for (int i = 0; i < 3; ++i) {                                        // Gaussian elimination, partial pivoting
-        int piv = i;
-        for (int r = i + 1; r < 3; ++r) if (fabs(G[r][i]) > fabs(G[piv][i])) piv = r;
-        if (piv != i) for (int k = 0; k < 4; ++k) { const double t = G[i][k]; G[i][k] = G[piv][k]; G[piv][k] = t; }
-        for (int r = i + 1; r < 3; ++r) {
-            const double m = G[r][i] / G[i][i];
-            for (int k = i; k < 4; ++k) G[r][k] -= m * G[i][k];
-        }
-    }
-    double x[3];
-    for (int i = 2; i >= 0; --i) {
-        double t = G[i][3];
-        for (int k = i + 1; k < 3; ++k) t -= G[i][k] * x[k];
-        x[i] = t / G[i][i];
-    }
-    out[0] = x[0] / c2; out[1] = x[1] / c1; out[2] = x[2] / c0;
-    a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
-}
-
-
-
 // ================================================================================================================
-// Lean snowfall prepass (round 4).  The chain above moves every ground row through three float64 scratch arrays (range,
-// I / cos, cos: written once, read twice -- 2.8 GB per 256-sweep step, more than the per-beam kernels fetch).  The snowfall
-// path needs less: k_lean_stats streams the rows ONCE and leaves, per 1024-row tile, everything that is a plain sum --
+// Lean snowfall prepass.  The chain above (kept by the wet-ground model, whose per-row rewrite needs range, angle and I / cos of every
+// ground row again) moves every ground row through three float64 scratch arrays -- written once, read twice: 2.8 GB per 256-sweep
+// step when the snowfall path used it too (rounds 1 - 3), more than the per-beam kernels fetch.  The snowfall path needs less: k_lean_stats streams the rows ONCE and leaves, per 1024-row tile, everything that is a plain sum --
 // count, sums and tile-centred second moments of (range, I / cos) for the regression line, the maximum for the histogram
 // range, and the sums of the quadratic fit, which are LINEAR in the noise line (y_i = nf (pmin0 d_i + pmin1) c_i, so
 // sum a y = nf (pmin0 sum a d c + pmin1 sum a c)) and can therefore be taken before the line is known; k_lean_hist streams
@@ -660,12 +582,17 @@ __global__ __launch_bounds__(PB) void k_lean_hist(PreArgs a)
     const int64_t base = a.frame_off[f], n = pre_rows(a, f);
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
-    if (a.part[((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS + LP_N] == 0.0) return;       // no ground row in this tile
+    // A frame that came unsorted (firing order) is read from the sort's sorted copy: neighbouring rows are then neighbouring azimuths
+    // of one laser again and fall into the same few bins (the tile's LDS table below), where a firing-order tile holds 64 lasers'
+    // rows and as many distinct bins (measured: 1.07 instead of 0.88 ms, beside the tiers).  The histogram does not depend on the
+    // row order.  The per-tile ground counts describe the tiles of the ARRIVAL order, so only sorted frames can skip by them.
+    const bool uns = a.frame_unsorted && a.frame_unsorted[f];
+    if (!uns && a.part[((int64_t)f * a.max_tiles + blockIdx.x) * LP_COLS + LP_N] == 0.0) return;       // no ground row in this tile
     const double *pl = a.plane + 4 * f;
     const double w0 = pl[0], w1 = pl[1], w2 = pl[2], h = pl[3];
     const double wn = sqrt((w0 * w0 + w1 * w1) + w2 * w2);
     const double ymaxv = a.fr[f].ymax;
-    const T *rows = (const T *)a.rows;
+    const T *rows = (const T *)(uns ? a.srows : a.rows);
     int32_t *hist = a.hist + (int64_t)f * HX * HY;
     T rx[4], ry[4], rz[4], ri[4];
     for (int q = 0; q < 4; ++q) {
@@ -1103,10 +1030,10 @@ extern "C" double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, i
 
 static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                     int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status, hipStream_t st,
-                    bool tiles_done)
+                    bool tiles_done, const void *srows, const int32_t *frame_unsorted)
 {
     PreArgs a{};
-    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
+    a.rows = rows; a.srows = srows; a.frame_unsorted = srows ? frame_unsorted : nullptr; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
     a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
     const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
     a.max_tiles = max_tiles;
@@ -1231,30 +1158,12 @@ extern "C" int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int d
     return 0;
 }
 
-extern "C" int sg_prepass_legacy(void)
-{
-    static const bool legacy = getenv("SNOWGPU_PREPASS_LEGACY") != nullptr;      // A/B: the three-scratch-array chain of rounds 1-3
-    return legacy ? 1 : 0;
-}
-
 extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                               int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
-                              int32_t *status, void *stream, int tiles_done)
+                              int32_t *status, void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted)
 {
-    hipStream_t st = (hipStream_t)stream;
-    if (!sg_prepass_legacy()) return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, st, tiles_done != 0);
-    PreArgs a{};
-    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
-    a.noise_floor = noise_floor; a.power_factor = 15.0; a.status = status;
-    int rc = estimate(s, a, dtype, n_total, max_frame, 3, 7 /* SNOWGPU_E_GROUND */, true, st);
-    if (rc) return rc;
-    dim3 grid((unsigned)a.max_tiles, (unsigned)n_frames);
-    if (dtype == 0) hipLaunchKernelGGL(k_pre_poly_part<float>, grid, dim3(PB), 0, st, a);
-    else hipLaunchKernelGGL(k_pre_poly_part<double>, grid, dim3(PB), 0, st, a);
-    LCHK();
-    hipLaunchKernelGGL(k_pre_poly_solve, dim3((unsigned)n_frames), dim3(64), 0, st, a, thr_poly);
-    LCHK();
-    return 0;
+    return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, (hipStream_t)stream, tiles_done != 0,
+                    srows, frame_unsorted);
 }
 
 extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,

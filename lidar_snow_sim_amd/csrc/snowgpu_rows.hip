@@ -287,7 +287,7 @@ __global__ __launch_bounds__(RW_BLOCK, PAIRWISE ? 2 : RW_WAVES) void k_rows(SgBe
         if (live) {
             g = work_list[work_off + bi];
             f = sg_frame_of(a, g);
-            const T *row = (const T *)a.rows + (a.frame_off[f] + a.perm[g]) * 5;
+            const T *row = sg_row<T>(a, f, g);
             px = row[0]; py = row[1]; pz = row[2];
             ch = (int)row[4];                                             // a flagged beam was simulated: valid channel
             tab = a.frame_tables[(int64_t)f * n_las + ch];
@@ -473,76 +473,6 @@ __global__ __launch_bounds__(RW_BLOCK, PAIRWISE ? 2 : RW_WAVES) void k_rows(SgBe
     }
 }
 
-// The scan of a later tier alone, as a row kernel: entry i of the class -> slot i of the tier's hand-over buffer (what
-// k_beams<.., LIST, DICT = 1> leaves for k_power<.., LISTQ>), G records per step instead of one.  The one-beam-per-lane scan of a
-// listed beam is a chain of 20 .. 60 dependent record loads (12 % VALU issue, 65 % waiting: profiles/r04a_*_pmc.txt) and stood on
-// the critical path of a step; the row scan needs two or three rounds of coalesced loads per bin.
-template <typename T, int G, int LMAX, bool EXACT>
-__global__ __launch_bounds__(RW_BLOCK, 4) void k_rows_scan(SgBeamArgs a)
-{
-    using R = Row<G>;
-    constexpr int RPW = R::RPW, P = 3 * LMAX + 2;
-    __shared__ RwSlot s_slot[RW_BLOCK];
-    const int tid = threadIdx.x, lj = R::lj(), rb = R::base(), wbase = tid & ~63;
-    RwSlot *row_slots = s_slot + wbase + rb;
-    const int n_las = a.las->n;
-    int64_t work_n = a.tier_info[a.cls];
-    if (work_n > a.work_hi) work_n = a.work_hi;
-    const int64_t work_off = (int64_t)a.cls * a.tier_stride;
-    const int waves = (int)gridDim.x * (RW_BLOCK / 64);
-    const int wave = (int)blockIdx.x * (RW_BLOCK / 64) + (tid >> 6);
-    for (int64_t chunk = (int64_t)a.work_lo + (int64_t)wave * RPW; chunk < work_n; chunk += (int64_t)waves * RPW) {
-        const int64_t bi = chunk + (rb / G);
-        const bool live = bi < work_n;                                    // row-uniform
-        int32_t g = 0;
-        int ch = 0;
-        T px = 1, py = 0, pz = 0;
-        SgTable tab{};
-        bool act = false;
-        if (live) {
-            g = a.tier_list[work_off + bi];
-            const int f = sg_frame_of(a, g);
-            const T *row = (const T *)a.rows + (a.frame_off[f] + a.perm[g]) * 5;
-            px = row[0]; py = row[1]; pz = row[2];
-            ch = (int)row[4];                                             // a flagged beam was simulated: valid channel
-            tab = a.frame_tables[(int64_t)f * n_las + ch];
-            act = tab.entries != nullptr;
-        }
-        T d_t = 0;
-        SgBeamGeo geo{};
-        if (act) geo = sg_beam_geometry<T>(px, py, pz, a.beam_div_deg, EXACT, d_t);
-        int nh;
-        double a1, a2, rho;
-        const int L = rw_scan_sort<G>(act, geo, tab, row_slots, nh, a1, a2, rho);
-        if (act && (nh > G || nh > LMAX) && lj == 0) {                    // a listed beam fits its tier by construction
-            atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
-            atomicCAS(&a.status[1], -1, g);
-        }
-        if (live) {
-            const int64_t slot = bi;                                      // entry i of the class -> slot i
-            if (act && L > 0 && nh <= LMAX) {
-                if (lj < L) {
-                    a.tq[(slot >> 6) * (int64_t)(P * 64) + (int64_t)(2 + 3 * lj) * 64 + (slot & 63)] = a1;
-                    a.tq[(slot >> 6) * (int64_t)(P * 64) + (int64_t)(3 + 3 * lj) * 64 + (slot & 63)] = a2;
-                    a.tq[(slot >> 6) * (int64_t)(P * 64) + (int64_t)(4 + 3 * lj) * 64 + (slot & 63)] = rho;
-                }
-                if (lj == 0) {
-                    a.tq[(slot >> 6) * (int64_t)(P * 64) + (slot & 63)] = (double)d_t;
-                    a.tq[(slot >> 6) * (int64_t)(P * 64) + 64 + (slot & 63)] = geo.theta_c;
-                    a.tq_sc[slot] = (uint16_t)(L | (ch << 8));
-                }
-            } else if (lj == 0) {
-                a.tq_sc[slot] = 0xffff;                                   // no flake list: the record below is final
-                a.rec[g] = 0u;
-                if (a.dbg_count && act) {                                 // debug tap: the dict of a clear beam is its hard target alone
-                    a.dbg_count[g] = 1;
-                    a.dbg_rj[(int64_t)g * a.dbg_cap] = (double)d_t;
-                    a.dbg_ratio[(int64_t)g * a.dbg_cap] = sg_clear_beam_ratio(geo.theta_c, a.beam_div_deg);
-                }
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 #define RW_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)
@@ -569,38 +499,6 @@ static int launch_rows_t(const SgBeamArgs *a, hipStream_t st)
     else hipLaunchKernelGGL((k_rows<T, G, false, true>), dim3(redo_blocks), dim3(RW_BLOCK), 0, st, *a);
     RW_CHECK_LAUNCH();
     return 0;
-}
-
-template <typename T, int G, int LMAX>
-static int launch_rows_scan_t(const SgBeamArgs *a, hipStream_t st)
-{
-    const int64_t n = (int64_t)a->work_hi - a->work_lo;
-    if (n <= 0) return 0;
-    int dev_id = 0, cus = 256;
-    (void)hipGetDevice(&dev_id);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id);
-    if (cus <= 0) cus = 256;
-    constexpr int RPW = 64 / G, WPB = RW_BLOCK / 64;
-    const int64_t want = (n + (int64_t)RPW * WPB - 1) / ((int64_t)RPW * WPB);
-    const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)cus * 4);      // what the chip holds at four waves per SIMD
-    if (a->exact_math) hipLaunchKernelGGL((k_rows_scan<T, G, LMAX, true>), dim3(blocks), dim3(RW_BLOCK), 0, st, *a);
-    else hipLaunchKernelGGL((k_rows_scan<T, G, LMAX, false>), dim3(blocks), dim3(RW_BLOCK), 0, st, *a);
-    RW_CHECK_LAUNCH();
-    return 0;
-}
-
-// the scan of class a->cls (capacity lmax = 8, 16 or 63) into the tier's hand-over buffer, entries [work_lo, work_hi)
-extern "C" int sg_launch_rows_scan(const SgBeamArgs *a, int dtype, int lmax, void *stream)
-{
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == 0) {
-        if (lmax == 8) return launch_rows_scan_t<float, 8, 8>(a, st);
-        if (lmax == 16) return launch_rows_scan_t<float, 16, 16>(a, st);
-        return launch_rows_scan_t<float, 64, SG_LCAP>(a, st);
-    }
-    if (lmax == 8) return launch_rows_scan_t<double, 8, 8>(a, st);
-    if (lmax == 16) return launch_rows_scan_t<double, 16, 16>(a, st);
-    return launch_rows_scan_t<double, 64, SG_LCAP>(a, st);
 }
 
 // class a->cls of the tier lists, capacity lmax (8, 16 or 63), entries [0, work_hi)

@@ -57,3 +57,9 @@ def synthetic_sweep(layers: int = 64, azimuths: int = 2048, seed: int = 1000, in
         raise ValueError(intensity)
     ch = np.repeat(np.arange(layers), azimuths).astype(np.float64)
     return np.column_stack((x, y, z, inten, ch)).astype(dtype)
+
+
+def firing_order(pc: np.ndarray, layers: int, azimuths: int) -> np.ndarray:
+    """The rows of a channel-major sweep in the order the sensor fires them: azimuth-major, the ``layers`` channels of one
+    azimuth step next to each other -- the row order of an STF ``.bin`` (precompute.py:78).  Same rows, another order."""
+    return np.ascontiguousarray(pc.reshape(layers, azimuths, pc.shape[1]).transpose(1, 0, 2).reshape(-1, pc.shape[1]))

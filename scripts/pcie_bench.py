@@ -40,7 +40,7 @@ def main():
     frames, ids = [], []
     for f in range(F):
         seed = args.seed_base + f
-        frames.append(bench.make_frame(layers, azimuths, seed, rscale))
+        frames.append(bench.make_frame(layers, azimuths, seed, rscale, args.workload in bench.FIRING_ORDER))
         random.seed(seed)
         order = list(range(layers))
         random.shuffle(order)

@@ -2,6 +2,8 @@
 with mismatch COUNTS (kept rows, labels, intensities) asserted to be zero and printed.
 
   C2     64 x 2048 sweeps, 2.5 mm/h @ 1.6 m/s (18 k flakes per line)            -- the headline workload
+  C2fire the C2 sweeps with their rows in firing order (azimuth-major, channels interleaved: the row order of an STF .bin) -- the
+         channel sort is a real permutation and the per-beam kernels read the sort's sorted copy
   C2far  the same sweeps with every range stretched x1.8 (long scatterer lists: capacity tiers 8 / 16 / 63 busy)
   C1     64 x 2048 sweeps, 0.5 mm/h @ 2.0 m/s (40 k flakes per line: the first tier is 8)
   C4     128 x 4096 sweeps, 10 mm/h @ 1.6 m/s, 128-entry laser table (the 64-entry one tiled)
@@ -48,7 +50,7 @@ def _frames(workload, dtype, n):
     out, orders = [], []
     for f in range(n):
         seed = 1000 + f
-        pc = bench.make_frame(layers, azimuths, seed, scale)
+        pc = bench.make_frame(layers, azimuths, seed, scale, workload in bench.FIRING_ORDER)
         random.seed(seed)                                   # SURVEY 8 d: random.seed(f); random.shuffle(order)
         order = list(range(layers))
         random.shuffle(order)
@@ -97,7 +99,7 @@ def _sum_counts(recs):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64], ids=["float32", "float64"])
-@pytest.mark.parametrize("workload", ["C2", "C2far", "C1", "C4"])
+@pytest.mark.parametrize("workload", ["C2", "C2fire", "C2far", "C1", "C4"])
 def test_fullsize_parity(workload, dtype, capsys):
     """Every row of N_FRAMES full-size frames: kept-row indices, labels and intensities bit-exact, xyz within 1e-6
     (float32 rows) / 1e-12 (float64 rows) relative, statistics equal."""

@@ -1234,3 +1234,86 @@ def test_device_fov_crop_against_the_float32_numpy_projection(eng, tables):
             edge = np.minimum.reduce([np.abs(u), np.abs(u - 1920), np.abs(v), np.abs(v - 1024)])
             assert np.all((edge < 1e-3) | (np.abs(depth) < 1e-4)), (edge.max(), np.abs(depth).min())
     assert n_diff <= 20          # a handful of boundary points in 262 144, if any
+
+
+def test_firing_order_rows_give_the_rows_of_the_channel_major_sweep(eng, so, tables):
+    """An STF .bin holds its rows in firing order -- azimuth-major, the 64 channels interleaved (precompute.py:78) --, for which the
+    channel sort (simulation.py:447) is a real permutation: the device makes a sorted copy and every later kernel reads that.  The
+    stable sort puts the rows of one channel in azimuth order whichever way they came, so the augmented rows equal those of the
+    channel-major sweep byte for byte and the source indices map through the reordering; a batch may mix both kinds of frame (each
+    frame decides for itself), ragged and shuffled ones included.  Float32 and float64; checked against the oracle too."""
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep, firing_order
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    for dtype in (np.float32, np.float64):
+        full = synthetic_sweep(64, 2048, seed=1021, intensity="lambert").reshape(64, 2048, 5)
+        cm = full[:, ::8, :].reshape(-1, 5).astype(dtype)                    # channel-major, 64 x 256
+        fire = firing_order(cm, 64, 256)
+        to_cm = np.arange(64 * 256).reshape(64, 256).T.reshape(-1)           # row of `fire` -> row of `cm`
+        rng = np.random.default_rng(3)
+        shuf_idx = rng.permutation(cm.shape[0])
+        shuf = cm[shuf_idx]                                                  # no order at all (the stable sort keeps arrival order per channel)
+        ragged = fire[: 64 * 100 + 17]                                       # a frame that ends inside an azimuth step
+        frames = [cm, fire, shuf, ragged, cm[:5000], fire[:3000]]
+        orders = [list(np.random.default_rng(40 + i).permutation(64)) for i in range(len(frames))]
+        planes = [[*PLANE[0], PLANE[1]]] * len(frames)
+        tids = [eng.table_ids_from_arrays(tl, o) for o in orders]
+        # every frame alone ...
+        singles = [eng.ctx.augment_batch(f, [0, f.shape[0]], [tids[i]], bd, plane=[planes[i]]) for i, f in enumerate(frames)]
+        # ... and all of them in one batch (sorted and unsorted frames side by side)
+        rows = np.concatenate(frames)
+        off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames])))
+        out, src, counts, stats, _ = eng.ctx.augment_batch(rows, off, tids, bd, plane=planes)
+        for i, f in enumerate(frames):
+            o1, s1, c1, st1, _ = singles[i]
+            a, m = int(off[i]), int(counts[i])
+            assert m == int(c1[0]) and np.array_equal(stats[i], st1[0])
+            assert np.array_equal(src[a:a + m], s1[:m]) and out[a:a + m].tobytes() == o1[:m].tobytes()
+            r_stats, r_aug, r_src = so.augment(f, tl, bd, orders[i], plane=PLANE)
+            assert tuple(int(v) for v in stats[i]) == tuple(int(v) for v in r_stats)
+            assert np.array_equal(s1[:m], r_src) and np.array_equal(o1[:m, 3:], r_aug[:, 3:])
+            assert np.allclose(o1[:m, :3], r_aug[:, :3], rtol=1e-6 if dtype == np.float32 else 1e-12, atol=0)
+        # same table order for the channel-major and the firing-order copy of one sweep: same rows, indices mapped
+        o_cm, s_cm, c_cm, st_cm, _ = eng.ctx.augment_batch(cm, [0, cm.shape[0]], [tids[0]], bd, plane=[planes[0]])
+        o_f, s_f, c_f, st_f, _ = eng.ctx.augment_batch(fire, [0, fire.shape[0]], [tids[0]], bd, plane=[planes[0]])
+        n = int(c_cm[0])
+        assert n == int(c_f[0]) and np.array_equal(st_cm, st_f) and o_cm[:n].tobytes() == o_f[:n].tobytes()
+        assert np.array_equal(to_cm[s_f[:n]], s_cm[:n])
+        assert int(st_cm[0][0]) > 0 and n < cm.shape[0]
+
+
+@pytest.mark.parametrize("switch,values", [("SNOWGPU_SERIAL", ("1",)), ("SNOWGPU_FEW", ("0", "1", "3")), ("SNOWGPU_TIER_ROWS", ("0", "1"))])
+def test_remaining_environment_switches_change_no_byte(so, tables, monkeypatch, switch, values):
+    """The environment switches that survive in csrc/ (INTEGRATION.md lists them) pick a schedule or a kernel variant, never a result:
+    SNOWGPU_SERIAL=1 (every kernel on the caller's stream: pure kernel times for the profiles), SNOWGPU_FEW=0..3 (beams with up to that
+    many flakes go through the register kernel k_power_few; default 2), SNOWGPU_TIER_ROWS=0 / 1 (the later capacity tiers as row
+    kernels: default only for batches up to four sweeps).  Same bytes as the default on stretched sweeps (long lists: every tier busy),
+    float32 in firing order and float64 channel-major, and equal to the oracle."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import firing_order
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    order = list(np.random.default_rng(9).permutation(64))
+    pc32 = firing_order(_stretched_subsweep(step=16, seed=1090), 64, 128)
+    pc64 = _stretched_subsweep(step=16, seed=1091).astype(np.float64)
+    results = []
+    for v in (None,) + tuple(values):
+        if v is None:
+            monkeypatch.delenv(switch, raising=False)
+        else:
+            monkeypatch.setenv(switch, v)
+        e = engine.Engine(0)
+        try:
+            tid = [e.table_ids_from_arrays(tl, order)]
+            results.append([e.ctx.augment_batch(pc, [0, pc.shape[0]], tid, bd, plane=[[*PLANE[0], PLANE[1]]]) for pc in (pc32, pc64)])
+        finally:
+            e.ctx.close()
+    for k, pc in enumerate((pc32, pc64)):
+        o0, s0, c0, st0, _ = results[0][k]
+        n = int(c0[0])
+        for res in results[1:]:
+            o1, s1, c1, st1, _ = res[k]
+            assert np.array_equal(c0, c1) and np.array_equal(st0, st1) and np.array_equal(s0[:n], s1[:n]) and o0[:n].tobytes() == o1[:n].tobytes()
+        r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, plane=PLANE)
+        assert tuple(int(v) for v in st0[0]) == tuple(int(v) for v in r_stats)
+        assert np.array_equal(s0[:n], r_src) and np.array_equal(o0[:n, 3:], r_aug[:, 3:])
