@@ -308,6 +308,29 @@ int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *fram
  * first-minimum fit: n_frames x 4 doubles (p slope, p intercept, noise-line slope, noise-line intercept).  One use; NULL clears. */
 int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines);
 
+/* estimation_method of ground_water_augmentation (reference: tools/wet_ground/augmentation.py:25, passed through by
+ * pointcloud_viewer.py:2820, :2851 as self.estimation) for every later wet-ground call of this context
+ * (snowgpu_wet_ground_batch, snowgpu_augment_wet_batch[_device]):
+ *   method 0  'linear' -- linregress for the laser power (:215-221) and for the noise level (:247-253); the default
+ *   method 1  'poly'   -- np.polyfit of degree 2 for the laser power (:223-229) and ransac_polyfit (:171-192: n = 15, k = 100,
+ *                         t = 0.1, d = 15, f = 0.8) for the noise level (:243-246).  The reference draws the RANSAC samples from
+ *                         NumPy's process-global UNSEEDED generator (np.random.randint, :183), so it differs from run to run;
+ *                         here trial t of frame f draws from Philox4x32-10 keyed by (seed; f, t): same cloud + same seed = same
+ *                         curves on every run and GPU.  Parity unpinned by construction.
+ * A frame in which fewer than 3 range rows of the 50 x 2555 histogram have their sparsest bin above 5 returns SNOWGPU_E_GROUND
+ * under 'poly' (np.polyfit raises / warns there).  snowgpu_set_wet_lines cannot be combined with 'poly'. */
+int snowgpu_set_wet_estimation(snowgpu_ctx *ctx, int method, uint64_t seed);
+
+/* The curves the last wet-ground call of this context fitted: per frame 8 doubles -- laser power c2, c1, c0
+ * (relative_output_intensity = power_factor * polyval(c, range), :221 / :228), noise level c2, c1, c0 (adaptive_noise_threshold =
+ * noise_floor * polyval(c, range), :245 / :252), ground rows, RANSAC trial whose consensus refit was kept (-1: the fit over all
+ * points).  'linear' frames report their two lines with c2 = 0. */
+int snowgpu_wet_last_fit(snowgpu_ctx *ctx, int n_frames, double *out);
+
+/* Parity tap of the 'poly' noise fit: the device's ransac_polyfit(x, y, order=2) (augmentation.py:171-192) on m (3 .. 50) host points
+ * with the Philox draws of (seed; frame): out4 = c2, c1, c0, trial kept (-1: the fit over all points). */
+int snowgpu_debug_ransac_polyfit(snowgpu_ctx *ctx, int m, const double *x, const double *y, uint64_t seed, uint64_t frame, double *out4);
+
 /*
  * augment() followed by ground_water_augmentation() on its output, as pointcloud_viewer.py:2807-2821 chains them
  * (snow first, then wet with replace=False), as ONE launch sequence: the intermediate cloud never leaves the device.

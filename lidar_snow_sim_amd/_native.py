@@ -26,8 +26,10 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit",
 ]
+
+WET_ESTIMATION = {"linear": 0, "poly": 1}
 
 PLANE_METHODS = {"reference": 0, "lsq": 1, "ransac": 2}
 
@@ -99,6 +101,12 @@ def lib():
             L.snowgpu_sample_table.argtypes = [vp, ctypes.c_int, dbl, dbl, dbl, ctypes.c_uint64, vp, i64, vp]
             L.snowgpu_set_wet_lines.restype = ctypes.c_int
             L.snowgpu_set_wet_lines.argtypes = [vp, ctypes.c_int, vp]
+            L.snowgpu_set_wet_estimation.restype = ctypes.c_int
+            L.snowgpu_set_wet_estimation.argtypes = [vp, ctypes.c_int, ctypes.c_uint64]
+            L.snowgpu_debug_ransac_polyfit.restype = ctypes.c_int
+            L.snowgpu_debug_ransac_polyfit.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_uint64, ctypes.c_uint64, vp]
+            L.snowgpu_wet_last_fit.restype = ctypes.c_int
+            L.snowgpu_wet_last_fit.argtypes = [vp, ctypes.c_int, vp]
             L.snowgpu_set_plane_method.restype = ctypes.c_int
             L.snowgpu_set_plane_method.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, dbl]
             L.snowgpu_estimate_planes.restype = ctypes.c_int
@@ -426,6 +434,29 @@ class Context:
                 int(bool(flat_earth)), float(delta), int(bool(replace)), _p(out_rows), _p(out_src), _p(counts), _p(stats),
                 _p(flags)))
         return out_rows, out_src, counts, stats, flags
+
+    def set_wet_estimation(self, method="linear", seed=0):
+        """estimation_method of the wet-ground calls of this context: 'linear' or 'poly' (RANSAC draws from Philox keyed by `seed`)."""
+        if method not in WET_ESTIMATION:
+            raise ValueError("estimation_method must be 'linear' or 'poly'")
+        with self._call_lock:
+            self._check(self._L.snowgpu_set_wet_estimation(self._h, WET_ESTIMATION[method], int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def debug_ransac_polyfit(self, x, y, seed=0, frame=0):
+        """The device's ransac_polyfit(x, y, order=2) with the draws of (seed; frame): (coefficients[3], trial kept or -1)."""
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.ascontiguousarray(y, np.float64)
+        out = np.zeros(4, np.float64)
+        with self._call_lock:
+            self._check(self._L.snowgpu_debug_ransac_polyfit(self._h, int(x.shape[0]), _p(x), _p(y), int(seed), int(frame), _p(out)))
+        return out[:3], int(out[3])
+
+    def wet_last_fit(self, n_frames):
+        """The curves the last wet-ground call fitted: n_frames x 8 (power c2 c1 c0, noise c2 c1 c0, ground rows, RANSAC trial kept or -1)."""
+        out = np.zeros((int(n_frames), 8), np.float64)
+        with self._call_lock:
+            self._check(self._L.snowgpu_wet_last_fit(self._h, int(n_frames), _p(out)))
+        return out
 
     def wet_ground_batch(self, rows, frame_offsets, plane, water_height, pavement_depth, noise_floor, power_factor,
                          flat_earth, delta, replace, lines=None):

@@ -12,6 +12,9 @@ struct SgWetParams {
     double water_height, pavement_depth, noise_floor, power_factor, delta;
     int flat_earth, replace;
     const double *lines;        // optional DEVICE array n_frames x 4: the two fitted lines supplied by the caller (snowgpu_set_wet_lines)
+    int estimation;             // 0: 'linear' (augmentation.py:215-221, :247-253), 1: 'poly' (:223-229, :243-246; seeded RANSAC)
+    uint64_t seed;              // 'poly': seed of the RANSAC draws
+    double *fit_out;            // optional DEVICE array n_frames x 8: the fitted curves (k_pre_export_fit)
 };
 
 #define SG_PRE_REC 18      /* doubles per frame of sg_prepass_stats_run's record */
@@ -34,6 +37,8 @@ int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *
 // out[off[f] + i] = first[off[f] + second[off[f] + i]] for i < counts[f] (device arrays)
 int sg_launch_compose_src(const int64_t *frame_off, const int64_t *counts, int n_frames, int64_t max_frame,
                           const int32_t *second, const int32_t *first, int32_t *out, void *stream);
+// ransac_polyfit (augmentation.py:171-192, order 2) on m <= 50 caller-supplied points in device memory: d_out[0..2] = coefficients, [3] = trial kept
+int sg_debug_ransac_quad(const double *d_x, const double *d_y, int m, uint64_t seed, uint64_t frame, double *d_out, void *stream);
 void sg_prepass_release(SgPrepassScratch *s);
 #ifdef __cplusplus
 }

@@ -152,6 +152,10 @@ struct snowgpu_ctx {
     int64_t pipe_rows = (int64_t)3 << 19;   // snowgpu_set_pipeline; 0: no pipeline (one upload, one download)
     std::vector<double> wet_lines;    // snowgpu_set_wet_lines: consumed by the next snowgpu_wet_ground_batch
     DevBuf<double> d_wet_lines;
+    int wet_estimation = 0;           // snowgpu_set_wet_estimation: 0 'linear', 1 'poly' (seeded RANSAC on the device)
+    uint64_t wet_seed = 0;
+    DevBuf<double> wet_fit;           // n_frames x 8: the curves the last wet-ground call fitted (snowgpu_wet_last_fit)
+    int wet_fit_frames = 0;
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
 };
 
@@ -293,7 +297,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
     if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
-    ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release();
+    ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release(); ctx->wet_fit.release();
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
@@ -1426,6 +1430,52 @@ extern "C" int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const doubl
     return SNOWGPU_OK;
 }
 
+// estimation_method of ground_water_augmentation (wet_ground/augmentation.py:25, :215-229, :243-253) for the wet-ground calls of this
+// context: 0 = 'linear' (two regression lines), 1 = 'poly' (np.polyfit of degree 2 for the laser power, ransac_polyfit for the noise
+// level -- the reference draws its RANSAC samples from NumPy's unseeded global generator; here they come from Philox keyed by `seed`).
+extern "C" int snowgpu_set_wet_estimation(snowgpu_ctx *ctx, int method, uint64_t seed)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (method != 0 && method != 1) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_wet_estimation: method 0 (linear) or 1 (poly)");
+    ctx->wet_estimation = method;
+    ctx->wet_seed = seed;
+    return SNOWGPU_OK;
+}
+
+// The curves the last wet-ground call of this context fitted, per frame: laser power c2, c1, c0 (relative_output_intensity =
+// power_factor * polyval), noise level c2, c1, c0 (adaptive_noise_threshold = noise_floor * polyval), ground rows, and the RANSAC
+// trial whose consensus refit was kept (-1: the fit over all points; 'linear': always -1 and c2 = 0).  out: n_frames x 8 doubles.
+extern "C" int snowgpu_wet_last_fit(snowgpu_ctx *ctx, int n_frames, double *out)
+{
+    if (!ctx || !out || n_frames <= 0) return SNOWGPU_E_INVALID;
+    if (n_frames != ctx->wet_fit_frames) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_wet_last_fit: the last wet-ground call had another number of frames");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, ctx->wet_fit.p, sizeof(double) * 8 * (size_t)n_frames, hipMemcpyDeviceToHost));
+    return SNOWGPU_OK;
+}
+
+// Parity tap of the 'poly' noise fit: the device's ransac_polyfit(x, y, order=2) on m (3 .. 50) caller-supplied points with the draws of
+// (seed; frame) -- out[0..2] = the quadratic's coefficients (highest power first), out[3] = the trial whose consensus refit was kept (-1: none).
+extern "C" int snowgpu_debug_ransac_polyfit(snowgpu_ctx *ctx, int m, const double *x, const double *y, uint64_t seed, uint64_t frame, double *out4)
+{
+    if (!ctx || !x || !y || !out4) return SNOWGPU_E_INVALID;
+    if (m < 3 || m > 50) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_debug_ransac_polyfit: 3 <= m <= 50");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBuf<double> d;
+    if (d.ensure(2 * 50 + 4)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed");
+    int rc = SNOWGPU_OK;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(d.p, x, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d.p + 50, y, sizeof(double) * (size_t)m, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = (hipError_t)sg_debug_ransac_quad(d.p, d.p + 50, m, seed, frame, d.p + 100, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out4, d.p + 100, sizeof(double) * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = fail(ctx, SNOWGPU_E_HIP, std::string("ransac tap: ") + hipGetErrorString(e));
+    d.release();
+    return rc;
+}
+
 extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
@@ -1528,6 +1578,9 @@ extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, 
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = wet_noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    wp.estimation = ctx->wet_estimation; wp.seed = ctx->wet_seed;
+    ENSURE(ctx, ctx->wet_fit, (size_t)n_frames * 8);
+    wp.fit_out = ctx->wet_fit.p; ctx->wet_fit_frames = n_frames;
     int e = 0;
     if (!d_wet_plane) {      // wet_ground/augmentation.py:41 calculate_plane(pointcloud) -- here the snowfall result -- on the device
         ENSURE(ctx, ctx->wet_plane_est, (size_t)n_frames * 4);
@@ -1689,6 +1742,10 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
     SgWetParams wp{};
     wp.water_height = water_height; wp.pavement_depth = pavement_depth; wp.noise_floor = noise_floor;
     wp.power_factor = power_factor; wp.flat_earth = flat_earth; wp.delta = delta; wp.replace = replace;
+    wp.estimation = ctx->wet_estimation; wp.seed = ctx->wet_seed;
+    ENSURE(ctx, ctx->wet_fit, (size_t)n_frames * 8);
+    wp.fit_out = ctx->wet_fit.p; ctx->wet_fit_frames = n_frames;
+    if (!ctx->wet_lines.empty() && ctx->wet_estimation != 0) { ctx->wet_lines.clear(); return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_wet_lines supplies LINES: not with estimation method 'poly'"); }
     if (!ctx->wet_lines.empty()) {                      // the caller's lines (one use)
         if (ctx->wet_lines.size() != (size_t)n_frames * 4) { ctx->wet_lines.clear(); return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_wet_lines was given another number of frames"); }
         ENSURE(ctx, ctx->d_wet_lines, ctx->wet_lines.size());
@@ -1706,8 +1763,12 @@ extern "C" int snowgpu_wet_ground_batch(snowgpu_ctx *ctx, int n_frames, const in
         HIPCHK(ctx, hipMemcpyAsync(out_rows, ctx->rows_out.p, n * 5 * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(out_src, ctx->out_src.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
     }
+    int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    return SNOWGPU_OK;
+    if (status[0] == SNOWGPU_E_GROUND)     // only 'poly' reports here: np.polyfit of degree 2 over fewer than 3 points (augmentation.py:243)
+        return fail(ctx, SNOWGPU_E_GROUND, "estimation method 'poly': fewer than 3 range rows of the histogram have a sparsest bin above 5");
+    return status_to_error(ctx, status);
 }
 
 

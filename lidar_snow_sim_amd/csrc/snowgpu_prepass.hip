@@ -17,6 +17,7 @@
 #include "sg_common.h"
 #include "sg_prepass.h"
 #include "sg_lean.h"
+#include "sg_philox.h"
 
 #define PB 256
 #define HX 50     /* range rows of the histogram (augmentation.py:232) */
@@ -30,6 +31,11 @@ struct PreFrame {          // per-frame state shared by the kernels
     double p0, p1;         // linregress(dist, normalised)            augmentation.py:216-219
     double pmin0, pmin1;   // noise line                              augmentation.py:248-251
     double poly[3];        // simulation.py:467
+    // wet model, estimation_method = 'poly' (augmentation.py:223-229, :243-246): quadratics in range instead of the two lines
+    double pq[3];          // np.polyfit(dist, normalised, 2)
+    double mq[3];          // ransac_polyfit(x, min_vals, order=2)
+    int32_t quad;          // 1: k_wet_apply evaluates pq / mq
+    int32_t ransac_trial;  // the trial whose consensus refit was kept (-1: the fit over all points)
     int32_t unchanged;     // wet path: < 1000 ground rows (augmentation.py:51-52)
     int32_t need_mean32;   // float32 rows and the noise line falls back to p (augmentation.py:250-251)
     // lean snowfall prepass (k_lean_*): centred second moments of (range, I / cos) and the sums of the quadratic fit
@@ -56,6 +62,8 @@ struct PreArgs {
                            // (augmentation.py:50), so range / mean are float64 whatever the input dtype
     double noise_floor, power_factor;
     const double *lines_override;   // optional n_frames x 4 (p slope, p intercept, noise-line slope, intercept): replaces the two fitted lines
+    double *qpart;         // estimation_method = 'poly': per tile the 8 sums of the quadratic fit of (range, I / cos)
+    uint64_t seed;         // ... and the seed of its RANSAC draws
     // per-row scratch (n_total)
     double *g_dist, *g_norm, *g_ang;   // range, I / cos(angle), incident angle (or its cosine: cos_only); g_norm = NaN for non-ground rows
     // per-tile partials: [frame][tile][k]
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(64) void k_pre_means(PreArgs a, int min_ground, int
         fr.need_mean32 = 0;
         fr.ymax = fabs(ym);                                              // np.abs(np.max(...)), augmentation.py:233
         fr.unchanged = 0;
+        fr.quad = 0; fr.ransac_trial = -1;
         if (c < (double)min_ground) {
             if (err_code) atomicCAS(&a.status[0], 0, err_code);          // snowfall: TypeError in the reference (Q7)
             fr.unchanged = 1;                                            // wet: frame returned unchanged
@@ -485,6 +494,217 @@ __global__ void k_pre_override_lines(PreArgs a)
     fr.p0 = a.lines_override[4 * f]; fr.p1 = a.lines_override[4 * f + 1];
     fr.pmin0 = a.lines_override[4 * f + 2]; fr.pmin1 = a.lines_override[4 * f + 3];
     fr.need_mean32 = 0;
+}
+
+// ================================================================================================================
+// estimation_method = 'poly' of the wet-ground model (augmentation.py:223-229, :243-246, ransac_polyfit :171-192).
+// Laser power: np.polyfit(range, I / cos, 2) over the ground rows -- least squares, here through the normal equations in the
+// centred and scaled variable u = (d - 60) / 60 (ranges live in [0, 120] m: the 3 x 3 system is then well conditioned in float64;
+// NumPy scales the Vandermonde columns and solves by SVD -- same minimiser, agreement ~1e-12 relative).
+// Noise level: ransac_polyfit(x, min_vals, order=2) over the <= 50 range rows of the histogram whose sparsest bin lies above 5 --
+// fit over all points first; then k = 100 trials: n = 15 indices drawn with replacement, a quadratic through them, its inliers
+// (|residual| < t = 0.1), and if there are more than d = 15 of them and more than f = 0.8 of all points a refit on the inliers,
+// kept when its summed absolute residual over the inliers undercuts the best so far (the first fit's is summed over ALL points,
+// as in the reference).  The reference draws from NumPy's process-global, unseeded generator (np.random.randint, :183), so two runs
+// of the reference disagree; here trial t of frame f draws from Philox4x32-10 keyed by (seed; f, t): same cloud + same seed = same
+// curve, on every run and GPU.  Parity is therefore unpinned by construction (DESIGN.md section 9b says how it is tested instead).
+#define PQ_C 60.0
+#define PQ_S 60.0
+#define PQ_COLS 8      /* sum u^4, u^3, u^2, u, 1, u^2 y, u y, y */
+#define RQ_N 15
+#define RQ_K 100
+#define RQ_T 0.1
+#define RQ_D 15
+#define RQ_F 0.8
+
+// least-squares quadratic from the 8 sums in u; returns false for a singular system (fewer than 3 distinct abscissae)
+__device__ __forceinline__ bool quad_solve_u(const double *q, double &c2, double &c1, double &c0)
+{
+    double G[3][4] = {{q[0], q[1], q[2], q[5]}, {q[1], q[2], q[3], q[6]}, {q[2], q[3], q[4], q[7]}};
+    for (int i = 0; i < 3; ++i) {                                        // Gaussian elimination, partial pivoting
+        int piv = i;
+        for (int r = i + 1; r < 3; ++r) if (fabs(G[r][i]) > fabs(G[piv][i])) piv = r;
+        if (piv != i) for (int k = 0; k < 4; ++k) { const double t = G[i][k]; G[i][k] = G[piv][k]; G[piv][k] = t; }
+        if (!(fabs(G[i][i]) > 1e-13 * (fabs(q[0]) + fabs(q[4]) + 1.0))) return false;
+        for (int r = i + 1; r < 3; ++r) {
+            const double m = G[r][i] / G[i][i];
+            for (int k = i; k < 4; ++k) G[r][k] -= m * G[i][k];
+        }
+    }
+    double x[3];
+    for (int i = 2; i >= 0; --i) {
+        double t = G[i][3];
+        for (int k = i + 1; k < 3; ++k) t -= G[i][k] * x[k];
+        x[i] = t / G[i][i];
+    }
+    c2 = x[0]; c1 = x[1]; c0 = x[2];
+    return true;
+}
+// y = c2 u^2 + c1 u + c0 with u = (d - C) / S, as coefficients of d (highest power first, np.polyfit's order)
+__device__ __forceinline__ void quad_u_to_d(double c2, double c1, double c0, double *out)
+{
+    const double a = c2 / (PQ_S * PQ_S), b = c1 / PQ_S;
+    out[0] = a;
+    out[1] = b - 2.0 * a * PQ_C;
+    out[2] = (a * PQ_C * PQ_C - b * PQ_C) + c0;
+}
+__device__ __forceinline__ double quad_eval_u(double c2, double c1, double c0, double u) { return (c2 * u + c1) * u + c0; }
+
+__global__ __launch_bounds__(PB) void k_pre_quad_part(PreArgs a)
+{
+    const int f = blockIdx.y;
+    const int64_t base = a.frame_off[f], n = pre_rows(a, f);
+    const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
+    if (tile0 >= n) return;
+    double v[PQ_COLS] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const double gn = r < n ? a.g_norm[base + r] : NAN;
+        if (gn != gn) continue;
+        const double u = (a.g_dist[base + r] - PQ_C) * (1.0 / PQ_S), u2 = u * u;
+        v[0] += u2 * u2; v[1] += u2 * u; v[2] += u2; v[3] += u; v[4] += 1.0; v[5] += u2 * gn; v[6] += u * gn; v[7] += gn;
+    }
+    __shared__ double sm[4 * PQ_COLS];
+    block_sum<PQ_COLS>(v, sm);
+    if (threadIdx.x == 0) {
+        double *o = a.qpart + ((int64_t)f * a.max_tiles + blockIdx.x) * PQ_COLS;
+        for (int k = 0; k < PQ_COLS; ++k) o[k] = v[k];
+    }
+}
+
+// ransac_polyfit(x, y, order=2) (augmentation.py:171-192) by one block of 128 threads: the fit over all m points (every thread, same
+// arithmetic), trial `tid` per thread, the reference's "first trial that reaches the smallest error" by thread 0.  xs / ys: the m <= 50
+// points in shared memory.  Returns (thread 0 only) the coefficients in u = (x - PQ_C) / PQ_S and the winning trial (-1: the first fit).
+__device__ __forceinline__ void ransac_quad_block(const double *xs, const double *ys, int m, uint64_t seed, uint64_t f, double *s_err,
+                                                  double (*s_fit)[3], double &b2, double &b1, double &b0, int &win)
+{
+    const int tid = threadIdx.x;
+    auto fit = [&](auto &&weight, double &c2, double &c1, double &c0) -> bool {     // least squares over the points with weight(i) copies
+        double q[PQ_COLS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < m; ++i) {
+            const double w = weight(i);
+            if (w == 0.0) continue;
+            const double u = (xs[i] - PQ_C) * (1.0 / PQ_S), u2 = u * u, y = ys[i];
+            q[0] += w * (u2 * u2); q[1] += w * (u2 * u); q[2] += w * u2; q[3] += w * u; q[4] += w; q[5] += w * (u2 * y); q[6] += w * (u * y); q[7] += w * y;
+        }
+        return quad_solve_u(q, c2, c1, c0);
+    };
+    // the fit over all points and its summed absolute residual (:179-180)
+    double best_err = 0.0;
+    b2 = 0; b1 = 0; b0 = 0;
+    if (!fit([](int) { return 1.0; }, b2, b1, b0)) { b2 = 0.0; b1 = 0.0; double sy = 0; for (int i = 0; i < m; ++i) sy += ys[i]; b0 = sy / m; }
+    for (int i = 0; i < m; ++i) best_err += fabs(quad_eval_u(b2, b1, b0, (xs[i] - PQ_C) * (1.0 / PQ_S)) - ys[i]);
+    // trial `tid` (:182-191)
+    double t_err = INFINITY, t2 = 0, t1 = 0, t0 = 0;
+    if (tid < RQ_K) {
+        unsigned char cnt[HX];
+        for (int i = 0; i < HX; ++i) cnt[i] = 0;
+        for (int d4 = 0; d4 < (RQ_N + 3) / 4; ++d4) {                    // n indices in [0, m), with replacement
+            uint32_t u[4];
+            philox_u32x4(seed, f, (uint32_t)(tid * 4 + d4), 0x504F4C59u /* "POLY" */, u);
+            for (int k = 0; k < 4 && d4 * 4 + k < RQ_N; ++k) cnt[(int)(((uint64_t)u[k] * (uint64_t)m) >> 32)]++;
+        }
+        double m2, m1, m0;
+        if (fit([&](int i) { return (double)cnt[i]; }, m2, m1, m0)) {
+            unsigned long long inl = 0;
+            int n_in = 0;
+            for (int i = 0; i < m; ++i)
+                if (fabs(quad_eval_u(m2, m1, m0, (xs[i] - PQ_C) * (1.0 / PQ_S)) - ys[i]) < RQ_T) { inl |= 1ull << i; ++n_in; }
+            if (n_in > RQ_D && (double)n_in > (double)m * RQ_F && fit([&](int i) { return ((inl >> i) & 1ull) ? 1.0 : 0.0; }, t2, t1, t0)) {
+                t_err = 0.0;
+                for (int i = 0; i < m; ++i)
+                    if ((inl >> i) & 1ull) t_err += fabs(quad_eval_u(t2, t1, t0, (xs[i] - PQ_C) * (1.0 / PQ_S)) - ys[i]);
+            }
+        }
+    }
+    s_err[tid] = t_err; s_fit[tid][0] = t2; s_fit[tid][1] = t1; s_fit[tid][2] = t0;
+    __syncthreads();
+    win = -1;
+    if (tid == 0) {                                                      // the reference's loop keeps the FIRST trial that reaches the smallest error
+        for (int t = 0; t < RQ_K; ++t)
+            if (s_err[t] < best_err) { best_err = s_err[t]; win = t; }
+        if (win >= 0) { b2 = s_fit[win][0]; b1 = s_fit[win][1]; b0 = s_fit[win][2]; }
+    }
+}
+
+// One block of 128 threads per frame: the power quadratic from the tile sums (wave 0), the noise quadratic by RANSAC (one trial per thread).
+__global__ __launch_bounds__(128) void k_pre_quad_fit(PreArgs a, int err_code)
+{
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    PreFrame &fr = a.fr[f];
+    if (fr.unchanged) return;
+    __shared__ double xs[HX], ys[HX], s_err[128];
+    __shared__ double s_fit[128][3];
+    __shared__ int s_m;
+    if (tid < 64) {                                                      // np.polyfit(dist, normalised, 2): fixed-order sums over the tiles
+        const int64_t n = pre_rows(a, f);
+        const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+        const double *part = a.qpart + (int64_t)f * a.max_tiles * PQ_COLS;
+        double q[PQ_COLS] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t t = lane; t < tiles; t += 64)
+            for (int k = 0; k < PQ_COLS; ++k) q[k] += part[t * PQ_COLS + k];
+        for (int k = 0; k < PQ_COLS; ++k)
+            for (int o = 32; o > 0; o >>= 1) q[k] += __shfl_xor(q[k], o);
+        if (tid == 0) {
+            double c2, c1, c0;
+            if (quad_solve_u(q, c2, c1, c0)) quad_u_to_d(c2, c1, c0, fr.pq);
+            else { fr.pq[0] = 0.0; fr.pq[1] = fr.p0; fr.pq[2] = fr.p1; }   // degenerate ranges: the regression line
+            int m = 0;                                                   // min_vals > 5 (augmentation.py:238), x = centres of those range rows (:240-241)
+            const double xstep = (70.0 - 10.0) / HX;
+            for (int r = 0; r < HX; ++r) {
+                const double mv = a.rowmin[(int64_t)f * HX + r];
+                if (mv > 5) {
+                    const double e0 = (double)r * xstep + 10.0;
+                    const double e1 = (r + 1 == HX) ? 70.0 : (double)(r + 1) * xstep + 10.0;
+                    xs[m] = (e0 + e1) / 2; ys[m] = mv; ++m;
+                }
+            }
+            s_m = m;
+        }
+    }
+    __syncthreads();
+    const int m = s_m;
+    if (m < 3) {                                                         // np.polyfit on fewer points than coefficients: TypeError / rank warning in the reference
+        if (tid == 0) { if (err_code) atomicCAS(&a.status[0], 0, err_code); fr.mq[0] = 0.0; fr.mq[1] = fr.pmin0; fr.mq[2] = fr.pmin1; fr.quad = 1; }
+        return;
+    }
+    double b2, b1, b0;
+    int win;
+    ransac_quad_block(xs, ys, m, a.seed, (uint64_t)f, s_err, s_fit, b2, b1, b0, win);
+    if (tid == 0) { quad_u_to_d(b2, b1, b0, fr.mq); fr.quad = 1; fr.ransac_trial = win; }
+}
+
+// debug / parity tap: ransac_polyfit on the caller's points (m <= 50), draws of (seed; frame): out = c2, c1, c0 (coefficients of x), trial kept
+__global__ __launch_bounds__(128) void k_debug_ransac_quad(const double *x, const double *y, int m, uint64_t seed, uint64_t frame, double *out)
+{
+    __shared__ double xs[HX], ys[HX], s_err[128];
+    __shared__ double s_fit[128][3];
+    for (int i = threadIdx.x; i < m; i += 128) { xs[i] = x[i]; ys[i] = y[i]; }
+    __syncthreads();
+    double b2, b1, b0;
+    int win;
+    ransac_quad_block(xs, ys, m, seed, frame, s_err, s_fit, b2, b1, b0, win);
+    if (threadIdx.x == 0) { quad_u_to_d(b2, b1, b0, out); out[3] = (double)win; }
+}
+
+extern "C" int sg_debug_ransac_quad(const double *d_x, const double *d_y, int m, uint64_t seed, uint64_t frame, double *d_out, void *stream)
+{
+    hipLaunchKernelGGL(k_debug_ransac_quad, dim3(1), dim3(128), 0, (hipStream_t)stream, d_x, d_y, m, seed, frame, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+// the fitted curves of the last estimate, per frame: (power c2, c1, c0, noise c2, c1, c0, ground rows, RANSAC trial kept or -1);
+// 'linear' frames report their lines as quadratics with c2 = 0
+__global__ void k_pre_export_fit(PreArgs a, double *out)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.n_frames) return;
+    const PreFrame &fr = a.fr[f];
+    double *o = out + (int64_t)f * 8;
+    if (fr.quad) { for (int k = 0; k < 3; ++k) { o[k] = fr.pq[k]; o[3 + k] = fr.mq[k]; } }
+    else { o[0] = 0.0; o[1] = fr.p0; o[2] = fr.p1; o[3] = 0.0; o[4] = fr.pmin0; o[5] = fr.pmin1; }
+    o[6] = fr.n_ground; o[7] = (double)fr.ransac_trial;
 }
 
 // ================================================================================================================
@@ -839,8 +1059,15 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
             const double gd = a.g_dist[base + r], ang = a.g_ang[base + r];
             const double gc = cos(ang);
             const double inten = (double)rows[(base + r) * 5 + 3];
-            const double rel = a.power_factor * (fr.p0 * gd + fr.p1);    // :221
-            const double thr = a.noise_floor * (fr.pmin0 * gd + fr.pmin1);   // :252-253
+            double rel, thr;
+            if (fr.quad) {                                               // estimation_method = 'poly'
+                const double gd2 = gd * gd;
+                rel = a.power_factor * ((fr.pq[0] * gd2 + fr.pq[1] * gd) + fr.pq[2]);        // :228-229
+                thr = a.noise_floor * ((fr.mq[0] * gd2 + fr.mq[1] * gd) + fr.mq[2]);         // :245-246
+            } else {
+                rel = a.power_factor * (fr.p0 * gd + fr.p1);             // :221
+                thr = a.noise_floor * (fr.pmin0 * gd + fr.pmin1);        // :252-253
+            }
             const double refl = inten / gc / rel;                        // :90
             double rho = refl < 0.05 ? 0.05 : (refl > 1 ? 1 : refl);     // :109 np.clip(reflectivities, 0.05, 1)
             const Fresnel aw = fresnel_power(ang, 1.0003, 1.33);         // phy_equations.py:81
@@ -953,7 +1180,8 @@ __global__ __launch_bounds__(PB) void k_compose_src(const int64_t *__restrict__ 
 // ================================================================================================================
 // host side
 
-enum { B_GDIST = 0, B_GNORM, B_GCOS, B_PART, B_HIST, B_ROWMIN, B_FRAME, B_CLS, B_NEWI, B_TCNT, B_TBASE, B_CDIST, B_LEAF, B_N };
+enum { B_GDIST = 0, B_GNORM, B_GCOS, B_PART, B_HIST, B_ROWMIN, B_FRAME, B_CLS, B_NEWI, B_TCNT, B_TBASE, B_CDIST, B_LEAF, B_QPART, B_N };
+static_assert(B_N <= 16, "SgPrepassScratch holds 16 buffers");
 
 static int ensure(SgPrepassScratch *s, int i, size_t bytes)
 {
@@ -1179,6 +1407,18 @@ extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, cons
     int rc = estimate(s, a, dtype, n_total, max_frame, 1000, 0, false, st);
     if (rc) return rc;
     const size_t n = (size_t)(n_total > 0 ? n_total : 1), nf = (size_t)n_frames;
+    if (wp->estimation == 1) {                       // 'poly': the two quadratics replace the two lines
+        if (ensure(s, B_QPART, nf * (size_t)a.max_tiles * PQ_COLS * 8)) return -1;
+        a.qpart = (double *)s->buf[B_QPART]; a.seed = wp->seed;
+        hipLaunchKernelGGL(k_pre_quad_part, dim3((unsigned)a.max_tiles, (unsigned)n_frames), dim3(PB), 0, st, a);
+        LCHK();
+        hipLaunchKernelGGL(k_pre_quad_fit, dim3((unsigned)n_frames), dim3(128), 0, st, a, 7 /* SNOWGPU_E_GROUND */);
+        LCHK();
+    }
+    if (wp->fit_out) {
+        hipLaunchKernelGGL(k_pre_export_fit, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, wp->fit_out);
+        LCHK();
+    }
     if (ensure(s, B_CLS, n) || ensure(s, B_NEWI, n * 8) || ensure(s, B_TCNT, nf * (size_t)a.max_tiles * 2 * 4) ||
         ensure(s, B_TBASE, nf * (size_t)a.max_tiles * 2 * 4))
         return -1;

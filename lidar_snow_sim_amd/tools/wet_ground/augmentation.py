@@ -9,6 +9,7 @@ function because it is part of the reference's importable surface (simulation.py
 import numpy as np
 
 from ... import engine as _engine
+from ..._native import SnowGPUError as _SnowGPUError
 from .planes import calculate_plane
 
 
@@ -26,8 +27,9 @@ def estimate_laser_parameters(pointcloud_planes, calculated_indicent_angle, powe
     """
     from scipy.stats import linregress
     if estimation_method != 'linear':
-        raise NotImplementedError("only estimation_method='linear' is reproducible (the 'poly' branch of the "
-                                  "reference draws from the unseeded global NumPy RNG, augmentation.py:171-192)")
+        raise NotImplementedError("this host mirror fits estimation_method='linear' only; 'poly' (np.polyfit + a RANSAC over the "
+                                  "unseeded global NumPy RNG, augmentation.py:171-192) runs on the device with seeded draws: "
+                                  "ground_water_augmentation(..., estimation_method='poly', poly_seed=...)")
     normalized = pointcloud_planes[:, 3] / np.cos(calculated_indicent_angle)       # :207
     distance = np.linalg.norm(pointcloud_planes[:, :3], axis=1)                    # :208
     if len(normalized) < 3:                                                        # :213-214
@@ -153,7 +155,7 @@ def noise_threshold_poly(pc_sorted, w, h, noise_floor=0.7, q8='first'):
 def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0012, noise_floor=0.7, power_factor=15,
                               estimation_method='linear', flat_earth=False, debug=True, delta=0.5, replace=True,
                               *, plane=None, device=0, return_src=False, q8='first', plane_method='reference', plane_seed=0,
-                              plane_trials=1000):
+                              plane_trials=1000, poly_seed=0):
     """Drop-in for tools/wet_ground/augmentation.py::ground_water_augmentation (:25-161).
 
     `debug` is accepted and ignored (the reference's debug branch only draws matplotlib figures).
@@ -163,11 +165,17 @@ def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0
     the noise line on the device through the FIRST sparsest histogram bin of every range row; 'numpy' fits the two lines on the
     host with THIS process' NumPy (np.argpartition verbatim, quirk Q8: what the reference itself computes on this machine) and
     hands them to the device, which does everything else.
+    estimation_method='poly' (the viewer passes it through: pointcloud_viewer.py:2820, :2851): np.polyfit of degree 2 for the laser
+    power (:223-229) and ransac_polyfit (:171-192) for the noise level (:243-246), both on the device.  The reference draws its RANSAC
+    samples from NumPy's unseeded global generator, so it differs from run to run; here the draws are Philox numbers keyed by
+    `poly_seed` -- same cloud + same seed = same result (parity unpinned; q8='numpy' is a 'linear'-only switch).
     Returns a float64 N' x 5 array (:150); the input object itself when fewer than 1000 ground rows
     exist (:51-52).
     """
-    if estimation_method != 'linear':
-        raise NotImplementedError("only estimation_method='linear' is reproducible (augmentation.py:171-192)")
+    if estimation_method not in ('linear', 'poly'):
+        raise ValueError("estimation_method must be 'linear' or 'poly' (augmentation.py:215, :223)")
+    if estimation_method == 'poly' and q8 == 'numpy':
+        raise ValueError("q8='numpy' fits the two LINES of estimation_method='linear' on the host; 'poly' runs on the device only")
     pc = np.asarray(pointcloud)
     rows = pc if pc.dtype in (np.float32, np.float64) else pc.astype(np.float64)
     eng = _engine.get_engine(device)
@@ -195,14 +203,22 @@ def ground_water_augmentation(pointcloud, water_height=0.001, pavement_depth=0.0
     with eng.batch_lock:
         if plane is None:                         # augmentation.py:41 calculate_plane(pointcloud): on the device
             eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=pc.shape[1])
+        if estimation_method == 'poly':
+            eng.ctx.set_wet_estimation('poly', poly_seed)
         try:
             out, src, counts, flags = eng.ctx.wet_ground_batch(
                 np.ascontiguousarray(rows[:, :5]), [0, rows.shape[0]],
                 None if plane is None else [[plane[0][0], plane[0][1], plane[0][2], plane[1]]], water_height,
                 pavement_depth, noise_floor, power_factor, flat_earth, delta, replace, lines=lines)
+        except _SnowGPUError as e:
+            if e.code == 7:                       # np.polyfit / linregress on too few points (augmentation.py:243)
+                raise TypeError(str(e)) from None
+            raise
         finally:
             if plane is None and plane_method != 'reference':
                 eng.ctx.set_plane_method('reference')
+            if estimation_method == 'poly':
+                eng.ctx.set_wet_estimation('linear')
     if flags[0]:
         return (pointcloud, np.arange(rows.shape[0])) if return_src else pointcloud
     n = int(counts[0])
