@@ -184,63 +184,118 @@ def spawn_ranks(n, dry):
     return subprocess.call(cmd, env=env)
 
 
+class DryBackend:
+    """`--dry`: stands where libsnowgpu.so stands in lidar_snow_sim_amd.stream, so that the reader / sharding / writer machinery of a
+    multi-rank C5 run can be exercised on a machine without a GPU.  It augments nothing: every frame comes back as it went in (and the
+    line says "dry": true) -- a harness of this file, not a path of the product."""
+
+    @staticmethod
+    def alloc_rows(n_rows):
+        return np.empty((n_rows, 5), np.float32)
+
+    @staticmethod
+    def augment_batch(frames, prefix, beam_divergence, **kw):
+        return [((0, 0, 0), np.array(frames.frame(i), copy=True)) for i in range(len(frames))]
+
+
+def c5_host_threads(world):
+    """Reader / writer / GPU-worker threads of one rank of the C5 stream: the 6 + 8 + 2 a lone rank runs on the 16 CPUs a GPU box grants,
+    scaled to this rank's share of the CPUs the process may use (a node's ranks share its cores and its page cache)."""
+    usable, info = usable_cpus()
+    share = max(1.0, usable / float(world))
+    readers = int(os.environ.get("SNOWGPU_C5_READERS", max(1, min(6, round(share * 6 / 16)))))
+    writers = int(os.environ.get("SNOWGPU_C5_WRITERS", max(1, min(8, round(share * 8 / 16)))))
+    workers = 2 if share >= 4 else 1
+    return readers, writers, workers, usable, info
+
+
 def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
     """BASELINE.json configs[4]: a stream of synthetic STF `.bin` frames sharded round-robin over the ranks, each rank through
     lidar_snow_sim_amd.stream (read .bin -> upload -> augment -> download -> write .bin; precompute.py:74-106).  The frame files of
     a rank are hard links to 64 distinct sweeps (bounded disk use; every frame is still read, processed and written); outputs
-    are unlinked right after they have been written.  One "step" = the whole stream; value = points of all ranks / max time."""
+    are unlinked right after they have been written.  One "step" = the whole stream; value = points of all ranks / max time.
+    The line carries every rank's stage times (read / gpu / write thread-seconds, wall) and the host-thread budget: the ranks of a node
+    share its cores and its page cache, which is where the scaling curve is expected to bend."""
     import random
     import torch
     from lidar_snow_sim_amd import dist as sdist
     from lidar_snow_sim_amd import stream
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+    dry = args.dry
     n_all = args.frames or 10000
     ids = [f"2018-02-03_{i:05d}" for i in range(n_all)]
     mine = sdist.shard_indices(n_all, rank, world)
-    base = Path(tempfile.mkdtemp(prefix=f"snowgpu_c5_r{rank}_"))
+    shared = args.c5_dir is not None                       # one tree for all ranks (tests look at what every rank wrote); else one per rank
+    base = Path(args.c5_dir) if shared else Path(tempfile.mkdtemp(prefix=f"snowgpu_c5_r{rank}_"))
     lidar = base / "lidar_hdl64_strongest"
-    lidar.mkdir(parents=True)
+    lidar.mkdir(parents=True, exist_ok=True)
+    layers, azimuths = (64, 2048) if not dry else (64, 64)             # (dry: small sweeps -- the GPU work is what is skipped)
     try:
         n_dist = min(64, max(len(mine), 1))
         for i in range(n_dist):
-            synthetic_sweep(64, 2048, seed=1000 + rank * 64 + i, intensity="lambert").tofile(lidar / f"src_{i:05d}.bin")
+            synthetic_sweep(layers, azimuths, seed=1000 + rank * 64 + i, intensity="lambert").tofile(lidar / f"src_r{rank}_{i:05d}.bin")
         for k, i in enumerate(mine):
-            os.link(lidar / f"src_{k % n_dist:05d}.bin", lidar / f"{ids[i]}.bin")
-        tables = make_tables(64, SNOWFALL, VELOCITY)
+            os.link(lidar / f"src_r{rank}_{k % n_dist:05d}.bin", lidar / f"{ids[i]}.bin")
         occ, rate = smp.compute_occupancy(SNOWFALL, VELOCITY), smp.snowfall_rate_to_rainfall_rate(SNOWFALL, VELOCITY)
         prefix = f"gunn_{rate}_{occ}"
-        kw = dict(modes=("gunn",), combos=[(rate, occ)], batch=64, particles_by_prefix={prefix: tables}, planes=([0.0, 0.0, -1.0], -1.7),
-                  workers=2, readers=int(os.environ.get("SNOWGPU_C5_READERS", "6")), writers=int(os.environ.get("SNOWGPU_C5_WRITERS", "8")),
-                  keep_outputs=False, device=local_rank)
-        random.seed(0)                                                        # warm-up: table upload, allocations, page-locked pools
-        stream.run(lidar, [ids[i] for i in mine[:128]], **kw)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        tables = None if dry else make_tables(64, SNOWFALL, VELOCITY)
+        readers, writers, workers, usable, cpu_info = c5_host_threads(world)
+        kw = dict(modes=("gunn",), combos=[(rate, occ)], batch=64 if not dry else 8, particles_by_prefix=None if dry else {prefix: tables},
+                  planes=([0.0, 0.0, -1.0], -1.7), workers=workers, readers=readers, writers=writers, keep_outputs=args.c5_keep, device=local_rank,
+                  backend=DryBackend() if dry else None)
+
+        def sync():
+            if not dry:
+                torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        sync()                                                                # every rank's input files exist before any rank plans
+        if not dry:
+            random.seed(0)                                                    # warm-up: table upload, allocations, page-locked pools
+            stream.run(lidar, [ids[i] for i in mine[:128]], **kw)
+            sync()
         rep = {}
         random.seed(1)
         t0 = time.perf_counter()
         n_files = stream.run(lidar, ids, rank=rank, world=world, report=rep, **kw)
-        torch.cuda.synchronize()
-        elapsed = sdist.max_over_ranks(time.perf_counter() - t0, device=dev)
+        if not dry:
+            torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        elapsed = sdist.max_over_ranks(wall, device=dev)
         tot = sdist.sum_over_ranks([n_files, rep["points_in"], rep["points_out"]], device=dev)
+        # every rank's stage times, gathered by a sum of one-hot rows (no collective the barrier / max / sum above did not need already)
+        mat = [0.0] * (4 * world)
+        mat[4 * rank:4 * rank + 4] = [rep["read_s"], rep["gpu_s"], rep["write_s"], wall]
+        mat = sdist.sum_over_ranks(mat, device=dev)
+        per_rank = [{"rank": r, "read_s": mat[4 * r], "gpu_s": mat[4 * r + 1], "write_s": mat[4 * r + 2], "wall_s": mat[4 * r + 3]} for r in range(world)]
         seen = ranks_seen()
         if rank == 0:
+            threads_all = world * (readers + writers + workers + 2)
             print(json.dumps({
                 "metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %", "value": tot[1] / elapsed, "unit": "points/s",
                 "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
-                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"C5: {n_all}-frame synthetic STF stream (64 x 2048 float32 .bin files), 2.5 mm/h @ 1.6 m/s gunn tables, "
-                                       "sharded round-robin over the ranks, file read + H2D + augment + D2H + file write inside the clock",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic", **({"dry": True} if dry else {}),
+                "config": {"workload": f"C5: {n_all}-frame synthetic STF stream ({layers} x {azimuths} float32 .bin files), 2.5 mm/h @ 1.6 m/s gunn tables, "
+                                       "sharded round-robin over the ranks, file read + H2D + augment + D2H + file write inside the clock"
+                                       + (" -- DRY: no GPU work, frames pass through unchanged" if dry else ""),
                            "frames": n_all, "files_written": int(tot[0]), "files_per_s": tot[0] / elapsed, "points_out": int(tot[2]),
-                           "sharding": f"frame-parallel x{world}, no collective", "ranks_seen": seen, "batch": 64,
-                           "rank0_stage_busy_s": {k: rep[k] for k in ("read_s", "gpu_s", "write_s")}, "host_logical_cpus": os.cpu_count()},
+                           "sharding": f"frame-parallel x{world}, no collective", "ranks_seen": seen, "batch": kw["batch"],
+                           "stage_busy_s_per_rank": per_rank, "rank0_stage_busy_s": {k: rep[k] for k in ("read_s", "gpu_s", "write_s")},
+                           "host": {"logical_cpus": os.cpu_count(), "cpus_usable": usable, "cpu_info": cpu_info,
+                                    "threads_per_rank": {"readers": readers, "gpu_workers": workers, "writers": writers, "feeder_drainer": 2},
+                                    "threads_all_ranks": threads_all, "threads_per_usable_cpu": threads_all / max(usable, 1),
+                                    "note": "reader / writer threads per rank are capped to this rank's share of the usable CPUs (6 + 8 on the 16 of "
+                                            "a one-GPU box); the ranks of a node share its page cache: wall_s of the slowest rank against its own "
+                                            "read_s + write_s shows where the host, not the GPU, sets the pace"}},
                 "per_gpu_value": tot[1] / elapsed / world}), flush=True)
     finally:
-        shutil.rmtree(base, ignore_errors=True)
+        if dist is not None:
+            dist.barrier()
+        if not shared:
+            shutil.rmtree(base, ignore_errors=True)
     if dist is not None:
-        dist.barrier()
         dist.destroy_process_group()
 
 
@@ -257,6 +312,8 @@ def main():
     ap.add_argument("--host-prepass", action="store_true", help="feed precomputed threshold polynomials (debug)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS) + ["C5"], help="C2 (default) is BASELINE.json's metric config")
     ap.add_argument("--dry", action="store_true", help="launch logic only: gloo on CPU, no GPU work (tests)")
+    ap.add_argument("--c5-dir", default=None, help="C5: one input / output tree shared by all ranks (default: a temporary one per rank)")
+    ap.add_argument("--c5-keep", action="store_true", help="C5: keep the written files (default: unlink each right after the write)")
     ap.add_argument("--tables", default="host", choices=("host", "device"),
                     help="host: dart_throwing on the host (bit-exact mirror of sampling.py), uploaded once; device: sampled and filed on the GPU "
                          "(snowgpu_sample_table, seed = f(prefix, line)): no table ever crosses the link; reports sampler throughput")
@@ -295,6 +352,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return int(t.item())
 
+    if args.dry and args.workload == "C5":
+        return run_c5(args, rank, local_rank, world, dist, dev, ranks_seen)
     if args.dry:
         # the launch / sharding / reduction logic of a multi-rank run without a GPU: seeds per rank, barrier, max over ranks
         from lidar_snow_sim_amd import dist as sdist

@@ -118,7 +118,8 @@ struct snowgpu_ctx {
     DevBuf<double> plane_est, wet_plane_est;
     DevBuf<int32_t> plane_info;
     int64_t resident_rows = -1;       // rows snowgpu_prepass_stats left in rows_in (and their dtype): a following snowgpu_augment_batch with
-    int resident_dtype = -1;          // rows == NULL computes on them instead of uploading the same rows again
+    int resident_dtype = -1;          // rows == NULL computes on them instead of uploading the same rows again ...
+    std::vector<int64_t> resident_off;   // ... if it names the same frames (frame offsets compared entry by entry)
     DevBuf<int32_t> stats_hist;       // snowgpu_prepass_stats: n_frames x 50 x 2555
     DevBuf<double> stats_rec;
     // fused snow + wet (snowgpu_augment_wet_batch*): the snowfall result stays here
@@ -1193,8 +1194,9 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     const int64_t n_total = frame_offsets[n_frames];
     if (n_total >= ((int64_t)1 << 31)) return fail(ctx, SNOWGPU_E_INVALID, "batch too large: split it below 2^31 rows");
     if (n_total > 0 && !out_rows) return fail(ctx, SNOWGPU_E_INVALID, "null row buffers");
-    if (n_total > 0 && !rows && (ctx->resident_rows != n_total || ctx->resident_dtype != dtype))
-        return fail(ctx, SNOWGPU_E_INVALID, "rows == NULL needs the rows of the last snowgpu_prepass_stats call (same size and dtype)");
+    if (n_total > 0 && !rows && (ctx->resident_rows != n_total || ctx->resident_dtype != dtype || (int)ctx->resident_off.size() != n_frames + 1 ||
+                                 !std::equal(ctx->resident_off.begin(), ctx->resident_off.end(), frame_offsets)))
+        return fail(ctx, SNOWGPU_E_INVALID, "rows == NULL needs the rows of the last snowgpu_prepass_stats call (same frame offsets and dtype)");
     if (rows) ctx->resident_rows = -1;                 // (a fresh upload replaces whatever was resident)
     if (!out_counts || !out_stats) return fail(ctx, SNOWGPU_E_INVALID, "null count/stat buffers");
     if (ctx->h_las.n <= 0) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_lasers has not been called");
@@ -1826,7 +1828,7 @@ extern "C" int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int
     HIPCHK(ctx, hipMemcpyAsync(ctx->frame_off.p, frame_offsets, sizeof(int64_t) * (nf + 1), hipMemcpyHostToDevice, st));
     if (ctx->plane_par.method != SG_PLANE_REFERENCE && n_total > 0) {       // (the reference-today plane reads no row)
         ctx->resident_rows = -1;
-    ENSURE(ctx, ctx->rows_in, (size_t)n_total * 5 * esz);
+        ENSURE(ctx, ctx->rows_in, (size_t)n_total * 5 * esz);
         HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, (size_t)n_total * 5 * esz, hipMemcpyHostToDevice, st));
     }
     int e = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, ctx->rows_in.p, dtype, ctx->frame_off.p, nullptr, n_frames, n_total, max_frame,
@@ -1885,5 +1887,6 @@ extern "C" int snowgpu_prepass_stats(snowgpu_ctx *ctx, int n_frames, const int64
     HIPCHK(ctx, hipMemcpyAsync(status, ctx->d_status, sizeof status, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     ctx->resident_rows = n_total; ctx->resident_dtype = dtype;
+    ctx->resident_off.assign(frame_offsets, frame_offsets + n_frames + 1);
     return status_to_error(ctx, status);
 }

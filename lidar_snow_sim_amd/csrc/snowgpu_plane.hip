@@ -268,7 +268,8 @@ __global__ __launch_bounds__(PLB) void k_plane_fit(PlaneArgs a)
             if (info) { info[0] = m; info[1] = model; info[2] = inl; info[3] = valid; }
         }
     };
-    if (m <= a.min_rows) { flat_earth(0, 0); return; }
+    // (a plane needs three rows: a direct C-ABI caller may set min_rows below 2, and the samples below index rows m - 1 and m - 2)
+    if (m <= a.min_rows || m < 3) { flat_earth(0, 0); return; }
     double c0, c1, b;
     bool ok;
     if (a.method == SG_PLANE_LSQ) {

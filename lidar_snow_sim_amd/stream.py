@@ -132,7 +132,8 @@ def plan(lidar_folder: Path, ids: Sequence[str], modes, combos, batch: int, n_la
 def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gunn', 'sekhon'), combos=None,
         batch: int = 32, calib=None, device: int = 0, rank: int = 0, world: int = 1, particles_by_prefix=None,
         planes=None, workers: int = 2, readers: int = 4, writers: int = 4, depth: int = 4, keep_outputs: bool = True,
-        report: dict = None, plane_method: str = 'reference', plane_seed: int = 0, existing=None, sample_missing: bool = False) -> int:
+        report: dict = None, plane_method: str = 'reference', plane_seed: int = 0, existing=None, sample_missing: bool = False,
+        backend=None) -> int:
     """Process this rank's share of `sample_ids`; returns the number of files written.
 
     workers   GPU worker threads, each with its own engine context on `device`
@@ -145,7 +146,10 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
               written).  Ranks of a sharded run must agree on it: start them against a quiescent output tree (they each list it
               before writing; a launcher-started run lists behind a barrier, see main()), or pass the same set to all
     keep_outputs=False  unlink every output right after it has been written (throughput dry runs on a small disk)
-    report    optional dict that receives wall time, files, points in / out and the per-stage busy times"""
+    report    optional dict that receives wall time, files, points in / out and the per-stage busy times
+    backend   None: the product (libsnowgpu.so through simulation.augment_batch, page-locked batch buffers from the engine).  Tests and
+              `bench.py --dry` inject an object with alloc_rows(n_rows) -> float32 (n, 5) array and augment_batch(frames, prefix,
+              beam_divergence, **kw) to drive the reader / writer / sharding machinery on a machine without a GPU"""
     lidar_folder = Path(lidar_folder)
     combos = rate_combos() if combos is None else combos
     ids = list(sample_ids)
@@ -153,6 +157,20 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
         raise ValueError("bad rank/world")
     if existing is None:
         existing = existing_outputs(lidar_folder, modes, combos)   # before the first write of this run (and see `existing` above)
+        if world > 1:
+            # A sharded run's ranks must take the listing before ANY of them writes: a rank that started late would otherwise skip items
+            # another rank has just written -- and their random.shuffle draws with them, after which its seeded permutations drift from
+            # the one-rank sequence.  With a process group up, every rank lists and then waits for the others here; without one there is
+            # nothing to wait on, and the caller has to pass the same `existing` set to every rank.
+            try:
+                import torch.distributed as _td
+                grouped = _td.is_available() and _td.is_initialized()
+            except ImportError:
+                grouped = False
+            if not grouped:
+                raise ValueError("stream.run(rank, world > 1) without `existing`: list the outputs once (stream.existing_outputs) and pass "
+                                 "the same set to every rank, or initialise torch.distributed so that the ranks can list behind a barrier")
+            _td.barrier()
     # drawn by the feeder thread while the pipeline runs; every rank draws for ALL ids and keeps its own (see plan_iter)
     jobs = plan_iter(lidar_folder, ids, modes, combos, batch, rank=rank, world=world, existing=existing)
     n_jobs = [0]
@@ -170,6 +188,8 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
             for i, b in enumerate(pin_pool):
                 if b.shape[0] >= n_rows:
                     return pin_pool.pop(i)
+        if backend is not None:
+            return backend.alloc_rows(max(n_rows, 1) * 9 // 8 + 1024)
         return _engine.get_engine(device, 0).ctx.pinned_empty((max(n_rows, 1) * 9 // 8 + 1024, 5), np.float32)
 
     def give_buffer(b):
@@ -246,7 +266,8 @@ def run(lidar_folder, sample_ids: Iterable[str], particle_root=None, modes=('gun
                     frames = fut.result()
                     t0 = time.perf_counter()
                     try:
-                        results = augment_batch(frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
+                        results = (augment_batch if backend is None else backend.augment_batch)(
+                                                frames, job[2], float(np.degrees(3e-3)), shuffle=False, root_path=particle_root,
                                                 particles=(particles_by_prefix[job[2]] if particles_by_prefix is not None
                                                            else ('missing' if sample_missing else None)),
                                                 planes=None if planes is None else [planes] * len(frames),
@@ -300,6 +321,7 @@ def main(argv=None):
     ap.add_argument('--writers', type=int, default=4)
     ap.add_argument('--seed', type=int, default=None, help='random.seed() before the permutations are drawn (same on every rank)')
     ap.add_argument('--plane-method', default='reference', choices=('reference', 'lsq', 'ransac'))
+    ap.add_argument('--plane-seed', type=int, default=0, help="seed of --plane-method ransac (Philox draws keyed by it: same cloud + same seed = same plane)")
     ap.add_argument('--sample-missing', action='store_true', help='sample particle tables that have no .npy file on the device')
     args = ap.parse_args(argv)
     rank, local_rank, world = sdist.env_rank_world()
@@ -320,7 +342,7 @@ def main(argv=None):
         random.seed(args.seed)                                  # the same seed on every rank: the reference's sequential draw order
     n = run(args.lidar, read_split(args.split), particle_root=args.particles, batch=args.batch, calib=calib,
             device=local_rank, rank=rank, world=world, workers=args.workers, readers=args.readers, writers=args.writers, report=rep,
-            existing=existing, plane_method=args.plane_method, sample_missing=args.sample_missing)
+            existing=existing, plane_method=args.plane_method, plane_seed=args.plane_seed, sample_missing=args.sample_missing)
     print(f'rank {rank}/{world}: wrote {n} files in {rep.get("wall_s", 0.0):.1f} s')
 
 

@@ -110,22 +110,23 @@ def noise_polys_from_device_stats(hist, rec, noise_floor=0.7, threads=None):
     else:
         per = max(1, -(-nf // workers))
         ymins = np.concatenate(list(_thread_pool(workers).map(lambda lo: select(lo, min(lo + per, nf)), range(0, nf, per))))
-    # the rest for all frames at once (augmentation.py:237-253, simulation.py:462-467)
+    # the noise line per frame (augmentation.py:237-253), on the COMPRESSED arrays x[use], min_vals[use] with the expressions of
+    # scipy.stats.linregress -- np.mean of each, np.cov(x, y, bias=1) -- so that the line is the one the host path
+    # (noise_threshold_poly -> estimate_laser_parameters) fits, operation for operation (a masked sum over all 50 bins adds the
+    # same numbers in another order: last-bit differences that a row sitting on the threshold can see)
     n_ground, ymax, p0, p1 = rec[:, 0], rec[:, 4], rec[:, 5], rec[:, 6]
     step = (np.abs(ymax) - 5.0) / 2555.0
     min_vals = ymins * step[:, None] + 5.0                                          # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
     use = min_vals > 5                                                              # :238
-    cnt = use.sum(axis=1)
-    ok = cnt > 3                                                                    # :248
-    cs = np.maximum(cnt, 1)
-    xm = (use * xmid).sum(axis=1) / cs
-    ym = (use * min_vals).sum(axis=1) / cs
-    dx, dy = (xmid - xm[:, None]) * use, (min_vals - ym[:, None]) * use
-    sxx = (dx * dx).sum(axis=1)
-    with np.errstate(divide='ignore', invalid='ignore'):
-        slope = (dx * dy).sum(axis=1) / sxx                                         # scipy linregress: ssxym / ssxm (:249)
-    m0 = np.where(ok, slope, p0)                                                    # :250-251: too few rows -> the regression line p
-    m1 = np.where(ok, ym - slope * xm, p1)
+    m0, m1 = p0.copy(), p1.copy()                                                   # :250-251: too few rows -> the regression line p
+    for f in range(nf):
+        u = use[f]
+        if int(u.sum()) > 3:                                                        # :248
+            x, y = xmid[u], min_vals[f][u]
+            xmean, ymean = np.mean(x), np.mean(y)
+            ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
+            m0[f] = ssxym / ssxm                                                    # :249 scipy linregress
+            m1[f] = ymean - m0[f] * xmean
     q = rec[:, 7:18]
     a22, a21, a2, a11, a1, a2gc, a2c, a1gc, a1c, gc, c = (q[:, k] for k in range(11))
     # normal equations of np.polyfit(d, nf (m0 d + m1) c, 2), columns scaled by their norms as polyfit scales them

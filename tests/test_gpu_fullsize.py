@@ -305,3 +305,31 @@ def test_L8_viewer_chain_follows_the_local_numpy_with_q8_numpy(golden, tables, c
     from conftest import numpy_matches_native_fixtures
     if numpy_matches_native_fixtures():
         assert bad == 0
+
+
+def test_q8_numpy_device_half_keeps_the_rows_of_the_host_fit_at_full_size(capsys):
+    """q8='numpy' has two routes to the threshold polynomial: the whole estimate on the host (device_prepass=False:
+    noise_threshold_poly, the reference's own NumPy / SciPy calls) and the device half (default: histogram and sums from
+    snowgpu_prepass_stats, row minima and the two fits in noise_polys_from_device_stats).  Both must keep the same rows of full
+    C2 sweeps -- float32 and float64, channel-major and firing order: the polynomials agree to the rounding of the fit (the
+    noise line is fitted with linregress's own expressions on the same compressed arrays; the quadratic from float64 normal
+    equations against np.polyfit's SVD), and a row can only flip if its intensity sits within that distance of the threshold."""
+    import bench
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    tables = _tables("C2")
+    n = max(2, N_FRAMES // 2)
+    total = {"frames": 0, "rows_kept": 0, "rows_differ": 0, "max_threshold_deviation": 0.0}
+    for workload, dtype in (("C2", np.float32), ("C2fire", np.float32), ("C2", np.float64)):
+        frames, orders = _frames(workload, dtype, n)
+        planes = [PLANE] * n
+        a = augment_batch(frames, "unused", BD, planes=planes, orders=orders, particles=tables, return_src=True, q8="numpy")
+        b = augment_batch(frames, "unused", BD, planes=planes, orders=orders, particles=tables, return_src=True, q8="numpy", device_prepass=False)
+        for (sa, ra, ia), (sb, rb, ib) in zip(a, b):
+            total["frames"] += 1
+            total["rows_kept"] += int(ia.shape[0])
+            same = ia.shape == ib.shape and np.array_equal(ia, ib)
+            total["rows_differ"] += 0 if same else int(np.setxor1d(ia, ib).size)
+            if same:
+                assert ra.tobytes() == rb.tobytes() and tuple(sa) == tuple(sb)
+    _report(capsys, dict(total, test="q8_numpy device half vs host fit"))
+    assert total["rows_differ"] == 0

@@ -139,3 +139,27 @@ def test_wet_ground_estimates_its_plane_on_the_device(eng):
     c = ground_water_augmentation(pc, **kw)                                 # default: the plane the reference returns today ...
     d = ground_water_augmentation(pc, plane=([0, 0, 1], -1.55), **kw)       # ... (rows of the far wall around z = +1.55 pass for "ground")
     assert np.array_equal(c, d)
+
+
+@pytest.mark.parametrize("method", ["lsq", "ransac"])
+def test_fewer_than_three_strip_rows_give_the_flat_earth_plane_whatever_min_rows_is(eng, method):
+    """A direct C-ABI caller may set min_rows below 2 (the Python mirror always passes the column count): a strip of 0, 1 or 2 rows
+    still has no plane, and the RANSAC draws -- which index rows m - 1 and m - 2 -- must not run (round-4 advisor)."""
+    pc = _road(3000, 5, np.float32)
+    pc[:, 0] = 5.0                                                         # nothing in the strip (x <= 10) ...
+    frames = []
+    for k in (0, 1, 2, 3):
+        f = pc.copy()
+        f[:k, :3] = [[20 + 7 * i, 0.5 * i, -1.7 - 0.01 * i] for i in range(k)]   # ... except k rows
+        frames.append(f)
+    rows = np.concatenate(frames)
+    off = np.arange(5) * pc.shape[0]
+    for min_rows in (0, 1):
+        eng.ctx.set_plane_method(method, seed=3, trials=64, min_rows=min_rows)
+        try:
+            planes, info = eng.ctx.estimate_planes(rows, off)
+        finally:
+            eng.ctx.set_plane_method("reference")
+        for k in (0, 1, 2):
+            assert tuple(planes[k]) == (0.0, 0.0, 1.0, -1.55), (method, min_rows, k, planes[k])
+        assert np.isfinite(planes[3]).all()
