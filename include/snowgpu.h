@@ -111,6 +111,21 @@ int snowgpu_table_count(const snowgpu_ctx *ctx);
 int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio, double diameter_scale_mm,
                          double r_0, uint64_t seed, double *xyr_out, int64_t cap, int64_t *n_out);
 
+/*
+ * How the results of a pipelined snowgpu_augment_batch cross the link (the reference returns a fresh N' x 5 array, simulation.py:523,
+ * :540-544; here the caller's out_rows / out_src receive the same bytes either way):
+ *   mode 0 (default)  output rows + source indices: 24 bytes per point down the link (20 with out_src = NULL)
+ *   mode 1 "packed"   per kept row its source row | label and its intensity (8 bytes; 12 for float64 rows), the moved coordinates of
+ *                     scattered rows (label 2, simulation.py:176-180) apart, every copy sized by the per-frame counts; `threads` host
+ *                     threads of the library (0: the CPUs this process may use minus two, at most 8; pinned to the NUMA node of the device) assemble the caller's rows --
+ *                     x, y, z and the channel of rows without a laser are COPIED from the caller's input rows, nothing is computed
+ *                     on the host.  A third of the download; for callers bound by the link with cores to spare.
+ * rows == NULL (resident rows) and single-chunk batches always use mode 0.
+ */
+int snowgpu_set_result_transfer(snowgpu_ctx *ctx, int mode, int threads);
+/* timeline of the last packed call, ms since its start: everything enqueued, every download landed, every row assembled; threads used */
+int snowgpu_debug_transfer_times(snowgpu_ctx *ctx, double *out4);
+
 /* Rows per chunk of the host-pointer entry's upload / compute / download pipeline (default 3 * 2^19, i.e. 12 sweeps of
  * 64 x 2048; environment SNOWGPU_PIPE_ROWS; chunks alternate between SNOWGPU_PIPE_LANES = 2 compute lanes); 0 = no pipeline: one upload, one launch sequence, one download.  The
  * reference has no counterpart (its arrays never leave the host; precompute.py:78 / :106 are its I/O boundary). */

@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -115,6 +115,10 @@ def lib():
             L.snowgpu_estimate_planes_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, vp, vp]
             L.snowgpu_prepass_stats.restype = ctypes.c_int
             L.snowgpu_prepass_stats.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp]
+            L.snowgpu_set_result_transfer.restype = ctypes.c_int
+            L.snowgpu_set_result_transfer.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+            L.snowgpu_debug_transfer_times.restype = ctypes.c_int
+            L.snowgpu_debug_transfer_times.argtypes = [vp, vp]
             L.snowgpu_set_pipeline.restype = ctypes.c_int
             L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
@@ -378,6 +382,19 @@ class Context:
         out = np.zeros(8, np.int32)
         self._check(self._L.snowgpu_last_status(self._h, _p(out)))
         return out
+
+    def set_result_transfer(self, mode="rows", threads=0):
+        """How a pipelined host batch's results cross the link: 'rows' (output rows + source indices) or 'packed' (source | label +
+        intensity per kept row; `threads` host threads of the library assemble the rows from the caller's input)."""
+        if mode not in ("rows", "packed"):
+            raise ValueError("mode must be 'rows' or 'packed'")
+        with self._call_lock:
+            self._check(self._L.snowgpu_set_result_transfer(self._h, 1 if mode == "packed" else 0, int(threads)))
+
+    def transfer_times(self):
+        out = np.zeros(4, np.float64)
+        self._check(self._L.snowgpu_debug_transfer_times(self._h, _p(out)))
+        return {"enqueued_ms": float(out[0]), "downloaded_ms": float(out[1]), "assembled_ms": float(out[2]), "host_threads": int(out[3])}
 
     def set_pipeline(self, chunk_rows: int):
         """Rows per chunk of the host entry's upload / compute / download pipeline (0: off)."""

@@ -210,11 +210,22 @@ int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *ti
                        int32_t *chunk_blk, const SgTable *tables, SgTable *resolved /* n_frames x n_las, or null */, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
+// Packed result transfer (snowgpu_set_result_transfer): what the compaction writes instead of 5-column rows -- per kept row of frame f, at
+// frame_off[f] + j: meta = source row (30 bits) | code << 30 (0 / 1 / 2 = label, 3 = label 0 whose column 4 keeps the input's channel value)
+// and the output intensity (row dtype); the moved coordinates of the batch's label-2 rows form one list in output order (frame after
+// frame: frame f's start = the sum of mv_counts of the frames before it), three values each, at mv.
+struct SgPackOut {
+    uint32_t *meta;
+    void *inten;
+    void *mv;
+    int64_t *mv_counts;          // n_frames: kept label-2 rows
+    int32_t *tile_mv, *tile_mv_base;   // scratch: n_frames x max_tiles
+};
 int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_unsorted, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,
-                      void *stream);
+                      const SgPackOut *pack /* or null: rows + out_src */, void *stream);
 int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
                          int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles, void *stream);
 int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,

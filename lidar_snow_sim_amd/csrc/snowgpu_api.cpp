@@ -3,9 +3,18 @@
 // snowgpu_kernels.hip / snowgpu_prepass.hip.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <pthread.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -44,6 +53,95 @@ template <typename T> struct DevBuf {
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+// The CPUs of the NUMA node a device hangs on (sysfs: the PCI device's numa_node, the node's cpulist), intersected with the CPUs this
+// process may use; false if anything is missing.  The threads that copy rows between page-locked buffers stay on that node: on a
+// two-socket host the other socket's cores reach that memory at a fraction of the speed (measured: 1.4 - 2.2 G points/s from run to run
+// with free-roaming threads).
+static bool device_node_cpus(int device, cpu_set_t *out)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    char path[256];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fh = std::fopen(path, "r");
+    if (!fh) return false;
+    int node = -1;
+    const int got = std::fscanf(fh, "%d", &node);
+    std::fclose(fh);
+    if (got != 1 || node < 0) return false;
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    fh = std::fopen(path, "r");
+    if (!fh) return false;
+    char list[4096] = {0};
+    const bool ok = std::fgets(list, (int)sizeof list, fh) != nullptr;
+    std::fclose(fh);
+    if (!ok) return false;
+    cpu_set_t allowed, node_set;
+    CPU_ZERO(&allowed); CPU_ZERO(&node_set);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return false;
+    for (char *p = list; *p;) {                       // "0-63,128-191"
+        char *end = nullptr;
+        long a = std::strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &node_set);
+        p = (*end == ',') ? end + 1 : end;
+        if (*end != ',' ) break;
+    }
+    if (CPU_COUNT(&node_set) == 0) return false;
+    *out = node_set;
+    return true;
+}
+
+// Host threads that put output rows together in the packed result transfer (snowgpu_set_result_transfer): plain copies, no arithmetic.
+struct AsmPool {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    std::deque<std::function<void()>> q;
+    size_t pending = 0;
+    bool stop = false;
+    void start(int n, const cpu_set_t *cpus)
+    {
+        for (int i = 0; i < n; ++i)
+            threads.emplace_back([this, cpus_copy = cpus ? *cpus : cpu_set_t{}, pin = cpus != nullptr]() {
+                if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &cpus_copy);      // (best effort)
+                for (;;) {
+                    std::function<void()> job;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [this]() { return stop || !q.empty(); });
+                        if (q.empty()) return;
+                        job = std::move(q.front());
+                        q.pop_front();
+                    }
+                    job();
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void push(std::function<void()> job)
+    {
+        { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(job)); ++pending; }
+        cv.notify_one();
+    }
+    void wait_idle()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [this]() { return pending == 0; });
+    }
+    ~AsmPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv.notify_all();
+        for (auto &t : threads) t.join();
+    }
 };
 
 }  // namespace
@@ -158,6 +256,19 @@ struct snowgpu_ctx {
     DevBuf<double> wet_fit;           // n_frames x 8: the curves the last wet-ground call fitted (snowgpu_wet_last_fit)
     int wet_fit_frames = 0;
     int32_t h_status[8] = {0, -1, 0, 0, 0, 0, 0, 0};   // status words of the last host-pointer batch (tier counts summed over chunks)
+    // Packed result transfer of the pipelined host entry (snowgpu_set_result_transfer): per kept row 4 + 4 (8 for float64 rows) bytes come
+    // down the link, the moved coordinates of scattered rows apart; host threads copy x, y, z from the caller's input rows.
+    int result_mode = 0;                  // 0: whole rows (+ source indices) over the link; 1: packed
+    int asm_threads = 0;                  // host threads of the packed mode (0: the CPUs this process may use, minus two, at most 8)
+    DevBuf<uint32_t> pk_meta;
+    DevBuf<uint8_t> pk_int, pk_mv;
+    DevBuf<int64_t> pk_mvcnt;
+    DevBuf<int32_t> pk_tile_mv, pk_tile_mv_base;      // per lane
+    char *st_pk = nullptr;                // page-locked staging: meta | intensities | moved coordinates | counts
+    size_t st_pk_cap = 0;
+    std::vector<hipEvent_t> pk_ev;        // [2 c] counts of chunk c on the host, [2 c + 1] its packed data
+    AsmPool *pool = nullptr;
+    double pk_times[4] = {0, 0, 0, 0};    // last packed call: ms until all enqueued, all downloads landed, all rows assembled; host bytes copied
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -299,6 +410,10 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
     if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
     ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release(); ctx->wet_fit.release();
+    delete ctx->pool; ctx->pool = nullptr;
+    if (ctx->st_pk) (void)hipHostFree(ctx->st_pk);
+    for (hipEvent_t e : ctx->pk_ev) (void)hipEventDestroy(e);
+    ctx->pk_meta.release(); ctx->pk_int.release(); ctx->pk_mv.release(); ctx->pk_mvcnt.release(); ctx->pk_tile_mv.release(); ctx->pk_tile_mv_base.release();
     for (hipEvent_t e : ctx->pipe_ev) (void)hipEventDestroy(e);
     ctx->pipe_off.release(); ctx->pipe_status.release();
     for (auto &t : ctx->tables) {
@@ -611,6 +726,7 @@ struct BatchDev {
     int32_t *perm_out = nullptr;   // where the permutation actually used lives (device)
     bool no_fov = false;           // debug tap: never crop
     bool want_perm = false;        // the caller reads perm_out back: the sort writes the permutation of channel-sorted frames too
+    SgPackOut *pack = nullptr;     // packed result transfer: the compaction writes these instead of out_rows / out_src (tile scratch filled in here)
     bool serial = false;           // every kernel on `stream`: no fork / join events (chunks of the host pipeline)
 };
 
@@ -633,6 +749,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (n == 0) {
         HIPCHK(ctx, hipMemsetAsync(b.out_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
         HIPCHK(ctx, hipMemsetAsync(b.out_stats, 0, sizeof(int64_t) * 3 * (size_t)b.n_frames, st));
+        if (b.pack) HIPCHK(ctx, hipMemsetAsync(b.pack->mv_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
         return SNOWGPU_OK;
     }
     // 0. noise-threshold prepass (simulation.py:449-467) unless the caller brought the polynomial.  Only the compaction
@@ -926,9 +1043,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 4. output rows from (sorted) rows + records, round, noise-floor filter, camera crop, compaction, stats
     // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
+    if (b.pack) {
+        ENSURE(ctx, ctx->pk_tile_mv, (size_t)b.n_frames * (size_t)max_tiles + 1);
+        ENSURE(ctx, ctx->pk_tile_mv_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
+        b.pack->tile_mv = ctx->pk_tile_mv.p; b.pack->tile_mv_base = ctx->pk_tile_mv_base.p;
+    }
     e = sg_launch_compact(b.rows, ctx->srows.p, ctx->frame_unsorted.p, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, st);
+                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, b.pack, st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
 }
@@ -1013,7 +1135,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     for (int f = 0; f < n_frames;) {
         int g = f;
         const int64_t base = frame_offsets[f];
-        while (g < n_frames && (g == f || frame_offsets[g + 1] - base <= ctx->pipe_rows)) ++g;
+        // (the last chunks are half size: what remains to be done after the last upload has landed -- the last chunk's kernels, its
+        // download, the assembly of its rows -- is the part of the call nothing overlaps)
+        const int64_t target = (n_total - base <= 2 * ctx->pipe_rows) ? std::max<int64_t>(ctx->pipe_rows / 2, 1) : ctx->pipe_rows;
+        while (g < n_frames && (g == f || frame_offsets[g + 1] - base <= target)) ++g;
         c_first.push_back(f);
         c_pos.push_back(h_off.size());
         for (int k = f; k <= g; ++k) h_off.push_back(frame_offsets[k] - base);
@@ -1034,8 +1159,55 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     ENSURE(ctx, ctx->table_ids, nf * nl);
     ENSURE(ctx, ctx->plane, nf * 4);
     ENSURE(ctx, ctx->rows_in, std::max<size_t>((size_t)n_total * rb, 8));
-    ENSURE(ctx, ctx->rows_out, std::max<size_t>((size_t)n_total * rb, 8));
-    ENSURE(ctx, ctx->out_src, std::max<size_t>((size_t)n_total, 1));
+    // Packed result transfer: the compaction leaves, per kept row, its source row | label code and its intensity, and the moved
+    // coordinates of the label-2 rows apart (SgPackOut); those cross the link in exact sizes once a chunk's counts have landed, and host
+    // threads put the caller's rows together -- x, y, z (and the channel of rows without a laser) copied from the caller's INPUT rows.
+    const bool packed = ctx->result_mode == 1 && rows != nullptr && n_total > 0;
+    const size_t nt = (size_t)n_total;
+    char *st_meta = nullptr, *st_int = nullptr, *st_mv = nullptr;
+    int64_t *st_cnt = nullptr, *st_mvcnt = nullptr;
+    if (packed) {
+        ENSURE(ctx, ctx->pk_meta, nt);
+        ENSURE(ctx, ctx->pk_int, nt * esz);
+        ENSURE(ctx, ctx->pk_mv, nt * 3 * esz);
+        ENSURE(ctx, ctx->pk_mvcnt, nf);
+        const size_t o_int = (nt * 4 + 63) / 64 * 64, o_mv = o_int + (nt * esz + 63) / 64 * 64, o_cnt = o_mv + (nt * 3 * esz + 63) / 64 * 64;
+        const size_t need = o_cnt + 16 * nf + 64;
+        if (need > ctx->st_pk_cap) {
+            if (ctx->st_pk) (void)hipHostFree(ctx->st_pk);
+            ctx->st_pk = nullptr; ctx->st_pk_cap = 0;
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->st_pk, need + need / 8, hipHostMallocDefault));
+            ctx->st_pk_cap = need + need / 8;
+        }
+        st_meta = ctx->st_pk; st_int = ctx->st_pk + o_int; st_mv = ctx->st_pk + o_mv;
+        st_cnt = (int64_t *)(ctx->st_pk + o_cnt); st_mvcnt = st_cnt + nf;
+        while ((int)ctx->pk_ev.size() < 2 * n_chunks) {
+            hipEvent_t e;
+            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->pk_ev.push_back(e);
+        }
+        if (!ctx->pool) {
+            int n_thr = ctx->asm_threads;
+            if (n_thr <= 0) {
+                cpu_set_t cs;
+                CPU_ZERO(&cs);
+                int avail = (sched_getaffinity(0, sizeof cs, &cs) == 0) ? CPU_COUNT(&cs) : (int)std::thread::hardware_concurrency();
+                if (FILE *fh = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {      // a container's CPU quota, if any
+                    long long q = 0, per = 0;
+                    if (std::fscanf(fh, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) avail = std::min<int>(avail, (int)((q + per - 1) / per));
+                    std::fclose(fh);
+                }
+                n_thr = std::max(1, std::min(8, avail - 2));      // (eight copy at the pace of the link: measured 6 .. 14 threads, 2.25 - 2.31 G points/s)
+            }
+            ctx->pool = new AsmPool();
+            cpu_set_t node_cpus;
+            const bool have_node = device_node_cpus(ctx->device, &node_cpus);
+            ctx->pool->start(n_thr, have_node ? &node_cpus : nullptr);
+        }
+    } else {
+        ENSURE(ctx, ctx->rows_out, std::max<size_t>((size_t)n_total * rb, 8));
+        ENSURE(ctx, ctx->out_src, std::max<size_t>((size_t)n_total, 1));
+    }
     // The small arrays lead the upload stream (chunk 0's event covers them).  On the compute stream they would leave it
     // "after a DMA copy" for the whole batch: 28 instead of 20 ms for 256 sweeps (measured).
     hipStream_t up = ctx->s_h2d;
@@ -1073,6 +1245,73 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     }
     const double t_up = now();
     int rc = SNOWGPU_OK;
+    // ---- packed result transfer: downloads sized by the counts, and the host threads that put the rows together ----------------------
+    int pk_enq = 0, pk_asm = 0;                      // chunks whose compute and download are enqueued / whose rows are with the pool
+    auto pk_mv_head = [](size_t chunk_rows) { return std::min(chunk_rows, std::max<size_t>(4096, chunk_rows / 8)); };
+    auto assemble_frame = [=](int f, int64_t kept, int64_t mv_at) {
+        // out row j of frame f = the caller's input row src_j with the device's intensity and label; label-2 rows take their moved coordinates
+        // (mv_at: where this frame's part of the batch's list of moved coordinates starts, in rows)
+        const int64_t o = frame_offsets[f];
+        const uint32_t *meta = (const uint32_t *)st_meta + o;
+        if (esz == 4) {
+            const float *in = (const float *)rows + (size_t)o * 5, *it = (const float *)st_int + o, *mv = (const float *)st_mv + (size_t)mv_at * 3;
+            float *out = (float *)out_rows + (size_t)o * 5;
+            for (int64_t j = 0; j < kept; ++j) {
+                const uint32_t m = meta[j], src = m & 0x3fffffffu, code = m >> 30;
+                const float *ip = in + (size_t)src * 5;
+                float *q = out + (size_t)j * 5;
+                if (code == 2) { q[0] = mv[0]; q[1] = mv[1]; q[2] = mv[2]; mv += 3; }
+                else { q[0] = ip[0]; q[1] = ip[1]; q[2] = ip[2]; }
+                q[3] = it[j];
+                q[4] = code == 3 ? ip[4] : (float)code;
+                if (out_src) out_src[o + j] = (int32_t)src;
+            }
+        } else {
+            const double *in = (const double *)rows + (size_t)o * 5, *it = (const double *)st_int + o, *mv = (const double *)st_mv + (size_t)mv_at * 3;
+            double *out = (double *)out_rows + (size_t)o * 5;
+            for (int64_t j = 0; j < kept; ++j) {
+                const uint32_t m = meta[j], src = m & 0x3fffffffu, code = m >> 30;
+                const double *ip = in + (size_t)src * 5;
+                double *q = out + (size_t)j * 5;
+                if (code == 2) { q[0] = mv[0]; q[1] = mv[1]; q[2] = mv[2]; mv += 3; }
+                else { q[0] = ip[0]; q[1] = ip[1]; q[2] = ip[2]; }
+                q[3] = it[j];
+                q[4] = code == 3 ? ip[4] : (double)code;
+                if (out_src) out_src[o + j] = (int32_t)src;
+            }
+        }
+    };
+    // Enqueue what has become possible: the downloads of chunks whose counts have landed; the assembly of chunks whose downloads have.
+    // wait = false: only what is ready now (called between the launches of later chunks); true: everything, blocking.
+    auto pk_progress = [&](bool wait) -> hipError_t {
+        while (pk_asm < pk_enq) {
+            const int c = pk_asm;
+            hipEvent_t ev = ctx->pk_ev[2 * (size_t)c];
+            hipError_t q = wait ? hipEventSynchronize(ev) : hipEventQuery(ev);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); return hipSuccess; }     // ("not ready" must not be what the next launch check finds)
+            if (q != hipSuccess) return q;
+            // the chunk's words, intensities, the head of its moved-coordinates list and its counts are here
+            const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1];
+            const size_t o = (size_t)frame_offsets[f0], head = pk_mv_head((size_t)(frame_offsets[f1] - frame_offsets[f0]));
+            size_t n_mv = 0;
+            for (int f = f0; f < f1; ++f) n_mv += (size_t)st_mvcnt[f];
+            if (n_mv > head) {                        // a list longer than its head (more than one row in eight scattered): the rest now, waited for
+                hipError_t e = hipMemcpyAsync(st_mv + (o + head) * 3 * esz, ctx->pk_mv.p + (o + head) * 3 * esz, (n_mv - head) * 3 * esz, hipMemcpyDeviceToHost, ctx->s_d2h);
+                if (e == hipSuccess) e = hipEventRecord(ctx->pk_ev[2 * (size_t)c + 1], ctx->s_d2h);
+                if (e == hipSuccess) e = hipEventSynchronize(ctx->pk_ev[2 * (size_t)c + 1]);
+                if (e != hipSuccess) return e;
+            }
+            if (trace) (void)hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h);
+            int64_t mv_at = frame_offsets[f0];
+            for (int f = f0; f < f1; ++f) {
+                const int64_t kept = st_cnt[f];
+                if (kept > 0) ctx->pool->push([=]() { assemble_frame(f, kept, mv_at); });
+                mv_at += st_mvcnt[f];
+            }
+            ++pk_asm;
+        }
+        return hipSuccess;
+    };
     // A failure inside the loop must not return while copies from / into the caller's buffers (and from h_off) are in flight:
     // every exit goes through the drain below.
 #define PIPECHK(call)                                                                                              \
@@ -1096,7 +1335,14 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.thr_poly = d_thr ? d_thr + 3 * (size_t)f0 : nullptr;
         b.plane = (!d_thr && plane) ? ctx->plane.p + 4 * (size_t)f0 : nullptr;
         b.noise_floor = noise_floor; b.perm = perm ? ctx->user_perm.p + r0 : nullptr;
-        b.out_rows = ctx->rows_out.p + (size_t)r0 * rb; b.out_src = ctx->out_src.p + r0;
+        SgPackOut po{};
+        if (packed) {
+            po.meta = ctx->pk_meta.p + r0; po.inten = ctx->pk_int.p + (size_t)r0 * esz; po.mv = ctx->pk_mv.p + (size_t)r0 * 3 * esz;
+            po.mv_counts = ctx->pk_mvcnt.p + f0;
+            b.pack = &po;
+        } else {
+            b.out_rows = ctx->rows_out.p + (size_t)r0 * rb; b.out_src = ctx->out_src.p + r0;
+        }
         b.out_counts = ctx->out_counts.p + f0; b.out_stats = ctx->out_stats.p + 3 * (size_t)f0;
         b.out_thr_poly = out_thr_poly ? ctx->out_thr.p + 3 * (size_t)f0 : nullptr;
         b.status = ctx->pipe_status.p + 8 * (size_t)c; b.stream = cs;
@@ -1106,6 +1352,27 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         b.serial = true;
         rc = run_batch(lc, b);
         if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
+        if (packed) {
+            // The chunk's words and intensities come down as two copies of its whole row range (the rows of a frame are compacted at the
+            // frame's offset: what lies behind a frame's kept rows travels unused -- a copy per frame instead cost ~20 us each, 17 ms per
+            // batch), then the head of its list of moved coordinates -- room for one row in eight: the list's length is only known on the
+            // device, and a copy sized by it would have to queue behind the copies of every later chunk --, then its counts.  A chunk with
+            // more scattered rows than that gets the rest of its list by one more copy (pk_progress).
+            PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
+            if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
+            PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
+            if (cn) {
+                PIPECHK(hipMemcpyAsync(st_meta + (size_t)r0 * 4, po.meta, (size_t)cn * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+                PIPECHK(hipMemcpyAsync(st_int + (size_t)r0 * esz, po.inten, (size_t)cn * esz, hipMemcpyDeviceToHost, ctx->s_d2h));
+                PIPECHK(hipMemcpyAsync(st_mv + (size_t)r0 * 3 * esz, po.mv, pk_mv_head((size_t)cn) * 3 * esz, hipMemcpyDeviceToHost, ctx->s_d2h));
+            }
+            PIPECHK(hipMemcpyAsync(st_cnt + f0, b.out_counts, sizeof(int64_t) * (size_t)cf, hipMemcpyDeviceToHost, ctx->s_d2h));
+            PIPECHK(hipMemcpyAsync(st_mvcnt + f0, po.mv_counts, sizeof(int64_t) * (size_t)cf, hipMemcpyDeviceToHost, ctx->s_d2h));
+            PIPECHK(hipEventRecord(ctx->pk_ev[2 * (size_t)c], ctx->s_d2h));
+            pk_enq = c + 1;
+            if (hipError_t pe = pk_progress(false); pe != hipSuccess) { rc = fail(ctx, SNOWGPU_E_HIP, std::string("packed download: ") + hipGetErrorString(pe)); break; }
+            continue;
+        }
         PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
         if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
         PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
@@ -1116,6 +1383,13 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         if (trace) PIPECHK(hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
     }
 #undef PIPECHK
+    if (packed) {
+        ctx->pk_times[0] = now() - t_begin;
+        if (rc == SNOWGPU_OK) { if (hipError_t pe = pk_progress(true); pe != hipSuccess) rc = fail(ctx, SNOWGPU_E_HIP, std::string("packed download (drain): ") + hipGetErrorString(pe)); }
+        ctx->pk_times[1] = now() - t_begin;
+        ctx->pool->wait_idle();                       // (also on errors: no thread may still touch the caller's buffers when this returns)
+        ctx->pk_times[2] = now() - t_begin;
+    }
     if (trace) fprintf(stderr, "pipe: %d chunks; uploads enqueued in %.3f ms, everything in %.3f ms\n", n_chunks, t_up - t_begin, now() - t_begin);
     hipError_t se = hipStreamSynchronize(ctx->s_h2d);
     for (int l = 1; l < L; ++l) {
@@ -1409,6 +1683,33 @@ extern "C" int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8)
 {
     if (!ctx || !out8) return SNOWGPU_E_INVALID;
     std::memcpy(out8, ctx->h_status, sizeof(int32_t) * 8);
+    return SNOWGPU_OK;
+}
+
+// How the results of a pipelined host-pointer batch cross the link.  mode 0 (default): the output rows and their source indices, 24 bytes
+// per point.  mode 1 ("packed"): per kept row its source row | label and its intensity (8 bytes; 12 for float64 rows), the moved
+// coordinates of scattered rows apart; `threads` host threads of the library (0: the CPUs this process may use minus two, at most 8) put
+// the caller's out_rows / out_src together from those and from the caller's INPUT rows -- same bytes in the caller's buffers, a third of
+// the download, and host cores busy copying.  For callers bound by the link who have the cores to spare.
+extern "C" int snowgpu_set_result_transfer(snowgpu_ctx *ctx, int mode, int threads)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if ((mode != 0 && mode != 1) || threads < 0 || threads > 256) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_set_result_transfer: mode 0 or 1, 0 <= threads <= 256");
+    if (mode == 1) {
+        if (ctx->pool && threads != ctx->asm_threads) { delete ctx->pool; ctx->pool = nullptr; }     // (made again, with `threads`, by the next packed call)
+        ctx->asm_threads = threads;
+    }
+    ctx->result_mode = mode;
+    return SNOWGPU_OK;
+}
+
+// Timeline of the last packed call of this context, milliseconds since its start: [0] everything enqueued, [1] every download landed,
+// [2] every row assembled; [3] host threads used.
+extern "C" int snowgpu_debug_transfer_times(snowgpu_ctx *ctx, double *out4)
+{
+    if (!ctx || !out4) return SNOWGPU_E_INVALID;
+    for (int i = 0; i < 3; ++i) out4[i] = ctx->pk_times[i];
+    out4[3] = ctx->pool ? (double)ctx->pool->threads.size() : 0.0;
     return SNOWGPU_OK;
 }
 

@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
                                                             const uint32_t *__restrict__ rec,
                                                             const uint32_t *__restrict__ rec_q, const T *__restrict__ rng, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
-                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov)
+                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov, int32_t *__restrict__ tile_mv)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
     if (tile0 >= n) return;
     const T *rows = frame_unsorted[f] ? srows : rows_in;            // sorted position g = row g (see k_sort_scatter)
     const double p0 = thr_poly[(int64_t)f * 3], p1 = thr_poly[(int64_t)f * 3 + 1], p2 = thr_poly[(int64_t)f * 3 + 2];
-    int c = 0;
+    int c = 0, mv = 0;                               // mv: kept rows with label 2 (packed result transfer: their coordinates travel apart)
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
         if (r >= n) continue;
@@ -1292,13 +1292,17 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         }
         keep[base + r] = (uint8_t)((k ? 1 : 0) | (noise_ok ? 2 : 0));
         c += k;
+        mv += (k && lab_i == 2) ? 1 : 0;
         c += (noise_ok && is_att) ? (1 << 16) : 0;                          // high half: rows that count in num_attenuated (:525, before the crop)
     }
-    __shared__ int s[4];
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+    __shared__ int s[4], s2[4];
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); mv += __shfl_down(mv, o); }
+    if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = c; s2[threadIdx.x >> 6] = mv; }
     __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];   // kept | attenuated << 16 (a tile has 1024 rows)
+    if (threadIdx.x == 0) {
+        tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];   // kept | attenuated << 16 (a tile has 1024 rows)
+        if (tile_mv) tile_mv[(int64_t)f * max_tiles + blockIdx.x] = s2[0] + s2[1] + s2[2] + s2[3];
+    }
 }
 
 // per frame: tile offsets of the kept rows and the statistics (simulation.py:522-530).  diff2 (per frame: twice the intensity-
@@ -1306,20 +1310,23 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
                                                            const int32_t *__restrict__ tile_cnt,
                                                            int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
-                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles)
+                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles,
+                                                           const int32_t *__restrict__ tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
 {
     const int f = blockIdx.x;
     const int64_t n = frame_off[f + 1] - frame_off[f];
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
     if (threadIdx.x == 0) {                      // <= a few hundred tiles per frame: a serial scan is fine
-        int run = 0;
+        int run = 0, mrun = 0;
         int64_t att = 0;
         for (int64_t t = 0; t < tiles; ++t) {
             const int c = tile_cnt[(int64_t)f * max_tiles + t];
             tile_base[(int64_t)f * max_tiles + t] = run;
             run += c & 0xffff;
             att += c >> 16;
+            if (tile_mv) { tile_mv_base[(int64_t)f * max_tiles + t] = mrun; mrun += tile_mv[(int64_t)f * max_tiles + t]; }
         }
+        if (out_mv_counts) out_mv_counts[f] = mrun;
         out_counts[f] = run;
         out_stats[f * 3 + 0] = att;              // num_attenuated (:525)
         out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522, + the camera crop :538)
@@ -1328,14 +1335,20 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__rest
     }
 }
 
-template <typename T>
+// PACK (packed result transfer, snowgpu_set_result_transfer): instead of the 5-column output row, per kept row a 4-byte word -- source row
+// (30 bits) | label 0 / 1 / 2, or 3 = "column 4 keeps the input's channel value" (Q5) -- and its output intensity (row dtype); the moved
+// coordinates of the label-2 rows (simulation.py:176-180), a small minority, go to a list of their own in output order.  The host side of
+// the library copies x, y, z (and the channel of code-3 rows) from the caller's INPUT rows: 8 instead of 24 bytes per point cross the link.
+struct SgPack { uint32_t *meta; void *inten; void *mv; const int32_t *tile_mv_base; const int64_t *mv_counts; };
+
+template <typename T, bool PACK>
 __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restrict__ rows_in, const T *__restrict__ srows, const int32_t *__restrict__ frame_unsorted,
                                                               const uint32_t *__restrict__ rec,
                                                               const uint32_t *__restrict__ rec_q, const uint8_t *__restrict__ keep, const int32_t *__restrict__ perm,
                                                               const int64_t *__restrict__ frame_off,
                                                               const int32_t *__restrict__ tile_base, T *__restrict__ out_rows,
                                                               int32_t *__restrict__ out_src, int64_t *__restrict__ out_stats,
-                                                              int64_t max_tiles)
+                                                              int64_t max_tiles, SgPack pk)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
@@ -1344,9 +1357,12 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     const bool uns = frame_unsorted[f] != 0;
     const T *rows = uns ? srows : rows_in;
     __shared__ int wave_cnt[4][4];               // [round][wave]
+    [[maybe_unused]] __shared__ int wave_mv[4][4];
     const int tid = threadIdx.x, w = tid >> 6;
     bool k[4];
     int pre[4];
+    [[maybe_unused]] uint32_t rcs[4];
+    [[maybe_unused]] int pre_mv[4];
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + tid;
         const int kb = r < n ? (int)keep[base + r] : 0;
@@ -1354,9 +1370,24 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
         const unsigned long long m = __ballot(k[q]);
         pre[q] = __popcll(m & sg_lanemask_lt());
         if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
+        if constexpr (PACK) {
+            uint32_t rc = 0;
+            if (k[q]) { rc = rec[base + r]; if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT]; }
+            rcs[q] = rc;
+            const unsigned long long mm = __ballot(k[q] && ((rc >> SG_REC_LABEL_SHIFT) & 3u) == 2u);
+            pre_mv[q] = __popcll(mm & sg_lanemask_lt());
+            if ((tid & 63) == 0) wave_mv[q][w] = __popcll(mm);
+        }
     }
     __syncthreads();
     int run = tile_base[(int64_t)f * max_tiles + blockIdx.x];
+    [[maybe_unused]] int64_t mrun = 0;
+    if constexpr (PACK) {
+        // the moved coordinates of a batch form ONE list in output order (one copy down the link): this frame's part starts behind
+        // those of the frames before it (a handful of frames per call: summed here rather than scanned by another launch)
+        for (int g = 0; g < f; ++g) mrun += pk.mv_counts[g];
+        mrun += pk.tile_mv_base[(int64_t)f * max_tiles + blockIdx.x];
+    }
     for (int q = 0; q < 4; ++q) {
         int off = run;
         for (int ww = 0; ww < w; ++ww) off += wave_cnt[q][ww];
@@ -1364,14 +1395,30 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
             const int64_t r = base + tile0 + q * SG_BLOCK + tid;
             const int64_t dst = base + off + pre[q];
             const int32_t src = uns ? perm[r] : (int32_t)(r - base);
-            uint32_t rc = rec[r];
-            if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
-            const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rc);
-            T *d = out_rows + dst * 5;
-            d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
-            out_src[dst] = src;
+            if constexpr (PACK) {
+                const uint32_t rc = rcs[q];
+                const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rc);
+                const uint32_t label = (rc >> SG_REC_LABEL_SHIFT) & 3u;
+                const uint32_t code = (label == 0 && (rc & SG_REC_COPY)) ? 3u : label;
+                pk.meta[dst] = (uint32_t)src | (code << 30);
+                ((T *)pk.inten)[dst] = o.i;
+                if (label == 2) {
+                    int64_t moff = mrun + pre_mv[q];
+                    for (int ww = 0; ww < w; ++ww) moff += wave_mv[q][ww];
+                    T *d = (T *)pk.mv + moff * 3;
+                    d[0] = o.x; d[1] = o.y; d[2] = o.z;
+                }
+            } else {
+                uint32_t rc = rec[r];
+                if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
+                const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rc);
+                T *d = out_rows + dst * 5;
+                d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
+                out_src[dst] = src;
+            }
         }
         run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
+        if constexpr (PACK) mrun += wave_mv[q][0] + wave_mv[q][1] + wave_mv[q][2] + wave_mv[q][3];
     }
 }
 
@@ -1733,22 +1780,29 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
 extern "C" int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_unsorted, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
-                                 int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, void *stream)
+                                 int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, const SgPackOut *pack, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     SgFov fv{};
     if (fov) fv = *fov;
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, (const float *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, (const double *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv);
+    int32_t *tile_mv = pack ? pack->tile_mv : nullptr;
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, (const float *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, (const double *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles);
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles,
+                       (const int32_t *)tile_mv, pack ? pack->tile_mv_base : (int32_t *)nullptr, pack ? pack->mv_counts : (int64_t *)nullptr);
     SG_CHECK_LAUNCH();
-    if (dtype == 0)
-        hipLaunchKernelGGL(k_compact_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles);
-    else
-        hipLaunchKernelGGL(k_compact_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles);
+    SgPack pk{};
+    if (pack) { pk.meta = pack->meta; pk.inten = pack->inten; pk.mv = pack->mv; pk.tile_mv_base = pack->tile_mv_base; pk.mv_counts = pack->mv_counts; }
+    if (dtype == 0) {
+        if (pack) hipLaunchKernelGGL((k_compact_scatter<float, true>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles, pk);
+        else hipLaunchKernelGGL((k_compact_scatter<float, false>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (float *)out_rows, out_src, out_stats, max_tiles, pk);
+    } else {
+        if (pack) hipLaunchKernelGGL((k_compact_scatter<double, true>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles, pk);
+        else hipLaunchKernelGGL((k_compact_scatter<double, false>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, keep, perm, frame_off, tile_base, (double *)out_rows, out_src, out_stats, max_tiles, pk);
+    }
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -1763,7 +1817,8 @@ extern "C" int sg_launch_crop_count(const void *rows, int dtype, const int64_t *
     if (dtype == 0) hipLaunchKernelGGL(k_crop_flag<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     else hipLaunchKernelGGL(k_crop_flag<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, (const unsigned long long *)nullptr, max_tiles);
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, (const unsigned long long *)nullptr, max_tiles,
+                       (const int32_t *)nullptr, (int32_t *)nullptr, (int64_t *)nullptr);
     SG_CHECK_LAUNCH();
     return 0;
 }

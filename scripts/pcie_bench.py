@@ -74,8 +74,24 @@ def main():
     digest = [int(counts.sum()), int(stats[:, 0].sum()), int(stats[:, 1].sum()), int(stats[:, 2].sum()),
               float(pin_out[:int(counts[0]), 3].sum()), int(pin_src[:int(counts[0])].astype(np.int64).sum())]
     s_nosrc, b_nosrc = timed(False)
+    # packed result transfer (snowgpu_set_result_transfer): source row | label + intensity per kept row over the link, the library's host
+    # threads assemble the caller's rows from those and from the input rows -- same bytes in pin_out / pin_src
+    packed = {}
+    for thr in ([0] if args.fast else [0, 8, 4]):
+        eng.ctx.set_result_transfer("packed", thr)
+        try:
+            s_pk, b_pk = timed(True)
+            _, _, c2, st2, _ = call(True)
+            tt = eng.ctx.transfer_times()
+            dg = [int(c2.sum()), int(st2[:, 0].sum()), int(st2[:, 1].sum()), int(st2[:, 2].sum()),
+                  float(pin_out[:int(c2[0]), 3].sum()), int(pin_src[:int(c2[0])].astype(np.int64).sum())]
+            s_pkn, _ = timed(False)
+            packed[str(tt["host_threads"])] = {"points_per_s": n_total / s_pk, "points_per_s_best": n_total / b_pk, "points_per_s_without_src": n_total / s_pkn,
+                                               "last_call_ms": tt, "same_digest_as_rows_mode": dg == digest}
+        finally:
+            eng.ctx.set_result_transfer("rows")
     if args.fast:
-        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc}))
+        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc, "packed": packed}))
         return
     # plane = NULL at the C ABI: calculate_plane (simulation.py:449) on the device inside the batch -- the reference's default call
     s_ref, _ = timed(True, "device")                                     # method 'reference': the plane the reference returns today
@@ -143,7 +159,7 @@ def main():
     pyl_ms, pyl_min = med(one_py_lsq)
     print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_best": n_total / b_src, "points_per_s_without_src": n_total / s_nosrc,
                       "points_per_s_without_src_best": n_total / b_nosrc, "frames": F, "reps": args.reps, "points_per_frame": n_per,
-                      "digest": digest, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
+                      "digest": digest, "packed": packed, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
                       "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules,
                       "default_plane": {"c_abi_points_per_s_reference": n_total / s_ref, "c_abi_points_per_s_lsq": n_total / s_lsq,
                                         "python_points_per_s_injected": n_total / py_inj, "python_points_per_s_reference": n_total / py_ref,

@@ -1317,3 +1317,93 @@ def test_remaining_environment_switches_change_no_byte(so, tables, monkeypatch, 
         r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, plane=PLANE)
         assert tuple(int(v) for v in st0[0]) == tuple(int(v) for v in r_stats)
         assert np.array_equal(s0[:n], r_src) and np.array_equal(o0[:n, 3:], r_aug[:, 3:])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_packed_result_transfer_fills_the_callers_buffers_with_the_same_bytes(tables, dtype):
+    """snowgpu_set_result_transfer(ctx, 1, threads): per kept row only its source row | label and its intensity (and the moved coordinates of
+    scattered rows) cross the link, host threads of the library copy the rest from the caller's input rows.  The caller's out_rows / out_src /
+    counts / statistics must hold the bytes of the default transfer: stretched sweeps (many scattered rows), firing order, ragged and empty
+    frames, channels without a laser (their column 4 keeps the channel value, Q5), device prepass and caller polynomials, out_src = NULL,
+    one and several host threads, an error in a middle chunk."""
+    from lidar_snow_sim_amd import _native, engine
+    from lidar_snow_sim_amd.synthetic import firing_order
+    rng = np.random.default_rng(21)
+    frames = []
+    for f in range(9):
+        pc = _stretched_subsweep(step=int(rng.integers(24, 48)), seed=1200 + f)
+        n_az = pc.shape[0] // 64
+        if f % 3 == 1:
+            pc = firing_order(pc, 64, n_az)
+        if f % 4 == 2:
+            pc = pc[: pc.shape[0] - 37]
+            pc[5::53, 4] = 70.0                              # no such laser: copied through with its channel value
+        frames.append(pc.astype(dtype))
+    frames[5] = np.zeros((0, 5), dtype)
+    F = len(frames)
+    tl = _tables64(tables)
+    bd = float(np.degrees(3e-3))
+    polys = [[1e-4 * f, 0.01, 2.0] for f in range(F)]
+    rows = np.concatenate(frames)
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+    e = engine.Engine(0)
+    try:
+        tids = [e.table_ids_from_arrays(tl, list(rng.permutation(64))) for _ in range(F)]
+
+        def run(mode, threads, **kw):
+            e.ctx.set_result_transfer(mode, threads)
+            e.ctx.set_pipeline(2500)
+            try:
+                o, s, c, st, _ = e.ctx.augment_batch(rows, off, tids, bd, **kw)
+                if mode == "packed":
+                    assert e.ctx.transfer_times()["host_threads"] == threads
+                return o.copy(), None if s is None else s.copy(), c.copy(), st.copy()
+            finally:
+                e.ctx.set_pipeline(3 << 19)
+                e.ctx.set_result_transfer("rows")
+
+        n_scattered = 0
+        for kw in (dict(thr_poly=polys), dict(thr_poly=polys, want_src=False)):
+            ref = run("rows", 0, **kw)
+            for threads in (1, 5):
+                got = run("packed", threads, **kw)
+                assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[3], got[3])
+                for f in range(F):
+                    a, n = int(off[f]), int(ref[2][f])
+                    assert ref[0][a:a + n].tobytes() == got[0][a:a + n].tobytes(), (kw.keys(), threads, f)
+                    if ref[1] is not None:
+                        assert np.array_equal(ref[1][a:a + n], got[1][a:a + n])
+                    n_scattered += int((ref[0][a:a + n, 4] == 2).sum())
+                assert (ref[1] is None) == (got[1] is None)
+        assert n_scattered > 100 and (ref[0][:, 4] == 70).any()
+        # the device prepass (plane given) on frames that all have ground rows
+        keep = [f for f in range(F) if frames[f].shape[0] > 0]
+        rows2 = np.concatenate([frames[f] for f in keep])
+        off2 = np.concatenate(([0], np.cumsum([frames[f].shape[0] for f in keep]))).astype(np.int64)
+        tids2 = [tids[f] for f in keep]
+        outs = []
+        for mode in ("rows", "packed"):
+            e.ctx.set_result_transfer(mode, 3)
+            e.ctx.set_pipeline(2500)
+            try:
+                o, s, c, st, _ = e.ctx.augment_batch(rows2, off2, tids2, bd, plane=[[0.0, 0.0, -1.0, -1.7]] * len(keep))
+                outs.append((o.copy(), s.copy(), c.copy(), st.copy()))
+            finally:
+                e.ctx.set_pipeline(3 << 19)
+                e.ctx.set_result_transfer("rows")
+        assert np.array_equal(outs[0][2], outs[1][2]) and np.array_equal(outs[0][3], outs[1][3])
+        for f in range(len(keep)):
+            a, n = int(off2[f]), int(outs[0][2][f])
+            assert outs[0][0][a:a + n].tobytes() == outs[1][0][a:a + n].tobytes() and np.array_equal(outs[0][1][a:a + n], outs[1][1][a:a + n])
+        # an error in a middle chunk still comes back as the reference's exception type, with no thread left behind
+        bad = rows.copy()
+        bad[int(off[6]) + 3, :3] = (150.0, 0.0, 0.0)
+        e.ctx.set_result_transfer("packed", 2)
+        e.ctx.set_pipeline(2500)
+        with pytest.raises(_native.SnowGPUError) as ei:
+            e.ctx.augment_batch(bad, off, tids, bd, thr_poly=polys)
+        assert ei.value.code == _native.E_RANGE
+        good = run("packed", 2, thr_poly=polys)
+        assert np.array_equal(good[2], ref[2])
+    finally:
+        e.ctx.close()
