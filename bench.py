@@ -42,6 +42,9 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# BASELINE.json's metric, and which of the line's figures `value` is (the round-4 review asked for the string to say so)
+METRIC = ("augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline % -- value: rows resident in HBM when the clock starts (device entry); "
+          "with H2D of the rows and D2H of the results inside the clock: value_pcie_inclusive")
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md
 PCIE_PEAK = 63.0e9         # B/s per direction, PCIe Gen5 x16 (same guide)
 DEFAULT_FRAMES = 256       # sweeps per step and GPU (BASELINE.json's C3 streams 256-frame batches of the C2 sweep)
@@ -274,7 +277,7 @@ def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
         if rank == 0:
             threads_all = world * (readers + writers + workers + 2)
             print(json.dumps({
-                "metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %", "value": tot[1] / elapsed, "unit": "points/s",
+                "metric": METRIC, "value": tot[1] / elapsed, "unit": "points/s",
                 "n_gpus": world, "steps": 1, "warmup": 1, "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong",
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic", **({"dry": True} if dry else {}),
                 "config": {"workload": f"C5: {n_all}-frame synthetic STF stream ({layers} x {azimuths} float32 .bin files), 2.5 mm/h @ 1.6 m/s gunn tables, "
@@ -366,7 +369,7 @@ def main():
         elapsed = sdist.max_over_ranks(time.perf_counter() - t0)
         seen = ranks_seen()
         if rank == 0:
-            print(json.dumps({"metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %", "value": 0.0, "unit": "points/s",
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "points/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3,
                               "higher_is_better": True, "scaling": "weak", "dry": True, "ranks_seen": seen, "backend": "gloo" if distributed else None,
                               "first_seed_of_rank0": seeds[0], "frames_per_step_per_gpu": F}), flush=True)
@@ -532,24 +535,35 @@ def main():
         dp = (child or {}).get("default_plane") or {}
         mine = [child["points_per_s"], child["points_per_s_without_src"]] if child else [n_total / inproc_s, n_total / inproc_s]
         mine += [dp.get("c_abi_points_per_s_reference", 0.0), dp.get("c_abi_points_per_s_lsq", 0.0)]
+        pk_all = (child or {}).get("packed") or {}
+        pk_key = next(iter(pk_all), None)                   # first entry: the library's default thread count
+        pk = pk_all.get(pk_key) if pk_key else None
+        mine += [pk["points_per_s"] if pk else 0.0]
         if distributed:
             tt = torch.tensor(mine, dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.SUM)
             mine = [float(v) for v in tt.tolist()]
-        pcie = {"value": mine[0], "value_without_src": mine[1], "steps": max(1, min(args.steps, 4)),
+        pcie = {"value": mine[4] if pk else mine[0], "value_rows_transfer": mine[0], "value_rows_transfer_without_src": mine[1],
+                "transfer": ("packed (snowgpu_set_result_transfer(ctx, 1, 0)): per kept row its source row | label and its intensity cross the link, "
+                             "the moved coordinates of scattered rows apart; " + str(pk_key) + " host threads of the library assemble the caller's rows "
+                             "from those and from its input rows -- same bytes in the caller's buffers as the rows transfer") if pk else "rows",
+                "packed_by_host_threads": pk_all or None,
+                "steps": max(1, min(args.steps, 4)),
                 "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
-                "bytes_per_point": {"h2d": 20, "d2h": 24, "d2h_without_src": 20},
-                "link_bound_points_per_s": PCIE_PEAK / 24.0 * world, "link_bound_points_per_s_without_src": PCIE_PEAK / 20.0 * world,
-                "frac_of_link_bound": mine[0] / (PCIE_PEAK / 24.0 * world),
-                "frac_of_link_bound_without_src": mine[1] / (PCIE_PEAK / 20.0 * world),
+                "bytes_per_point": {"h2d": 20, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
+                "link_bound_points_per_s": {"upload_20B": PCIE_PEAK / 20.0 * world, "download_rows_24B": PCIE_PEAK / 24.0 * world,
+                                            "download_rows_without_src_20B": PCIE_PEAK / 20.0 * world},
+                "frac_of_link_bound": {"packed_vs_upload_bound": (mine[4] / (PCIE_PEAK / 20.0 * world)) if pk else None,
+                                       "rows_vs_download_bound": mine[0] / (PCIE_PEAK / 24.0 * world),
+                                       "rows_without_src_vs_download_bound": mine[1] / (PCIE_PEAK / 20.0 * world)},
                 "in_process_with_pytorch": n_total / inproc_s,
-                "matches_device_entry": host_same and (child is None or child["digest"] == digest),
+                "matches_device_entry": host_same and (child is None or child["digest"] == digest) and (pk is None or bool(pk.get("same_digest_as_rows_mode"))),
                 "q8_numpy": (child or {}).get("q8_numpy"),
                 "default_plane": dp or None, "default_plane_all_ranks": {"reference": mine[2], "lsq": mine[3]} if dp else None,
                 "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
                         "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
-                        "(snowgpu_set_pipeline); ceiling = 63 GB/s per direction / 24 B per point (rows + source indices back) or / 20 B "
-                        "(out_src = NULL)"}
+                        "(snowgpu_set_pipeline); ceilings at 63 GB/s per direction: 20 B per point up; 24 B per point down with the rows "
+                        "transfer (20 with out_src = NULL), ~9.5 with the packed one, which the upload then bounds"}
         if child and rank == 0:
             single = {"c_abi_pinned": {"ms": child["single_frame_c_abi_ms"], "min_ms": child["single_frame_c_abi_min_ms"],
                                        "points_per_s": n_per / (child["single_frame_c_abi_ms"] * 1e-3)},
@@ -621,7 +635,7 @@ def main():
                 except Exception:
                     traffic = None
         result = {
-            "metric": "augmented points/s/GPU (64x2048 sweep, 2.5 mm/h); HBM roofline %",
+            "metric": METRIC,
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -652,9 +666,11 @@ def main():
                                  "(24 B per flake per channel per frame) is dropped -- frac_tables_counted keeps it (251.3 B/point on C2)"},
         }
         result["value_metric_definition"] = ("value: rows resident in HBM (device entry); SURVEY 8(d)'s metric with H2D + D2H inside the clock is "
-                                             "value_pcie_inclusive (plane injected) / value_pcie_inclusive_default_plane (plane = NULL: estimated on the device)")
+                                             "value_pcie_inclusive (packed result transfer, plane injected) / value_pcie_inclusive_rows_transfer (whole rows + "
+                                             "source indices down the link) / value_pcie_inclusive_default_plane (rows transfer, plane = NULL: estimated on the device)")
         if pcie is not None:
             result["value_pcie_inclusive"] = pcie["value"]
+            result["value_pcie_inclusive_rows_transfer"] = pcie["value_rows_transfer"]
             if pcie.get("default_plane_all_ranks"):
                 result["value_pcie_inclusive_default_plane"] = pcie["default_plane_all_ranks"]["reference"]
                 result["value_pcie_inclusive_lsq_plane"] = pcie["default_plane_all_ranks"]["lsq"]

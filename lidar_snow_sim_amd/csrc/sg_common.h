@@ -191,7 +191,7 @@ int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_
                    int32_t *frame_unsorted, void *srows, int identity_perm /* 1: perm also for sorted frames (debug tap) */, void *stream);
 // a caller-supplied permutation: the sorted copy by a plain gather, every frame flagged unsorted
 int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total, int64_t max_frame,
-                          const int32_t *perm, void *srows, int32_t *frame_unsorted, void *stream);
+                          const int32_t *perm, void *srows, int32_t *frame_unsorted, int32_t *status, void *stream);
 // direct == 1: the pass over all rows (dict hand-over to sg_launch_power); else list mode over class a->cls,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
@@ -208,6 +208,10 @@ int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *ti
                        int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
                        int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk,
                        int32_t *chunk_blk, const SgTable *tables, SgTable *resolved /* n_frames x n_las, or null */, void *stream);
+int sg_launch_segments_small(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
+                             int n_las, int n_tables, int block, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame,
+                             int32_t *seg_n, int32_t *seg_of_blk, int32_t *chunk_blk, const SgTable *tables, SgTable *resolved,
+                             unsigned long long *zero, int64_t n_zero, void *stream);
 int sg_beams_block(int lmax);
 int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out, void *stream);
 // Packed result transfer (snowgpu_set_result_transfer): what the compaction writes instead of 5-column rows -- per kept row of frame f, at
@@ -225,7 +229,7 @@ int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_
                       const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                       int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
                       int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles_per_frame,
-                      const SgPackOut *pack /* or null: rows + out_src */, void *stream);
+                      const SgPackOut *pack /* or null: rows + out_src */, unsigned long long *tiles_done /* n_frames words, zero */, void *stream);
 int sg_launch_crop_count(const void *rows, int dtype, const int64_t *frame_off, int n_frames, uint8_t *keep, int32_t *tile_cnt,
                          int32_t *tile_base, int64_t *out_counts, int64_t *stats_scratch, const SgFov *fov, int64_t max_tiles, void *stream);
 int sg_launch_crop_scatter(const void *rows, int dtype, const uint8_t *keep, const int64_t *frame_off, const int64_t *new_off,

@@ -29,7 +29,9 @@ int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int dtype, const
 // srows / frame_unsorted: optional -- the channel sort's sorted copy and the per-frame flags that say where it is valid
 int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                    int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status,
-                   void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted);
+                   void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted, int hist_cleared);
+// clears the prepass' histogram on `stream` ahead of time (independent of the batch's data): sg_prepass_run(.., hist_cleared = 1) then skips its fill
+int sg_prepass_clear_hist(SgPrepassScratch *s, int n_frames, void *stream);
 double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, int64_t max_frame);
 int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
                const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,

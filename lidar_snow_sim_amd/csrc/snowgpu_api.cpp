@@ -744,9 +744,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     hipStream_t st = b.stream;
     const bool serial = R->serial || b.serial;
     hipStream_t s_aux = serial ? st : ctx->aux, s_aux2 = serial ? st : ctx->aux2, s_aux3 = serial ? st : ctx->aux3;
-    HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));
-    HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));   // status[1] = first offending row, -1 = none
+    HIPCHK(ctx, hipMemsetAsync(b.status, 0, sizeof(int32_t) * 8, st));      // (status[1] = first offending row, -1 = none: set by the first kernel)
     if (n == 0) {
+        HIPCHK(ctx, hipMemsetAsync(b.status + 1, 0xff, sizeof(int32_t), st));
         HIPCHK(ctx, hipMemsetAsync(b.out_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
         HIPCHK(ctx, hipMemsetAsync(b.out_stats, 0, sizeof(int64_t) * 3 * (size_t)b.n_frames, st));
         if (b.pack) HIPCHK(ctx, hipMemsetAsync(b.pack->mv_counts, 0, sizeof(int64_t) * (size_t)b.n_frames, st));
@@ -775,6 +775,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         lean_part = sg_prepass_reserve_tiles(&ctx->prepass, b.n_frames, b.max_frame);
         if (!lean_part) return fail(ctx, SNOWGPU_E_HIP, "prepass: allocation");
     }
+    bool hist_early = false;
     auto launch_prepass = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
         HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
@@ -788,7 +789,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             pl = ctx->plane_est.p;
         }
         int e = sg_prepass_run(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, pl,
-                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2, fuse_stats ? 1 : 0, ctx->srows.p, ctx->frame_unsorted.p);
+                               b.noise_floor, ctx->thr_poly.p, b.status, s_aux2, fuse_stats ? 1 : 0, ctx->srows.p, ctx->frame_unsorted.p, hist_early ? 1 : 0);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
         if (b.out_thr_poly)
             HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, ctx->thr_poly.p, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, s_aux2));
@@ -799,6 +800,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (!thr) {
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
+        if (!serial) {           // the prepass' histogram fill runs on ITS stream now, beside the sort (that stream's last user was the batch before)
+            int he = sg_prepass_clear_hist(&ctx->prepass, b.n_frames, s_aux2);
+            if (he) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (he > 0 ? hipGetErrorString((hipError_t)he) : "allocation"));
+            hist_early = true;
+        }
     } else if (b.out_thr_poly) {
         HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
     }
@@ -821,7 +827,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;
     } else {
-        int e = sg_launch_gather_rows(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, perm, ctx->srows.p, ctx->frame_unsorted.p, st);
+        int e = sg_launch_gather_rows(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, b.max_frame, perm, ctx->srows.p, ctx->frame_unsorted.p, b.status, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("gather launch: ") + hipGetErrorString((hipError_t)e));
     }
     b.perm_out = const_cast<int32_t *>(perm);
@@ -846,9 +852,28 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // (The pass over all rows is ONE launch.  Cut into several, with k_power of one range beside the scan of the next, it gained
     // nothing: both are bound by the LDS their lists need, so sharing a CU only trades waves.)
     const int64_t total_blocks_ub = (b.n_total + first_block - 1) / first_block + (use_seg ? (int64_t)b.n_frames * 256 : 0);
-    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
-    {
+    // Everything this step counts up from zero lies in ONE block, cleared by one fill (each fill is a launch on the chain between
+    // the sort and the scan): per region the queue counter and the SG_MAX_CLASSES tier-list counters; per frame the intensity
+    // statistics; the tier lists' lengths, the work-item counters, the row kernels' redo counters.
+    static_assert(SG_MAX_CLASSES * sizeof(int32_t) == 2 * sizeof(unsigned long long), "a region's tier counters are two 64-bit words");
+    const size_t q_chunk = 8 * (size_t)first_block;
+    const size_t regions = std::max<size_t>((size_t)b.n_frames * 256, n / q_chunk + 2);
+    const size_t zero_words = 3 * regions + 2 * (size_t)b.n_frames + 8;      // (.. and per frame the compaction's count of finished tiles)
+    ENSURE(ctx, ctx->qn, zero_words);
+    ENSURE(ctx, ctx->tbase, SG_MAX_CLASSES * regions);
+    // A batch of up to four frames builds its segments (and clears the zero block) with ONE block on the caller's stream: no fill, no hop
+    // to the side stream and back between the sort and the scan.
+    bool seg_small = false;
+    if (use_seg) {
+        const int se = sg_launch_segments_small(b.frame_off, b.n_frames, ctx->tile_base.p, max_tiles, b.table_ids, R->h_las.n, (int)R->tables.size(), first_block,
+                                                ctx->seg_blk.p, ctx->seg_start.p, ctx->seg_cnt.p, ctx->seg_frame.p, ctx->seg_n.p, ctx->seg_of_blk.p,
+                                                ctx->chunk_blk.p, R->d_tables, ctx->frame_tables.p, ctx->qn.p, (int64_t)zero_words, st);
+        if (se > 0) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)se));
+        seg_small = se == 0;
+    }
+    if (!seg_small) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fork, 0));
         int e = 0;
         if (!use_seg) e = sg_launch_resolve_tables(R->d_tables, (int)R->tables.size(), b.table_ids, n_ft, ctx->frame_tables.p, s_aux);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("table resolve launch: ") + hipGetErrorString((hipError_t)e));
@@ -858,8 +883,8 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
                                    ctx->seg_n.p, ctx->seg_of_blk.p, ctx->chunk_blk.p, R->d_tables, ctx->frame_tables.p, s_aux);
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, s_aux));
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, s_aux));
     // 3. beams
     ENSURE(ctx, ctx->rec, n);
     ENSURE(ctx, ctx->rec_q, n);
@@ -915,27 +940,19 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->tq_sc[k], (size_t)tq_caps[k]);
     }
     // Regions of the first pass = slices of its dict queue: the segments, or plain chunks of 8 blocks in linear order.
-    a.q_chunk = 8 * first_block;
+    a.q_chunk = (int32_t)q_chunk;
     {
         const size_t planes = 3 * (size_t)tiers[0] + 2;        // range, azimuth, three values per flake
         if (n * planes * sizeof(double) > ((size_t)64 << 30))
             return fail(ctx, SNOWGPU_E_INVALID, "batch too large for the dict queue of this table density: split it");
         if (b.n_frames >= (1 << 22)) return fail(ctx, SNOWGPU_E_INVALID, "too many frames in one batch");
-        const size_t regions = std::max<size_t>((size_t)b.n_frames * 256, n / (size_t)a.q_chunk + 2);
         ENSURE(ctx, ctx->dq, (n + 64) * planes);          // blocked SoA: groups of 64 slots
         ENSURE(ctx, ctx->dq_g, n);
         ENSURE(ctx, ctx->dq_sc, n);
-        // Everything this step counts up from zero lies in ONE block, cleared by one fill (each fill is a launch on the chain between
-        // the sort and the scan): per region the queue counter and the SG_MAX_CLASSES tier-list counters; per frame the intensity
-        // statistics; the tier lists' lengths, the work-item counters, the row kernels' redo counters.
-        static_assert(SG_MAX_CLASSES * sizeof(int32_t) == 2 * sizeof(unsigned long long), "a region's tier counters are two 64-bit words");
-        const size_t zero_words = 3 * regions + (size_t)b.n_frames + 8;
-        ENSURE(ctx, ctx->qn, zero_words);
-        ENSURE(ctx, ctx->tbase, SG_MAX_CLASSES * regions);
-        HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * zero_words, st));
+        if (!seg_small) HIPCHK(ctx, hipMemsetAsync(ctx->qn.p, 0, sizeof(unsigned long long) * zero_words, st));     // (else k_seg_small cleared it)
         a.tn = (int32_t *)(ctx->qn.p + regions); a.tbase = ctx->tbase.p;
         a.diff2 = ctx->qn.p + 3 * regions;
-        int32_t *small = (int32_t *)(ctx->qn.p + 3 * regions + (size_t)b.n_frames);      // 16 ints
+        int32_t *small = (int32_t *)(ctx->qn.p + 3 * regions + (size_t)b.n_frames);      // 16 ints; behind them the compaction's per-frame tile counters
         a.tier_info = small; a.pw_count = small + 8; a.redo_cnt = small + 12;
         a.dq = ctx->dq.p; a.dq_g = ctx->dq_g.p; a.dq_sc = ctx->dq_sc.p; a.qn = ctx->qn.p; a.dq_n = b.n_total;
         const int lanes = first_block < 64 ? first_block : 64;
@@ -959,7 +976,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
     const bool few_first = a.pw_items1 && !serial && b.n_total > ((int64_t)1 << 19);
-    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    if (!seg_small) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     // measurement hooks: one event pair around the whole per-beam region
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
     if (timed) { HIPCHK(ctx, hipEventRecord(ctx->ev_start[(size_t)ctx->ev_used], st)); ctx->prof_stream = st; }
@@ -1000,11 +1017,14 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // the third on (the 63-entry and the global-list tier: few beams, long dependent chains) behind k_power on ITS stream, which is
     // free long before the 8- and 16-entry tiers are through (C2 4.41 -> 4.30 ms, C2far 9.20 -> 8.64 ms against "behind class 1").
     const bool side3 = n_cls >= 2;
-    const bool tail_aux = n_cls >= 3 && !serial;
+    // (a small batch -- no k_power_few-first schedule -- is bound by the longest chain of dependent launches: there the rare tiers go behind
+    // the 8-entry tier on the caller's stream, the shortest of the three chains in a single sweep's trace)
+    const bool tail_main = n_cls >= 3 && !serial && !few_first;
+    const bool tail_aux = n_cls >= 3 && !serial && !tail_main;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
     if (tail_aux) HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_lists, 0));
     for (int k = 0; k < n_cls && !e; ++k) {
-        hipStream_t sk = k == 0 ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
+        hipStream_t sk = (k == 0 || (tail_main && k >= 2)) ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
         a.seg_blk = nullptr;
         a.cls = k;
         if (k == n_cls - 1) {                            // the global-list tier
@@ -1050,7 +1070,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     }
     e = sg_launch_compact(b.rows, ctx->srows.p, ctx->frame_unsorted.p, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
                           ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, b.pack, st);
+                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, b.pack,
+                          b.n_total <= ((int64_t)1 << 19) ? ctx->qn.p + 3 * regions + (size_t)b.n_frames + 8 : nullptr,      // (small batches: the scan inside the count kernel)
+                          st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
 }

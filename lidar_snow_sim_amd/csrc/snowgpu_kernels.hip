@@ -78,6 +78,9 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
                                                         int32_t *__restrict__ tile_unsorted)
 {
     const int f = blockIdx.y;
+    // status[1] ("first offending row", -1 = none: nobody writes it before the per-beam kernels) is set here, so that ONE fill clears the
+    // status words of a batch instead of two (each fill is a launch on the chain of a small batch)
+    if (blockIdx.x == 0 && f == 0 && threadIdx.x == 0) status[1] = -1;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
     if (tile0 >= n) return;
@@ -244,11 +247,12 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_scatter(const T *__restrict__
 // The sorted copy for a caller-supplied permutation (no device sort): a plain gather; every frame counts as unsorted.
 template <typename T>
 __global__ __launch_bounds__(SG_BLOCK) void k_gather_rows(const T *__restrict__ rows, const int64_t *__restrict__ frame_off, const int32_t *__restrict__ perm,
-                                                          T *__restrict__ srows, int32_t *__restrict__ frame_unsorted)
+                                                          T *__restrict__ srows, int32_t *__restrict__ frame_unsorted, int32_t *__restrict__ status)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     if (blockIdx.x == 0 && threadIdx.x == 0) frame_unsorted[f] = 1;
+    if (blockIdx.x == 0 && f == 0 && threadIdx.x == 0) status[1] = -1;       // (see k_sort_hist)
     for (int64_t r = (int64_t)blockIdx.x * SG_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * SG_BLOCK) {
         const T *p = rows + (base + perm[base + r]) * 5;
         T *d = srows + (base + r) * 5;
@@ -1198,6 +1202,63 @@ __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ f
     for (int q = 0; q < nb; ++q) seg_of_blk[b0 + q] = slot;      // block -> segment: one load per block in k_beams
 }
 
+// The three kernels above as ONE block for batches of up to four frames (1024 (frame, channel) pairs) and up to SG_SEG_SMALL_TABLES
+// tables: per-table counts, their scan and the placement through LDS, and on the way the fill that clears everything the step counts up
+// from zero (`zero`, n_zero 64-bit words).  A small batch is bound by its chain of dependent launches: this is one link instead of five
+// (fill, three kernels, fill) and it runs on the caller's stream, so the scan needs no hop to a side stream and back (55 us between the
+// end of the sort and the start of the scan in a single sweep's trace, ~10 us now).  Same segments as the three kernels build (the order
+// inside a table is whatever the atomics give, there as here).
+#define SG_SEG_SMALL_TABLES 4096
+__global__ __launch_bounds__(1024) void k_seg_small(const int64_t *__restrict__ frame_off, int n_frames, const int32_t *__restrict__ tile_base,
+                                                    int64_t max_tiles, const int32_t *__restrict__ table_ids, int n_las, int n_tables, int blk,
+                                                    int64_t *__restrict__ seg_start, int32_t *__restrict__ seg_cnt, int32_t *__restrict__ seg_frame,
+                                                    int32_t *__restrict__ seg_blk, int32_t *__restrict__ seg_of_blk, int32_t *__restrict__ seg_n,
+                                                    int32_t *__restrict__ one_chunk_blk, const SgTable *__restrict__ tables, SgTable *__restrict__ resolved,
+                                                    unsigned long long *__restrict__ zero, int64_t n_zero)
+{
+    __shared__ unsigned long long cnt[SG_SEG_SMALL_TABLES + 1], sc[1024];
+    const int t = threadIdx.x, p = t;
+    for (int64_t i = t; i < n_zero; i += 1024) zero[i] = 0ull;
+    for (int i = t; i <= n_tables; i += 1024) cnt[i] = 0ull;
+    __syncthreads();
+    const bool mine = p < n_frames * 256;
+    SgPair r{};
+    int nb = 0;
+    if (mine) {
+        if ((p & 255) < n_las) {                      // table descriptor of (frame, channel)
+            const int64_t i = (int64_t)(p >> 8) * n_las + (p & 255);
+            const int id = table_ids[i];
+            SgTable d{};
+            if (id >= 0 && id < n_tables) d = tables[id];
+            resolved[i] = d;
+        }
+        r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
+        nb = (r.rows + blk - 1) / blk;
+        if (r.rows > 0) atomicAdd(&cnt[r.key], (1ull << 32) | (unsigned long long)nb);
+    }
+    __syncthreads();
+    // exclusive scan of the packed per-table counts (segments << 32 | blocks)
+    const int n = n_tables + 1, per = (n + 1023) / 1024, b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
+    unsigned long long sum = 0;
+    for (int k = b0; k < b1; ++k) sum += cnt[k];
+    sc[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const unsigned long long add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
+    unsigned long long run = sc[t] - sum;
+    for (int k = b0; k < b1; ++k) { const unsigned long long c = cnt[k]; cnt[k] = run; run += c; }     // cnt: now the table's base, bumped below as its cursor
+    if (t == 1023) {
+        seg_n[0] = (int32_t)(sc[1023] >> 32); seg_n[1] = (int32_t)(sc[1023] & 0xffffffffull);
+        one_chunk_blk[0] = 0; one_chunk_blk[1] = (int32_t)(sc[1023] & 0xffffffffull);
+    }
+    __syncthreads();
+    if (mine && r.rows > 0) {
+        const unsigned long long c = atomicAdd(&cnt[r.key], (1ull << 32) | (unsigned long long)nb);
+        const int slot = (int)(c >> 32), bb = (int)(c & 0xffffffffull);
+        seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = bb;
+        for (int q = 0; q < nb; ++q) seg_of_blk[bb + q] = slot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Output row of a sorted position, rebuilt from its ORIGINAL row and its result record (simulation.py:160-192, :516):
 // unchanged rows keep their coordinates and get np.round(intensity); attenuated rows (label 1) the new intensity; scattered
@@ -1244,6 +1305,43 @@ __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, do
     return u >= 0 && u < v.img_w && w >= 0 && w < v.img_h && depth >= 0;
 }
 
+// per frame: tile offsets of the kept rows and the statistics (simulation.py:522-530).  diff2 (per frame: twice the intensity-
+// difference sum of the attenuated beams, final once the per-beam kernels are through) may be null: the pre-augment crop has none.
+// One thread; tile_cnt / tile_mv may have been written by other blocks of the running launch (k_compact_count's last block): read past the L1.
+__device__ __forceinline__ void sg_compact_scan_frame(int f, int64_t n, const int32_t *tile_cnt, int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
+                                                      int64_t *__restrict__ out_stats, const unsigned long long *diff2, int64_t max_tiles,
+                                                      const int32_t *tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
+{
+    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    const volatile int32_t *vc = tile_cnt, *vm = tile_mv;
+    int run = 0, mrun = 0;
+    int64_t att = 0;
+    for (int64_t t = 0; t < tiles; ++t) {        // <= a few hundred tiles per frame: a serial scan is fine
+        const int c = vc[(int64_t)f * max_tiles + t];
+        tile_base[(int64_t)f * max_tiles + t] = run;
+        run += c & 0xffff;
+        att += c >> 16;
+        if (tile_mv) { tile_mv_base[(int64_t)f * max_tiles + t] = mrun; mrun += vm[(int64_t)f * max_tiles + t]; }
+    }
+    if (out_mv_counts) out_mv_counts[f] = mrun;
+    out_counts[f] = run;
+    out_stats[f * 3 + 0] = att;              // num_attenuated (:525)
+    out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522, + the camera crop :538)
+    const double diff_sum = diff2 ? (double)(long long)((const volatile unsigned long long *)diff2)[f] / 2.0 : 0.0;
+    out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // :527-530 int()
+}
+
+__global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
+                                                           const int32_t *__restrict__ tile_cnt,
+                                                           int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
+                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles,
+                                                           const int32_t *__restrict__ tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x == 0)
+        sg_compact_scan_frame(f, frame_off[f + 1] - frame_off[f], tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
+}
+
 // Stable compaction of kept rows, per frame.  keep byte: bit 0 = row is in the output, bit 1 = row passed the noise filter
 // (num_attenuated counts those, before the camera crop: simulation.py:525 precedes :532-540).
 template <typename T>
@@ -1251,12 +1349,21 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
                                                             const uint32_t *__restrict__ rec,
                                                             const uint32_t *__restrict__ rec_q, const T *__restrict__ rng, const double *__restrict__ thr_poly,
                                                             uint8_t *__restrict__ keep, const int64_t *__restrict__ frame_off,
-                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov, int32_t *__restrict__ tile_mv)
+                                                            int32_t *__restrict__ tile_cnt, int64_t max_tiles, SgFov fov, int32_t *__restrict__ tile_mv,
+                                                            unsigned long long *__restrict__ tiles_done, int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
+                                                            int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2,
+                                                            int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
 {
     const int f = blockIdx.y;
     const int64_t base = frame_off[f], n = frame_off[f + 1] - base;
     const int64_t tile0 = (int64_t)blockIdx.x * SG_TILE;
-    if (tile0 >= n) return;
+    if (tile0 >= n) {
+        if (tiles_done && blockIdx.x == 0 && threadIdx.x == 0) {       // an empty frame has no tile to complete it: its counts here
+            out_counts[f] = 0; out_stats[f * 3 + 0] = 0; out_stats[f * 3 + 1] = 0; out_stats[f * 3 + 2] = 0;
+            if (out_mv_counts) out_mv_counts[f] = 0;
+        }
+        return;
+    }
     const T *rows = frame_unsorted[f] ? srows : rows_in;            // sorted position g = row g (see k_sort_scatter)
     const double p0 = thr_poly[(int64_t)f * 3], p1 = thr_poly[(int64_t)f * 3 + 1], p2 = thr_poly[(int64_t)f * 3 + 2];
     int c = 0, mv = 0;                               // mv: kept rows with label 2 (packed result transfer: their coordinates travel apart)
@@ -1302,36 +1409,17 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
     if (threadIdx.x == 0) {
         tile_cnt[(int64_t)f * max_tiles + blockIdx.x] = s[0] + s[1] + s[2] + s[3];   // kept | attenuated << 16 (a tile has 1024 rows)
         if (tile_mv) tile_mv[(int64_t)f * max_tiles + blockIdx.x] = s2[0] + s2[1] + s2[2] + s2[3];
-    }
-}
-
-// per frame: tile offsets of the kept rows and the statistics (simulation.py:522-530).  diff2 (per frame: twice the intensity-
-// difference sum of the attenuated beams, final once the per-beam kernels are through) may be null: the pre-augment crop has none.
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
-                                                           const int32_t *__restrict__ tile_cnt,
-                                                           int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
-                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles,
-                                                           const int32_t *__restrict__ tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
-{
-    const int f = blockIdx.x;
-    const int64_t n = frame_off[f + 1] - frame_off[f];
-    const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    if (threadIdx.x == 0) {                      // <= a few hundred tiles per frame: a serial scan is fine
-        int run = 0, mrun = 0;
-        int64_t att = 0;
-        for (int64_t t = 0; t < tiles; ++t) {
-            const int c = tile_cnt[(int64_t)f * max_tiles + t];
-            tile_base[(int64_t)f * max_tiles + t] = run;
-            run += c & 0xffff;
-            att += c >> 16;
-            if (tile_mv) { tile_mv_base[(int64_t)f * max_tiles + t] = mrun; mrun += tile_mv[(int64_t)f * max_tiles + t]; }
+        // Small batches (tiles_done != null): the block that completes a frame scans its tiles -- what k_compact_scan does as a launch of its
+        // own: one link less on the chain.  Not for large batches: the device-scope fence this needs writes back the L2 of the block's XCD
+        // (eight XCDs, eight L2s), and 32 768 of them made this kernel 1.37 ms long on 256 sweeps instead of 0.15.
+        if (tiles_done) {
+            __threadfence();
+            const unsigned long long tiles = (unsigned long long)((n + SG_TILE - 1) / SG_TILE);
+            if (atomicAdd(&tiles_done[f], 1ull) == tiles - 1) {
+                __threadfence();
+                sg_compact_scan_frame(f, n, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
+            }
         }
-        if (out_mv_counts) out_mv_counts[f] = mrun;
-        out_counts[f] = run;
-        out_stats[f * 3 + 0] = att;              // num_attenuated (:525)
-        out_stats[f * 3 + 1] = n - run;          // num_removed (simulation.py:522, + the camera crop :538)
-        const double diff_sum = diff2 ? (double)(long long)diff2[f] / 2.0 : 0.0;
-        out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // :527-530 int()
     }
 }
 
@@ -1547,14 +1635,14 @@ extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_
 }
 
 extern "C" int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total, int64_t max_frame,
-                                     const int32_t *perm, void *srows, int32_t *frame_unsorted, void *stream)
+                                     const int32_t *perm, void *srows, int32_t *frame_unsorted, int32_t *status, void *stream)
 {
     (void)n_total;
     if (n_frames <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((max_frame + SG_BLOCK - 1) / SG_BLOCK, 256)), (unsigned)n_frames);
-    if (dtype == 0) hipLaunchKernelGGL(k_gather_rows<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, perm, (float *)srows, frame_unsorted);
-    else hipLaunchKernelGGL(k_gather_rows<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, perm, (double *)srows, frame_unsorted);
+    if (dtype == 0) hipLaunchKernelGGL(k_gather_rows<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, perm, (float *)srows, frame_unsorted, status);
+    else hipLaunchKernelGGL(k_gather_rows<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, perm, (double *)srows, frame_unsorted, status);
     SG_CHECK_LAUNCH();
     return 0;
 }
@@ -1758,6 +1846,19 @@ extern "C" int sg_launch_huge(const SgBeamArgs *a, int dtype, void *stream)
     return 0;
 }
 
+// the same for a small batch (see k_seg_small); returns -1 if the batch is not small (nothing launched)
+extern "C" int sg_launch_segments_small(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
+                                        int n_las, int n_tables, int block, int32_t *seg_blk, int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame,
+                                        int32_t *seg_n, int32_t *seg_of_blk, int32_t *chunk_blk, const SgTable *tables, SgTable *resolved,
+                                        unsigned long long *zero, int64_t n_zero, void *stream)
+{
+    if (n_frames * 256 > 1024 || n_tables + 1 > SG_SEG_SMALL_TABLES || n_zero > (1 << 16)) return -1;
+    hipLaunchKernelGGL(k_seg_small, dim3(1), dim3(1024), 0, (hipStream_t)stream, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block,
+                       seg_start, seg_cnt, seg_frame, seg_blk, seg_of_blk, seg_n, chunk_blk, tables, resolved, zero, n_zero);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const int32_t *tile_base, int64_t max_tiles, const int32_t *table_ids,
                                   int n_las, int n_tables, int block, unsigned long long *tbl_cnt, unsigned long long *tbl_base, int32_t *seg_blk,
                                   int64_t *seg_start, int32_t *seg_cnt, int32_t *seg_frame, int32_t *seg_n, int32_t *seg_of_blk,
@@ -1780,7 +1881,8 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
 extern "C" int sg_launch_compact(const void *rows, const void *srows, const int32_t *frame_unsorted, int dtype, const uint32_t *rec, const uint32_t *rec_q, const void *rng, const double *thr_poly, uint8_t *keep, const int32_t *perm,
                                  const int64_t *frame_off, int n_frames, int64_t n_total, int32_t *tile_cnt,
                                  int32_t *tile_base, void *out_rows, int32_t *out_src, int64_t *out_counts,
-                                 int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, const SgPackOut *pack, void *stream)
+                                 int64_t *out_stats, const unsigned long long *diff2, const SgFov *fov, int64_t max_tiles, const SgPackOut *pack,
+                                 unsigned long long *tiles_done /* n_frames words, zero */, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
@@ -1788,12 +1890,18 @@ extern "C" int sg_launch_compact(const void *rows, const void *srows, const int3
     SgFov fv{};
     if (fov) fv = *fov;
     int32_t *tile_mv = pack ? pack->tile_mv : nullptr;
-    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, (const float *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv);
-    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, (const double *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv);
+    int32_t *tmb = pack ? pack->tile_mv_base : nullptr;
+    int64_t *mvc = pack ? pack->mv_counts : nullptr;
+    if (dtype == 0) hipLaunchKernelGGL(k_compact_count<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, (const float *)srows, frame_unsorted, rec, rec_q, (const float *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv,
+                                       tiles_done, tile_base, out_counts, out_stats, diff2, tmb, mvc);
+    else hipLaunchKernelGGL(k_compact_count<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, (const double *)srows, frame_unsorted, rec, rec_q, (const double *)rng, thr_poly, keep, frame_off, tile_cnt, max_tiles, fv, tile_mv,
+                            tiles_done, tile_base, out_counts, out_stats, diff2, tmb, mvc);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles,
-                       (const int32_t *)tile_mv, pack ? pack->tile_mv_base : (int32_t *)nullptr, pack ? pack->mv_counts : (int64_t *)nullptr);
-    SG_CHECK_LAUNCH();
+    if (!tiles_done) {
+        hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles,
+                           (const int32_t *)tile_mv, tmb, mvc);
+        SG_CHECK_LAUNCH();
+    }
     SgPack pk{};
     if (pack) { pk.meta = pack->meta; pk.inten = pack->inten; pk.mv = pack->mv; pk.tile_mv_base = pack->tile_mv_base; pk.mv_counts = pack->mv_counts; }
     if (dtype == 0) {

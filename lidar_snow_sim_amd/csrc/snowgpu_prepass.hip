@@ -34,6 +34,7 @@ struct PreFrame {          // per-frame state shared by the kernels
     // wet model, estimation_method = 'poly' (augmentation.py:223-229, :243-246): quadratics in range instead of the two lines
     double pq[3];          // np.polyfit(dist, normalised, 2)
     double mq[3];          // ransac_polyfit(x, min_vals, order=2)
+    int32_t rows_done;     // lean chain: histogram rows whose minimum has been taken (k_lean_rowmin_solve: the block that completes the frame fits its lines)
     int32_t quad;          // 1: k_wet_apply evaluates pq / mq
     int32_t ransac_trial;  // the trial whose consensus refit was kept (-1: the fit over all points)
     int32_t unchanged;     // wet path: < 1000 ground rows (augmentation.py:51-52)
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(64) void k_lean_means(PreArgs a, int min_ground, in
         fr.ymax = fabs(ym);                                              // np.abs(np.max(...)), augmentation.py:233
         fr.unchanged = 0;
         fr.sxx = mxx; fr.sxy = mxy;
+        fr.rows_done = 0;
         for (int k = 0; k < 11; ++k) fr.q[k] = q[k];
         if (cnt < (double)min_ground) {
             if (err_code) atomicCAS(&a.status[0], 0, err_code);          // TypeError in the reference (Q7)
@@ -865,7 +867,7 @@ __device__ __forceinline__ void lean_lines_frame(const PreArgs &a, int f, int xm
     int m = 0;
     const double xstep = (70.0 - 10.0) / HX;
     for (int r = 0; r < HX; ++r) {
-        const double mv = a.rowmin[(int64_t)f * HX + r];
+        const double mv = ((const volatile double *)a.rowmin)[(int64_t)f * HX + r];   // (written by other blocks of this launch in k_lean_rowmin_solve: past the L1)
         if (mv > 5) {                                                    // augmentation.py:238
             const double e0 = (double)r * xstep + 10.0;
             const double e1 = (r + 1 == HX) ? 70.0 : (double)(r + 1) * xstep + 10.0;
@@ -961,7 +963,7 @@ __device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
 }
 
-// lines and (unless the frame needs NumPy's float32 mean first) the quadratic, one thread per frame, after k_pre_rowmin
+// lines and (unless the frame needs NumPy's float32 mean first) the quadratic, one thread per frame, after k_pre_rowmin (large batches)
 __global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f32, double *thr_poly)
 {
     const int f = blockIdx.x * 64 + threadIdx.x;
@@ -970,35 +972,42 @@ __global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f3
     if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
 }
 
-// Row minima of the frame's histogram, the two lines, and -- unless the frame needs NumPy's float32 mean first (k_lean_gather,
-// k_lean_mean32_solve) -- the quadratic: one block per frame instead of three launches (rowmin / lines / solve) in the chain of
-// dependent launches a small batch is bound by.  16 waves: wave w takes histogram rows w, w + 16, ...
-__global__ __launch_bounds__(1024) void k_lean_finish(PreArgs a, int xmean_f32, double *thr_poly)
+// Small batches (up to 16 frames: bound by their chain of dependent launches): row minima of a frame's histogram (one block per range
+// row: 50 per frame) and -- by whichever block completes the frame -- the two lines and, unless the frame needs NumPy's float32 mean
+// first (k_lean_gather, k_pre_mean32), the quadratic, in ONE launch (a single 1024-thread block per frame did this before: 78 us of a
+// single sweep's 460, the longest link of its prepass chain).  Large batches keep k_pre_rowmin + k_lean_lines_solve: "the block that
+// completes the frame" costs a device-scope fence per block, and on this chip -- eight XCDs, each with its own L2 -- such a fence writes
+// the XCD's L2 back: 12 800 of them made this kernel 0.74 ms long on 256 sweeps, against 0.10 ms for the two launches.
+__global__ __launch_bounds__(PB) void k_lean_rowmin_solve(PreArgs a, int xmean_f32, double *thr_poly)
 {
-    const int f = blockIdx.x;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const PreFrame &fr = a.fr[f];
+    const int f = blockIdx.y, row = blockIdx.x;
+    const int32_t *h = a.hist + ((int64_t)f * HX + row) * HY;
+    PreFrame &fr = a.fr[f];
     const int ng = (int)fr.n_ground;
-    const double step = (fr.ymax - 5.0) / HY;
-    for (int row = wv; row < HX; row += 16) {
-        const int32_t *h = a.hist + ((int64_t)f * HX + row) * HY;
-        int best = 0x7fffffff, bidx = 0x7fffffff;
-        for (int b = lane; b < HY; b += 64) {
-            int c = h[b];
-            if (c == 0) c = ng;                                              // hist[hist == 0] = len(ground) (augmentation.py:234-235)
-            if (c < best) { best = c; bidx = b; }                            // ascending b per lane: first minimum
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            const int ob = __shfl_xor(best, o), oi = __shfl_xor(bidx, o);
-            if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
-        }
-        if (lane == 0) a.rowmin[(int64_t)f * HX + row] = (bidx == HY) ? fr.ymax : (double)bidx * step + 5.0;   // yedges[ymins] (:237)
+    int best = 0x7fffffff, bidx = 0x7fffffff;
+    for (int b = threadIdx.x; b < HY; b += PB) {
+        int c = h[b];
+        if (c == 0) c = ng;                                                  // hist[hist == 0] = len(ground) (augmentation.py:234-235)
+        if (c < best) { best = c; bidx = b; }                                // ascending b per thread: first minimum
     }
-    __threadfence_block();
+    for (int o = 32; o > 0; o >>= 1) {
+        const int ob = __shfl_down(best, o), oi = __shfl_down(bidx, o);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    __shared__ int sb[4], si[4];
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bidx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        lean_lines_frame(a, f, xmean_f32);
-        if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
+        for (int w = 1; w < 4; ++w)
+            if (sb[w] < best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
+        const double step = (fr.ymax - 5.0) / HY;
+        a.rowmin[(int64_t)f * HX + row] = (bidx == HY) ? fr.ymax : (double)bidx * step + 5.0;   // yedges[ymins] (:237)
+        __threadfence();                                                     // the row's minimum before the count that announces it
+        if (atomicAdd(&fr.rows_done, 1) == HX - 1) {                         // this block completed the frame
+            __threadfence();
+            lean_lines_frame(a, f, xmean_f32);
+            if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
+        }
     }
 }
 
@@ -1256,9 +1265,19 @@ extern "C" double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, i
     return (double *)s->buf[B_PART];
 }
 
+// The histogram of the snowfall prepass, cleared ahead of time: the fill depends on nothing of the batch, so it can run on the prepass
+// stream beside the sort instead of in the prepass' own chain (sg_prepass_run is then told with hist_cleared = 1).
+extern "C" int sg_prepass_clear_hist(SgPrepassScratch *s, int n_frames, void *stream)
+{
+    const size_t nf = (size_t)n_frames;
+    if (ensure(s, B_HIST, nf * HX * HY * 4)) return -1;
+    hipError_t e = hipMemsetAsync(s->buf[B_HIST], 0, nf * HX * HY * 4, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                     int64_t max_frame, const double *plane, double noise_floor, double *thr_poly, int32_t *status, hipStream_t st,
-                    bool tiles_done, const void *srows, const int32_t *frame_unsorted)
+                    bool tiles_done, const void *srows, const int32_t *frame_unsorted, bool hist_cleared)
 {
     PreArgs a{};
     a.rows = rows; a.srows = srows; a.frame_unsorted = srows ? frame_unsorted : nullptr; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
@@ -1271,8 +1290,10 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
         return -1;
     a.part = (double *)s->buf[B_PART]; a.hist = (int32_t *)s->buf[B_HIST]; a.rowmin = (double *)s->buf[B_ROWMIN];
     a.fr = (PreFrame *)s->buf[B_FRAME]; a.cdist = (float *)s->buf[B_CDIST];
-    hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
-    if (e != hipSuccess) return (int)e;
+    if (!hist_cleared) {
+        hipError_t e = hipMemsetAsync(a.hist, 0, nf * HX * HY * 4, st);
+        if (e != hipSuccess) return (int)e;
+    }
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     if (!tiles_done) {                               // (else the channel sort's first kernel left the tile partials on its way over the rows)
         if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, st, a);
@@ -1284,10 +1305,10 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     if (dtype == 0) hipLaunchKernelGGL(k_lean_hist<float>, grid, dim3(PB), 0, st, a);
     else hipLaunchKernelGGL(k_lean_hist<double>, grid, dim3(PB), 0, st, a);
     LCHK();
-    if (n_frames <= 16) {        // small batches are bound by their chain of dependent launches: row minima, lines and quadratic in one
-        hipLaunchKernelGGL(k_lean_finish, dim3((unsigned)n_frames), dim3(1024), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
+    if (n_frames <= 16) {
+        hipLaunchKernelGGL(k_lean_rowmin_solve, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
         LCHK();
-    } else {                     // large ones by throughput: 50 blocks per frame read the histogram (one block per frame took 0.9 ms of a 256-sweep step)
+    } else {
         hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
         LCHK();
         hipLaunchKernelGGL(k_lean_lines_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
@@ -1388,10 +1409,10 @@ extern "C" int sg_prepass_stats_run(SgPrepassScratch *s, const void *rows, int d
 
 extern "C" int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames,
                               int64_t n_total, int64_t max_frame, const double *plane, double noise_floor, double *thr_poly,
-                              int32_t *status, void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted)
+                              int32_t *status, void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted, int hist_cleared)
 {
     return lean_run(s, rows, dtype, frame_off, n_frames, n_total, max_frame, plane, noise_floor, thr_poly, status, (hipStream_t)stream, tiles_done != 0,
-                    srows, frame_unsorted);
+                    srows, frame_unsorted, hist_cleared != 0);
 }
 
 extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,

@@ -150,7 +150,8 @@ def test_fewer_than_three_strip_rows_give_the_flat_earth_plane_whatever_min_rows
     frames = []
     for k in (0, 1, 2, 3):
         f = pc.copy()
-        f[:k, :3] = [[20 + 7 * i, 0.5 * i, -1.7 - 0.01 * i] for i in range(k)]   # ... except k rows
+        for i in range(k):
+            f[i, :3] = (20 + 7 * i, 0.5 * i, -1.7 - 0.01 * i)                # ... except k rows
         frames.append(f)
     rows = np.concatenate(frames)
     off = np.arange(5) * pc.shape[0]
