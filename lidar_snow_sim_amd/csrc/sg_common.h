@@ -188,7 +188,8 @@ extern "C" {
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, int32_t *tile_unsorted,
-                   int32_t *frame_unsorted, void *srows, int identity_perm /* 1: perm also for sorted frames (debug tap) */, void *stream);
+                   int32_t *frame_unsorted, void *srows, int identity_perm /* 1: perm also for sorted frames (debug tap) */,
+                   int phase /* 1: histogram + per-frame scan; 2: second pass (sorted copy + perm of unsorted frames); 3: both */, void *stream);
 // a caller-supplied permutation: the sorted copy by a plain gather, every frame flagged unsorted
 int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total, int64_t max_frame,
                           const int32_t *perm, void *srows, int32_t *frame_unsorted, int32_t *status, void *stream);

@@ -821,9 +821,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->rank, n);
         ENSURE(ctx, ctx->perm, n);
         ENSURE(ctx, ctx->keep, n);                // channel bytes between the two sort passes; flag / keep bytes afterwards
+        // (first pass and per-frame scan here; the second pass -- the sorted copy of unsorted frames -- further down, so that the segment
+        // builder, which needs the scan only, runs on its side stream beside it)
         int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
                                ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, fuse_stats ? early_plane : nullptr, lean_part,
-                               ctx->tile_unsorted.p, ctx->frame_unsorted.p, ctx->srows.p, b.want_perm ? 1 : 0, st);
+                               ctx->tile_unsorted.p, ctx->frame_unsorted.p, ctx->srows.p, b.want_perm ? 1 : 0, 1, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;
     } else {
@@ -884,6 +886,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("segment launch: ") + hipGetErrorString((hipError_t)e));
         }
         HIPCHK(ctx, hipEventRecord(ctx->ev_join, s_aux));
+    }
+    if (!b.perm) {
+        int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
+                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, nullptr, nullptr,
+                               ctx->tile_unsorted.p, ctx->frame_unsorted.p, ctx->srows.p, b.want_perm ? 1 : 0, 2, st);
+        if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
     }
     // 3. beams
     ENSURE(ctx, ctx->rec, n);
@@ -1004,6 +1012,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
             // the tiers, the prepass and k_power do better behind it than beside it (measured: 4.37 against 4.69 ms per 256 sweeps when
             // they all start together; the other way round for a single sweep, where nothing fills anything).
+            // k_tier_gather stays BEHIND this wait although it needs nothing of k_power_few: with it ahead the tiers and the prepass start
+            // the moment k_power_few ends, together with k_power<4>, and take the CUs its persistent blocks would have taken -- 4.43 - 4.49
+            // against 4.22 - 4.24 ms per step on one box (round 5); the 30 us it costs give k_power<4> its head start.
             if (few_first) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
             e = sg_launch_tier_gather(&a, st);
         }

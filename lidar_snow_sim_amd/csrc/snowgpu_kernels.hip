@@ -1611,13 +1611,14 @@ extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, con
 extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                               int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                               int64_t max_tiles, const double *lean_plane, double *lean_part, int32_t *tile_unsorted, int32_t *frame_unsorted,
-                              void *srows, int identity_perm, void *stream)
+                              void *srows, int identity_perm, int phase /* 1: histogram + scan; 2: scatter; 3: both */, void *stream)
 {
     (void)n_total;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
     SgLeanTile lt{};
     lt.plane = lean_plane; lt.delta = 0.5; lt.part = lean_part; lt.max_tiles = max_tiles;
+    if (!(phase & 1)) goto scatter;
     if (lean_plane && lean_part) {
         if (dtype == 0) hipLaunchKernelGGL((k_sort_hist<float, true>), grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
         else hipLaunchKernelGGL((k_sort_hist<double, true>), grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, tile_hist, rank, ch8, status, max_tiles, lt, tile_unsorted);
@@ -1628,6 +1629,8 @@ extern "C" int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_
     SG_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_sort_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_hist, tile_base, max_tiles, tile_unsorted, frame_unsorted);
     SG_CHECK_LAUNCH();
+scatter:
+    if (!(phase & 2)) return 0;
     if (dtype == 0) hipLaunchKernelGGL(k_sort_scatter<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, ch8, frame_off, tile_hist, tile_base, rank, perm, (float *)srows, frame_unsorted, identity_perm, max_tiles);
     else hipLaunchKernelGGL(k_sort_scatter<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, ch8, frame_off, tile_hist, tile_base, rank, perm, (double *)srows, frame_unsorted, identity_perm, max_tiles);
     SG_CHECK_LAUNCH();
