@@ -549,6 +549,7 @@ def main():
                              "from those and from its input rows -- same bytes in the caller's buffers as the rows transfer") if pk else "rows",
                 "packed_by_host_threads": pk_all or None,
                 "steps": max(1, min(args.steps, 4)),
+                "process_affinity": (child or {}).get("process_affinity"),
                 "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
                 "bytes_per_point": {"h2d": 20, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
                 "link_bound_points_per_s": {"upload_20B": PCIE_PEAK / 20.0 * world, "download_rows_24B": PCIE_PEAK / 24.0 * world,

@@ -5,6 +5,8 @@
 #include <dlfcn.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -55,25 +57,15 @@ template <typename T> struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
-// The CPUs of the NUMA node a device hangs on (sysfs: the PCI device's numa_node, the node's cpulist), intersected with the CPUs this
-// process may use; false if anything is missing.  The threads that copy rows between page-locked buffers stay on that node: on a
-// two-socket host the other socket's cores reach that memory at a fraction of the speed (measured: 1.4 - 2.2 G points/s from run to run
-// with free-roaming threads).
-static bool device_node_cpus(int device, cpu_set_t *out)
+// NUMA placement of the host threads that copy rows (packed result transfer).  On a two-socket host a core reaches the other socket's
+// memory at a fraction of the speed: with free-roaming threads the same call gave 1.4 - 2.2 G points/s from run to run, with the threads
+// on the wrong node 1.3, on the right one 2.3.  The right one is where the caller's row buffers live (asked of the kernel per call:
+// get_mempolicy on their first pages); if that cannot be told -- a container may forbid the call -- the node the device hangs on.
+static bool cpus_of_node(int node, cpu_set_t *out)
 {
-    char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return false; }
-    for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
-    char path[256];
-    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
-    FILE *fh = std::fopen(path, "r");
-    if (!fh) return false;
-    int node = -1;
-    const int got = std::fscanf(fh, "%d", &node);
-    std::fclose(fh);
-    if (got != 1 || node < 0) return false;
+    char path[128];
     std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
-    fh = std::fopen(path, "r");
+    FILE *fh = std::fopen(path, "r");
     if (!fh) return false;
     char list[4096] = {0};
     const bool ok = std::fgets(list, (int)sizeof list, fh) != nullptr;
@@ -88,12 +80,36 @@ static bool device_node_cpus(int device, cpu_set_t *out)
         if (end == p) break;
         if (*end == '-') { p = end + 1; b = std::strtol(p, &end, 10); }
         for (long c = a; c <= b && c < CPU_SETSIZE; ++c) if (CPU_ISSET((int)c, &allowed)) CPU_SET((int)c, &node_set);
-        p = (*end == ',') ? end + 1 : end;
-        if (*end != ',' ) break;
+        if (*end != ',') break;
+        p = end + 1;
     }
     if (CPU_COUNT(&node_set) == 0) return false;
     *out = node_set;
     return true;
+}
+
+static int node_of_device(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char *c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    char path[256];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *fh = std::fopen(path, "r");
+    if (!fh) return -1;
+    int node = -1;
+    const int got = std::fscanf(fh, "%d", &node);
+    std::fclose(fh);
+    return got == 1 ? node : -1;
+}
+
+static int node_of_address(const void *p)
+{
+    if (!p) return -1;
+    int node = -1;
+    // get_mempolicy(&node, NULL, 0, addr, MPOL_F_NODE | MPOL_F_ADDR): the node of the page that holds addr
+    const long rc = syscall(SYS_get_mempolicy, &node, nullptr, 0UL, const_cast<void *>(p), 1UL /* MPOL_F_NODE */ | 2UL /* MPOL_F_ADDR */);
+    return rc == 0 ? node : -1;
 }
 
 // Host threads that put output rows together in the packed result transfer (snowgpu_set_result_transfer): plain copies, no arithmetic.
@@ -104,11 +120,22 @@ struct AsmPool {
     std::deque<std::function<void()>> q;
     size_t pending = 0;
     bool stop = false;
-    void start(int n, const cpu_set_t *cpus)
+    cpu_set_t want{};                 // where the threads should run (set_node), applied by each thread before its next job
+    std::atomic<int> want_gen{0};
+    int node = -2;
+    void set_node(int nd)
+    {
+        if (nd == node) return;
+        cpu_set_t c;
+        if (nd < 0 || !cpus_of_node(nd, &c)) return;
+        { std::lock_guard<std::mutex> lk(mu); want = c; node = nd; }
+        want_gen.fetch_add(1);
+    }
+    void start(int n)
     {
         for (int i = 0; i < n; ++i)
-            threads.emplace_back([this, cpus_copy = cpus ? *cpus : cpu_set_t{}, pin = cpus != nullptr]() {
-                if (pin) (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &cpus_copy);      // (best effort)
+            threads.emplace_back([this]() {
+                int seen = 0;
                 for (;;) {
                     std::function<void()> job;
                     {
@@ -117,6 +144,10 @@ struct AsmPool {
                         if (q.empty()) return;
                         job = std::move(q.front());
                         q.pop_front();
+                        if (seen != want_gen.load()) {      // (best effort: a forbidden call leaves the thread where it is)
+                            seen = want_gen.load();
+                            (void)pthread_setaffinity_np(pthread_self(), sizeof(cpu_set_t), &want);
+                        }
                     }
                     job();
                     {
@@ -1233,9 +1264,13 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
                 n_thr = std::max(1, std::min(8, avail - 2));      // (eight copy at the pace of the link: measured 6 .. 14 threads, 2.25 - 2.31 G points/s)
             }
             ctx->pool = new AsmPool();
-            cpu_set_t node_cpus;
-            const bool have_node = device_node_cpus(ctx->device, &node_cpus);
-            ctx->pool->start(n_thr, have_node ? &node_cpus : nullptr);
+            ctx->pool->start(n_thr);
+        }
+        {   // the threads go where the rows they copy live (see node_of_address); the device's node if that cannot be told
+            const int n_in = node_of_address(rows), n_out = node_of_address(out_rows);
+            int nd = (n_out >= 0) ? n_out : n_in;
+            if (nd < 0) nd = node_of_device(ctx->device);
+            ctx->pool->set_node(nd);
         }
     } else {
         ENSURE(ctx, ctx->rows_out, std::max<size_t>((size_t)n_total * rb, 8));

@@ -18,6 +18,29 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 
 
+def pin_to_device_node(device):
+    """sched_setaffinity to the CPUs of the NUMA node of HIP device `device` (sysfs; rocm-smi order = /sys/class/drm/card* order is NOT assumed:
+    the node is the same for all GPUs of a socket, and a one-GPU box has one).  Returns the CPU list used, or None."""
+    import glob
+    import os
+    try:
+        nodes = sorted({int(open(p).read()) for p in glob.glob("/sys/class/drm/card*/device/numa_node")})
+        nodes = [n for n in nodes if n >= 0]
+        if len(nodes) != 1:
+            return None                                # several sockets hold GPUs (or none is reported): leave the placement to the launcher
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{nodes[0]}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return f"node {nodes[0]}: {len(cpus)} cpus"
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=256)
@@ -26,7 +49,13 @@ def main():
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--seed-base", type=int, default=1000)
     ap.add_argument("--fast", action="store_true", help="the two headline figures only (A/B runs)")
+    ap.add_argument("--numa", default="device", choices=("device", "none"),
+                    help="device (default): run on the CPUs of the NUMA node the GPU hangs on, as a launcher would place a rank (numactl): on a "
+                         "two-socket host page-locked buffers touched from the far socket cost the packed transfer a quarter of its rate")
     args = ap.parse_args()
+    affinity = None
+    if args.numa == "device":
+        affinity = pin_to_device_node(args.device)
     import bench                      # helpers only: bench.py imports torch lazily, inside main()
     assert "torch" not in sys.modules
     import random
@@ -91,7 +120,7 @@ def main():
         finally:
             eng.ctx.set_result_transfer("rows")
     if args.fast:
-        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc, "packed": packed}))
+        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc, "packed": packed, "process_affinity": affinity}))
         return
     # plane = NULL at the C ABI: calculate_plane (simulation.py:449) on the device inside the batch -- the reference's default call
     s_ref, _ = timed(True, "device")                                     # method 'reference': the plane the reference returns today
@@ -159,7 +188,7 @@ def main():
     pyl_ms, pyl_min = med(one_py_lsq)
     print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_best": n_total / b_src, "points_per_s_without_src": n_total / s_nosrc,
                       "points_per_s_without_src_best": n_total / b_nosrc, "frames": F, "reps": args.reps, "points_per_frame": n_per,
-                      "digest": digest, "packed": packed, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
+                      "digest": digest, "packed": packed, "process_affinity": affinity, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
                       "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules,
                       "default_plane": {"c_abi_points_per_s_reference": n_total / s_ref, "c_abi_points_per_s_lsq": n_total / s_lsq,
                                         "python_points_per_s_injected": n_total / py_inj, "python_points_per_s_reference": n_total / py_ref,

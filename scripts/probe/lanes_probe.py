@@ -92,11 +92,12 @@ def main():
             p.close()
         return n
 
-    ns = os.environ.get("SNOWGPU_X_STREAMS", "4")
-    d0 = run(f"one_batch_{ns}streams_ms", [(0, F)], False)
-    run(f"two_batches_{ns}streams_ms_per_batch", [(0, F), (0, F)], False, 2.0)
-    run(f"two_halves_{ns}streams_ms", [(0, F // 2), (F // 2, F)], False)
+    d0 = run("one_batch_4streams_ms", [(0, F)], False)
+    run("one_batch_serial_ms", [(0, F)], True)
+    run("two_halves_serial_ms", [(0, F // 2), (F // 2, F)], True)
     run("two_batches_serial_ms_per_batch", [(0, F), (0, F)], True, 2.0)
+    run("two_halves_4streams_each_ms", [(0, F // 2), (F // 2, F)], False)
+    run("two_batches_4streams_each_ms_per_batch", [(0, F), (0, F)], False, 2.0)
     print(json.dumps(res))
 
 
