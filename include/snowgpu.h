@@ -123,6 +123,9 @@ int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio,
  * rows == NULL (resident rows) and single-chunk batches always use mode 0.
  */
 int snowgpu_set_result_transfer(snowgpu_ctx *ctx, int mode, int threads);
+/* NUMA node HIP device `device` hangs on (sysfs, by PCI bus id), or -1 if it cannot be told: a launcher that runs one process per GPU should
+ * start it on that node's CPUs (page-locked buffers touched from the other socket cost the packed transfer a quarter of its rate). */
+int snowgpu_device_numa_node(int device);
 /* timeline of the last packed call, ms since its start: everything enqueued, every download landed, every row assembled; threads used */
 int snowgpu_debug_transfer_times(snowgpu_ctx *ctx, double *out4);
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_device_numa_node",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -115,6 +115,8 @@ def lib():
             L.snowgpu_estimate_planes_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, vp, vp]
             L.snowgpu_prepass_stats.restype = ctypes.c_int
             L.snowgpu_prepass_stats.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp]
+            L.snowgpu_device_numa_node.restype = ctypes.c_int
+            L.snowgpu_device_numa_node.argtypes = [ctypes.c_int]
             L.snowgpu_set_result_transfer.restype = ctypes.c_int
             L.snowgpu_set_result_transfer.argtypes = [vp, ctypes.c_int, ctypes.c_int]
             L.snowgpu_debug_transfer_times.restype = ctypes.c_int

@@ -1754,6 +1754,14 @@ extern "C" int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8)
     return SNOWGPU_OK;
 }
 
+// NUMA node the HIP device hangs on (sysfs, by its PCI bus id), or -1: for launchers that place one process per GPU next to it.
+extern "C" int snowgpu_device_numa_node(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return -1;
+    return node_of_device(device);
+}
+
 // How the results of a pipelined host-pointer batch cross the link.  mode 0 (default): the output rows and their source indices, 24 bytes
 // per point.  mode 1 ("packed"): per kept row its source row | label and its intensity (8 bytes; 12 for float64 rows), the moved
 // coordinates of scattered rows apart; `threads` host threads of the library (0: the CPUs this process may use minus two, at most 8) put

@@ -7,7 +7,7 @@ from collections import defaultdict
 from pathlib import Path
 root = Path(__file__).resolve().parent.parent
 ev = root / "gpurun_out" / "evidence"
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 prof = root / "profiles"
 REGION = ("k_beams", "k_power", "k_tier")
 
@@ -18,7 +18,7 @@ def short(name):
 
 # ---- bench lines --------------------------------------------------------------------------------------------------
 lines = {}
-for w in ("C2", "C2far", "C1", "C4", "C3", "C2_device_tables"):
+for w in ("C2", "C2far", "C1", "C4", "C3", "C2fire", "C2_device_tables"):
     f = ev / f"bench_{w}.json"
     if f.exists():
         got = [l for l in f.read_text().splitlines() if l.startswith("{")]
@@ -32,7 +32,8 @@ for name in ("timeline", "timeline_serial"):
     if (ev / f"{name}.txt").exists():
         shutil.copy(ev / f"{name}.txt", prof / f"{tag}_{name}_one_step.txt")
 # ---- HBM-side bytes per kernel (dumped by bench.py's own counter passes) + counter calibration ------------------------
-for name in ("pmc_fetch_write_per_kernel.csv", "pmc_calibration.json", "pmc_calibration.txt", "pipeline_trace.txt", "pipeline_timeline.txt"):
+for name in ("pmc_fetch_write_per_kernel.csv", "pmc_calibration.json", "pmc_calibration.txt", "pipeline_trace.txt", "pipeline_trace_packed.txt", "pipeline_timeline.txt",
+             "single_sweep_timeline.txt", "packed_threads.json"):
     if (ev / name).exists():
         shutil.copy(ev / name, prof / f"{tag}_{name}")
 if bench and bench.get("roofline", {}).get("traffic"):

@@ -19,24 +19,23 @@ sys.path.insert(0, str(ROOT))
 
 
 def pin_to_device_node(device):
-    """sched_setaffinity to the CPUs of the NUMA node of HIP device `device` (sysfs; rocm-smi order = /sys/class/drm/card* order is NOT assumed:
-    the node is the same for all GPUs of a socket, and a one-GPU box has one).  Returns the CPU list used, or None."""
-    import glob
+    """sched_setaffinity to the CPUs of the NUMA node HIP device `device` hangs on (snowgpu_device_numa_node: sysfs by PCI bus id), as a
+    launcher would place a rank.  Returns a description of the placement, or None if the node cannot be told."""
     import os
+    from lidar_snow_sim_amd import _native
     try:
-        nodes = sorted({int(open(p).read()) for p in glob.glob("/sys/class/drm/card*/device/numa_node")})
-        nodes = [n for n in nodes if n >= 0]
-        if len(nodes) != 1:
-            return None                                # several sockets hold GPUs (or none is reported): leave the placement to the launcher
+        node = int(_native.lib().snowgpu_device_numa_node(int(device)))
+        if node < 0:
+            return None
         cpus = set()
-        for part in open(f"/sys/devices/system/node/node{nodes[0]}/cpulist").read().strip().split(","):
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
             a, _, b = part.partition("-")
             cpus.update(range(int(a), int(b or a) + 1))
         cpus &= os.sched_getaffinity(0)
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
-        return f"node {nodes[0]}: {len(cpus)} cpus"
+        return f"node {node}: {len(cpus)} cpus"
     except (OSError, ValueError):
         return None
 
