@@ -98,9 +98,9 @@ struct SgBeamGeo {
     double d;                 // range, widened from the row dtype
     double theta_c;           // azimuth in [0, 2 pi]
     double theta_r, theta_l;  // beam limits
-    double ar, br, al, bl;    // limit lines a x + b y = 0 (vertical only at exactly pi/2, 3 pi/2)
-    double den_r, den_l;      // sqrt(a^2 + b^2)
+    double sr, cr, sl, cl;    // direction (sin, cos) of the two limit rays, to ~5e-16: the fast form of the distance test
     bool wrap;                // the wedge crosses the 0 / 2 pi seam (simulation.py:361)
+    bool exact;               // every distance test by the reference's expression with the math library's tan (snowgpu_set_exact_math)
 };
 
 // the part of the geometry that follows from the azimuth alone (recomputed, not stored, where a beam's parameters travel)
@@ -126,36 +126,80 @@ __device__ __forceinline__ SgBeamGeo sg_beam_geometry(T px, T py, T pz, double b
     }
     g.d = (double)d_t;
     sg_geo_limits(g, beam_div_deg);
-    // beam-limit lines, geometry.angles_to_lines (geometry.py:94-106)
-    if (g.theta_r == SG_PI / 2 || g.theta_r == 3 * SG_PI / 2) { g.ar = 1.0; g.br = 0.0; } else { g.ar = -(EXACT_TAN ? tan(g.theta_r) : sg_tan_0_2pi(g.theta_r)); g.br = 1.0; }
-    if (g.theta_l == SG_PI / 2 || g.theta_l == 3 * SG_PI / 2) { g.al = 1.0; g.bl = 0.0; } else { g.al = -(EXACT_TAN ? tan(g.theta_l) : sg_tan_0_2pi(g.theta_l)); g.bl = 1.0; }
-    g.den_r = sqrt(g.ar * g.ar + g.br * g.br);                  // geometry.py:133
-    g.den_l = sqrt(g.al * g.al + g.bl * g.bl);
+    // directions of the limit rays theta_c -+ half: one sincos of the azimuth, rotated by the half divergence (a launch constant)
+    double sc, cc, sh, ch;
+    sg_sincos_0_2pi(g.theta_c, sc, cc);
+    const double h = (beam_div_deg / 2) * (SG_PI / 180.0);
+    if (h < 0.015625) {
+        const double q = h * h;
+        sh = h * (1.0 - q * (1.0 / 6) * (1.0 - q * (1.0 / 20) * (1.0 - q * (1.0 / 42))));
+        ch = 1.0 - q * 0.5 * (1.0 - q * (1.0 / 12) * (1.0 - q * (1.0 / 30)));
+    } else {
+        sg_sincos_0_2pi(h, sh, ch);
+    }
+    g.sr = sc * ch - cc * sh; g.cr = cc * ch + sc * sh;
+    g.sl = sc * ch + cc * sh; g.cl = cc * ch - sc * sh;
+    g.exact = EXACT_TAN;
     return g;
+}
+
+// geometry.py:94-106 (angles_to_lines: a = -tan(theta), b = 1; vertical only at exactly pi/2, 3 pi/2) and :131-135
+// (|a x + b y + 0| / sqrt(a^2 + b^2) < r), literally -- the reference's decision for one flake and one limit ray.
+__device__ __forceinline__ bool sg_near_ray_reference(double theta, double fx, double fy, double fr, bool libm_tan)
+{
+    double a, b;
+    if (theta == SG_PI / 2 || theta == 3 * SG_PI / 2) { a = 1.0; b = 0.0; }
+    else { a = -(libm_tan ? tan(theta) : sg_tan_0_2pi(theta)); b = 1.0; }
+    const double den = sqrt(a * a + b * b);                     // geometry.py:133
+    const double num = fabs((fx * a + fy * b) + 0.0);
+    return (num / den) < fr;
+}
+
+// The same decision without tangent, root and quotient wherever that is safe: the distance of the flake centre from the
+// ray's line is |y cos(theta) - x sin(theta)|.  That value and the reference's quotient are both within
+// ~1e-15 (|x| + |y|) of the true distance (rounding of theta_c -+ half, of the slope and of the products; the slope's
+// own error cancels where it is large: |a| >> 1 means num / den = |x + y / a|), so outside a band a thousand times
+// wider both give the same answer; inside the band (one test in ~1e8) and for NaNs the reference's expression decides.
+// DEFER: the caller cannot afford the reference's expression where it stands (the pass over all rows: five waves per SIMD,
+// 96 registers -- tangent, root and quotient inside its loop spill, measured +5 % on the whole step); an undecided test is
+// reported in `undecided` and the beam is redone by a kernel that can (sg_wave_scan).
+template <bool DEFER = false>
+__device__ __forceinline__ bool sg_near_ray(double theta, double s, double c, double fx, double fy, double fr, bool exact, bool &undecided)
+{
+    const double dist = fabs(fy * c - fx * s);
+    const double band = 1e-12 * (fabs(fx) + fabs(fy));
+    const bool clear = fabs(dist - fr) > band;                  // false for NaNs
+    if constexpr (DEFER) {
+        undecided = undecided || !clear;
+        return dist < fr;
+    } else {
+        if (!exact && clear) return dist < fr;
+        return sg_near_ray_reference(theta, fx, fy, fr, exact);
+    }
 }
 
 // The reference's exact predicates for one flake against one beam (simulation.py:359-389; geometry.py:113-135, :193-223):
 // does the disk intersect the wedge, and if so its interval angles (geometry.py:14-29: a limit ray that cuts the disk
 // replaces the tangent angle on its side).
-__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2)
+template <bool DEFER = false>
+__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2, bool &undecided)
 {
     const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
     const bool centre = (g.theta_r <= phi && phi <= g.theta_l)                        // :359
                      || (g.wrap && g.theta_r - SG_TWO_PI <= phi && phi <= g.theta_l)  // :360
                      || (g.wrap && g.theta_r <= phi && phi <= g.theta_l + SG_TWO_PI); // :362
-    // geometry.py:131-135: |a x + b y + 0| / sqrt(a^2 + b^2) < r.  The quotient is only compared, so the
-    // division is done only when the product form num < r * den cannot decide it: outside a band of
-    // 2^-48 around equality both forms agree whatever the rounding of the quotient.
-    const double num_r = fabs((fx * g.ar + fy * g.br) + 0.0), num_l = fabs((fx * g.al + fy * g.bl) + 0.0);
-    const double lim_r = fr * g.den_r, lim_l = fr * g.den_l;
-    bool near_r = num_r < lim_r, near_l = num_l < lim_l;
-    if (fabs(num_r - lim_r) <= lim_r * 3.6e-15) near_r = (num_r / g.den_r) < fr;
-    if (fabs(num_l - lim_l) <= lim_l * 3.6e-15) near_l = (num_l / g.den_l) < fr;
+    const bool near_r = sg_near_ray<DEFER>(g.theta_r, g.sr, g.cr, fx, fy, fr, g.exact, undecided);      // geometry.py:131-135
+    const bool near_l = sg_near_ray<DEFER>(g.theta_l, g.sl, g.cl, fx, fy, fr, g.exact, undecided);
     const bool hit_r = near_r && sg_forward(g.theta_r, phi);            // :379-384
     const bool hit_l = near_l && sg_forward(g.theta_l, phi);            // :379-385
     na1 = hit_r ? g.theta_r : f.t0;                                     // geometry.py:26
     na2 = hit_l ? g.theta_l : f.t1;                                     // geometry.py:27
     return centre || hit_r || hit_l;                                    // :389
+}
+__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2)
+{
+    bool undecided = false;
+    return sg_flake_hits<false>(g, f, na1, na2, undecided);
 }
 
 // ---- beam geometry + phase 1 (candidate scan) for one beam (per lane) -----------------------------------------------
@@ -223,7 +267,10 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
 // its owner's list through an LDS counter; every beam sorts its few entries by (range, scan order) afterwards, which is the
 // order the per-lane scan produces.  Bins beyond the second (wedges wider than a bin) keep the per-lane loop.
 // s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries); s_st: two ints per lane.
-template <typename T, int LMAX, int STRIDE>
+// DEFER (the pass over all rows in the default arithmetic): a beam one of whose distance tests falls inside the band of
+// sg_near_ray is not decided here: SG_HITS_UNDECIDED is set in its flake count (with `overflow`), nothing is kept of its list, and the
+// caller sends it to the global-list tier, whose scan carries the reference's expression.  About one test in 1e8 on ordinary input.
+template <typename T, int LMAX, int STRIDE, bool DEFER = false>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
                                             bool EXACT_TAN, double *ov_blk = nullptr, int ov_cap = 0)
@@ -281,7 +328,6 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     const int excl = incl - cnt;
     const int total = __shfl(incl, 63);
-    const int vflags = (g.br == 0.0 ? 1 : 0) | (g.bl == 0.0 ? 2 : 0);
     const unsigned long long ent_bits = (unsigned long long)tab.entries;
     for (int base = 0; base < total; base += 64) {
         const int p = base + lane;
@@ -299,17 +345,17 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         const uint32_t e = j < n0o ? st0o + (uint32_t)j : st2o + (uint32_t)(j - n0o);
         SgBeamGeo og;
         og.d = __shfl(g.d, o); og.theta_c = __shfl(g.theta_c, o);
-        og.ar = __shfl(g.ar, o); og.al = __shfl(g.al, o); og.den_r = __shfl(g.den_r, o); og.den_l = __shfl(g.den_l, o);
-        const int of = __shfl(vflags, o);
+        og.sr = __shfl(g.sr, o); og.cr = __shfl(g.cr, o); og.sl = __shfl(g.sl, o); og.cl = __shfl(g.cl, o);
+        og.exact = EXACT_TAN;
         const SgEntry *oent = (const SgEntry *)(((unsigned long long)__shfl((unsigned)(ent_bits >> 32), o) << 32) | (unsigned long long)__shfl((unsigned)ent_bits, o));
         if (valid) {
-            og.br = (of & 1) ? 0.0 : 1.0; og.bl = (of & 2) ? 0.0 : 1.0;
             sg_geo_limits(og, beam_div_deg);
             const SgEntry f = oent[e];
             double na1, na2;
-            if (!(j >= n0o && !(f.flags & 1u)) && sg_flake_hits(og, f, na1, na2)) {      // a flake filed under both bins counts once
+            bool und = false;
+            if (!(j >= n0o && !(f.flags & 1u)) && sg_flake_hits<DEFER>(og, f, na1, na2, und)) {      // a flake filed under both bins counts once
                 const int col = wbase + o;
-                const int pos = atomicAdd(&s_cnt[col], 1);
+                const int pos = und ? LMAX + ov_cap : atomicAdd(&s_cnt[col], 1);
                 if (pos < LMAX) {
                     s_a1[pos * STRIDE + col] = na1; s_a2[pos * STRIDE + col] = na2; s_rho[pos * STRIDE + col] = f.rho;
                     s_key[pos * STRIDE + col] = p;
@@ -318,9 +364,12 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                     sp[0] = na1; sp[1] = na2; sp[2] = f.rho;
                 }
             }
+            if (DEFER && und) atomicOr(&s_cnt[wbase + o], SG_HITS_UNDECIDED);            // (later appends of this beam then land nowhere)
         }
     }
     int hits = ((volatile int *)s_cnt)[tid];                    // bumped by other lanes of this wave
+    bool undecided = DEFER && (hits & SG_HITS_UNDECIDED);
+    if (undecided) hits &= ~SG_HITS_UNDECIDED;
     int L = hits < LMAX ? hits : LMAX;
     if (act && span >= 2) {                                     // wedges wider than a bin: the further bins, per lane
         int b = b_lo + 2 >= nb ? b_lo + 2 - nb : b_lo + 2;
@@ -333,7 +382,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                 ++key;
                 if (!(f.flags & 1u)) continue;
                 double na1, na2;
-                if (!sg_flake_hits(g, f, na1, na2)) continue;
+                if (!sg_flake_hits<DEFER>(g, f, na1, na2, undecided)) continue;
                 ++hits;
                 if (L == LMAX) {
                     if (hits <= ov_cap) {
@@ -362,6 +411,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
     }
     out.n_hits = hits;
     if (hits > LMAX) out.overflow = 1;
+    if (undecided) { out.n_hits = hits | SG_HITS_UNDECIDED; out.overflow = 1; }
     return L;
 }
 

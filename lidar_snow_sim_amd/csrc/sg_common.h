@@ -9,6 +9,7 @@
 #define SG_NBINS 2048           /* azimuth bins per table: 3.07 mrad, one beam width at 3 mrad */
 #define SG_BIN_MARGIN 1e-6      /* rad; flakes are filed under every bin their angular interval +- margin touches */
 #define SG_BEAM_MARGIN 1e-9     /* rad; a beam scans every bin its wedge +- margin touches */
+#define SG_HITS_UNDECIDED 0x40000000   /* in a beam's flake count: a distance test of the pass over all rows was too close to call (sg_beam.h: sg_near_ray) */
 #define SG_MAX_LASERS 256
 #define SG_LCAP 63              /* hard cap on flakes intersecting one beam (slow path capacity) */
 #define SG_TILE 1024            /* rows per sort / compaction tile */

@@ -214,3 +214,25 @@ __device__ __forceinline__ double sg_tan_0_2pi(double theta)
     // tan(x + n pi/2) = sin/cos for even n, -cos/sin for odd n
     return (n & 1) ? -(cs / sn) : (sn / cs);
 }
+
+// sin and cos of theta in [0, 2 pi] to ~2e-16 absolute (two-part quadrant reduction, the same kernel coefficients, no
+// tail terms): the FAST form of the beam-limit test (sg_beam.h: sg_flake_hits) needs the limit rays' directions only to
+// 1e-13; whatever it cannot decide within that goes to the reference's own expression.
+__device__ __forceinline__ void sg_sincos_0_2pi(double theta, double &s, double &c)
+{
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double PIO2_1 = 1.57079632673412561417e+00, PIO2_1T = 6.07710050650619224932e-11;
+    const double fn = rint(theta * TWO_OVER_PI);
+    const int n = (int)fn;
+    const double x = (theta - fn * PIO2_1) - fn * PIO2_1T;
+    const double z = x * x;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double sn = x + (x * z) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double cs = (1.0 - 0.5 * z) + (z * z) * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double a = (n & 1) ? cs : sn, b = (n & 1) ? sn : cs;      // sin(x + n pi/2), cos(x + n pi/2)
+    s = (n & 2) ? -a : a;
+    c = ((n + 1) & 2) ? -b : b;
+}

@@ -285,7 +285,7 @@ __device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 //                 live lanes, 32 KB of LDS per block instead of 131 KB -- a block that needs most of a CU's LDS waits until
 //                 one has drained, and meanwhile holds up everything queued behind it.
 template <typename T, int LMAX, int BLOCK, bool LIST, int DICT>
-__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK == 256) ? SG_FP_WAVES : 1) void k_beams(SgBeamArgs a)
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLOCK == 256) ? SG_FP_WAVES : 1) void k_beams(SgBeamArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // hand-over passes keep three LMAX-entry lists (interval angles, range); the in-place passes four of LMAX + 1 entries
@@ -392,8 +392,10 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
             if constexpr (!LIST) {
                 if (a.ov_cap > 0) ov_blk = a.ov + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_OV_STRIDE;
             }
-            L = sg_wave_scan<T, LMAX, BLOCK>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
-                                             a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
+            // DICT == 1: distance tests too close to call are not decided here (sg_beam.h: sg_near_ray); DICT == 2 (exact-math mode) and the
+            // wave scan in a tier: every test by the reference's expression, in place
+            L = sg_wave_scan<T, LMAX, BLOCK, !LIST && DICT == 1>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
+                                                                 a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
             if (ov_blk && act && o.overflow && o.n_hits <= a.ov_cap) {   // header and the flakes the LDS list holds: the slot is complete
                 double *sp = ov_blk + (size_t)tid * SG_OV_STRIDE;
                 sp[0] = (double)d_t; sp[1] = theta_c;
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT && BLOCK ==
             o.has_power = 0;
             int k = 0;                                // the first later tier that holds every flake of this beam
             while (k < a.n_cls && o.n_hits > a.cls_cap[k]) ++k;
+            if (!LIST && (o.n_hits & SG_HITS_UNDECIDED)) k = a.n_cls - 1;   // an undecided distance test: the global-list tier scans this beam again
             if (LIST || k >= a.n_cls) {               // a listed beam fits its tier by construction
                 atomicCAS(&a.status[0], 0, 6 /* SNOWGPU_E_OVERFLOW */);
                 atomicCAS(&a.status[1], -1, (int32_t)g);
@@ -1702,6 +1705,7 @@ template <typename T, int LMAX, int BLOCK>
 static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStream_t st)
 {
     if (direct) {
+        if (a->exact_math) return launch_beams_t<T, LMAX, BLOCK, false, 2>(a, st);   // (registers to spare for tangent, root and quotient in its loop)
         return launch_beams_t<T, LMAX, BLOCK, false, 1>(a, st);
     }
     return dict_only ? launch_beams_t<T, LMAX, BLOCK, true, 1>(a, st) : launch_beams_t<T, LMAX, BLOCK, true, 0>(a, st);

@@ -25,6 +25,7 @@ __host__ inline unsigned long long __ballot(int p) { return p ? 1ull : 0ull; }
 __host__ inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 __host__ inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 __host__ inline int atomicAdd(int *p, int v) { int o = *p; *p += v; return o; }
+__host__ inline int atomicOr(int *p, int v) { int o = *p; *p |= v; return o; }
 struct { unsigned x = 0, y = 0, z = 0; } threadIdx_host;
 #undef __device__
 #define __device__

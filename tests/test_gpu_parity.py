@@ -1407,3 +1407,62 @@ def test_packed_result_transfer_fills_the_callers_buffers_with_the_same_bytes(ta
         assert np.array_equal(good[2], ref[2])
     finally:
         e.ctx.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_flakes_a_hair_off_tangent_to_a_limit_ray_are_redone_with_the_reference_expression(so, tables, dtype):
+    """geometry.py:131-135 decides `distance(flake centre, limit ray) < r` from tangent, root and quotient.  The pass over all rows tests
+    |y cos - x sin| < r instead and leaves every test within 1e-12 (|x| + |y|) of equality undecided (csrc/sg_beam.h: sg_near_ray<DEFER>):
+    such a beam is sent to the global-list tier, whose scan evaluates the reference's expression.  Here every beam has one flake whose
+    centre lies OUTSIDE its wedge at r -+ 3e-13 .. 3e-12 m from a limit ray -- inside the band, far outside the last-bit noise of
+    any tangent -- so the flake counts or not by that test alone: the beams must take the global-list tier (device status word 5),
+    and occlusion dicts and output rows must be the oracle's."""
+    from lidar_snow_sim_amd import engine
+    rng = np.random.default_rng(131)
+    n = 400
+    bd = float(np.degrees(3e-3))
+    az = rng.uniform(-np.pi, np.pi, n)
+    d = rng.uniform(25.0, 100.0, n)
+    el = rng.uniform(-0.2, 0.02, n)
+    pc = np.column_stack((d * np.cos(el) * np.cos(az), d * np.cos(el) * np.sin(az), d * np.sin(el), rng.integers(0, 256, n), np.zeros(n))).astype(dtype)
+    th = np.arctan2(pc[:, 1], pc[:, 0])                          # simulation.py:91-92 in the row dtype
+    th = np.where(th < 0, th + dtype(2 * np.pi), th).astype(np.float64)
+    half = np.radians(bd / 2)
+    side = rng.integers(0, 2, n)                                 # 0: right limit ray, 1: left
+    ray = np.where(side == 0, th - half, th + half)              # :96-101
+    ray = np.where(ray < 0, ray + 2 * np.pi, ray)
+    ray = np.where(ray > 2 * np.pi, ray - 2 * np.pi, ray)
+    rho = rng.uniform(3.0, 15.0, n)
+    fr = rng.uniform(1e-3, 4e-3, n)
+    gap = np.exp(rng.uniform(np.log(3e-13), np.log(3e-12), n)) * rng.choice([-1.0, 1.0], n)
+    L = np.longdouble
+    c, s = np.cos(ray.astype(L)), np.sin(ray.astype(L))
+    off = (fr.astype(L) + gap.astype(L)) * np.where(side == 0, -1, 1)          # beyond the right ray / beyond the left ray
+    flakes = np.column_stack(((rho.astype(L) * c - off * s).astype(np.float64), (rho.astype(L) * s + off * c).astype(np.float64), fr))
+    tl = [np.concatenate([tables["t"][0], flakes])] + _tables64(tables)[1:]
+    order = list(range(64))
+    poly = [0.0, 0.0, 1.0]
+    las = so.load_lasers()
+    _, _, (c0, k0, r0, q0) = so.process_single_channel(pc, tl[0], bd, las, 0, dump=True)
+    _, _, (c1, _, _, _) = so.process_single_channel(pc, tables["t"][0], bd, las, 0, dump=True)
+    assert 0.25 * n < int((c0 != c1).sum()) < 0.75 * n          # the test flake counts for about half of the beams: the sign of `gap` decides
+    e = engine.Engine(0)
+    try:
+        tids = e.table_ids_from_arrays(tl, order)
+        out, src, counts, stats, _ = e.ctx.augment_batch(pc, [0, n], [tids], bd, thr_poly=[poly])
+        st = e.ctx.last_status()
+        cnt, rj, ratio, dsrc = e.ctx.debug_occlusions(pc, tids, bd)
+    finally:
+        e.ctx.close()
+    # float32 rows: NumPy's float32 arctan2 and the kernels' differ in the last bit for some rows -- those beams' flakes are not near-tangent
+    assert st[5] >= (0.9 if dtype == np.float64 else 0.5) * n, st
+    assert np.array_equal(dsrc, np.arange(n)) and np.array_equal(cnt, c0)
+    start = np.concatenate(([0], np.cumsum(c0)))
+    for i in range(n):
+        assert np.array_equal(rj[i, :c0[i]], r0[start[i]:start[i + 1]])
+        np.testing.assert_allclose(ratio[i, :c0[i]], q0[start[i]:start[i + 1]], rtol=0, atol=0 if dtype == np.float32 else 1e-12)
+    r_stats, r_aug, r_src = so.augment(pc, tl, bd, order, thr_poly=np.array(poly))
+    m = int(counts[0])
+    assert tuple(int(v) for v in stats[0]) == tuple(int(v) for v in r_stats)
+    assert np.array_equal(src[:m], r_src) and np.array_equal(out[:m, 3:], r_aug[:, 3:])
+    np.testing.assert_allclose(out[:m, :3], r_aug[:, :3], rtol=1e-6 if dtype == np.float32 else 1e-12, atol=0)

@@ -65,3 +65,21 @@ def test_device_per_beam_chain_equals_the_oracle_byte_for_byte(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("beams<")]
     assert len(lines) == 5 and all(" 0 mismatches" in ln for ln in lines), r.stdout
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
+def test_fast_limit_ray_test_decides_as_the_reference_expression(tmp_path):
+    """sg_near_ray (csrc/sg_beam.h: |y cos - x sin| < r, the reference's tangent / root / quotient only inside a band of
+    1e-12 (|x| + |y|) around equality) against the reference's expression (geometry.py:94-106, :131-135) on 3 x 1.6 million flakes placed
+    at r (1 +- eps) from a limit ray, eps down to 1e-17, rays at and next to the quadrant boundaries included: no decision differs,
+    the two distances agree to 1e-14 (|x| + |y|) (measured: 7e-16), and on ordinary input the band decides fewer than 1e-5 of the tests."""
+    exe = tmp_path / "near_ray"
+    src = ROOT / "tests" / "host_harness" / "near_ray_vs_reference.cpp"
+    cmd = [HIPCC, "--cuda-host-only", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-w",
+           "-I", str(ROOT / "lidar_snow_sim_amd" / "csrc"), "-I", str(ROOT / "include"), str(src), "-o", str(exe), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), "100000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("near<")]
+    assert len(lines) == 3 and all(" 0 mismatches" in ln for ln in lines), r.stdout
