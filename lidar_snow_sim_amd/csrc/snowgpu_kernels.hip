@@ -1310,22 +1310,36 @@ __device__ __forceinline__ bool sg_in_fov(const SgFov &v, double x, double y, do
 
 // per frame: tile offsets of the kept rows and the statistics (simulation.py:522-530).  diff2 (per frame: twice the intensity-
 // difference sum of the attenuated beams, final once the per-beam kernels are through) may be null: the pre-augment crop has none.
-// One thread; tile_cnt / tile_mv may have been written by other blocks of the running launch (k_compact_count's last block): read past the L1.
+// One WAVE (all 64 lanes call it): lane l takes tiles l, l + 64, .. -- the counts come in one round of loads per 64 tiles and are summed by
+// shuffles (one thread walking the tiles waited for every load in turn: 21 us for a sweep's 47 tiles, a tenth of a single sweep's chain).
+// tile_cnt / tile_mv may have been written by other blocks of the running launch (k_compact_count's last block): read past the L1.
 __device__ __forceinline__ void sg_compact_scan_frame(int f, int64_t n, const int32_t *tile_cnt, int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
                                                       int64_t *__restrict__ out_stats, const unsigned long long *diff2, int64_t max_tiles,
                                                       const int32_t *tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
 {
+    const int lane = threadIdx.x & 63;
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
-    const volatile int32_t *vc = tile_cnt, *vm = tile_mv;
+    const volatile int32_t *vc = tile_cnt + (int64_t)f * max_tiles, *vm = tile_mv ? tile_mv + (int64_t)f * max_tiles : nullptr;
     int run = 0, mrun = 0;
     int64_t att = 0;
-    for (int64_t t = 0; t < tiles; ++t) {        // <= a few hundred tiles per frame: a serial scan is fine
-        const int c = vc[(int64_t)f * max_tiles + t];
-        tile_base[(int64_t)f * max_tiles + t] = run;
-        run += c & 0xffff;
-        att += c >> 16;
-        if (tile_mv) { tile_mv_base[(int64_t)f * max_tiles + t] = mrun; mrun += vm[(int64_t)f * max_tiles + t]; }
+    for (int64_t t0 = 0; t0 < tiles; t0 += 64) {
+        const int64_t t = t0 + lane;
+        const int c = t < tiles ? vc[t] : 0;
+        const int m = (vm && t < tiles) ? vm[t] : 0;
+        const int kc = c & 0xffff;
+        int ik = kc, im = m, ia = c >> 16;       // inclusive prefix of the kept / moved counts, total of the attenuated
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(ik, o), b = __shfl_up(im, o);
+            if (lane >= o) { ik += a; im += b; }
+            ia += __shfl_xor(ia, o);
+        }
+        if (t < tiles) {
+            tile_base[(int64_t)f * max_tiles + t] = run + ik - kc;
+            if (vm) tile_mv_base[(int64_t)f * max_tiles + t] = mrun + im - m;
+        }
+        run += __shfl(ik, 63); mrun += __shfl(im, 63); att += ia;
     }
+    if (lane != 0) return;
     if (out_mv_counts) out_mv_counts[f] = mrun;
     out_counts[f] = run;
     out_stats[f * 3 + 0] = att;              // num_attenuated (:525)
@@ -1334,15 +1348,14 @@ __device__ __forceinline__ void sg_compact_scan_frame(int f, int64_t n, const in
     out_stats[f * 3 + 2] = att > 0 ? (int64_t)(diff_sum / (double)att) : 0;   // :527-530 int()
 }
 
-__global__ __launch_bounds__(SG_BLOCK) void k_compact_scan(const int64_t *__restrict__ frame_off,
-                                                           const int32_t *__restrict__ tile_cnt,
-                                                           int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
-                                                           int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles,
-                                                           const int32_t *__restrict__ tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
+__global__ __launch_bounds__(64) void k_compact_scan(const int64_t *__restrict__ frame_off,
+                                                     const int32_t *__restrict__ tile_cnt,
+                                                     int32_t *__restrict__ tile_base, int64_t *__restrict__ out_counts,
+                                                     int64_t *__restrict__ out_stats, const unsigned long long *__restrict__ diff2, int64_t max_tiles,
+                                                     const int32_t *__restrict__ tile_mv, int32_t *__restrict__ tile_mv_base, int64_t *__restrict__ out_mv_counts)
 {
     const int f = blockIdx.x;
-    if (threadIdx.x == 0)
-        sg_compact_scan_frame(f, frame_off[f + 1] - frame_off[f], tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
+    sg_compact_scan_frame(f, frame_off[f + 1] - frame_off[f], tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
 }
 
 // Stable compaction of kept rows, per frame.  keep byte: bit 0 = row is in the output, bit 1 = row passed the noise filter
@@ -1405,7 +1418,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         mv += (k && lab_i == 2) ? 1 : 0;
         c += (noise_ok && is_att) ? (1 << 16) : 0;                          // high half: rows that count in num_attenuated (:525, before the crop)
     }
-    __shared__ int s[4], s2[4];
+    __shared__ int s[4], s2[4], s_last;
     for (int o = 32; o > 0; o >>= 1) { c += __shfl_down(c, o); mv += __shfl_down(mv, o); }
     if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6] = c; s2[threadIdx.x >> 6] = mv; }
     __syncthreads();
@@ -1418,11 +1431,14 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         if (tiles_done) {
             __threadfence();
             const unsigned long long tiles = (unsigned long long)((n + SG_TILE - 1) / SG_TILE);
-            if (atomicAdd(&tiles_done[f], 1ull) == tiles - 1) {
-                __threadfence();
-                sg_compact_scan_frame(f, n, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
-            }
+            s_last = atomicAdd(&tiles_done[f], 1ull) == tiles - 1;
+            if (s_last) __threadfence();
         }
+    }
+    if (tiles_done) {                                 // (kernel argument: uniform)
+        __syncthreads();
+        if (s_last && threadIdx.x < 64)
+            sg_compact_scan_frame(f, n, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles, tile_mv, tile_mv_base, out_mv_counts);
     }
 }
 
@@ -1905,7 +1921,7 @@ extern "C" int sg_launch_compact(const void *rows, const void *srows, const int3
                             tiles_done, tile_base, out_counts, out_stats, diff2, tmb, mvc);
     SG_CHECK_LAUNCH();
     if (!tiles_done) {
-        hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles,
+        hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(64), 0, st, frame_off, tile_cnt, tile_base, out_counts, out_stats, diff2, max_tiles,
                            (const int32_t *)tile_mv, tmb, mvc);
         SG_CHECK_LAUNCH();
     }
@@ -1932,7 +1948,7 @@ extern "C" int sg_launch_crop_count(const void *rows, int dtype, const int64_t *
     if (dtype == 0) hipLaunchKernelGGL(k_crop_flag<float>, grid, dim3(SG_BLOCK), 0, st, (const float *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     else hipLaunchKernelGGL(k_crop_flag<double>, grid, dim3(SG_BLOCK), 0, st, (const double *)rows, frame_off, keep, tile_cnt, max_tiles, *fov);
     SG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(SG_BLOCK), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, (const unsigned long long *)nullptr, max_tiles,
+    hipLaunchKernelGGL(k_compact_scan, dim3(n_frames), dim3(64), 0, st, frame_off, tile_cnt, tile_base, out_counts, stats_scratch, (const unsigned long long *)nullptr, max_tiles,
                        (const int32_t *)nullptr, (int32_t *)nullptr, (int64_t *)nullptr);
     SG_CHECK_LAUNCH();
     return 0;
