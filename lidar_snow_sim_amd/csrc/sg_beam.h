@@ -20,6 +20,16 @@
 #include "sg_math.h"
 #include "sg_atan_cr.h"
 
+// A pointer that was itself read from memory (the members of an SgTable) is a GENERIC pointer to the compiler: loads through it are
+// flat_load, which count on the LDS counter as well as on the memory counter -- so every wait for a cross-lane read or an LDS list
+// also waited for every record load in flight.  These tables live in device memory: say so.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SG_GLOBAL __attribute__((address_space(1)))
+#else
+#define SG_GLOBAL
+#endif
+template <typename P> __device__ __forceinline__ const SG_GLOBAL P *sg_gptr(const P *p) { return (const SG_GLOBAL P *)p; }
+
 template <typename T> struct SgReal;
 template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
 template <> struct SgReal<double> { static constexpr bool is_f32 = false; };
@@ -181,20 +191,30 @@ __device__ __forceinline__ bool sg_near_ray(double theta, double s, double c, do
 // The reference's exact predicates for one flake against one beam (simulation.py:359-389; geometry.py:113-135, :193-223):
 // does the disk intersect the wedge, and if so its interval angles (geometry.py:14-29: a limit ray that cuts the disk
 // replaces the tangent angle on its side).
+// The decision alone needs the FIRST HALF of a record -- azimuth, centre, radius: 32 of its 64 bytes (sg_common.h: SgEntry) -- and the pass
+// over all rows reads the second half (range, bin flag, tangent angles) only of the records that intersect, about one in eight:
+// every lane of a record load is a cache access of its own, and those accesses (95 % of the L1's cycles busy in that pass:
+// profiles/r05_*ta*) are what the scan waits for.
 template <bool DEFER = false>
-__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2, bool &undecided)
+__device__ __forceinline__ bool sg_flake_test(const SgBeamGeo &g, double phi, double fx, double fy, double fr, bool &hit_r, bool &hit_l, bool &undecided)
 {
-    const double phi = f.phi, fx = f.x, fy = f.y, fr = f.r;
     const bool centre = (g.theta_r <= phi && phi <= g.theta_l)                        // :359
                      || (g.wrap && g.theta_r - SG_TWO_PI <= phi && phi <= g.theta_l)  // :360
                      || (g.wrap && g.theta_r <= phi && phi <= g.theta_l + SG_TWO_PI); // :362
     const bool near_r = sg_near_ray<DEFER>(g.theta_r, g.sr, g.cr, fx, fy, fr, g.exact, undecided);      // geometry.py:131-135
     const bool near_l = sg_near_ray<DEFER>(g.theta_l, g.sl, g.cl, fx, fy, fr, g.exact, undecided);
-    const bool hit_r = near_r && sg_forward(g.theta_r, phi);            // :379-384
-    const bool hit_l = near_l && sg_forward(g.theta_l, phi);            // :379-385
+    hit_r = near_r && sg_forward(g.theta_r, phi);                       // :379-384
+    hit_l = near_l && sg_forward(g.theta_l, phi);                       // :379-385
+    return centre || hit_r || hit_l;                                    // :389
+}
+template <bool DEFER = false>
+__device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2, bool &undecided)
+{
+    bool hit_r, hit_l;
+    const bool hit = sg_flake_test<DEFER>(g, f.phi, f.x, f.y, f.r, hit_r, hit_l, undecided);
     na1 = hit_r ? g.theta_r : f.t0;                                     // geometry.py:26
     na2 = hit_l ? g.theta_l : f.t1;                                     // geometry.py:27
-    return centre || hit_r || hit_l;                                    // :389
+    return hit;
 }
 __device__ __forceinline__ bool sg_flake_hits(const SgBeamGeo &g, const SgEntry &f, double &na1, double &na2)
 {
@@ -258,6 +278,19 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
     return L;
 }
 
+// COMPACT lists (sg_wave_scan): one word per intersecting flake instead of its two interval angles -- the record's index | bit 30: a limit
+// ray cuts the disk on the right | bit 31: on the left (geometry.py:26-27: that ray's angle then replaces the tangent angle)
+__device__ __forceinline__ uint32_t sg_hit_word(uint32_t e, bool hit_r, bool hit_l)
+{
+    return e | (hit_r ? 0x40000000u : 0u) | (hit_l ? 0x80000000u : 0u);
+}
+__device__ __forceinline__ void sg_hit_angles(uint32_t w, const SgEntry *__restrict__ entries, double theta_r, double theta_l, double &a1, double &a2)
+{
+    const SG_GLOBAL SgEntry *f = sg_gptr(entries) + (w & 0x3fffffffu);
+    a1 = (w & 0x40000000u) ? theta_r : f->t0;                   // geometry.py:26
+    a2 = (w & 0x80000000u) ? theta_l : f->t1;                   // geometry.py:27
+}
+
 // ---- the same scan, one WAVE for its 64 beams ---------------------------------------------------------------------------
 // A beam tests every record of its bins that is nearer than its target -- a handful for a ground return, dozens for a far
 // wall -- and with one beam per lane a wave is as slow as its farthest beam (SQ counters: 45 % of the lanes active).  Here the
@@ -270,7 +303,11 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
 // DEFER (the pass over all rows in the default arithmetic): a beam one of whose distance tests falls inside the band of
 // sg_near_ray is not decided here: SG_HITS_UNDECIDED is set in its flake count (with `overflow`), nothing is kept of its list, and the
 // caller sends it to the global-list tier, whose scan carries the reference's expression.  About one test in 1e8 on ordinary input.
-template <typename T, int LMAX, int STRIDE, bool DEFER = false>
+// COMPACT (the pass over all rows): the list keeps, per flake, its range (the sort key) and ONE word instead of the two interval angles --
+// the record's index in the table | bit 30: the left angle is the beam's right limit | bit 31: the right angle is the beam's left limit
+// (geometry.py:26-27; otherwise they are the record's tangent angles t0 / t1) -- in the column s_a1 points to, read as uint32_t; s_a2 is
+// not used.  The caller resolves the word when it hands the list on (sg_hit_angles).  19 KB of LDS per 256 beams instead of 31.
+template <typename T, int LMAX, int STRIDE, bool DEFER = false, bool COMPACT = false>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
                                             bool EXACT_TAN, double *ov_blk = nullptr, int ov_cap = 0)
@@ -293,16 +330,18 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         span = b_hi - b_lo;
         if (span < 0) span += nb;
         const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
-        st0 = tab.bin_start[b_lo];
-        uint32_t hi0 = tab.bin_start[b_lo + 1];
-        st2 = tab.bin_start[b_nx];
-        uint32_t hi1 = span >= 1 ? tab.bin_start[b_nx + 1] : st2;
+        const SG_GLOBAL uint32_t *g_start = sg_gptr(tab.bin_start);
+        const SG_GLOBAL SgEntry *g_ent = sg_gptr(tab.entries);
+        st0 = g_start[b_lo];
+        uint32_t hi0 = g_start[b_lo + 1];
+        st2 = g_start[b_nx];
+        uint32_t hi1 = span >= 1 ? g_start[b_nx + 1] : st2;
         uint32_t lo0 = st0, lo1 = st2;                          // records with rho < d: a prefix of each (sorted) bin
         if (tab.bin_q) {   // the coarse range index brackets the prefix (counts below the multiples of SG_QSTEP_M around d): the search
             // below then looks at the one or two records in between instead of halving the whole bin
             const double dq = g.d * (1.0 / SG_QSTEP_M);
             const int kk = dq < (double)(SG_QSTEPS - 1) ? (int)dq : SG_QSTEPS - 1;
-            const uint32_t *q0 = tab.bin_q + (size_t)b_lo * SG_QSTEPS + kk, *q1 = tab.bin_q + (size_t)b_nx * SG_QSTEPS + kk;
+            const SG_GLOBAL uint32_t *q0 = sg_gptr(tab.bin_q) + (size_t)b_lo * SG_QSTEPS + kk, *q1 = sg_gptr(tab.bin_q) + (size_t)b_nx * SG_QSTEPS + kk;
             const uint32_t c0 = q0[0], c1 = q1[0];
             const uint32_t u0 = kk < SG_QSTEPS - 1 ? q0[1] : 0u, u1 = kk < SG_QSTEPS - 1 ? q1[1] : 0u;
             lo0 = st0 + c0;
@@ -312,7 +351,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         }
         while (lo0 < hi0 || lo1 < hi1) {
             const uint32_t m0 = (lo0 + hi0) >> 1, m1 = (lo1 + hi1) >> 1;
-            const double r0 = lo0 < hi0 ? tab.entries[m0].rho : 0.0, r1 = lo1 < hi1 ? tab.entries[m1].rho : 0.0;
+            const double r0 = lo0 < hi0 ? g_ent[m0].rho : 0.0, r1 = lo1 < hi1 ? g_ent[m1].rho : 0.0;
             if (lo0 < hi0) { if (r0 < g.d) lo0 = m0 + 1; else hi0 = m0; }
             if (lo1 < hi1) { if (r1 < g.d) lo1 = m1 + 1; else hi1 = m1; }
         }
@@ -350,20 +389,27 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         const SgEntry *oent = (const SgEntry *)(((unsigned long long)__shfl((unsigned)(ent_bits >> 32), o) << 32) | (unsigned long long)__shfl((unsigned)ent_bits, o));
         if (valid) {
             sg_geo_limits(og, beam_div_deg);
-            const SgEntry f = oent[e];
-            double na1, na2;
-            bool und = false;
-            if (!(j >= n0o && !(f.flags & 1u)) && sg_flake_hits<DEFER>(og, f, na1, na2, und)) {      // a flake filed under both bins counts once
-                const int col = wbase + o;
-                const int pos = und ? LMAX + ov_cap : atomicAdd(&s_cnt[col], 1);
-                if (pos < LMAX) {
-                    s_a1[pos * STRIDE + col] = na1; s_a2[pos * STRIDE + col] = na2; s_rho[pos * STRIDE + col] = f.rho;
-                    s_key[pos * STRIDE + col] = p;
-                } else if (pos < ov_cap) {
-                    double *sp = ov_blk + (size_t)col * SG_OV_STRIDE + 2 + 3 * pos;
-                    sp[0] = na1; sp[1] = na2; sp[2] = f.rho;
+            const SG_GLOBAL SgEntry *fp = sg_gptr(oent) + e;
+            const double phi = fp->phi, fx = fp->x, fy = fp->y, fr = fp->r;         // the record's first half
+            bool und = false, hit_r, hit_l;
+            if (sg_flake_test<DEFER>(og, phi, fx, fy, fr, hit_r, hit_l, und)) {
+                const double rho = fp->rho;                                         // ... and, one time in eight, (part of) its second
+                const uint32_t flags = fp->flags;
+                if (!(j >= n0o && !(flags & 1u))) {                                 // a flake filed under both bins counts once
+                    const int col = wbase + o;
+                    const int pos = und ? LMAX + ov_cap : atomicAdd(&s_cnt[col], 1);
+                    if (pos < LMAX) {
+                        if constexpr (COMPACT) reinterpret_cast<uint32_t *>(s_a1)[pos * STRIDE + col] = sg_hit_word(e, hit_r, hit_l);
+                        else { s_a1[pos * STRIDE + col] = hit_r ? og.theta_r : fp->t0; s_a2[pos * STRIDE + col] = hit_l ? og.theta_l : fp->t1; }
+                        s_rho[pos * STRIDE + col] = rho;
+                        s_key[pos * STRIDE + col] = p;
+                    } else if (pos < ov_cap) {
+                        double *sp = ov_blk + (size_t)col * SG_OV_STRIDE + 2 + 3 * pos;
+                        sp[0] = hit_r ? og.theta_r : fp->t0; sp[1] = hit_l ? og.theta_l : fp->t1; sp[2] = rho;
+                    }
                 }
             }
+            // (an undecided test of a record that would not have counted -- filed under an earlier bin too -- sends the beam round as well: harmless)
             if (DEFER && und) atomicOr(&s_cnt[wbase + o], SG_HITS_UNDECIDED);            // (later appends of this beam then land nowhere)
         }
     }
@@ -391,13 +437,30 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
                     }
                     continue;
                 }
-                s_a1[L * STRIDE + tid] = na1; s_a2[L * STRIDE + tid] = na2; s_rho[L * STRIDE + tid] = f.rho; s_key[L * STRIDE + tid] = key;
+                if constexpr (COMPACT) reinterpret_cast<uint32_t *>(s_a1)[L * STRIDE + tid] = sg_hit_word(e, na1 != f.t0, na2 != f.t1);   // (an angle equal to the tangent angle bit for bit may as well be read from the record)
+                else { s_a1[L * STRIDE + tid] = na1; s_a2[L * STRIDE + tid] = na2; }
+                s_rho[L * STRIDE + tid] = f.rho; s_key[L * STRIDE + tid] = key;
                 ++L;
             }
             if (++b == nb) b = 0;
         }
     }
     // order by (range, scan order): insertion sort of <= LMAX entries (simulation.py:413-417)
+    if constexpr (COMPACT) {
+        uint32_t *s_rec = reinterpret_cast<uint32_t *>(s_a1);
+        for (int i = 1; i < L; ++i) {
+            const double r = s_rho[i * STRIDE + tid];
+            const uint32_t w = s_rec[i * STRIDE + tid];
+            const int k = s_key[i * STRIDE + tid];
+            int q = i;
+            while (q > 0 && (s_rho[(q - 1) * STRIDE + tid] > r || (s_rho[(q - 1) * STRIDE + tid] == r && s_key[(q - 1) * STRIDE + tid] > k))) {
+                s_rho[q * STRIDE + tid] = s_rho[(q - 1) * STRIDE + tid]; s_rec[q * STRIDE + tid] = s_rec[(q - 1) * STRIDE + tid];
+                s_key[q * STRIDE + tid] = s_key[(q - 1) * STRIDE + tid];
+                --q;
+            }
+            s_rho[q * STRIDE + tid] = r; s_rec[q * STRIDE + tid] = w; s_key[q * STRIDE + tid] = k;
+        }
+    } else
     for (int i = 1; i < L; ++i) {
         const double r = s_rho[i * STRIDE + tid], x1 = s_a1[i * STRIDE + tid], x2 = s_a2[i * STRIDE + tid];
         const int k = s_key[i * STRIDE + tid];

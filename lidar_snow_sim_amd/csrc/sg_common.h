@@ -16,11 +16,11 @@
 
 // One filed flake, 64 bytes = one half cache line, beam-independent quantities hoisted out of
 // get_occlusions' beam loop (simulation.py:351-354, :405; geometry.py:138-190, :32-80).
-struct SgEntry {
-    double rho;      // sqrt(x^2 + y^2)                         simulation.py:332
+struct SgEntry {      // 64 bytes; the first half decides whether the flake meets a beam, the second is read of those that do (sg_beam.h: sg_flake_test)
     double phi;      // atan2(y, x) in [0, 2 pi]                simulation.py:351-352
-    double t0, t1;   // tangent angles (right, left)            geometry.py:32-80
     double x, y, r;  // table row                               simulation.py:329-330
+    double t0, t1;   // tangent angles (right, left)            geometry.py:32-80
+    double rho;      // sqrt(x^2 + y^2)                         simulation.py:332
     uint32_t flags;  // bit 0: this bin is the first bin of the flake's (circular) bin range
     uint32_t src;    // row in the uploaded table
 };

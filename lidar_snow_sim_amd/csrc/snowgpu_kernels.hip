@@ -27,7 +27,7 @@
 #define SG_KP_WIN 3       /* k_power: a work item of the multi-flake beams is this many waves' worth of slots, taken in order of flake count */
 #endif
 #ifndef SG_FP_WAVES
-#define SG_FP_WAVES 5     /* waves per SIMD the pass over all rows is compiled for = what its LDS lists allow (<= 96 VGPRs; it uses 90, no scratch -- DESIGN.md section 5 on how it got there from 100) */
+#define SG_FP_WAVES 6     /* waves per SIMD the pass over all rows is compiled for (<= 80 VGPRs; its LDS -- 19 KB per block -- would allow 8) */
 #endif
 #ifndef SG_NB_TIERS
 #define SG_NB_TIERS 8     /* ... and by the later tiers */
@@ -291,11 +291,14 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
     // hand-over passes keep three LMAX-entry lists (interval angles, range); the in-place passes four of LMAX + 1 entries
     // (the dict and the scatterer list of phase 3 carry the hard target as entry n_flakes <= LMAX)
     constexpr int ROWS = DICT ? LMAX : LMAX + 1;
-    double *s_a1 = (double *)smem;
-    double *s_a2 = s_a1 + ROWS * BLOCK;
-    double *s_rho = s_a2 + ROWS * BLOCK;
+    // the pass over all rows keeps ONE word per listed flake instead of its two interval angles (sg_beam.h: sg_wave_scan, COMPACT): ranges,
+    // words, scan order, counts, bin starts = 19 KB per 256 beams (three double columns: 31 KB, and a fifth of the waves the registers allow)
+    constexpr bool COMPACT = !LIST && DICT != 0;
+    double *s_rho = COMPACT ? (double *)smem : (double *)smem + 2 * ROWS * BLOCK;
+    double *s_a1 = COMPACT ? s_rho + ROWS * BLOCK : (double *)smem;       // COMPACT: the words (uint32_t), half a double column
+    double *s_a2 = COMPACT ? nullptr : s_a1 + ROWS * BLOCK;
     double *s_ratio = DICT ? nullptr : s_rho + ROWS * BLOCK;
-    int *s_cnt = DICT ? (int *)(s_rho + ROWS * BLOCK) : nullptr;          // wave scan: flakes met per beam ...
+    int *s_cnt = DICT ? (COMPACT ? (int *)(reinterpret_cast<uint32_t *>(s_a1) + ROWS * BLOCK) : (int *)(s_rho + ROWS * BLOCK)) : nullptr;   // wave scan: flakes met per beam ...
     int *s_key = DICT ? s_cnt + (BLOCK < 64 ? 64 : BLOCK) : nullptr;      // ... and the scan order of the stored ones
     int *s_st = DICT ? s_key + LMAX * BLOCK : nullptr;                    // ... and where its two bins start (two ints per lane)
     const int tid = threadIdx.x;
@@ -394,13 +397,24 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
             }
             // DICT == 1: distance tests too close to call are not decided here (sg_beam.h: sg_near_ray); DICT == 2 (exact-math mode) and the
             // wave scan in a tier: every test by the reference's expression, in place
-            L = sg_wave_scan<T, LMAX, BLOCK, !LIST && DICT == 1>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
-                                                                 a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
+            L = sg_wave_scan<T, LMAX, BLOCK, !LIST && DICT == 1, COMPACT>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
+                                                                          a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
             if (ov_blk && act && o.overflow && o.n_hits <= a.ov_cap) {   // header and the flakes the LDS list holds: the slot is complete
                 double *sp = ov_blk + (size_t)tid * SG_OV_STRIDE;
                 sp[0] = (double)d_t; sp[1] = theta_c;
-                for (int j = 0; j < LMAX; ++j) {
-                    sp[2 + 3 * j] = s_a1[j * BLOCK + tid]; sp[3 + 3 * j] = s_a2[j * BLOCK + tid]; sp[4 + 3 * j] = s_rho[j * BLOCK + tid];
+                if constexpr (COMPACT) {
+                    double th_r, th_l;
+                    sg_beam_limits(theta_c, a.beam_div_deg, th_r, th_l);
+#pragma unroll
+                    for (int j = 0; j < LMAX; ++j) {
+                        double x1, x2;
+                        sg_hit_angles(reinterpret_cast<const uint32_t *>(s_a1)[j * BLOCK + tid], tab.entries, th_r, th_l, x1, x2);
+                        sp[2 + 3 * j] = x1; sp[3 + 3 * j] = x2; sp[4 + 3 * j] = s_rho[j * BLOCK + tid];
+                    }
+                } else {
+                    for (int j = 0; j < LMAX; ++j) {
+                        sp[2 + 3 * j] = s_a1[j * BLOCK + tid]; sp[3 + 3 * j] = s_a2[j * BLOCK + tid]; sp[4 + 3 * j] = s_rho[j * BLOCK + tid];
+                    }
                 }
                 a.ov_sc[g] = (uint16_t)(o.n_hits | (ch << 8));
             }
@@ -466,10 +480,38 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
         auto hand_over = [&](double *q, int64_t slot) {
             q[sg_qaddr<P>(slot, 0)] = (double)d_t;
             q[sg_qaddr<P>(slot, 1)] = theta_c;
-            for (int j = 0; j < L; ++j) {
-                q[sg_qaddr<P>(slot, 2 + 3 * j)] = s_a1[j * BLOCK + tid];
-                q[sg_qaddr<P>(slot, 3 + 3 * j)] = s_a2[j * BLOCK + tid];
-                q[sg_qaddr<P>(slot, 4 + 3 * j)] = s_rho[j * BLOCK + tid];
+            if constexpr (COMPACT) {
+                // the interval angles from the words: the beam's limits, or the records' tangent angles (read here, by the few beams that
+                // listed a flake -- the records' lines are what the scan just read)
+                double th_r, th_l;
+                sg_beam_limits(theta_c, a.beam_div_deg, th_r, th_l);
+                if constexpr (LMAX <= 4) {
+                    double x1[LMAX], x2[LMAX];
+#pragma unroll
+                    for (int j = 0; j < LMAX; ++j)
+                        if (j < L) sg_hit_angles(reinterpret_cast<const uint32_t *>(s_a1)[j * BLOCK + tid], tab.entries, th_r, th_l, x1[j], x2[j]);
+#pragma unroll
+                    for (int j = 0; j < LMAX; ++j)
+                        if (j < L) {
+                            q[sg_qaddr<P>(slot, 2 + 3 * j)] = x1[j];
+                            q[sg_qaddr<P>(slot, 3 + 3 * j)] = x2[j];
+                            q[sg_qaddr<P>(slot, 4 + 3 * j)] = s_rho[j * BLOCK + tid];
+                        }
+                } else {
+                    for (int j = 0; j < L; ++j) {
+                        double x1, x2;
+                        sg_hit_angles(reinterpret_cast<const uint32_t *>(s_a1)[j * BLOCK + tid], tab.entries, th_r, th_l, x1, x2);
+                        q[sg_qaddr<P>(slot, 2 + 3 * j)] = x1;
+                        q[sg_qaddr<P>(slot, 3 + 3 * j)] = x2;
+                        q[sg_qaddr<P>(slot, 4 + 3 * j)] = s_rho[j * BLOCK + tid];
+                    }
+                }
+            } else {
+                for (int j = 0; j < L; ++j) {
+                    q[sg_qaddr<P>(slot, 2 + 3 * j)] = s_a1[j * BLOCK + tid];
+                    q[sg_qaddr<P>(slot, 3 + 3 * j)] = s_a2[j * BLOCK + tid];
+                    q[sg_qaddr<P>(slot, 4 + 3 * j)] = s_rho[j * BLOCK + tid];
+                }
             }
         };
         if constexpr (!LIST) {
@@ -1692,7 +1734,9 @@ static int sg_set_lds(K kernel, size_t lds, bool *attr_set)
 template <typename T, int LMAX, int BLOCK, bool LIST, int DICT>
 static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 {
-    const size_t lds = DICT ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX + sizeof(int) * (3 * (size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
+    // (the pass over all rows: ranges + one word per listed flake; a list-mode scan: three double columns -- see k_beams)
+    const size_t lds = DICT ? (LIST ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX : (sizeof(double) + sizeof(uint32_t)) * (size_t)BLOCK * (size_t)LMAX)
+                                  + sizeof(int) * (3 * (size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
                             : sizeof(double) * (size_t)BLOCK * 4 * ((size_t)LMAX + 1);
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
