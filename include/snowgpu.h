@@ -137,7 +137,10 @@ int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows);
 /* Validation switch for the received-power term A * sin^2(pi (R - r) / (c tau_h)) (simulation.py:549).
  * 0 (default): the engine's own sine (one reduction step + odd polynomial, < 1 ULP) and a multiplication by
  * 1 / (c tau_h); 1: the device math library's sin and a true division, operation for operation what NumPy
- * evaluates.  Both modes give the same labels / intensities (tests/test_gpu_parity.py); mode 1 is ~3x slower. */
+ * evaluates.  Both modes give the same labels / intensities (tests/test_gpu_parity.py); mode 1 is ~3x slower.
+ * The switch also covers the beam-limit distance test (geometry.py:94-106, :131-135): 0 decides it as |y cos - x sin| < r and falls
+ * back on the reference's tangent / root / quotient only within 1e-12 (|x| + |y|) of equality; 1 evaluates the reference's expression,
+ * with the math library's tan, for every flake. */
 int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
 
 /* Debug / parity tap: per-flake quantities of a filed table, by table row: range (simulation.py:332), azimuth in
