@@ -169,9 +169,9 @@ __device__ __forceinline__ bool sg_near_ray_reference(double theta, double fx, d
 // ray's line is |y cos(theta) - x sin(theta)|.  That value and the reference's quotient are both within
 // ~1e-15 (|x| + |y|) of the true distance (rounding of theta_c -+ half, of the slope and of the products; the slope's
 // own error cancels where it is large: |a| >> 1 means num / den = |x + y / a|), so outside a band a thousand times
-// wider both give the same answer; inside the band (one test in ~1e8) and for NaNs the reference's expression decides.
-// DEFER: the caller cannot afford the reference's expression where it stands (the pass over all rows: five waves per SIMD,
-// 96 registers -- tangent, root and quotient inside its loop spill, measured +5 % on the whole step); an undecided test is
+// wider both give the same answer; inside the band (roughly one test in 1e9) and for NaNs the reference's expression decides.
+// DEFER: the caller cannot afford the reference's expression where it stands (the pass over all rows: held to 96, now 80
+// registers -- tangent, root and quotient inside its loop spilled, measured +5 % on the whole step); an undecided test is
 // reported in `undecided` and the beam is redone by a kernel that can (sg_wave_scan).
 template <bool DEFER = false>
 __device__ __forceinline__ bool sg_near_ray(double theta, double s, double c, double fx, double fy, double fr, bool exact, bool &undecided)

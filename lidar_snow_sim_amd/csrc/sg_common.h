@@ -95,6 +95,7 @@ struct SgBeamArgs {
     void *rng;                   // per sorted position: the beam's range in the row dtype (simulation.py:89), written by the pass over
                                  // all rows for every simulated beam: the noise-floor pass reads 4 bytes instead of gathering the row
     int32_t *status;             // [0] error code, [1] first offending sorted row
+    int32_t *tier_hint;          // page-locked host words the device can write (or null): beams per later tier of THIS batch, read by the host when it schedules a later one
     unsigned long long *diff2;   // per frame: sum over attenuated rows of 2 * (0.9 * max_intensity - new_i)
     int32_t exact_math;          // 1: libm sin / tan + true division (validation mode)
     int32_t per_lane_scan;       // candidate scan: >= 0: the wave flattens it in the pass over all rows, one beam per lane in the tiers;
@@ -198,7 +199,7 @@ int sg_launch_gather_rows(const void *rows, int dtype, const int64_t *frame_off,
 // dict_only == 1: hand the dicts to sg_launch_power_list, 0: received power in place
 int sg_launch_beams(const SgBeamArgs *args, int dtype, int lmax, int direct, int dict_only, void *stream);
 int sg_launch_power(const SgBeamArgs *args, int dtype, int lmax, void *stream, int plan_only /* 1: k_power_plan alone; 0: the kernels it feeds */,
-                    void *ev_few /* hipEvent_t recorded behind k_power_few, or null */);
+                    void *ev_few /* hipEvent_t recorded behind k_power_few, or null */, int which /* 1: k_power_few alone, 2: k_power alone, 3: both */);
 int sg_launch_tier_gather(const SgBeamArgs *args, void *stream);
 int sg_launch_power_list(const SgBeamArgs *args, int dtype, int lmax, void *stream);
 int sg_launch_huge(const SgBeamArgs *args, int dtype, void *stream);

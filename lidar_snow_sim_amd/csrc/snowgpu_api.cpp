@@ -184,6 +184,7 @@ struct snowgpu_ctx {
     hipStream_t aux = nullptr;            // table resolve + segment order (next to the prepass), later k_power of the first pass
     hipStream_t aux2 = nullptr;           // noise-threshold prepass (only the compaction needs its result)
     hipStream_t aux3 = nullptr;           // later capacity tiers beyond the first of them
+    int32_t *tier_hint_h = nullptr, *tier_hint_d = nullptr;   // beams per later tier of a recent batch, written by the device into page-locked host memory
     hipEvent_t ev_fork0 = nullptr, ev_join0 = nullptr;   // prepass
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // resolve / segments
     hipEvent_t ev_fp = nullptr, ev_join2 = nullptr;       // the pass over all rows (and its plan) done -> k_power_few / k_power
@@ -228,6 +229,7 @@ struct snowgpu_ctx {
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
     int few = 2;                      // SNOWGPU_FEW=0..3: beams with up to this many flakes go through k_power_few (0: all through k_power)
+    int heavy_tail = -1;              // SNOWGPU_HEAVY_TAIL=0 / 1: never / always the long-tail order of the received-power phase (default: by the last batches' tier counts)
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
@@ -364,6 +366,10 @@ static int init_streams(snowgpu_ctx *ctx)
     }
     for (hipEvent_t *ep : {&ctx->ev_fork0, &ctx->ev_join0, &ctx->ev_fork, &ctx->ev_join, &ctx->ev_join2, &ctx->ev_lists, &ctx->ev_join3, &ctx->ev_few, &ctx->ev_fp})
         HIPCHK(ctx, hipEventCreateWithFlags(ep, hipEventDisableTiming));
+    if (hipHostMalloc((void **)&ctx->tier_hint_h, 64, hipHostMallocMapped) == hipSuccess) {
+        std::memset(ctx->tier_hint_h, 0, 64);
+        if (hipHostGetDevicePointer((void **)&ctx->tier_hint_d, ctx->tier_hint_h, 0) != hipSuccess) ctx->tier_hint_d = nullptr;
+    } else { (void)hipGetLastError(); ctx->tier_hint_h = nullptr; }
     return SNOWGPU_OK;
 }
 
@@ -406,6 +412,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_TIER_CAP"); ctx->tier_cap_override = v ? std::atoll(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FIRST_TIER"); ctx->first_tier_override = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
+    { const char *v = std::getenv("SNOWGPU_HEAVY_TAIL"); ctx->heavy_tail = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; ctx->tier_rows_auto = !v; }
@@ -438,6 +445,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->lanes.clear();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    if (ctx->tier_hint_h) (void)hipHostFree(ctx->tier_hint_h);
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
     if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
     ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release(); ctx->wet_fit.release();
@@ -1015,6 +1023,21 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
     const bool few_first = a.pw_items1 && !serial && b.n_total > ((int64_t)1 << 19);
+    // Where k_power<4> goes when the rare tiers are not rare.  The 63-entry and the global-list tier run behind k_power on its stream; with
+    // 71 000 beams in them (C1: 40 k flakes per line) that chain -- 3.8 ms -- is the last thing to finish, and it only starts when k_power is
+    // through.  The device leaves every batch's tier counts in page-locked memory (k_tier_gather); if the most recent ones that have landed
+    // say that chain outlasts the 16-entry tier (per beam it costs ~22x as much: 53 - 129 ns against 2.4), k_power goes to the caller's
+    // stream, ahead of the 8-entry tier, and the chain starts right behind k_power_few: C1 8.16 -> 7.93 ms.  Where the 16-entry tier is the
+    // last to finish that order LOSES (C2far 8.49 -> 8.85 ms, C2 4.13 -> 4.23: the chain then takes CUs from the kernel everything waits for).
+    // Whatever the words say, both orders give the same bytes (tests/test_gpu_fullsize.py).
+    bool heavy_tail = false;
+    if (few_first && n_cls >= 3 && ctx->tier_hint_d) {
+        const volatile int32_t *hint = ctx->tier_hint_h;
+        long tail = 0;
+        for (int k = 2; k < n_cls && k < SG_MAX_CLASSES; ++k) tail += hint[k];
+        heavy_tail = R->heavy_tail < 0 ? (tail >= 4096 && tail * 22 > (long)hint[1]) : R->heavy_tail == 1;
+        a.tier_hint = ctx->tier_hint_d;
+    }
     if (!seg_small) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
     // measurement hooks: one event pair around the whole per-beam region
     const bool timed = ctx->prof && ctx->ev_used < (int)ctx->ev_start.size();
@@ -1033,11 +1056,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         // The plan of what the pass queued (work items of k_power_few / k_power; where each region's slice of the tier lists goes)
         // runs behind it on the same stream -- the tiers then start with one short kernel (k_tier_gather) and no hop between streams --
         // and the received-power kernels it feeds on a side stream, next to the later capacity tiers.
-        if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr);
+        if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr, 3);
         if (!e) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp, st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp, 0));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr, heavy_tail ? 1 : 3);
         }
         if (!e) {
             // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
@@ -1065,6 +1088,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const bool tail_aux = n_cls >= 3 && !serial && !tail_main;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
     if (tail_aux) HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_lists, 0));
+    if (heavy_tail) {                                    // (behind the event the other tiers' streams wait for: they start with it, not after it)
+        e = sg_launch_power(&a, b.dtype, tiers[0], st, 0, nullptr, 2);
+    }
     for (int k = 0; k < n_cls && !e; ++k) {
         hipStream_t sk = (k == 0 || (tail_main && k >= 2)) ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
         a.seg_blk = nullptr;

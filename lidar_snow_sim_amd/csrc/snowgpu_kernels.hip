@@ -273,9 +273,12 @@ __device__ __forceinline__ int64_t sg_qaddr(int64_t slot, int plane)
 }
 
 // ------------------------------------------------------------------------------------------------
-// The per-beam kernel.  Dynamic LDS: four per-thread lists of LMAX + 1 float64 entries, strided by the block size.
-//   LIST = false  direct mode, the pass over all rows: phases 1-2 (scan, occlusion dict).  A beam without flakes is
-//                 finished (record written); a beam with flakes hands its dict to k_power through its region's slice
+// The per-beam kernel.  Dynamic LDS: per-thread lists, strided by the block size -- four of LMAX + 1 float64 entries where phases 1-3 run
+// in place, three of LMAX where the list is handed on, and in the pass over all rows one float64 (range) and one 4-byte word per entry.
+//   DICT          0: phases 1-3 in place; 1: the list is handed to k_power; 2: as 1, every distance test by the reference's expression
+//                 (exact-math mode of the pass over all rows: see sg_beam.h, sg_near_ray).
+//   LIST = false  direct mode, the pass over all rows: phase 1 (scan).  A beam without flakes is
+//                 finished (record written); a beam with flakes hands its flake list to k_power (which builds the dict: phase 2) through its region's slice
 //                 of the dict queue; a beam with more flakes than the list holds is appended to the list of the capacity tier that
 //                 takes all of them (the scan counts on, so the count is exact).
 //   LIST = true   a later capacity tier over its class of the tier lists; DICT = true: dict hand-over to
@@ -717,6 +720,7 @@ __global__ __launch_bounds__(256) void k_tier_gather(SgBeamArgs a, int n_regions
 {
     const int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     if (blockIdx.x == 0 && threadIdx.x < SG_MAX_CLASSES) a.status[2 + threadIdx.x] = a.tier_info[threadIdx.x];   // beams per later tier
+    if (blockIdx.x == 0 && threadIdx.x < SG_MAX_CLASSES && a.tier_hint) a.tier_hint[threadIdx.x] = a.tier_info[threadIdx.x];
     int q_size = 0, f1 = 0;
     int64_t q_base = 0;
     if (!sg_region(a, r, n_regions_ub, q_base, q_size, f1)) return;
@@ -1772,7 +1776,7 @@ static int launch_beams_m(const SgBeamArgs *a, int direct, int dict_only, hipStr
 }
 
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = false, hipEvent_t ev_few = nullptr)
+static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = false, hipEvent_t ev_few = nullptr, int which = 3)
 {
     const size_t lds = sizeof(double) * ((size_t)BLOCK * ((SG_KP_THREE_MAX > 0 && LMAX <= SG_KP_THREE_MAX && LMAX >= SG_KP_THREE_MIN) ? 3 : 4) * (LMAX + 1));
     static bool attr_set[64] = {};
@@ -1802,7 +1806,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = 
             SG_CHECK_LAUNCH();
             return 0;
         }
-        if (a->pw_items1) {                           // the beams with few flakes: ahead of k_power on its stream (beside it, on the
+        if (a->pw_items1 && (which & 1)) {            // the beams with few flakes: ahead of k_power on its stream (beside it, on the
             hipStream_t s1 = st;                      // tiers' stream, was measured: 4.67 instead of 4.59 ms)
             const unsigned g1 = (unsigned)std::min<int64_t>((int64_t)sg_cu_count(dev_id) * 4, (a->n_total / LANES + a->n_regions_ub + 3) / 4);
             if (g1 > 0) {
@@ -1814,6 +1818,7 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = 
             if (ev_few && hipEventRecord(ev_few, st) != hipSuccess) return (int)hipGetLastError();
         }
     }
+    if (!(which & 2)) return 0;
     hipLaunchKernelGGL((k_power<T, LMAX, BLOCK, LISTQ>), dim3((unsigned)blocks), dim3(THREADS), lds, st, *a);
     SG_CHECK_LAUNCH();
     return 0;
@@ -1862,21 +1867,21 @@ extern "C" int sg_launch_beams(const SgBeamArgs *a, int dtype, int lmax, int dir
 
 // the received-power kernel for the queue a direct-mode pass of capacity lmax filled
 // plan_only = 1: k_power_plan alone (work items of k_power / k_power_few, places of the tier lists' slices); 0: k_power_few and k_power
-extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, int plan_only, void *ev_few)
+extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *stream, int plan_only, void *ev_few, int which)
 {
     hipStream_t st = (hipStream_t)stream;
     const bool po = plan_only != 0;
     hipEvent_t ef = (hipEvent_t)ev_few;
     if (dtype == 0) {
-        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, po, ef);
-        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, po, ef);
-        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, po, ef);
-        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, po, ef);
+        if (lmax == 4) return launch_power_t<float, 4, 256, false>(a, st, po, ef, which);
+        if (lmax == 8) return launch_power_t<float, 8, SG_LANES_8, false>(a, st, po, ef, which);
+        if (lmax == 16) return launch_power_t<float, 16, SG_LANES_16, false>(a, st, po, ef, which);
+        return launch_power_t<float, SG_LCAP, SG_LANES_63, false>(a, st, po, ef, which);
     }
-    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, po, ef);
-    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, po, ef);
-    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, po, ef);
-    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, po, ef);
+    if (lmax == 4) return launch_power_t<double, 4, 256, false>(a, st, po, ef, which);
+    if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, po, ef, which);
+    if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, po, ef, which);
+    return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, po, ef, which);
 }
 
 extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)

@@ -333,3 +333,41 @@ def test_q8_numpy_device_half_keeps_the_rows_of_the_host_fit_at_full_size(capsys
                 assert ra.tobytes() == rb.tobytes() and tuple(sa) == tuple(sb)
     _report(capsys, dict(total, test="q8_numpy device half vs host fit"))
     assert total["rows_differ"] == 0
+
+
+def test_long_tail_order_of_the_received_power_phase_changes_no_byte(monkeypatch, capsys):
+    """Large batches run k_power_few first; where k_power<4> goes after it depends on how many beams the 63-entry / global-list tiers held in
+    the batches before (page-locked words the device leaves behind: snowgpu_api.cpp, `heavy_tail`): behind k_power_few with those tiers
+    behind it, or on the caller's stream ahead of the 8-entry tier with those tiers right behind k_power_few.  SNOWGPU_HEAVY_TAIL=0 / 1 forces
+    either.  Six C1 sweeps (40 k flakes per line: thousands of beams in the 63-entry tier) in one device-entry batch: both orders, and the
+    default called three times in a row (the third call sees the first calls' counts), give the same rows, sources, counts and statistics."""
+    from lidar_snow_sim_amd import engine
+    tl = _tables("C1")
+    frames, orders = _frames("C1", np.float32, 6)
+    off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+    rows = np.concatenate(frames)
+    assert rows.shape[0] > (1 << 19)
+    results = []
+    for v in ("0", "1", None):
+        if v is None:
+            monkeypatch.delenv("SNOWGPU_HEAVY_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("SNOWGPU_HEAVY_TAIL", v)
+        e = engine.Engine(0)
+        try:
+            tids = [e.table_ids_from_arrays(tl, o) for o in orders]
+            planes = [[*PLANE[0], PLANE[1]]] * len(frames)
+            for _ in range(3 if v is None else 1):
+                res = e.ctx.augment_batch(rows, off, tids, BD, plane=planes)
+                st = e.ctx.last_status()
+            results.append((res, st))
+        finally:
+            e.ctx.close()
+    (o0, s0, c0, t0, _), st0 = results[0]
+    assert int(st0[4]) + int(st0[5]) > 500, st0                # beams in the 63-entry and the global-list tier
+    n = int(c0.sum())
+    same = True
+    for (o1, s1, c1, t1, _), _ in results[1:]:
+        same = same and np.array_equal(c0, c1) and np.array_equal(t0, t1) and np.array_equal(s0[:n], s1[:n]) and o0[:n].tobytes() == o1[:n].tobytes()
+    _report(capsys, {"test": "long-tail order vs default order", "rows_kept": n, "tail_beams": int(st0[4]) + int(st0[5]), "same_bytes": bool(same)})
+    assert same
