@@ -92,18 +92,25 @@ __global__ __launch_bounds__(SG_BLOCK) void k_sort_hist(const T *__restrict__ ro
     [[maybe_unused]] T sx[4], sy[4], sz[4], si[4];
     [[maybe_unused]] bool sv[4];
     int descends = 0;
+    // every load of the thread's four rows first (the rounds below are chains of ballots and LDS updates: a load inside one waits its turn)
+    T sc[4], scp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + w * 256 + q * 64 + lane;
+        const bool valid = r < n;
+        const T *p = rows + (base + (valid ? r : 0)) * 5;
+        if constexpr (STATS) { sx[q] = p[0]; sy[q] = p[1]; sz[q] = p[2]; si[q] = p[3]; sv[q] = valid; }
+        sc[q] = p[4];
+        scp[q] = (valid && lane == 0 && r > 0) ? p[-1] : (T)0;        // lane 0: the channel of the row before this round's first (earlier round, wave or tile)
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + w * 256 + q * 64 + lane;
         const bool valid = r < n;
         int bucket = -1;
-        if constexpr (STATS) {
-            const T *p = rows + (base + (valid ? r : 0)) * 5;
-            sx[q] = p[0]; sy[q] = p[1]; sz[q] = p[2]; si[q] = p[3]; sv[q] = valid;
-        }
-        T c_prev = 0;                                 // lane 0: the channel of the row before this round's first (earlier round, wave or tile)
+        const T c_prev = scp[q];
         if (valid) {
-            const T c = rows[(base + r) * 5 + 4];
-            if (lane == 0 && r > 0) c_prev = rows[(base + r - 1) * 5 + 4];
+            const T c = sc[q];
             const int ci = (int)c;
             if ((T)ci == c && ci >= 0 && ci < 256) bucket = ci;
             else { atomicCAS(&status[0], 0, 5 /* SNOWGPU_E_CHANNELS */); bucket = 255; }
@@ -1429,13 +1436,26 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
     const T *rows = frame_unsorted[f] ? srows : rows_in;            // sorted position g = row g (see k_sort_scatter)
     const double p0 = thr_poly[(int64_t)f * 3], p1 = thr_poly[(int64_t)f * 3 + 1], p2 = thr_poly[(int64_t)f * 3 + 2];
     int c = 0, mv = 0;                               // mv: kept rows with label 2 (packed result transfer: their coordinates travel apart)
+    // the four rows of a thread side by side: records and ranges first, then the records behind queue slots (a dependent gather for a third
+    // of the rows), then the decisions -- row after row the kernel was a chain of up to twelve latencies per thread (1.9 TB/s)
+    uint32_t rcs[4];
+    T dds[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
+        rcs[q] = r < n ? rec[base + r] : 0u;
+        dds[q] = (r < n && rng != nullptr) ? rng[base + r] : (T)0;      // (unused for rows the pass over all rows did not simulate)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (rcs[q] & SG_REC_SLOT) rcs[q] = rec_q[rcs[q] & ~SG_REC_SLOT];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + threadIdx.x;
         if (r >= n) continue;
         // keep = (label == 2) | (intensity > p0 d^2 + p1 d + p2), d the ORIGINAL range, d^2 in the row dtype
         // (simulation.py:465, :469, :518-520)
-        uint32_t rc = rec[base + r];
-        if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
+        const uint32_t rc = rcs[q];
         const int lab_i = (int)((rc >> SG_REC_LABEL_SHIFT) & 3u);
         // Without the camera crop the decision needs the label, the (new or original) intensity and the original range only: a
         // beam the pass over all rows simulated left its range in rng, and the record holds the intensity unless the beam came
@@ -1444,7 +1464,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_count(const T *__restrict_
         bool noise_ok, is_att;
         bool k;
         if (from_rec) {
-            const T dd = rng[base + r];
+            const T dd = dds[q];
             const T dd2 = dd * dd;
             const double thr = (p0 * (double)dd2 + p1 * (double)dd) + p2;
             noise_ok = (lab_i == 2) || ((double)(T)(int)(rc & 255u) > thr);
@@ -1514,20 +1534,27 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
     const int tid = threadIdx.x, w = tid >> 6;
     bool k[4];
     int pre[4];
-    [[maybe_unused]] uint32_t rcs[4];
+    uint32_t rcs[4];
     [[maybe_unused]] int pre_mv[4];
+    // keep flags, then the kept rows' records, then the records behind queue slots: each kind for the thread's four rows at once (row after
+    // row they were a chain of dependent loads; see k_compact_count)
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * SG_BLOCK + tid;
-        const int kb = r < n ? (int)keep[base + r] : 0;
-        k[q] = kb & 1;
+        k[q] = r < n && (keep[base + r] & 1);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rcs[q] = k[q] ? rec[base + tile0 + q * SG_BLOCK + tid] : 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (rcs[q] & SG_REC_SLOT) rcs[q] = rec_q[rcs[q] & ~SG_REC_SLOT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
         const unsigned long long m = __ballot(k[q]);
         pre[q] = __popcll(m & sg_lanemask_lt());
         if ((tid & 63) == 0) wave_cnt[q][w] = __popcll(m);
         if constexpr (PACK) {
-            uint32_t rc = 0;
-            if (k[q]) { rc = rec[base + r]; if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT]; }
-            rcs[q] = rc;
-            const unsigned long long mm = __ballot(k[q] && ((rc >> SG_REC_LABEL_SHIFT) & 3u) == 2u);
+            const unsigned long long mm = __ballot(k[q] && ((rcs[q] >> SG_REC_LABEL_SHIFT) & 3u) == 2u);
             pre_mv[q] = __popcll(mm & sg_lanemask_lt());
             if ((tid & 63) == 0) wave_mv[q][w] = __popcll(mm);
         }
@@ -1562,9 +1589,7 @@ __global__ __launch_bounds__(SG_BLOCK) void k_compact_scatter(const T *__restric
                     d[0] = o.x; d[1] = o.y; d[2] = o.z;
                 }
             } else {
-                uint32_t rc = rec[r];
-                if (rc & SG_REC_SLOT) rc = rec_q[rc & ~SG_REC_SLOT];
-                const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rc);
+                const SgRow<T> o = sg_rebuild_row<T>(rows + r * 5, rcs[q]);
                 T *d = out_rows + dst * 5;
                 d[0] = o.x; d[1] = o.y; d[2] = o.z; d[3] = o.i; d[4] = o.lab;
                 out_src[dst] = src;
