@@ -9,6 +9,7 @@
 #define SG_NBINS 2048           /* azimuth bins per table: 3.07 mrad, one beam width at 3 mrad */
 #define SG_BIN_MARGIN 1e-6      /* rad; flakes are filed under every bin their angular interval +- margin touches */
 #define SG_BEAM_MARGIN 1e-9     /* rad; a beam scans every bin its wedge +- margin touches */
+#define SG_BLKREC 8          /* int32 words per block record of the segment order (five used) */
 #define SG_HITS_UNDECIDED 0x40000000   /* in a beam's flake count: a distance test of the pass over all rows was too close to call (sg_beam.h: sg_near_ray) */
 #define SG_MAX_LASERS 256
 #define SG_LCAP 63              /* hard cap on flakes intersecting one beam (slow path capacity) */
@@ -111,7 +112,7 @@ struct SgBeamArgs {
     const int32_t *seg_cnt;      // n_seg: rows
     const int32_t *seg_frame;    // n_seg: frame | channel << 22
     const int32_t *seg_n;        // [0] = n_seg, [1] = blocks in all segments
-    const int32_t *seg_of_blk;   // grid_blocks: segment of block b (valid below seg_blk[n_seg])
+    const int32_t *seg_of_blk;   // grid_blocks x SG_BLKREC: per block of the segment order {segment, its first sorted position, its rows, frame | channel << 22, its first block}
     int64_t grid_blocks;         // host: blocks of this launch (upper bound; surplus blocks leave at once)
     int32_t q_chunk;             // linear mode: sorted positions per region (a multiple of the block size)
     // The pass runs as a few launches over consecutive block ranges, so that k_power of one range runs next to the scan

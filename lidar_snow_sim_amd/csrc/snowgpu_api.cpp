@@ -887,7 +887,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         ENSURE(ctx, ctx->seg_tbl_cnt, R->tables.size() + 1); ENSURE(ctx, ctx->seg_tbl_base, R->tables.size() + 1);
         ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
-        ENSURE(ctx, ctx->seg_of_blk, (size_t)((b.n_total + first_block - 1) / first_block) + P);
+        ENSURE(ctx, ctx->seg_of_blk, ((size_t)((b.n_total + first_block - 1) / first_block) + P) * SG_BLKREC);
         ENSURE(ctx, ctx->chunk_blk, 2);
     }
     // (The pass over all rows is ONE launch.  Cut into several, with k_power of one range beside the scan of the next, it gained

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
     int seg_f = -1, seg_ch = -1;                      // segment-ordered direct mode: the block's frame and channel
     int64_t seg_g = -1, q_base = 0;
     int q_size = 0, region = 0;
+    [[maybe_unused]] int seg_blk0 = 0;                // segment-ordered direct mode: first block of the block's segment
     int64_t blk = blockIdx.x;                         // direct mode: this launch walks blocks [lo, hi) of the pass
     if (!LIST) {
         const int64_t lo = a.chunk_blk ? a.chunk_blk[a.chunk] : a.blk_lo, hi = a.chunk_blk ? a.chunk_blk[a.chunk + 1] : a.blk_hi;
@@ -332,13 +333,17 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
         if (a.seg_blk) {
             // block-uniform values, pinned to scalar registers (left to itself the compiler kept the region index in a vector
             // register pair for the whole kernel -- and spilled it when the kernel was held to five waves per SIMD)
-            const int sg = __builtin_amdgcn_readfirstlane(a.seg_of_blk[blk]);   // one load instead of a dependent search per block
-            const int blk0 = __builtin_amdgcn_readfirstlane((int)a.seg_blk[sg]);
+            // the block's record -- segment, its first sorted position, its rows, frame | channel, its first block: ONE round trip (block ->
+            // segment -> the segment's four arrays were two, on the chain of a dozen that a wave of this pass is)
+            const int32_t *br = a.seg_of_blk + blk * SG_BLKREC;
+            const int sg = __builtin_amdgcn_readfirstlane(br[0]);
+            const int blk0 = __builtin_amdgcn_readfirstlane(br[4]);
+            seg_blk0 = blk0;
             const int off = ((int)blk - blk0) * BLOCK + tid;
-            const int fc = __builtin_amdgcn_readfirstlane(a.seg_frame[sg]);
+            const int fc = __builtin_amdgcn_readfirstlane(br[3]);
             seg_f = fc & 0x3fffff; seg_ch = (int)((unsigned)fc >> 22);
-            q_base = (int64_t)__builtin_amdgcn_readfirstlane((int)a.seg_start[sg]);      // segments exist for n_total < 2^31
-            q_size = __builtin_amdgcn_readfirstlane(a.seg_cnt[sg]); region = sg;
+            q_base = (int64_t)__builtin_amdgcn_readfirstlane(br[1]);      // segments exist for n_total < 2^31
+            q_size = __builtin_amdgcn_readfirstlane(br[2]); region = sg;
             if (tid < BLOCK && off < q_size) seg_g = q_base + off;
         } else {
             region = (int)((blk * BLOCK) / a.q_chunk);
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
             // overflow slot of this block's column 0 (sorted positions follow the columns) -- the pass over all rows only
             double *ov_blk = nullptr;
             if constexpr (!LIST) {
-                if (a.ov_cap > 0) ov_blk = a.ov + (size_t)(seg_f >= 0 ? q_base + (blk - a.seg_blk[region]) * BLOCK : chunk) * SG_OV_STRIDE;
+                if (a.ov_cap > 0) ov_blk = a.ov + (size_t)(seg_f >= 0 ? q_base + (blk - seg_blk0) * BLOCK : chunk) * SG_OV_STRIDE;
             }
             // DICT == 1: distance tests too close to call are not decided here (sg_beam.h: sg_near_ray); DICT == 2 (exact-math mode) and the
             // wave scan in a tier: every test by the reference's expression, in place
@@ -1255,7 +1260,10 @@ __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ f
     const int slot = (int)(base >> 32) + (int)(c >> 32);
     const int b0 = (int)(base & 0xffffffffull) + (int)(c & 0xffffffffull);
     seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = b0;
-    for (int q = 0; q < nb; ++q) seg_of_blk[b0 + q] = slot;      // block -> segment: one load per block in k_beams
+    for (int q = 0; q < nb; ++q) {                               // block -> what k_beams needs of its segment: one round trip per block there
+        int32_t *br = seg_of_blk + (int64_t)(b0 + q) * SG_BLKREC;
+        br[0] = slot; br[1] = (int32_t)r.start; br[2] = r.rows; br[3] = (p >> 8) | ((p & 255) << 22); br[4] = b0;
+    }
 }
 
 // The three kernels above as ONE block for batches of up to four frames (1024 (frame, channel) pairs) and up to SG_SEG_SMALL_TABLES
@@ -1311,7 +1319,10 @@ __global__ __launch_bounds__(1024) void k_seg_small(const int64_t *__restrict__ 
         const unsigned long long c = atomicAdd(&cnt[r.key], (1ull << 32) | (unsigned long long)nb);
         const int slot = (int)(c >> 32), bb = (int)(c & 0xffffffffull);
         seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = bb;
-        for (int q = 0; q < nb; ++q) seg_of_blk[bb + q] = slot;
+        for (int q = 0; q < nb; ++q) {
+            int32_t *br = seg_of_blk + (int64_t)(bb + q) * SG_BLKREC;
+            br[0] = slot; br[1] = (int32_t)r.start; br[2] = r.rows; br[3] = (p >> 8) | ((p & 255) << 22); br[4] = bb;
+        }
     }
 }
 
