@@ -193,8 +193,8 @@ __device__ __forceinline__ bool sg_near_ray(double theta, double s, double c, do
 // replaces the tangent angle on its side).
 // The decision alone needs the FIRST HALF of a record -- azimuth, centre, radius: 32 of its 64 bytes (sg_common.h: SgEntry) -- and the pass
 // over all rows reads the second half (range, bin flag, tangent angles) only of the records that intersect, about one in eight:
-// every lane of a record load is a cache access of its own, and those accesses (95 % of the L1's cycles busy in that pass:
-// profiles/r05_*ta*) are what the scan waits for.
+// every lane of a record load is a cache access of its own (the L1's address unit is busy 70 % of that pass's cycles:
+// profiles/r05_probe_l1_path.txt).  Measured: 43 % fewer accesses in the pair loop, the same time -- kept as the smaller load.
 template <bool DEFER = false>
 __device__ __forceinline__ bool sg_flake_test(const SgBeamGeo &g, double phi, double fx, double fy, double fr, bool &hit_r, bool &hit_l, bool &undecided)
 {
