@@ -30,6 +30,12 @@
 #endif
 template <typename P> __device__ __forceinline__ const SG_GLOBAL P *sg_gptr(const P *p) { return (const SG_GLOBAL P *)p; }
 
+// (beam, record) pairs a wave of sg_wave_scan takes per trip: its 64 lanes.  The host harness runs the scan as a wave of one lane
+// (tests/host_harness/wave_vs_lane.cpp) and sets 1.
+#ifndef SG_PAIR_WINDOW
+#define SG_PAIR_WINDOW 64
+#endif
+
 template <typename T> struct SgReal;
 template <> struct SgReal<float> { static constexpr bool is_f32 = true; };
 template <> struct SgReal<double> { static constexpr bool is_f32 = false; };
@@ -368,7 +374,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
     const int excl = incl - cnt;
     const int total = __shfl(incl, 63);
     const unsigned long long ent_bits = (unsigned long long)tab.entries;
-    for (int base = 0; base < total; base += 64) {
+    for (int base = 0; base < total; base += SG_PAIR_WINDOW) {
         const int p = base + lane;
         const bool valid = p < total;
         int lo = 0, hi = 63;                                    // owner = first lane whose inclusive count exceeds p

@@ -83,3 +83,22 @@ def test_fast_limit_ray_test_decides_as_the_reference_expression(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("near<")]
     assert len(lines) == 3 and all(" 0 mismatches" in ln for ln in lines), r.stdout
+
+
+@pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
+def test_wave_scan_with_one_word_lists_equals_the_per_lane_scan(tmp_path):
+    """sg_wave_scan (csrc/sg_beam.h: the candidate scan of the pass over all rows -- counts per bin through the coarse range index and the search,
+    pair numbering, the records' first half for the decision and the second for the list, ONE word per listed flake and its resolution, the sort
+    by (range, scan order), counting on beyond a full list, deferred distance tests) run as a wave of one lane on the host, against sg_beam_scan
+    (one beam per lane, held to the oracle by the test above): 175 000 random float32 / float64 beams, 3 and 30 mrad wide, tables with and without the
+    coarse index -- the same number of intersecting flakes and the same lists, bit for bit."""
+    exe = tmp_path / "wave_vs_lane"
+    src = ROOT / "tests" / "host_harness" / "wave_vs_lane.cpp"
+    cmd = [HIPCC, "--cuda-host-only", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-w",
+           "-I", str(ROOT / "lidar_snow_sim_amd" / "csrc"), "-I", str(ROOT / "include"), str(src), "-o", str(exe), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe), "50000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("wave<")]
+    assert len(lines) == 5 and all(" 0 mismatches" in ln for ln in lines), r.stdout
