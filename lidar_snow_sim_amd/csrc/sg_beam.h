@@ -198,9 +198,10 @@ __device__ __forceinline__ bool sg_near_ray(double theta, double s, double c, do
 // does the disk intersect the wedge, and if so its interval angles (geometry.py:14-29: a limit ray that cuts the disk
 // replaces the tangent angle on its side).
 // The decision alone needs the FIRST HALF of a record -- azimuth, centre, radius: 32 of its 64 bytes (sg_common.h: SgEntry) -- and the pass
-// over all rows reads the second half (range, bin flag, tangent angles) only of the records that intersect, about one in eight:
+// over all rows reads the second half (range, bin flag, tangent angles) only of the records that intersect, about half of those tested
+// (scripts/probe/bin_width_probe.cpp: 1.4 pairs per beam of a bench sweep, 49 % of them intersect):
 // every lane of a record load is a cache access of its own (the L1's address unit is busy 70 % of that pass's cycles:
-// profiles/r05_probe_l1_path.txt).  Measured: 43 % fewer accesses in the pair loop, the same time -- kept as the smaller load.
+// profiles/r05_probe_l1_path.txt).  Measured: a quarter fewer accesses in the pair loop, the same time -- kept as the smaller load.
 template <bool DEFER = false>
 __device__ __forceinline__ bool sg_flake_test(const SgBeamGeo &g, double phi, double fx, double fy, double fr, bool &hit_r, bool &hit_l, bool &undecided)
 {
@@ -399,7 +400,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
             const double phi = fp->phi, fx = fp->x, fy = fp->y, fr = fp->r;         // the record's first half
             bool und = false, hit_r, hit_l;
             if (sg_flake_test<DEFER>(og, phi, fx, fy, fr, hit_r, hit_l, und)) {
-                const double rho = fp->rho;                                         // ... and, one time in eight, (part of) its second
+                const double rho = fp->rho;                                         // ... and, for the half that intersect, (part of) its second
                 const uint32_t flags = fp->flags;
                 if (!(j >= n0o && !(flags & 1u))) {                                 // a flake filed under both bins counts once
                     const int col = wbase + o;
