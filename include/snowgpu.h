@@ -151,6 +151,13 @@ int snowgpu_debug_table(snowgpu_ctx *ctx, int table_id, double *out, int64_t cap
  * entry of this context: e.g. out8[2..5] = beams each later list capacity took (summed over the chunks of a pipelined batch). */
 int snowgpu_last_status(snowgpu_ctx *ctx, int32_t *out8);
 
+/* What the status words of a DEVICE-pointer entry mean: the caller of snowgpu_augment_batch_device / snowgpu_augment_wet_batch_device
+ * downloads its int32[8] `d_status` once the stream has caught up and hands the words to this function, which returns the SNOWGPU_E_*
+ * code the host-pointer entries would have returned for them and leaves the message in snowgpu_last_error (0 and no message for
+ * status8[0] == 0).  Same exception mapping as the host entries in the Python mirror: SNOWGPU_E_RANGE -> IndexError
+ * (simulation.py:149), SNOWGPU_E_GROUND -> TypeError (simulation.py:462). */
+int snowgpu_status_error(snowgpu_ctx *ctx, const int32_t *status8);
+
 /* The 1230-entry range grid of simulation.py:106-116 as the library computes it (for tests). */
 int snowgpu_range_grid(double *out /* SNOWGPU_RANGE_BINS */);
 

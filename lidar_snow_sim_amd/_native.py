@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_device_numa_node",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_device_numa_node",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -95,6 +95,8 @@ def lib():
             L.snowgpu_set_fov_precrop.argtypes = [vp, ctypes.c_int]
             L.snowgpu_last_status.restype = ctypes.c_int
             L.snowgpu_last_status.argtypes = [vp, vp]
+            L.snowgpu_status_error.restype = ctypes.c_int
+            L.snowgpu_status_error.argtypes = [vp, vp]
             L.snowgpu_set_fov.restype = ctypes.c_int
             L.snowgpu_set_fov.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int]
             L.snowgpu_sample_table.restype = ctypes.c_int
@@ -384,6 +386,12 @@ class Context:
         out = np.zeros(8, np.int32)
         self._check(self._L.snowgpu_last_status(self._h, _p(out)))
         return out
+
+    def check_status(self, status8):
+        """Raise what the int32[8] status words of a device-pointer call say (snowgpu_status_error); no-op for status8[0] == 0."""
+        st = np.ascontiguousarray(status8, np.int32)
+        if st[0] != 0:
+            self._check(self._L.snowgpu_status_error(self._h, _p(st)))
 
     def set_result_transfer(self, mode="rows", threads=0):
         """How a pipelined host batch's results cross the link: 'rows' (output rows + source indices) or 'packed' (source | label +

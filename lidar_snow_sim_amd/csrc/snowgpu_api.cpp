@@ -839,7 +839,13 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (!thr) {
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
-        if (!serial) {           // the prepass' histogram fill runs on ITS stream now, beside the sort (that stream's last user was the batch before)
+        if (!serial) {           // the prepass' histogram fill runs on ITS stream, beside the sort
+            // Forked from the caller's stream FIRST: the fill is then ordered behind whatever the caller queued before this call (the wet
+            // kernels of a fused call fill and read the same histogram on `st`), and a stream capture of this call records it in the graph --
+            // issued on a stream that has not joined the capture it ran once, eagerly, and every replay but the first added into a stale
+            // histogram.
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
+            HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
             int he = sg_prepass_clear_hist(&ctx->prepass, b.n_frames, s_aux2);
             if (he) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (he > 0 ? hipGetErrorString((hipError_t)he) : "allocation"));
             hist_early = true;
@@ -1168,6 +1174,12 @@ static int status_to_error(snowgpu_ctx *ctx, const int32_t st[8])
         snprintf(buf, sizeof buf, "device status %d", st[0]);
         return fail(ctx, SNOWGPU_E_INVALID, buf);
     }
+}
+
+extern "C" int snowgpu_status_error(snowgpu_ctx *ctx, const int32_t *status8)
+{
+    if (!ctx || !status8) return SNOWGPU_E_INVALID;
+    return status_to_error(ctx, status8);
 }
 
 extern "C" int snowgpu_augment_batch_device(snowgpu_ctx *ctx, int n_frames, int64_t n_total, int64_t max_frame_rows,

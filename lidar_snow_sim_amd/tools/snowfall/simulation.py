@@ -144,7 +144,7 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                   noise_floor: float = 0.7, root_path: str = None, *, planes=None, orders=None, particles=None,
                   thr_polys=None, device: int = 0, return_src: bool = False, device_prepass: bool = True, slot: int = 0,
                   calib=None, pre_crop: bool = False, q8: str = 'first', plane_method: str = 'reference', plane_seed: int = 0,
-                  plane_trials: int = 1000):
+                  plane_trials: int = 1000, **device_kw):
     """augment() for a list of frames in one launch sequence -- the throughput entry point.
 
     frames      sequence of N_i x 5 arrays (one dtype for the whole batch); further columns are carried through
@@ -170,7 +170,21 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 whatever the reference itself would compute on this machine (AVX2 / AVX-512 builds of NumPy pick a different
                 one of the three smallest bins); everything else still runs on the device
     Returns a list of (stats, aug_pc) -- or (stats, aug_pc, src) with return_src=True.
+
+    torch CUDA tensors (a list of N_i x 5 tensors, an F x N x 5 tensor, or a lidar_snow_sim_amd.tensors.DeviceBatch) take the
+    device-resident boundary instead: rows are read where they lie, the call runs on torch's current stream, aug_pc / src come back
+    as device tensors and no row crosses the link (lidar_snow_sim_amd/tensors.py, which also documents sync=False and wet=...).
     """
+    from ... import tensors as _tensors
+    if _tensors.is_device_input(frames):
+        if not device_prepass:
+            raise ValueError("device_prepass=False fits the threshold on the host: it needs host arrays, not CUDA tensors")
+        return _tensors.augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=shuffle, noise_floor=noise_floor,
+                                      root_path=root_path, planes=planes, orders=orders, particles=particles, thr_polys=thr_polys,
+                                      device=None, return_src=return_src, slot=slot, calib=calib, pre_crop=pre_crop, q8=q8,
+                                      plane_method=plane_method, plane_seed=plane_seed, plane_trials=plane_trials, **device_kw)
+    if device_kw:
+        raise TypeError(f"{sorted(device_kw)}: arguments of the torch-tensor boundary only")
     eng = _engine.get_engine(device, slot)
     flat_in = frames if isinstance(frames, FlatBatch) else None
     rows = [flat_in.frame(i) for i in range(len(flat_in))] if flat_in is not None else [_as_rows(f) for f in frames]
@@ -327,6 +341,9 @@ def augment(pc: np.ndarray, particle_file_prefix: str, beam_divergence: float, s
     :param root_path:               Optional root path of <root>/training/snowflakes/npy.
 
     :return:                        ((num_attenuated, num_removed, avg_intensity_diff), N'-by-5 array)
+
+    `pc` may also be an N-by-5 torch CUDA tensor: it is read in place and the result is a tensor on the same device
+    (lidar_snow_sim_amd/tensors.py) -- the training-time boundary (`root_path`, simulation.py:53).
 
     Keyword-only extras: plane=(w, h), order=<permutation>, particles=<tables>, thr_poly, calib, device,
     return_src (append the source-row index of every output row to the result), q8 ('first' | 'numpy', see augment_batch),

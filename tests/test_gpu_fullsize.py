@@ -193,6 +193,57 @@ def test_fullsize_parity_C3_snow_and_wet_fused(dtype, capsys):
     assert tot["mismatched_intensity"] == 0 and tot["xyz_over_tol"] == 0 and stat_bad == 0
 
 
+N_BATCH = int(os.environ.get("SNOWGPU_FULLSIZE_BATCH", "32"))
+
+
+@pytest.mark.parametrize("workload", ["C2", "C2fire", "C3"])
+def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
+    """The batch shape of the headline number: N_BATCH (32) full-size float32 sweeps as ONE device-resident batch through the torch-tensor
+    boundary (augment_batch on CUDA tensors -> snowgpu_augment_batch_device / snowgpu_augment_wet_batch_device on torch's stream) --
+    above the 16-frame switch of the prepass (k_pre_rowmin + k_lean_lines_solve instead of the fused finish), above the four-sweep
+    schedule of the received-power phase (k_power_few first, long-tail order, separate compaction scan), none of which a host-entry
+    batch reaches (the host pipeline cuts it into chunks of a dozen sweeps).  Every kept row, label and intensity against the threaded
+    oracle; C3 = snowfall + wet ground fused (pointcloud_viewer.py:2807-2821)."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    from oracle import snow_oracle as so
+    fused = workload == "C3"
+    wl = "C2" if fused else workload
+    tables = _tables(wl)
+    frames, orders = _frames(wl, np.float32, N_BATCH)
+    wet = dict(water_height=0.0008, pavement_depth=0.001, power_factor=15, flat_earth=False, delta=0.5, replace=False)
+    dev = torch.device("cuda:0")
+    t_frames = [torch.from_numpy(f).to(dev) for f in frames]
+    assert sum(f.shape[0] for f in frames) > 16 * 131072
+    kw = dict(wet=dict(wet, noise_floor=0.7, plane=PLANE)) if fused else {}
+    t0 = time.perf_counter()
+    res = augment_batch(t_frames, "unused", BD, planes=[PLANE] * N_BATCH, orders=orders, particles=tables, return_src=True, **kw)
+    t_gpu = time.perf_counter() - t0
+    assert all(r[1].is_cuda and r[2].is_cuda for r in res)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    recs, stat_bad, int_max = [], 0, 0.0
+    for f in range(N_BATCH):
+        s0, a0, src0 = so.augment(frames[f], tables, BD, orders[f], plane=PLANE, threads=threads)
+        st, aug, src = res[f]
+        got, gsrc = aug.cpu().numpy(), src.cpu().numpy()
+        if fused:
+            a0, wsrc0 = so.ground_water_augmentation(a0, noise_floor=0.7, plane=PLANE, return_src=True, **wet)
+            src0 = src0[wsrc0]
+        rec = _count_mismatches(got, gsrc, a0, src0, 1e-6)
+        if fused:                                   # wet-ground intensities are float64 values of a float chain: 1e-6 relative on float32 rows
+            _, ig, ir = np.intersect1d(gsrc, src0, return_indices=True)
+            rel = np.abs(got[ig, 3] - a0[ir, 3]) / np.maximum(np.abs(a0[ir, 3]), 1e-30)
+            rec["mismatched_intensity"] = int((rel > 1e-6).sum())
+            int_max = max(int_max, float(rel.max()) if rel.size else 0.0)
+        recs.append(rec)
+        stat_bad += tuple(int(v) for v in st) != tuple(int(v) for v in s0)
+    tot = _sum_counts(recs)
+    tot.update(workload=f"{workload} (one device batch, tensor boundary)", dtype="float32", frames=N_BATCH, points=int(sum(f.shape[0] for f in frames)),
+               mismatched_stats=int(stat_bad), gpu_call_s=round(t_gpu, 3), **({"wet_intensity_max_rel": int_max} if fused else {}))
+    _report(capsys, tot)
+    assert tot["mismatched_src"] == 0 and tot["same_order"] and tot["mismatched_labels"] == 0
+    assert tot["mismatched_intensity"] == 0 and tot["xyz_over_tol"] == 0 and stat_bad == 0
+
+
 def test_L5_counts_against_the_native_numpy_flavour(golden, tables, capsys):
     """The reference's own numbers depend on NumPy's SIMD dispatch: the product pins the portable
     flavour by default.  This test REPORTS how far the HIP path is from the AVX-512 flavour of the same reference on the L5

@@ -745,21 +745,39 @@ def test_device_entry_can_be_captured_into_a_hip_graph(eng, tables):
                                      plane.data_ptr(), 0.7, 0, out.data_ptr(), src.data_ptr(), cnt.data_ptr(), st.data_ptr(), 0,
                                      status.data_ptr(), s.cuda_stream)
 
+    other = [synthetic_sweep(64, 256, seed=1070 + f, intensity="lambert") for f in range(F)]
+    inputs = [rows.clone(), torch.from_numpy(np.concatenate(other)).to(dev), rows.clone()]
+
+    def result():
+        return out.clone(), src.clone(), cnt.clone(), st.clone()
+
     with torch.cuda.stream(s):
-        call()
-        call()
-        s.synchronize()
-        want = (out.clone(), src.clone(), cnt.clone(), st.clone())
+        want = []
+        for inp in inputs:                       # what plain calls give for each input (two calls each: the second allocates nothing)
+            rows.copy_(inp)
+            call()
+            call()
+            s.synchronize()
+            want.append(result())
+        assert not torch.equal(want[0][3], want[1][3])          # the inputs really differ
+        rows.copy_(inputs[0])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             call()
-        out.zero_(); src.zero_(); cnt.zero_(); st.zero_()
-        g.replay()
-        s.synchronize()
-    assert int(status[0]) == 0 and torch.equal(cnt, want[2]) and torch.equal(st, want[3])
-    for f in range(F):
-        m = int(cnt[f])
-        assert m > 0 and torch.equal(out[f * n:f * n + m], want[0][f * n:f * n + m]) and torch.equal(src[f * n:f * n + m], want[1][f * n:f * n + m])
+        # Replayed three times on changing input: everything a call counts up from zero (the prepass histogram, the queue counters) has to
+        # be cleared INSIDE the graph -- a fill issued on a side stream before it joined the capture ran once, at capture time, and the
+        # second replay would fit its noise threshold to a histogram that still held the first one's counts.
+        for k, inp in enumerate(inputs):
+            rows.copy_(inp)
+            out.zero_(); src.zero_(); cnt.zero_(); st.zero_()
+            g.replay()
+            s.synchronize()
+            assert int(status[0]) == 0 and torch.equal(cnt, want[k][2]), k
+            assert torch.equal(st, want[k][3]), (k, st, want[k][3])
+            for f in range(F):
+                m = int(cnt[f])
+                assert m > 0 and torch.equal(out[f * n:f * n + m], want[k][0][f * n:f * n + m]), (k, f)
+                assert torch.equal(src[f * n:f * n + m], want[k][1][f * n:f * n + m]), (k, f)
 
 
 def _stretched_subsweep(step=8, scale=1.8, seed=1060):
@@ -899,9 +917,10 @@ def test_fused_snow_and_wet_device_entry_is_capturable(eng, so, tables):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             call()
-        out.zero_(); src.zero_(); cnt.zero_(); st.zero_()
-        g.replay()
-        s.synchronize()
+        for _ in range(3):                       # (replayed more than once: whatever a call clears has to be cleared inside the graph)
+            out.zero_(); src.zero_(); cnt.zero_(); st.zero_()
+            g.replay()
+            s.synchronize()
     assert int(status[0]) == 0
     for f in range(F):
         s0, a0, src0 = so.augment(frames[f], tl, bd, order, plane=PLANE)

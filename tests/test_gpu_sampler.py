@@ -179,3 +179,26 @@ def test_stream_driver_with_an_empty_particle_directory_samples_on_the_device(sm
             augment(frames[ids[0]], "mytables", bd, only_camera_fov=False, particles="device")     # a prefix that names no (mode, rate, occupancy)
     finally:
         eng.keep_sampled_rows = False
+
+
+def test_offline_generator_in_device_mode_writes_the_tables_augment_samples_on_the_fly(smp, tmp_path):
+    """python -m lidar_snow_sim_amd.sample_tables --device (tools/snowfall/sampling.py:360-413 with the device sampler): the files of a
+    (mode, pair) hold exactly the rows augment(particles='device') samples for the same prefix and line (seed = f(prefix, line)), carry
+    the reference's names, and a second run skips them."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd import sample_tables as st
+    occ, rate = _params(smp, 2.5, 1.6)
+    rep = st.generate(tmp_path, ["gunn"], [[rate, occ]], range(1, 4), device=0, verbose=False)
+    assert rep["written"] == 3 and rep["flakes"] > 3 * 15000
+    prefix = f"gunn_{rate}_{occ}"
+    assert sorted(p.name for p in tmp_path.iterdir()) == [f"{prefix}_{k}.npy" for k in (1, 2, 3)]
+    e = engine.Engine(0)
+    try:
+        e.keep_sampled_rows = True
+        for line in (1, 2, 3):
+            e.sampled_table_id(prefix, line)
+            assert np.load(tmp_path / f"{prefix}_{line}.npy").tobytes() == e.sampled_rows[(prefix, line)].tobytes()
+    finally:
+        e.ctx.close()
+    again = st.generate(tmp_path, ["gunn"], [[rate, occ]], range(1, 5), device=0, verbose=False)
+    assert again["written"] == 1 and again["skipped"] == 3
