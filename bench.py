@@ -457,9 +457,11 @@ def main():
     if fused_wet:
         call_kw["wet"] = dict(WET, plane=plane)
     res = [None]
+    side = torch.cuda.Stream(device=dev)       # (a stream of the caller's: on torch's legacy default stream the boundary forks to one of its own)
 
     def step():
-        res[0] = snow_tensors.augment_batch(batch, call_prefix, BEAM_DIV, noise_floor=0.7, sync=False, out=res[0], **call_kw)
+        with torch.cuda.stream(side):
+            res[0] = snow_tensors.augment_batch(batch, call_prefix, BEAM_DIV, noise_floor=0.7, sync=False, out=res[0], **call_kw)
 
     step()                                                  # (first call of the size: result tensors, library scratch)
     torch.cuda.synchronize()

@@ -117,10 +117,12 @@ int snowgpu_sample_table(snowgpu_ctx *ctx, int table_id, double occupancy_ratio,
  *   mode 0 (default)  output rows + source indices: 24 bytes per point down the link (20 with out_src = NULL)
  *   mode 1 "packed"   per kept row its source row | label and its intensity (8 bytes; 12 for float64 rows), the moved coordinates of
  *                     scattered rows (label 2, simulation.py:176-180) apart, every copy sized by the per-frame counts; `threads` host
- *                     threads of the library (0: the CPUs this process may use minus two, at most 8; pinned to the NUMA node of the device) assemble the caller's rows --
+ *                     threads of the library (0: the CPUs this process may use minus two, at most 8; they run on the NUMA node the caller's row
+ *                     buffers live on, the device's node if that cannot be told) assemble the caller's rows --
  *                     x, y, z and the channel of rows without a laser are COPIED from the caller's input rows, nothing is computed
  *                     on the host.  A third of the download; for callers bound by the link with cores to spare.
- * rows == NULL (resident rows) and single-chunk batches always use mode 0.
+ * rows == NULL (resident rows) and single-chunk batches always use mode 0.  Mode 1 reads `rows` while it writes `out_rows`: the two must
+ * not overlap (SNOWGPU_E_INVALID; mode 0 tolerates rows == out_rows), and a frame holds fewer than 2^30 rows (30-bit source rows).
  */
 int snowgpu_set_result_transfer(snowgpu_ctx *ctx, int mode, int threads);
 /* NUMA node HIP device `device` hangs on (sysfs, by PCI bus id), or -1 if it cannot be told: a launcher that runs one process per GPU should
@@ -130,7 +132,7 @@ int snowgpu_device_numa_node(int device);
 int snowgpu_debug_transfer_times(snowgpu_ctx *ctx, double *out4);
 
 /* Rows per chunk of the host-pointer entry's upload / compute / download pipeline (default 3 * 2^19, i.e. 12 sweeps of
- * 64 x 2048; environment SNOWGPU_PIPE_ROWS; chunks alternate between SNOWGPU_PIPE_LANES = 2 compute lanes); 0 = no pipeline: one upload, one launch sequence, one download.  The
+ * 64 x 2048; chunks alternate between SNOWGPU_PIPE_LANES = 2 compute lanes); 0 = no pipeline: one upload, one launch sequence, one download.  The
  * reference has no counterpart (its arrays never leave the host; precompute.py:78 / :106 are its I/O boundary). */
 int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows);
 
@@ -345,8 +347,10 @@ int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines);
  *                         NumPy's process-global UNSEEDED generator (np.random.randint, :183), so it differs from run to run;
  *                         here trial t of frame f draws from Philox4x32-10 keyed by (seed; f, t): same cloud + same seed = same
  *                         curves on every run and GPU.  Parity unpinned by construction.
- * A frame in which fewer than 3 range rows of the 50 x 2555 histogram have their sparsest bin above 5 returns SNOWGPU_E_GROUND
- * under 'poly' (np.polyfit raises / warns there).  snowgpu_set_wet_lines cannot be combined with 'poly'. */
+ * A frame in which NO range row of the 50 x 2555 histogram has its sparsest bin above 5 returns SNOWGPU_E_GROUND under 'poly'
+ * (np.polyfit raises TypeError on an empty vector); with one or two such rows the noise curve is np.polyfit's answer to the
+ * under-determined system -- the minimum-norm solution of its column-scaled Vandermonde system -- as in the reference, whose RANSAC
+ * cannot replace it there (a consensus set needs more than d = 15 points).  snowgpu_set_wet_lines cannot be combined with 'poly'. */
 int snowgpu_set_wet_estimation(snowgpu_ctx *ctx, int method, uint64_t seed);
 
 /* The curves the last wet-ground call of this context fitted: per frame 8 doubles -- laser power c2, c1, c0

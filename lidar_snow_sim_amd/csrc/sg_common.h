@@ -130,7 +130,12 @@ struct SgBeamArgs {
     uint16_t *dq_sc;             // per slot: flakes in the list | channel << 8
     unsigned long long *qn;      // per region
     int2_t *pw_items;            // work items of k_power (k_power_plan): {first slot, count | (frame + 1) << 10}
-    int32_t *pw_count;           // [0] items planned, [1] items of k_power_few (reset per chunk)
+    int32_t *pw_count;           // [0] items planned, [1] items of k_power_few, [2] beams on back_list, [3] k_power_all's item ticket (reset per chunk)
+    // One work list for the received-power phase (k_power_all): the multi-flake beams of ALL regions closed up -- back_list[i] = queue slot,
+    // region r's back run at bbase[r] (k_power_plan) copied by k_tier_gather -- so that a wave's 64 lanes are 64 beams whatever region they
+    // came from (per region the back run is ~80 slots at C2: a round of 64 and a round of 16).  null: the regions' runs are the items.
+    int32_t *back_list;
+    int32_t *bbase;
     int2_t *pw_items1;           // work items of k_power_few (the front of every region's slice), or null: k_power takes them too
     int32_t front_max;           // beams with up to this many flakes fill a region's slice from the front (1 .. 3 with pw_items1; else 1)
     int64_t n_regions_ub;        // host: upper bound of the regions (segments / linear chunks)
@@ -188,6 +193,11 @@ struct SgFov {
 #ifdef __cplusplus
 extern "C" {
 #endif
+// ONE persistent kernel for everything k_power_few left: the 16-entry class (overflow slots), the 8-entry class (overflow slots) and the
+// multi-flake beams of the main queue (a->back_list), in that order -- longest lists first -- from one item space; waves_per_cu persistent
+// one-wave blocks per CU; ticket: items by an atomic cursor (a->pw_count[3]) instead of striding.  cls8 / cls16: the classes' indices in
+// the tier lists, or -1.
+int sg_launch_power_all(const SgBeamArgs *a, int dtype, int cls8, int cls16, int waves_per_cu, int ticket, void *stream);
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, int32_t *tile_unsorted,

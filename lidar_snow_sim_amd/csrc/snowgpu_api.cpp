@@ -219,6 +219,7 @@ struct snowgpu_ctx {
     DevBuf<uint16_t> dq_sc;
     DevBuf<unsigned long long> qn;    // per region: front | back << 32
     DevBuf<int2_t> pw_items;          // work items of k_power
+    DevBuf<int32_t> back_list, bbase; // k_power_all: the multi-flake beams of all regions closed up; where each region's run goes
     DevBuf<double> ov;                // overflow slots of the pass over all rows (SG_OV_STRIDE doubles per sorted position)
     DevBuf<uint16_t> ov_sc;
     DevBuf<int32_t> tier_list, tier_sparse, tbase, redo_list;
@@ -229,6 +230,9 @@ struct snowgpu_ctx {
     int64_t tier_cap_override = 0;    // tests: SNOWGPU_TIER_CAP=<entries> shrinks the hand-over buffers (in-place fallback runs)
     int first_tier_override = 0;      // tests: SNOWGPU_FIRST_TIER=4|8|16|63
     int few = 2;                      // SNOWGPU_FEW=0..3: beams with up to this many flakes go through k_power_few (0: all through k_power)
+    int kp_all = 0;                   // SNOWGPU_KP_ALL=1: large batches run ONE work queue / persistent kernel (k_power_all) for what k_power_few leaves instead of k_power<4> / <8> / <16> side by side (A/B; same bytes)
+    int kp_all_waves = 6;             // SNOWGPU_KP_ALL_WAVES: persistent one-wave blocks of k_power_all per CU (8 fit; the prepass runs beside it)
+    int kp_all_ticket = 0;            // SNOWGPU_KP_ALL_TICKET=1: its waves draw items from an atomic cursor instead of striding
     int heavy_tail = -1;              // SNOWGPU_HEAVY_TAIL=0 / 1: never / always the long-tail order of the received-power phase (default: by the last batches' tier counts)
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
@@ -414,6 +418,9 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
     { const char *v = std::getenv("SNOWGPU_HEAVY_TAIL"); ctx->heavy_tail = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_KP_ALL"); if (v) ctx->kp_all = v[0] != '0'; }
+    { const char *v = std::getenv("SNOWGPU_KP_ALL_WAVES"); if (v) ctx->kp_all_waves = std::min(std::max(std::atoi(v), 1), 8); }
+    { const char *v = std::getenv("SNOWGPU_KP_ALL_TICKET"); if (v) ctx->kp_all_ticket = v[0] == '1'; }
     { const char *v = std::getenv("SNOWGPU_PER_LANE_SCAN"); ctx->per_lane_scan = v ? std::atoi(v) : 0; }
     { const char *v = std::getenv("SNOWGPU_TIER_ROWS"); ctx->tier_rows = v && v[0] == '1'; ctx->tier_rows_auto = !v; }
     // In a process that has loaded PyTorch's HIP runtime layer the runtime moves device-to-host copies with a full-grid blit
@@ -1029,6 +1036,17 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.seg_n = ctx->seg_n.p; a.seg_of_blk = ctx->seg_of_blk.p; a.chunk_blk = ctx->chunk_blk.p;
     }
     const bool few_first = a.pw_items1 && !serial && b.n_total > ((int64_t)1 << 19);
+    // Large batches: ONE work queue and ONE persistent kernel (k_power_all) for everything k_power_few leaves -- the 16-entry class, the
+    // 8-entry class (both from the overflow slots) and the multi-flake beams of the main queue, closed up over all regions -- instead of
+    // k_power<4> / <8> / <16> side by side on three streams, each with a grid sized for a chip of its own.
+    int cls8 = -1, cls16 = -1;
+    for (int k = 0; k + 1 < n_cls; ++k) { if (tiers[k + 1] == 8) cls8 = k; if (tiers[k + 1] == 16) cls16 = k; }
+    const bool kp_all = R->kp_all && few_first && use_ov && tiers[0] == 4 && !b.dbg_count && !tier_rows && b.n_total < ((int64_t)1 << 31);
+    if (kp_all) {
+        ENSURE(ctx, ctx->back_list, n + 64);
+        ENSURE(ctx, ctx->bbase, regions);
+        a.back_list = ctx->back_list.p; a.bbase = ctx->bbase.p;
+    }
     // Where k_power<4> goes when the rare tiers are not rare.  The 63-entry and the global-list tier run behind k_power on its stream; with
     // 71 000 beams in them (C1: 40 k flakes per line) that chain -- 3.8 ms -- is the last thing to finish, and it only starts when k_power is
     // through.  The device leaves every batch's tier counts in page-locked memory (k_tier_gather); if the most recent ones that have landed
@@ -1066,8 +1084,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (!e) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp, st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp, 0));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr, heavy_tail ? 1 : 3);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr, (heavy_tail || kp_all) ? 1 : 3);
         }
+        // (one work queue: the lists it takes are closed up beside k_power_few -- nothing starts with them until that kernel has ended)
+        if (!e && kp_all) e = sg_launch_tier_gather(&a, st);
         if (!e) {
             // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
             // the tiers, the prepass and k_power do better behind it than beside it (measured: 4.37 against 4.69 ms per 256 sweeps when
@@ -1076,7 +1096,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             // the moment k_power_few ends, together with k_power<4>, and take the CUs its persistent blocks would have taken -- 4.43 - 4.49
             // against 4.22 - 4.24 ms per step on one box (round 5); the 30 us it costs give k_power<4> its head start.
             if (few_first) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
-            e = sg_launch_tier_gather(&a, st);
+            if (!kp_all) e = sg_launch_tier_gather(&a, st);
         }
     }
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
@@ -1094,10 +1114,16 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     const bool tail_aux = n_cls >= 3 && !serial && !tail_main;
     if (side3) { HIPCHK(ctx, hipEventRecord(ctx->ev_lists, st)); HIPCHK(ctx, hipStreamWaitEvent(s_aux3, ctx->ev_lists, 0)); }
     if (tail_aux) HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_lists, 0));
-    if (heavy_tail) {                                    // (behind the event the other tiers' streams wait for: they start with it, not after it)
+    if (heavy_tail && !kp_all) {                         // (behind the event the other tiers' streams wait for: they start with it, not after it)
         e = sg_launch_power(&a, b.dtype, tiers[0], st, 0, nullptr, 2);
     }
+    if (kp_all) {
+        a.seg_blk = nullptr; a.tq = nullptr; a.tq_sc = nullptr; a.tq_cap = 0; a.tq_unsorted = 0;
+        a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
+        e = sg_launch_power_all(&a, b.dtype, cls8, cls16, R->kp_all_waves, R->kp_all_ticket, st);
+    }
     for (int k = 0; k < n_cls && !e; ++k) {
+        if (kp_all && (k == cls8 || k == cls16)) continue;            // (taken by k_power_all)
         hipStream_t sk = (k == 0 || (tail_main && k >= 2)) ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
         a.seg_blk = nullptr;
         a.cls = k;
@@ -1266,6 +1292,15 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // threads put the caller's rows together -- x, y, z (and the channel of rows without a laser) copied from the caller's INPUT rows.
     const bool packed = ctx->result_mode == 1 && rows != nullptr && n_total > 0;
     const size_t nt = (size_t)n_total;
+    if (packed) {
+        // the host threads read the caller's INPUT rows while they write out_rows: the two must not overlap (the rows transfer tolerates
+        // rows == out_rows, this one would corrupt frames whose rows do not come channel-sorted); a word holds a 30-bit source row
+        const char *r0 = (const char *)rows, *r1 = r0 + nt * 5 * esz, *o0 = (const char *)out_rows, *o1 = o0 + nt * 5 * esz;
+        if (r0 < o1 && o0 < r1) return fail(ctx, SNOWGPU_E_INVALID, "packed result transfer: out_rows overlaps rows (the rows are assembled from the input rows)");
+        for (int f = 0; f < n_frames; ++f)
+            if (frame_offsets[f + 1] - frame_offsets[f] >= ((int64_t)1 << 30))
+                return fail(ctx, SNOWGPU_E_INVALID, "packed result transfer: a frame of 2^30 rows or more (30-bit source rows); use the rows transfer");
+    }
     char *st_meta = nullptr, *st_int = nullptr, *st_mv = nullptr;
     int64_t *st_cnt = nullptr, *st_mvcnt = nullptr;
     if (packed) {
@@ -1354,16 +1389,20 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // ---- packed result transfer: downloads sized by the counts, and the host threads that put the rows together ----------------------
     int pk_enq = 0, pk_asm = 0;                      // chunks whose compute and download are enqueued / whose rows are with the pool
     auto pk_mv_head = [](size_t chunk_rows) { return std::min(chunk_rows, std::max<size_t>(4096, chunk_rows / 8)); };
-    auto assemble_frame = [=](int f, int64_t kept, int64_t mv_at) {
+    auto assemble_frame = [=](int f, int64_t kept, int64_t mv_at) mutable {
         // out row j of frame f = the caller's input row src_j with the device's intensity and label; label-2 rows take their moved coordinates
         // (mv_at: where this frame's part of the batch's list of moved coordinates starts, in rows)
         const int64_t o = frame_offsets[f];
+        const uint32_t n_rows = (uint32_t)(frame_offsets[f + 1] - o);          // (what came back from the device bounds no host loop or index unchecked)
+        if (kept > (int64_t)n_rows) kept = n_rows;
         const uint32_t *meta = (const uint32_t *)st_meta + o;
         if (esz == 4) {
             const float *in = (const float *)rows + (size_t)o * 5, *it = (const float *)st_int + o, *mv = (const float *)st_mv + (size_t)mv_at * 3;
             float *out = (float *)out_rows + (size_t)o * 5;
             for (int64_t j = 0; j < kept; ++j) {
-                const uint32_t m = meta[j], src = m & 0x3fffffffu, code = m >> 30;
+                const uint32_t m = meta[j], code = m >> 30;
+                uint32_t src = m & 0x3fffffffu;
+                if (src >= n_rows) src = n_rows - 1;
                 const float *ip = in + (size_t)src * 5;
                 float *q = out + (size_t)j * 5;
                 if (code == 2) { q[0] = mv[0]; q[1] = mv[1]; q[2] = mv[2]; mv += 3; }
@@ -1376,7 +1415,9 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
             const double *in = (const double *)rows + (size_t)o * 5, *it = (const double *)st_int + o, *mv = (const double *)st_mv + (size_t)mv_at * 3;
             double *out = (double *)out_rows + (size_t)o * 5;
             for (int64_t j = 0; j < kept; ++j) {
-                const uint32_t m = meta[j], src = m & 0x3fffffffu, code = m >> 30;
+                const uint32_t m = meta[j], code = m >> 30;
+                uint32_t src = m & 0x3fffffffu;
+                if (src >= n_rows) src = n_rows - 1;
                 const double *ip = in + (size_t)src * 5;
                 double *q = out + (size_t)j * 5;
                 if (code == 2) { q[0] = mv[0]; q[1] = mv[1]; q[2] = mv[2]; mv += 3; }

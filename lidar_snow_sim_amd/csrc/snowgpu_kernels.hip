@@ -714,6 +714,12 @@ __global__ __launch_bounds__(256) void k_power_plan(SgBeamArgs a, int lanes, int
         if ((threadIdx.x & 63) == 63 && total > 0) b = atomicAdd(counter, total);
         return __shfl(b, 63) + inc - n;
     };
+    if (a.back_list) {                                // one list for k_power_all: the region's back run goes to bbase[r] (k_tier_gather copies it)
+        const int bb = reserve(nb, a.pw_count + 2);
+        if (mine) a.bbase[r] = bb;
+        n_items -= (nb + lanes_back - 1) / lanes_back;
+        nb = 0;                                       // (no per-region items for the back runs)
+    }
     int base = reserve(n_items, a.pw_count);
     if (a.pw_items1) {
         int base1 = reserve(n_one, a.pw_count + 1);
@@ -743,6 +749,12 @@ __global__ __launch_bounds__(256) void k_tier_gather(SgBeamArgs a, int n_regions
         int32_t *dst = a.tier_list + (int64_t)k * a.tier_stride + a.tbase[(int64_t)r * SG_MAX_CLASSES + k];
         for (int i = lane; i < c; i += 64) dst[i] = src[i];
     }
+    if (a.back_list) {                                // the region's multi-flake beams: the last nb slots of its slice of the queue
+        const int nb = (int)(a.qn[r] >> 32);
+        int32_t *dst = a.back_list + a.bbase[r];
+        const int first = (int)(q_base + q_size - nb);
+        for (int i = lane; i < nb; i += 64) dst[i] = first + i;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -752,18 +764,19 @@ __global__ __launch_bounds__(256) void k_tier_gather(SgBeamArgs a, int n_regions
 //   LISTQ = false  the direct-mode pass's queue: work items from k_power_plan (runs of live slots: 64 one-flake slots, or a
 //                  window of SG_KP_WIN x 64 multi-flake slots)
 //   LISTQ = true   a list-mode pass's hand-over buffer: item i = window i of the class
-// PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
-// barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
-// that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
-// then bound by the latency of its first loads.  (Requesting the slot data of a wave's NEXT item before it computes the
-// current one was measured too: since phase 2 moved here the registers that costs outweigh the latency it hides.)
+// ONE work item of the received-power phase: `cnt` hand-over slots from `start` on (a run of live slots of the direct-mode queue, LISTQ = false;
+// a window of a list-mode class, LISTQ = true, whose lists lie in the overflow slots (ov_list) or in the class' hand-over buffer, in scan
+// order if tq_unsorted), by the calling WAVE, whose LDS columns start at `smem` (BLOCK >= 64: the block's columns, the wave takes its 64).
+// item_f: the item's frame (direct-mode items carry it), or -1.  Called by k_power -- one capacity per launch -- and by k_power_all, where a
+// wave takes items of any capacity from one list.
 template <typename T, int LMAX, int BLOCK, bool LISTQ>
-__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : (LMAX <= 16 ? SG_KP_WAVES_TIERS : 1)) void k_power(SgBeamArgs a)
+__device__ __forceinline__ void sg_kp_item(const SgBeamArgs &a, char *smem, const int ov_list, const int tq_unsorted, const int64_t work_off,
+                                           const int start, const int cnt, const int item_f, const int32_t *__restrict__ slot_list = nullptr)
 {
-    constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
+    // slot_list (LISTQ = false): the item is entries [start, start + cnt) of this list of queue slots (k_power_all: the closed-up back runs)
+    constexpr int LANES = BLOCK < 64 ? BLOCK : 64;
     constexpr int WIN = BLOCK < 64 ? 1 : SG_KP_WIN;       // waves' worth of slots per work item
     constexpr int P = SG_QPLANES(LMAX);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     double *s_a1 = (double *)smem;
     // Three list columns for capacities up to 16 (THREE): interval angles a1, a2 and the ratio / range column -- the flakes' ranges
     // stay in the hand-over queue until the dict is done (sg_beam_dict<.., KEEP_RHO = false> returns which list entry each dict
@@ -776,6 +789,195 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     double *s_work = THREE ? s_a2 : s_ratio;                              // stage-A work list: low words of the window column / own column
     const int tid = threadIdx.x, lane = tid & 63;
     const int ltid = BLOCK < 64 ? lane : tid;          // column of the LDS lists
+    const double *planes = LISTQ ? a.tq : a.dq;
+    const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
+    static_assert(WIN <= 4, "the window's permutation passes through one 64-double row segment of the wave");
+    uint16_t *s_perm = (uint16_t *)(s_ratio + (BLOCK < 64 ? 0 : (tid & ~63)));   // dead between two beams: this wave's columns of row 0
+    int perm[WIN];
+    // A window of several waves' worth of slots is taken in order of flake count: the cost of phases 2 and 3 grows
+    // steeply with the list length, and a wave is as slow as its longest list (counting sort by ballots; the slots of
+    // a window are neighbours in every plane of the queue, so the permuted reads touch the same lines).
+    const bool sorted = WIN > 1 && cnt > LANES;          // wave-uniform
+    if constexpr (WIN > 1) {
+        if (sorted) {
+            int key[WIN], rank[WIN];
+#pragma unroll
+            for (int r = 0; r < WIN; ++r) {
+                const int idx = r * 64 + lane;
+                key[r] = 255;                             // past the end of the window: last
+                if (idx < cnt) {
+                    const unsigned sc = (LISTQ && ov_list) ? a.ov_sc[a.tier_list[work_off + start + idx]]
+                                                           : scs[(!LISTQ && slot_list) ? (int64_t)slot_list[start + idx] : (int64_t)start + idx];
+                    key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
+                }
+                rank[r] = 0;
+            }
+            int base = 0;
+            auto place = [&](int c) {
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) {
+                    const unsigned long long m = __ballot(key[r] == c);
+                    if (key[r] == c) rank[r] = base + (int)__popcll(m & sg_lanemask_lt());
+                    base += (int)__popcll(m);
+                }
+            };
+            for (int c = 0; c <= LMAX; ++c) place(c);
+            place(254); place(255);
+#pragma unroll
+            for (int r = 0; r < WIN; ++r) s_perm[rank[r]] = (uint16_t)(r * 64 + lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written and read by the lanes of one wave: no barrier, but keep the order
+#pragma unroll
+            for (int r = 0; r < WIN; ++r) perm[r] = s_perm[r * 64 + lane];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the lists of the first beam overwrite it)
+        }
+    }
+    const int rounds = (cnt + LANES - 1) / LANES;
+    for (int r = 0; r < rounds; ++r) {
+        const int idx = r * LANES + lane;
+        const bool in = lane < LANES && idx < cnt;
+        int pos = idx;
+        if constexpr (WIN > 1) {
+            if (sorted) {
+#pragma unroll
+                for (int q = 0; q < WIN; ++q) if (q == r) pos = perm[q];
+            }
+        }
+        int64_t slot = (int64_t)start + pos;
+        if constexpr (!LISTQ) { if (slot_list && in) slot = slot_list[slot]; }
+        unsigned sc = 0xffffu;
+        int32_t g = 0;
+        double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
+        // where the beam's hand-over data lies: plane p at qb[p * qs] -- a slot of a blocked-SoA queue (stride 64), or the
+        // overflow slot of its sorted position (stride 1)
+        const double *qb = planes;
+        int qs = 64;
+        if (in) {                                         // everything a beam surely has, in one round of loads
+            g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
+            if (LISTQ && ov_list) { qb = a.ov + (size_t)g * SG_OV_STRIDE; qs = 1; sc = a.ov_sc[g]; }
+            else { qb = planes + sg_qaddr<P>(slot, 0); sc = scs[slot]; }
+            d = qb[0];                                    // the beam's range (simulation.py:89), widened from the row dtype
+            tc = qb[qs];
+            f_a1 = qb[2 * qs]; f_a2 = qb[3 * qs]; f_rho = qb[4 * qs];
+        }
+        const bool live = in && sc != 0xffffu;            // 0xffff: a listed beam without a flake (its record is final)
+        const int L = (int)(sc & 255u), ch = (int)(sc >> 8);
+        int f = 0;
+        SgBeamOut o;
+        o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
+        constexpr int NB = LMAX <= 4 ? SG_NB4 : SG_NB_TIERS;   // bins of the power profile carried together
+        int S = 0, nw = 0, k_best = 0;
+        double best = 0.0;
+        if (live) {
+            f = item_f >= 0 ? item_f : sg_frame_of(a, g);
+            // ord: 4 bits per list entry -- the hit (scan order) it came from; identity unless the scan left the flakes unsorted
+            unsigned long long ord = 0xfedcba9876543210ull;
+            if (LISTQ && (tq_unsorted || ov_list)) {
+                // the flakes as the scan met them: insertion by range, scan order on equal ranges (simulation.py:413-417).  The
+                // ranges pass through the ratio / range column (free until the dict); THREE: they go back to being fetched from
+                // the queue afterwards, through `ord`.
+                s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
+                if constexpr (THREE) ord = 0;
+                // first every flake into the columns as it lies in the queue -- independent loads, all in flight together --, then
+                // the insertion sort on LDS alone (a load per step of the sort would put a memory latency into every step)
+#pragma unroll 4
+                for (int h = 1; h < L; ++h) {
+                    s_a1[h * BLOCK + ltid] = qb[(2 + 3 * h) * qs];
+                    s_a2[h * BLOCK + ltid] = qb[(3 + 3 * h) * qs];
+                    s_rho[h * BLOCK + ltid] = qb[(4 + 3 * h) * qs];
+                }
+                for (int h = 1; h < L; ++h) {
+                    const double x1 = s_a1[h * BLOCK + ltid], x2 = s_a2[h * BLOCK + ltid], r = s_rho[h * BLOCK + ltid];
+                    int q = h;
+                    // (equal ranges of different flakes -- probability zero for sampled tables -- fall back on the interval angles, so
+                    // that the order never depends on the order in which the scan's lanes reached the slot)
+                    while (q > 0 && (s_rho[(q - 1) * BLOCK + ltid] > r ||
+                                     (s_rho[(q - 1) * BLOCK + ltid] == r && ov_list &&
+                                      (s_a1[(q - 1) * BLOCK + ltid] > x1 || (s_a1[(q - 1) * BLOCK + ltid] == x1 && s_a2[(q - 1) * BLOCK + ltid] > x2))))) {
+                        s_rho[q * BLOCK + ltid] = s_rho[(q - 1) * BLOCK + ltid]; s_a1[q * BLOCK + ltid] = s_a1[(q - 1) * BLOCK + ltid];
+                        s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid];
+                        --q;
+                    }
+                    if (q != h) { s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2; }
+                    if constexpr (THREE) {
+                        const unsigned long long low = (1ull << (4 * q)) - 1ull;
+                        ord = (ord & low) | ((unsigned long long)h << (4 * q)) | ((ord & ~low) << 4);
+                    }
+                }
+            } else {
+                s_a1[ltid] = f_a1; s_a2[ltid] = f_a2;
+                if constexpr (!THREE) s_rho[ltid] = f_rho;
+                for (int j = 1; j < L; ++j) {
+                    s_a1[j * BLOCK + ltid] = qb[(2 + 3 * j) * qs];
+                    s_a2[j * BLOCK + ltid] = qb[(3 + 3 * j) * qs];
+                    if constexpr (!THREE) s_rho[j * BLOCK + ltid] = qb[(4 + 3 * j) * qs];
+                }
+            }
+            auto queue_rho = [&](int j) -> double {       // range of list entry j (THREE: from the queue)
+                const int h = (int)((ord >> (4 * j)) & 15ull);
+                return h == 0 ? f_rho : qb[(4 + 3 * h) * qs];
+            };
+            int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
+            double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
+            double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)g * a.dbg_cap : nullptr;
+            unsigned long long srcmap = 0;
+            if constexpr (THREE) S = sg_beam_dict<LMAX, BLOCK, false>(L, tc, d, a.beam_div_deg, s_a1, s_a2, nullptr, s_ratio, ltid, 0, nullptr, nullptr, nullptr, 0, &srcmap);
+            else S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
+            if constexpr (THREE) {
+                if (dc) {                                   // debug tap: ratios now, ranges from the queue
+                    *dc = S + 1;
+                    for (int t = 0; t <= S && t < a.dbg_cap; ++t) {
+                        const int j = (int)((srcmap >> (4 * t)) & 15ull);
+                        drj[t] = t == S ? d : queue_rho(j);
+                        dra[t] = s_ratio[t * BLOCK + ltid];
+                    }
+                }
+            }
+            if (S > 0) {                                // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
+                const T d_t = (T)d;                     // exact
+                if constexpr (THREE) {
+                    sg_beam_amp3<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, ltid, o,
+                                                 [&](int t) { return queue_rho((int)((srcmap >> (4 * t)) & 15ull)); });
+                } else sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
+                if (o.range_error) {
+                    atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
+                    atomicCAS(&a.status[1], -1, g);
+                }
+                // stage A of the received-power profile, lane by lane: the few groups of bins that can hold its maximum
+                if (a.exact_math) nw = sg_power_plan<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
+                else nw = sg_power_plan<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
+            } else S = 0;
+        }
+        // stage B, the whole wave over the groups of its 64 beams
+        {
+            const int colbase = BLOCK < 64 ? 0 : (tid & ~63);
+            if (a.exact_math) sg_wave_eval<BLOCK, true, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
+            else sg_wave_eval<BLOCK, false, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
+        }
+        if (live) {
+            uint32_t rec = 0;
+            if (S > 0) {
+                sg_beam_decide(d, ch, a.las, best, k_best, o);
+                rec = sg_pack_record(o);
+            }
+            if (LISTQ) a.rec[g] = rec;
+            else a.rec_q[slot] = rec;                   // the row's record points here (SG_REC_SLOT)
+        }
+        sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+    }
+}
+
+// PERSISTENT WAVES: the grid is what the chip holds at once, and every wave strides over the items on its own (no block
+// barrier anywhere).  A queue of many short items keeps few live waves resident if each item is its own block -- blocks
+// that turn out empty, and blocks that wait for their slowest wave, hold the LDS the next ones need -- and the kernel is
+// then bound by the latency of its first loads.  (Requesting the slot data of a wave's NEXT item before it computes the
+// current one was measured too: since phase 2 moved here the registers that costs outweigh the latency it hides.)
+template <typename T, int LMAX, int BLOCK, bool LISTQ>
+__global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : (LMAX <= 16 ? SG_KP_WAVES_TIERS : 1)) void k_power(SgBeamArgs a)
+{
+    constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
+    constexpr int WIN = BLOCK < 64 ? 1 : SG_KP_WIN;       // waves' worth of slots per work item
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
     int64_t work_n = 0, work_off = 0;
     int n_items;
     const int step = (int)gridDim.x * WAVES;
@@ -791,11 +993,6 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     } else {
         n_items = *a.pw_count;
     }
-    const double *planes = LISTQ ? a.tq : a.dq;
-    const uint16_t *scs = LISTQ ? a.tq_sc : a.dq_sc;
-    static_assert(WIN <= 4, "the window's permutation passes through one 64-double row segment of the wave");
-    uint16_t *s_perm = (uint16_t *)(s_ratio + (BLOCK < 64 ? 0 : (tid & ~63)));   // dead between two beams: this wave's columns of row 0
-    int perm[WIN];
     // (the item index is wave-uniform; said so explicitly, it and everything read through it live in scalar registers)
     for (int i = (int)blockIdx.x * WAVES + __builtin_amdgcn_readfirstlane(tid >> 6); i < n_items; i += step) {
         int start, cnt, item_f = -1;
@@ -808,173 +1005,65 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
             const int dy = __builtin_amdgcn_readfirstlane(d.y);
             cnt = dy & 1023; item_f = (dy >> 10) - 1;
         }
-        // A window of several waves' worth of slots is taken in order of flake count: the cost of phases 2 and 3 grows
-        // steeply with the list length, and a wave is as slow as its longest list (counting sort by ballots; the slots of
-        // a window are neighbours in every plane of the queue, so the permuted reads touch the same lines).
-        const bool sorted = WIN > 1 && cnt > LANES;          // wave-uniform
-        if constexpr (WIN > 1) {
-            if (sorted) {
-                int key[WIN], rank[WIN];
-#pragma unroll
-                for (int r = 0; r < WIN; ++r) {
-                    const int idx = r * 64 + lane;
-                    key[r] = 255;                             // past the end of the window: last
-                    if (idx < cnt) {
-                        const unsigned sc = (LISTQ && a.ov_list) ? a.ov_sc[a.tier_list[work_off + start + idx]] : scs[(int64_t)start + idx];
-                        key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
-                    }
-                    rank[r] = 0;
-                }
-                int base = 0;
-                auto place = [&](int c) {
-#pragma unroll
-                    for (int r = 0; r < WIN; ++r) {
-                        const unsigned long long m = __ballot(key[r] == c);
-                        if (key[r] == c) rank[r] = base + (int)__popcll(m & sg_lanemask_lt());
-                        base += (int)__popcll(m);
-                    }
-                };
-                for (int c = 0; c <= LMAX; ++c) place(c);
-                place(254); place(255);
-#pragma unroll
-                for (int r = 0; r < WIN; ++r) s_perm[rank[r]] = (uint16_t)(r * 64 + lane);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // written and read by the lanes of one wave: no barrier, but keep the order
-#pragma unroll
-                for (int r = 0; r < WIN; ++r) perm[r] = s_perm[r * 64 + lane];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the lists of the first beam overwrite it)
-            }
+        sg_kp_item<T, LMAX, BLOCK, LISTQ>(a, smem, a.ov_list, a.tq_unsorted, work_off, start, cnt, item_f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ONE work queue for everything k_power_few left (large batches).  Rounds 2 - 5 ran k_power<4> (main queue, half of every CU), k_power<8> and
+// k_power<16> (overflow slots) as three persistent kernels on three streams: each sized its grid for a chip of its own, and whichever got
+// to a CU first kept it -- the 16-entry class' waves lived 0.1 ms of a kernel 1 ms long, the rest of which it queued for CUs
+// (profiles/r05_timeline_one_step.txt).  Here one grid of one-wave blocks takes the items of all three from one item space, longest
+// lists first (a long item started last is the tail of the phase):
+//     [0, it16)            the 16-entry class: L16 lanes per item (3 x 17 x L16 doubles of LDS: 19.6 KB at 48 lanes -- eight waves per CU)
+//     [it16, it16 + it8)   the 8-entry class: windows of SG_KP_WIN x 64 entries, taken in order of flake count
+//     [.., + it4)          the multi-flake beams of the main queue: windows of the CLOSED-UP back list (SgBeamArgs::back_list) -- per
+//                          region a back run is ~80 slots at C2, a round of 64 and a round of 16 lanes: a third of k_power<4>'s rounds
+//                          ran a quarter full
+// Items by striding, or (ticket) by an atomic cursor: a wave that drew short items takes more of them.
+struct SgKpAll {
+    int32_t cls8, cls16;         // index of the class in the tier lists, -1: none
+    int32_t ticket;
+};
+
+template <typename T, int L16>
+__global__ __launch_bounds__(64, 2) void k_power_all(SgBeamArgs a, SgKpAll u)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WIN = SG_KP_WIN;
+    const int n_waves = (int)gridDim.x;
+    const int lane = (int)(threadIdx.x & 63);
+    int n16 = u.cls16 >= 0 ? a.tier_info[u.cls16] : 0, n8 = u.cls8 >= 0 ? a.tier_info[u.cls8] : 0;
+    if (n16 > a.work_hi) n16 = a.work_hi;
+    if (n8 > a.work_hi) n8 = a.work_hi;
+    const int n4 = a.back_list ? a.pw_count[2] : 0;
+    // (a class the resident waves take in one round of single-wave items gains nothing from windows: see k_power)
+    const int slots8 = n8 <= n_waves * 64 ? 64 : 64 * WIN, slots4 = n4 <= n_waves * 64 ? 64 : 64 * WIN;
+    const int it16 = (n16 + L16 - 1) / L16, it8 = (n8 + slots8 - 1) / slots8, it4 = (n4 + slots4 - 1) / slots4;
+    const int total = it16 + it8 + it4;
+    int i = (int)blockIdx.x;
+    if (u.ticket) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(&a.pw_count[3], 1);
+        i = __builtin_amdgcn_readfirstlane(t);
+    }
+    while (i < total) {
+        if (i < it16) {
+            const int start = i * L16;
+            sg_kp_item<T, 16, L16, true>(a, smem, 1, 0, (int64_t)u.cls16 * a.tier_stride, start, n16 - start < L16 ? n16 - start : L16, -1);
+        } else if (i < it16 + it8) {
+            const int start = (i - it16) * slots8;
+            sg_kp_item<T, 8, 64, true>(a, smem, 1, 0, (int64_t)u.cls8 * a.tier_stride, start, n8 - start < slots8 ? n8 - start : slots8, -1);
+        } else {
+            const int start = (i - it16 - it8) * slots4;
+            sg_kp_item<T, 4, 64, false>(a, smem, 0, 0, 0, start, n4 - start < slots4 ? n4 - start : slots4, -1, a.back_list);
         }
-        const int rounds = (cnt + LANES - 1) / LANES;
-        for (int r = 0; r < rounds; ++r) {
-            const int idx = r * LANES + lane;
-            const bool in = lane < LANES && idx < cnt;
-            int pos = idx;
-            if constexpr (WIN > 1) {
-                if (sorted) {
-#pragma unroll
-                    for (int q = 0; q < WIN; ++q) if (q == r) pos = perm[q];
-                }
-            }
-            const int64_t slot = (int64_t)start + pos;
-            unsigned sc = 0xffffu;
-            int32_t g = 0;
-            double d = 0.0, tc = 0.0, f_a1 = 0.0, f_a2 = 0.0, f_rho = 0.0;
-            // where the beam's hand-over data lies: plane p at qb[p * qs] -- a slot of a blocked-SoA queue (stride 64), or the
-            // overflow slot of its sorted position (stride 1)
-            const double *qb = planes;
-            int qs = 64;
-            if (in) {                                         // everything a beam surely has, in one round of loads
-                g = LISTQ ? a.tier_list[work_off + slot] : a.dq_g[slot];
-                if (LISTQ && a.ov_list) { qb = a.ov + (size_t)g * SG_OV_STRIDE; qs = 1; sc = a.ov_sc[g]; }
-                else { qb = planes + sg_qaddr<P>(slot, 0); sc = scs[slot]; }
-                d = qb[0];                                    // the beam's range (simulation.py:89), widened from the row dtype
-                tc = qb[qs];
-                f_a1 = qb[2 * qs]; f_a2 = qb[3 * qs]; f_rho = qb[4 * qs];
-            }
-            const bool live = in && sc != 0xffffu;            // 0xffff: a listed beam without a flake (its record is final)
-            const int L = (int)(sc & 255u), ch = (int)(sc >> 8);
-            int f = 0;
-            SgBeamOut o;
-            o.overflow = 0; o.range_error = 0; o.diff2 = 0.0; o.has_power = 0; o.n_flakes = 0; o.n_hits = 0; o.label = 0; o.new_i = 0; o.k_best = 0;
-            constexpr int NB = LMAX <= 4 ? SG_NB4 : SG_NB_TIERS;   // bins of the power profile carried together
-            int S = 0, nw = 0, k_best = 0;
-            double best = 0.0;
-            if (live) {
-                f = item_f >= 0 ? item_f : sg_frame_of(a, g);
-                // ord: 4 bits per list entry -- the hit (scan order) it came from; identity unless the scan left the flakes unsorted
-                unsigned long long ord = 0xfedcba9876543210ull;
-                if (LISTQ && (a.tq_unsorted || a.ov_list)) {
-                    // the flakes as the scan met them: insertion by range, scan order on equal ranges (simulation.py:413-417).  The
-                    // ranges pass through the ratio / range column (free until the dict); THREE: they go back to being fetched from
-                    // the queue afterwards, through `ord`.
-                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2; s_rho[ltid] = f_rho;
-                    if constexpr (THREE) ord = 0;
-                    // first every flake into the columns as it lies in the queue -- independent loads, all in flight together --, then
-                    // the insertion sort on LDS alone (a load per step of the sort would put a memory latency into every step)
-#pragma unroll 4
-                    for (int h = 1; h < L; ++h) {
-                        s_a1[h * BLOCK + ltid] = qb[(2 + 3 * h) * qs];
-                        s_a2[h * BLOCK + ltid] = qb[(3 + 3 * h) * qs];
-                        s_rho[h * BLOCK + ltid] = qb[(4 + 3 * h) * qs];
-                    }
-                    for (int h = 1; h < L; ++h) {
-                        const double x1 = s_a1[h * BLOCK + ltid], x2 = s_a2[h * BLOCK + ltid], r = s_rho[h * BLOCK + ltid];
-                        int q = h;
-                        // (equal ranges of different flakes -- probability zero for sampled tables -- fall back on the interval angles, so
-                        // that the order never depends on the order in which the scan's lanes reached the slot)
-                        while (q > 0 && (s_rho[(q - 1) * BLOCK + ltid] > r ||
-                                         (s_rho[(q - 1) * BLOCK + ltid] == r && a.ov_list &&
-                                          (s_a1[(q - 1) * BLOCK + ltid] > x1 || (s_a1[(q - 1) * BLOCK + ltid] == x1 && s_a2[(q - 1) * BLOCK + ltid] > x2))))) {
-                            s_rho[q * BLOCK + ltid] = s_rho[(q - 1) * BLOCK + ltid]; s_a1[q * BLOCK + ltid] = s_a1[(q - 1) * BLOCK + ltid];
-                            s_a2[q * BLOCK + ltid] = s_a2[(q - 1) * BLOCK + ltid];
-                            --q;
-                        }
-                        if (q != h) { s_rho[q * BLOCK + ltid] = r; s_a1[q * BLOCK + ltid] = x1; s_a2[q * BLOCK + ltid] = x2; }
-                        if constexpr (THREE) {
-                            const unsigned long long low = (1ull << (4 * q)) - 1ull;
-                            ord = (ord & low) | ((unsigned long long)h << (4 * q)) | ((ord & ~low) << 4);
-                        }
-                    }
-                } else {
-                    s_a1[ltid] = f_a1; s_a2[ltid] = f_a2;
-                    if constexpr (!THREE) s_rho[ltid] = f_rho;
-                    for (int j = 1; j < L; ++j) {
-                        s_a1[j * BLOCK + ltid] = qb[(2 + 3 * j) * qs];
-                        s_a2[j * BLOCK + ltid] = qb[(3 + 3 * j) * qs];
-                        if constexpr (!THREE) s_rho[j * BLOCK + ltid] = qb[(4 + 3 * j) * qs];
-                    }
-                }
-                auto queue_rho = [&](int j) -> double {       // range of list entry j (THREE: from the queue)
-                    const int h = (int)((ord >> (4 * j)) & 15ull);
-                    return h == 0 ? f_rho : qb[(4 + 3 * h) * qs];
-                };
-                int32_t *dc = a.dbg_count ? a.dbg_count + g : nullptr;
-                double *drj = a.dbg_count ? a.dbg_rj + (int64_t)g * a.dbg_cap : nullptr;
-                double *dra = a.dbg_count ? a.dbg_ratio + (int64_t)g * a.dbg_cap : nullptr;
-                unsigned long long srcmap = 0;
-                if constexpr (THREE) S = sg_beam_dict<LMAX, BLOCK, false>(L, tc, d, a.beam_div_deg, s_a1, s_a2, nullptr, s_ratio, ltid, 0, nullptr, nullptr, nullptr, 0, &srcmap);
-                else S = sg_beam_dict<LMAX, BLOCK>(L, tc, d, a.beam_div_deg, s_a1, s_a2, s_rho, s_ratio, ltid, a.dbg_cap, dc, drj, dra);
-                if constexpr (THREE) {
-                    if (dc) {                                   // debug tap: ratios now, ranges from the queue
-                        *dc = S + 1;
-                        for (int t = 0; t <= S && t < a.dbg_cap; ++t) {
-                            const int j = (int)((srcmap >> (4 * t)) & 15ull);
-                            drj[t] = t == S ? d : queue_rho(j);
-                            dra[t] = s_ratio[t * BLOCK + ltid];
-                        }
-                    }
-                }
-                if (S > 0) {                                // S == 0: no flake owns a slot -> label 0 (simulation.py:133)
-                    const T d_t = (T)d;                     // exact
-                    if constexpr (THREE) {
-                        sg_beam_amp3<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, ltid, o,
-                                                     [&](int t) { return queue_rho((int)((srcmap >> (4 * t)) & 15ull)); });
-                    } else sg_beam_amp<T, LMAX, BLOCK>(d_t, S, ch, a.las, s_a1, s_a2, s_rho, s_ratio, ltid, o, 0);
-                    if (o.range_error) {
-                        atomicCAS(&a.status[0], 0, 4 /* SNOWGPU_E_RANGE */);
-                        atomicCAS(&a.status[1], -1, g);
-                    }
-                    // stage A of the received-power profile, lane by lane: the few groups of bins that can hold its maximum
-                    if (a.exact_math) nw = sg_power_plan<BLOCK, true, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
-                    else nw = sg_power_plan<BLOCK, false, NB, LMAX>(S, a.rgrid, s_a1, s_a2, s_rho, s_work, ltid, best, k_best);
-                } else S = 0;
-            }
-            // stage B, the whole wave over the groups of its 64 beams
-            {
-                const int colbase = BLOCK < 64 ? 0 : (tid & ~63);
-                if (a.exact_math) sg_wave_eval<BLOCK, true, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
-                else sg_wave_eval<BLOCK, false, NB>(nw, S, a.rgrid, s_a1, s_a2, s_rho, s_work, colbase, best, k_best);
-            }
-            if (live) {
-                uint32_t rec = 0;
-                if (S > 0) {
-                    sg_beam_decide(d, ch, a.las, best, k_best, o);
-                    rec = sg_pack_record(o);
-                }
-                if (LISTQ) a.rec[g] = rec;
-                else a.rec_q[slot] = rec;                   // the row's record points here (SG_REC_SLOT)
-            }
-            sg_add_diff2(a.diff2, live, f, live ? (long long)o.diff2 : 0);
+        if (u.ticket) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&a.pw_count[3], 1);
+            i = __builtin_amdgcn_readfirstlane(t);
+        } else {
+            i += n_waves;
         }
     }
 }
@@ -1918,6 +2007,30 @@ extern "C" int sg_launch_power(const SgBeamArgs *a, int dtype, int lmax, void *s
     if (lmax == 8) return launch_power_t<double, 8, SG_LANES_8, false>(a, st, po, ef, which);
     if (lmax == 16) return launch_power_t<double, 16, SG_LANES_16, false>(a, st, po, ef, which);
     return launch_power_t<double, SG_LCAP, SG_LANES_63, false>(a, st, po, ef, which);
+}
+
+template <typename T>
+static int launch_power_all_t(const SgBeamArgs *a, int cls8, int cls16, int waves_per_cu, int ticket, hipStream_t st)
+{
+    constexpr int L16 = 48;
+    const size_t lds = sizeof(double) * std::max<size_t>(std::max<size_t>((size_t)64 * 4 * 5, (size_t)64 * 3 * 9), (size_t)L16 * 3 * 17);
+    static bool attr_set[64] = {};
+    if (int e = sg_set_lds(k_power_all<T, L16>, lds, attr_set)) return e;
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    const int per_cu = std::max(1, std::min(waves_per_cu, (int)((size_t)(160 * 1024) / lds)));
+    const int64_t blocks = std::min<int64_t>((int64_t)sg_cu_count(dev_id) * per_cu, a->n_total / 48 + 3);
+    if (blocks <= 0) return 0;
+    SgKpAll u{cls8, cls16, ticket};
+    hipLaunchKernelGGL((k_power_all<T, L16>), dim3((unsigned)blocks), dim3(64), lds, st, *a, u);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sg_launch_power_all(const SgBeamArgs *a, int dtype, int cls8, int cls16, int waves_per_cu, int ticket, void *stream)
+{
+    return dtype == 0 ? launch_power_all_t<float>(a, cls8, cls16, waves_per_cu, ticket, (hipStream_t)stream)
+                      : launch_power_all_t<double>(a, cls8, cls16, waves_per_cu, ticket, (hipStream_t)stream);
 }
 
 extern "C" int sg_launch_tier_gather(const SgBeamArgs *a, void *stream)

@@ -665,8 +665,36 @@ __global__ __launch_bounds__(128) void k_pre_quad_fit(PreArgs a, int err_code)
     }
     __syncthreads();
     const int m = s_m;
-    if (m < 3) {                                                         // np.polyfit on fewer points than coefficients: TypeError / rank warning in the reference
+    if (m == 0) {                                                        // np.polyfit on an empty vector: TypeError in the reference (augmentation.py:179)
         if (tid == 0) { if (err_code) atomicCAS(&a.status[0], 0, err_code); fr.mq[0] = 0.0; fr.mq[1] = fr.pmin0; fr.mq[2] = fr.pmin1; fr.quad = 1; }
+        return;
+    }
+    if (m < 3) {
+        // One or two usable range rows: np.polyfit(x, y, 2) (:179) answers an under-determined system with the MINIMUM-NORM solution of its
+        // column-scaled Vandermonde system (lstsq on lhs / sqrt(sum lhs^2), then c / scale) and a RankWarning; no RANSAC trial can replace
+        // it (a consensus set needs more than d = 15 points, :187), so ransac_polyfit returns exactly that fit.  Columns x^2, x, 1.
+        if (tid == 0) {
+            double sc[3] = {0, 0, 0}, A[2][3];
+            for (int i = 0; i < m; ++i) { const double x = xs[i]; sc[0] += (x * x) * (x * x); sc[1] += x * x; sc[2] += 1.0; }
+            for (int k = 0; k < 3; ++k) sc[k] = sqrt(sc[k]);
+            for (int i = 0; i < m; ++i) { const double x = xs[i]; A[i][0] = sc[0] > 0 ? x * x / sc[0] : 0.0; A[i][1] = sc[1] > 0 ? x / sc[1] : 0.0; A[i][2] = 1.0 / sc[2]; }
+            double w[2] = {0, 0};
+            if (m == 1) {
+                const double g = A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2];
+                w[0] = ys[0] / g;
+            } else {
+                const double g00 = A[0][0] * A[0][0] + A[0][1] * A[0][1] + A[0][2] * A[0][2], g11 = A[1][0] * A[1][0] + A[1][1] * A[1][1] + A[1][2] * A[1][2];
+                const double g01 = A[0][0] * A[1][0] + A[0][1] * A[1][1] + A[0][2] * A[1][2], det = g00 * g11 - g01 * g01;
+                if (fabs(det) > 1e-14 * g00 * g11) { w[0] = (g11 * ys[0] - g01 * ys[1]) / det; w[1] = (g00 * ys[1] - g01 * ys[0]) / det; }
+                else { w[0] = w[1] = 0.5 * (ys[0] + ys[1]) / (g00 + g01); }          // the same abscissa twice: rank one
+            }
+            for (int k = 0; k < 3; ++k) {
+                double c = 0;
+                for (int i = 0; i < m; ++i) c += A[i][k] * w[i];
+                fr.mq[k] = sc[k] > 0 ? c / sc[k] : 0.0;
+            }
+            fr.quad = 1;
+        }
         return;
     }
     double b2, b1, b0;

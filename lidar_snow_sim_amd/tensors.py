@@ -236,6 +236,16 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
         if wet is not None and o_flags is None:
             o_flags = torch.empty(nf, dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev)
+        # The C ABI reads stream = NULL as "the context's own stream", which is not ordered against anything of torch's.  torch's legacy
+        # default stream HAS the handle 0, so a call made on it runs on a side stream of the engine, forked from and joined back into the
+        # default stream (two event waits): uploads queued before the call are seen, and whoever reads the results on the caller's stream
+        # afterwards -- or synchronises it -- waits for the call.
+        run = stream
+        if stream.cuda_stream == 0:
+            run = eng.__dict__.get("_torch_side_stream")
+            if run is None or run.device != dev:
+                run = eng.__dict__["_torch_side_stream"] = torch.cuda.Stream(device=dev)
+            run.wait_stream(stream)
         ptr = lambda t: 0 if t is None else t.data_ptr()   # noqa: E731
         with eng.batch_lock:
             if calib is not None:
@@ -247,7 +257,7 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
                 if wet is None:
                     eng.ctx.augment_batch_device(nf, n, max_rows, d_off.data_ptr(), rows.data_ptr(), code, d_tids.data_ptr(),
                                                  float(beam_divergence), ptr(d_poly), ptr(d_plane), float(noise_floor), 0, o_rows.data_ptr(),
-                                                 o_src.data_ptr(), o_cnt.data_ptr(), o_st.data_ptr(), 0, o_status.data_ptr(), stream.cuda_stream)
+                                                 o_src.data_ptr(), o_cnt.data_ptr(), o_st.data_ptr(), 0, o_status.data_ptr(), run.cuda_stream)
                 else:
                     w = dict(water_height=0.001, pavement_depth=0.0012, noise_floor=0.7, power_factor=15, flat_earth=False, delta=0.5,
                              replace=True)
@@ -261,8 +271,10 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
                                                      float(beam_divergence), ptr(d_poly), ptr(d_plane), float(noise_floor), 0, ptr(d_wet_plane),
                                                      w["water_height"], w["pavement_depth"], w["noise_floor"], w["power_factor"],
                                                      w["flat_earth"], w["delta"], w["replace"], o_rows.data_ptr(), o_src.data_ptr(),
-                                                     o_cnt.data_ptr(), o_st.data_ptr(), o_flags.data_ptr(), o_status.data_ptr(), stream.cuda_stream)
+                                                     o_cnt.data_ptr(), o_st.data_ptr(), o_flags.data_ptr(), o_status.data_ptr(), run.cuda_stream)
             finally:
+                if run is not stream:
+                    stream.wait_stream(run)
                 if calib is not None:
                     eng.ctx.set_fov(None)
                 if plane_method != 'reference':

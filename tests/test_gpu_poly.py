@@ -149,11 +149,28 @@ def test_poly_argument_handling(eng, golden):
         estimate_laser_parameters(pc[:100], np.full(100, 0.3), debug=False, estimation_method="poly")
     out = ground_water_augmentation(pc[:900], estimation_method="poly", plane=PLANE, debug=False)
     assert out is pc[:900] or out.shape == pc[:900].shape                # fewer than 1000 ground rows: the input comes back (:51-52)
-    # a cloud whose ground rows all lie in one range row of the histogram: np.polyfit of degree 2 over fewer than 3 points
+    # A cloud whose ground rows all lie in one or two range rows of the histogram: np.polyfit of degree 2 over fewer than 3 points answers
+    # with the minimum-norm solution and a RankWarning, and ransac_polyfit returns that fit (no trial can gather d = 15 inliers,
+    # augmentation.py:179-191) -- so does the device; only an EMPTY x raises (np.polyfit's TypeError).
     ring = pc[np.abs(np.linalg.norm(pc[:, :3], axis=1) - 20.0) < 0.5]
     if ring.shape[0] >= 1000:
-        with pytest.raises(TypeError):
-            ground_water_augmentation(ring, estimation_method="poly", plane=PLANE, debug=False)
+        import warnings
+        out = ground_water_augmentation(ring, estimation_method="poly", plane=PLANE, debug=False)
+        fit = eng.ctx.wet_last_fit(1)[0]
+        w = np.asarray(PLANE[0], np.float64)
+        hog = ring[:, :3].astype(np.float64) @ w
+        g = ring[np.abs(hog + PLANE[1]) < 0.5].astype(np.float64)
+        dist = np.linalg.norm(g[:, :3], axis=1)
+        norm = g[:, 3] / ((g[:, :3] @ w) / (dist * np.linalg.norm(w)))
+        hist, xe, ye = np.histogram2d(dist, norm, bins=(50, 2555), range=((10, 70), (5, np.abs(np.max(norm)))))
+        hist[hist == 0] = len(g)
+        mv = ye[np.argmin(hist, axis=1)]
+        sel = np.where(mv > 5)[0]
+        assert 1 <= len(sel) <= 2 and out.shape[1] == 5
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = np.polyfit((xe[sel] + xe[sel + 1]) / 2, mv[sel], 2)
+        np.testing.assert_allclose(fit[3:6], want, rtol=1e-8, atol=1e-12)
 
 
 def test_fused_snow_and_wet_batch_with_poly_equals_the_chained_calls(eng, golden, tables):
