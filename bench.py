@@ -319,6 +319,7 @@ def main():
     ap.add_argument("--dry", action="store_true", help="launch logic only: gloo on CPU, no GPU work (tests)")
     ap.add_argument("--c5-dir", default=None, help="C5: one input / output tree shared by all ranks (default: a temporary one per rank)")
     ap.add_argument("--c5-keep", action="store_true", help="C5: keep the written files (default: unlink each right after the write)")
+    ap.add_argument("--lanes", type=int, default=1, help="batches in flight in the timed loop (compute lanes of the tensor boundary; 1: each step waits for the one before it)")
     ap.add_argument("--tables", default="host", choices=("host", "device"),
                     help="host: dart_throwing on the host (bit-exact mirror of sampling.py), uploaded once; device: sampled and filed on the GPU "
                          "(snowgpu_sample_table, seed = f(prefix, line)): no table ever crosses the link; reports sampler throughput")
@@ -456,12 +457,24 @@ def main():
         call_kw["planes"] = np.asarray(planes, np.float64)
     if fused_wet:
         call_kw["wet"] = dict(WET, plane=plane)
-    res = [None]
+    # --lanes L > 1: L batches in flight -- step k runs on compute lane k mod L (an engine context and stream of its own) and keeps its own
+    # result tensors; nothing waits for a step but the next step on the same lane and the synchronise that ends the timed region.
+    L = max(1, args.lanes)
+    res = [None] * L
     side = torch.cuda.Stream(device=dev)       # (a stream of the caller's: on torch's legacy default stream the boundary forks to one of its own)
+    step_no = [0]
+    if L > 1 and layers != 64:
+        for k in range(1, L):
+            engine.get_engine(local_rank, k).set_lasers(engine.load_lasers() * (layers // 64))
 
     def step():
+        k = step_no[0] % L
+        step_no[0] += 1
         with torch.cuda.stream(side):
-            res[0] = snow_tensors.augment_batch(batch, call_prefix, BEAM_DIV, noise_floor=0.7, sync=False, out=res[0], **call_kw)
+            res[k] = snow_tensors.augment_batch(batch, call_prefix, BEAM_DIV, noise_floor=0.7, sync=False, out=res[k], lane=k if L > 1 else None, **call_kw)
+
+    for _ in range(L - 1):
+        step()
 
     step()                                                  # (first call of the size: result tensors, library scratch)
     torch.cuda.synchronize()
@@ -724,6 +737,38 @@ def main():
                 if not fused_wet:
                     ok = ok and tuple(int(v) for v in out_stats[fi].cpu().numpy()) == tuple(int(v) for v in s_ref)
                 same = same and bool(ok)
+            # (iii) the build's own CPU twin (libsnowcpu.so: the kernels' per-beam device code compiled for the host, binned tables and all;
+            # include/snowgpu_cpu.h, SURVEY 8 b / 8 d) on the same frames, every usable CPU and one; the polynomials are the device prepass's
+            twin = None
+            if not fused_wet:
+                try:
+                    from lidar_snow_sim_amd import _cpu_twin
+                    pin_rows = eng.ctx.pinned_empty((n_cpu * n_per, 5), np.float32)
+                    pin_rows[...] = host_rows[:n_cpu * n_per]
+                    _, _, _, _, thr_dev = eng.ctx.augment_batch(pin_rows, np.arange(n_cpu + 1, dtype=np.int64) * n_per, np.asarray(table_ids[:n_cpu], np.int32), BEAM_DIV,
+                                                                plane=np.asarray(planes[:n_cpu], np.float64), want_thr=True, want_src=False)
+                    _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=cores)      # (loads the library, files nothing twice)
+                    c0 = time.perf_counter()
+                    tw = _cpu_twin.augment_batch(frames[:n_cpu], tables, orders[:n_cpu], BEAM_DIV, thr_dev, lasers=las, threads=cores)
+                    tw_s = time.perf_counter() - c0
+                    c0 = time.perf_counter()
+                    _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=1)
+                    tw1_s = time.perf_counter() - c0
+                    tw_same = True
+                    for fi in range(n_cpu):
+                        n0, lo = int(out_counts[fi].item()), fi * n_per
+                        tw_same = tw_same and n0 == tw[fi][1].shape[0] and out_rows[lo:lo + n0].cpu().numpy().tobytes() == tw[fi][1].tobytes() \
+                            and np.array_equal(out_src[lo:lo + n0].cpu().numpy(), tw[fi][2])
+                    twin = {"value": n_cpu * n_per / tw_s, "unit": "points/s", "cores": cores, "single_core_value": n_per / tw1_s,
+                            "kind": "the build's own restatement: libsnowcpu.so = the HIP kernels' per-beam device code (csrc/sg_beam.h, sg_table_host.h, sg_row.h) "
+                                    "compiled for the host, one beam at a time on host threads (include/snowgpu_cpu.h); table filing inside the clock, "
+                                    "threshold polynomials given (the device prepass's)",
+                            "sample": f"frames 0..{n_cpu - 1} of the batch, {tw_s:.2f} s on {cores} threads; one thread on frame 0: {tw1_s:.2f} s",
+                            "same_bytes_as_gpu": bool(tw_same)}
+                except Exception as ex:      # the twin is a side measurement: the line does not depend on it
+                    twin = {"error": repr(ex)}
+            if twin is not None:
+                result["cpu_twin"] = twin
             result["cpu_baseline"] = {"value": n_cpu * n_per / cpu_s, "unit": "points/s", "cores": used, "kind": "port",
                                       "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "host_cpus_usable": cpu_info,
                                       "sample": f"frames 0..{n_cpu - 1} of the batch ({n_cpu * n_per} points): oracle/snow_oracle.c (scalar C "

@@ -1,4 +1,5 @@
-"""Build libsnowgpu.so (hand-written HIP for gfx950) in-tree with hipcc.
+"""Build libsnowgpu.so (hand-written HIP for gfx950) in-tree with hipcc -- and libsnowcpu.so, the same per-beam device code compiled for the host
+(the CPU twin of include/snowgpu_cpu.h: a measurement baseline and parity check, never loaded by the package).
 
     python -m lidar_snow_sim_amd.build [--force]
 
@@ -21,6 +22,22 @@ SOURCES = ["snowgpu_kernels.hip", "snowgpu_rows.hip", "snowgpu_prepass.hip", "sn
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
+CPU_LIB = PKG / "libsnowcpu.so"          # the CPU twin (include/snowgpu_cpu.h): the kernels' device code compiled for the host -- a baseline, never loaded by the package
+
+
+def build_cpu_twin(force: bool = False, verbose: bool = True) -> Path:
+    src = CSRC / "snowcpu.cpp"
+    deps = [src] + [p for p in CSRC.glob("*.h")] + [PKG.parent / "include" / "snowgpu_cpu.h"]
+    if not force and CPU_LIB.exists() and all(p.stat().st_mtime <= CPU_LIB.stat().st_mtime for p in deps):
+        return CPU_LIB
+    cmd = [hipcc(), "--cuda-host-only", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-pthread", "-w",
+           "-I", str(CSRC), "-I", str(PKG.parent / "include"), str(src), "-o", str(CPU_LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return CPU_LIB
+
+
 def hipcc() -> str:
     exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not Path(exe).exists():
@@ -32,11 +49,12 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [p for p in CSRC.glob("*") if p.is_file()] + [PKG.parent / "include" / "snowgpu.h"]
+    deps = [p for p in CSRC.glob("*") if p.is_file() and p.name != "snowcpu.cpp"] + [PKG.parent / "include" / "snowgpu.h"]
     return any(p.stat().st_mtime > t for p in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> Path:
+    build_cpu_twin(force, verbose)
     if not force and not needs_build():
         return LIB
     objs = []

@@ -153,6 +153,7 @@ struct SgBeamArgs {
     int32_t *tn, *tbase;         // per region x SG_MAX_CLASSES: entries, start in the closed-up list
     int32_t cls;
     int32_t work_lo, work_hi;
+    int32_t work_hint;           // host: beams this class is expected to hold (from the batches before; 0: unknown) -- sizes the grids of its kernels
     // row kernels (snowgpu_rows.hip): beams whose dict needs NumPy's pairwise sum (an owner with >= 8 slots) are deferred to a
     // second instantiation through this list (laid out like tier_list: class k at k * tier_stride) and its per-class counters
     int32_t *redo_list;

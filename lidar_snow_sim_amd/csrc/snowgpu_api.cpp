@@ -1081,13 +1081,18 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         // runs behind it on the same stream -- the tiers then start with one short kernel (k_tier_gather) and no hop between streams --
         // and the received-power kernels it feeds on a side stream, next to the later capacity tiers.
         if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], st, 1, nullptr, 3);
-        if (!e) {
+        if (!e && kp_all) {
+            // One work queue: the lists are closed up AHEAD of k_power_few (beside it, k_tier_gather's 4096 short blocks sat on the CUs when
+            // k_power_few's persistent blocks arrived; those that found no room started when others had ended and walked their whole share
+            // then: 0.78 instead of 0.54 ms), and k_power_few stays on the caller's stream -- it has the chip to itself anyway; what runs
+            // beside k_power_all (the 63-entry / global-list chain, the prepass) forks behind it.
+            e = sg_launch_tier_gather(&a, st);
+            if (!e) e = sg_launch_power(&a, b.dtype, tiers[0], st, 0, ctx->ev_few, 1);
+        } else if (!e) {
             HIPCHK(ctx, hipEventRecord(ctx->ev_fp, st));
             HIPCHK(ctx, hipStreamWaitEvent(s_aux, ctx->ev_fp, 0));
-            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr, (heavy_tail || kp_all) ? 1 : 3);
+            e = sg_launch_power(&a, b.dtype, tiers[0], s_aux, 0, few_first ? ctx->ev_few : nullptr, heavy_tail ? 1 : 3);
         }
-        // (one work queue: the lists it takes are closed up beside k_power_few -- nothing starts with them until that kernel has ended)
-        if (!e && kp_all) e = sg_launch_tier_gather(&a, st);
         if (!e) {
             // Large batches: k_power_few has the chip to itself for its turn -- four waves per SIMD of it fill the register file, and
             // the tiers, the prepass and k_power do better behind it than beside it (measured: 4.37 against 4.69 ms per 256 sweeps when
@@ -1095,7 +1100,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             // k_tier_gather stays BEHIND this wait although it needs nothing of k_power_few: with it ahead the tiers and the prepass start
             // the moment k_power_few ends, together with k_power<4>, and take the CUs its persistent blocks would have taken -- 4.43 - 4.49
             // against 4.22 - 4.24 ms per step on one box (round 5); the 30 us it costs give k_power<4> its head start.
-            if (few_first) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
+            if (few_first && !kp_all) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
             if (!kp_all) e = sg_launch_tier_gather(&a, st);
         }
     }
@@ -1122,8 +1127,18 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         a.work_lo = 0; a.work_hi = (int32_t)std::min<int64_t>(b.n_total, INT32_MAX);
         e = sg_launch_power_all(&a, b.dtype, cls8, cls16, R->kp_all_waves, R->kp_all_ticket, st);
     }
+    // what the classes held in a recent batch (page-locked words the device leaves behind, scaled to this batch's size): grids of the rare tiers
+    int32_t cls_hint[SG_MAX_CLASSES] = {0, 0, 0, 0};
+    if (a.tier_hint && ctx->tier_hint_h) {
+        const volatile int32_t *hint = ctx->tier_hint_h;
+        const int64_t then_k = hint[SG_MAX_CLASSES];
+        if (then_k > 0)
+            for (int k = 0; k < SG_MAX_CLASSES; ++k)
+                cls_hint[k] = (int32_t)std::min<int64_t>(INT32_MAX / 8, ((int64_t)hint[k] * ((b.n_total >> 10) + 1)) / then_k + 64);
+    }
     for (int k = 0; k < n_cls && !e; ++k) {
         if (kp_all && (k == cls8 || k == cls16)) continue;            // (taken by k_power_all)
+        a.work_hint = k >= 2 ? cls_hint[k] : 0;
         hipStream_t sk = (k == 0 || (tail_main && k >= 2)) ? st : ((tail_aux && k >= 2) ? s_aux : s_aux3);
         a.seg_blk = nullptr;
         a.cls = k;
@@ -1389,12 +1404,12 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // ---- packed result transfer: downloads sized by the counts, and the host threads that put the rows together ----------------------
     int pk_enq = 0, pk_asm = 0;                      // chunks whose compute and download are enqueued / whose rows are with the pool
     auto pk_mv_head = [](size_t chunk_rows) { return std::min(chunk_rows, std::max<size_t>(4096, chunk_rows / 8)); };
-    auto assemble_frame = [=](int f, int64_t kept, int64_t mv_at) mutable {
+    auto assemble_frame = [=](int f, int64_t kept_dev, int64_t mv_at) {
         // out row j of frame f = the caller's input row src_j with the device's intensity and label; label-2 rows take their moved coordinates
         // (mv_at: where this frame's part of the batch's list of moved coordinates starts, in rows)
         const int64_t o = frame_offsets[f];
         const uint32_t n_rows = (uint32_t)(frame_offsets[f + 1] - o);          // (what came back from the device bounds no host loop or index unchecked)
-        if (kept > (int64_t)n_rows) kept = n_rows;
+        const int64_t kept = kept_dev > (int64_t)n_rows ? (int64_t)n_rows : kept_dev;
         const uint32_t *meta = (const uint32_t *)st_meta + o;
         if (esz == 4) {
             const float *in = (const float *)rows + (size_t)o * 5, *it = (const float *)st_int + o, *mv = (const float *)st_mv + (size_t)mv_at * 3;

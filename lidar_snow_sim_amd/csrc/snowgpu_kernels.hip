@@ -18,6 +18,7 @@
 #include "sg_few.h"
 #include "sg_kutil.h"
 #include "sg_lean.h"
+#include "sg_row.h"
 
 #define SG_BLOCK 256
 #ifndef SG_NB4
@@ -739,6 +740,7 @@ __global__ __launch_bounds__(256) void k_tier_gather(SgBeamArgs a, int n_regions
     const int r = blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     if (blockIdx.x == 0 && threadIdx.x < SG_MAX_CLASSES) a.status[2 + threadIdx.x] = a.tier_info[threadIdx.x];   // beams per later tier
     if (blockIdx.x == 0 && threadIdx.x < SG_MAX_CLASSES && a.tier_hint) a.tier_hint[threadIdx.x] = a.tier_info[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.tier_hint) a.tier_hint[SG_MAX_CLASSES] = (int32_t)((a.n_total >> 10) + 1);   // ... of a batch of this many K rows
     int q_size = 0, f1 = 0;
     int64_t q_base = 0;
     if (!sg_region(a, r, n_regions_ub, q_base, q_size, f1)) return;
@@ -1415,36 +1417,6 @@ __global__ __launch_bounds__(1024) void k_seg_small(const int64_t *__restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Output row of a sorted position, rebuilt from its ORIGINAL row and its result record (simulation.py:160-192, :516):
-// unchanged rows keep their coordinates and get np.round(intensity); attenuated rows (label 1) the new intensity; scattered
-// rows (label 2) move to d_max on their ray; rows of channels without a laser keep their channel value in column 4 (Q5).
-// dd = the ORIGINAL range in the row dtype (simulation.py:465).
-template <typename T> struct SgRow { T x, y, z, i, lab, dd; };
-
-template <typename T>
-__device__ __forceinline__ SgRow<T> sg_rebuild_row(const T *__restrict__ row, uint32_t rec)
-{
-    SgRow<T> r;
-    const T px = row[0], py = row[1], pz = row[2], pint = row[3], pch = row[4];
-    if constexpr (sizeof(T) == 4) r.dd = sqrtf((px * px + py * py) + pz * pz);
-    else r.dd = sqrt((px * px + py * py) + pz * pz);
-    r.x = px; r.y = py; r.z = pz;
-    const int label = (int)((rec >> SG_REC_LABEL_SHIFT) & 3u);
-    if (label == 0) {
-        if constexpr (sizeof(T) == 4) r.i = rintf(pint); else r.i = rint(pint);      // :516 np.round (half to even)
-        r.lab = (rec & SG_REC_COPY) ? pch : (T)0;
-    } else {
-        r.i = (T)(int)(rec & 255u);
-        r.lab = (T)label;
-        if (label == 2) {
-            const double scale = sg_scatter_scale((int)((rec >> SG_REC_K_SHIFT) & 2047u), (double)r.dd);   // :176
-            r.x = (T)((double)px * scale); r.y = (T)((double)py * scale); r.z = (T)((double)pz * scale);   // :178-180
-        }
-    }
-    return r;
-}
-
 // get_fov_flag(calib.lidar_to_rect(xyz), (h, w), calib) (simulation.py:39-47, :535-536) in float64, fixed operation order.
 // The projection is OpenPCDet's (pcdet/utils/calibration_kitti.py, the reference's un-vendored submodule lib/OpenPCDet:
 // parity unpinned, SURVEY 8 c): rect_to_img divides the image coordinates by the RECTIFIED point's z, not by the third
@@ -1915,7 +1887,8 @@ static int launch_power_t(const SgBeamArgs *a, hipStream_t st, bool plan_only = 
     // later tiers and the prepass run beside it -- it takes a share (in quarters) of what fits
     if (!LISTQ && a->kp_lds_quarters > 0 && a->kp_lds_quarters < 4) per_cu = std::max(1u, per_cu * (unsigned)a->kp_lds_quarters / 4u);
     int64_t blocks = (int64_t)sg_cu_count(dev_id) * per_cu;
-    const int64_t items_ub = LISTQ ? ((int64_t)a->work_hi + LANES - 1) / LANES : (a->n_total + LANES - 1) / LANES + 2 * a->n_regions_ub;
+    int64_t items_ub = LISTQ ? ((int64_t)a->work_hi + LANES - 1) / LANES : (a->n_total + LANES - 1) / LANES + 2 * a->n_regions_ub;
+    if (LISTQ && a->work_hint > 0) items_ub = std::min<int64_t>(items_ub, (4 * (int64_t)a->work_hint + LANES - 1) / LANES + 8);   // (see launch_tier_scan_t)
     blocks = std::min<int64_t>(blocks, (items_ub + THREADS / 64 - 1) / (THREADS / 64));
     if (blocks <= 0) return 0;
     if (!LISTQ) {
@@ -1957,7 +1930,11 @@ static int launch_tier_scan_t(const SgBeamArgs *a, int lmax, hipStream_t st)
     if (n <= 0) return 0;
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
-    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, (int64_t)sg_cu_count(dev_id) * 8);
+    int64_t want = (n + 255) / 256;
+    // (a class that held a handful of beams in the batches before gets a grid for four times that, not one for its buffer: 8192 waves queued
+    // for CUs beside the persistent kernels of the phase to find 23 beams -- 0.36 ms; the fixed grid strides, so a low guess only costs time)
+    if (a->work_hint > 0) want = std::min<int64_t>(want, (4 * (int64_t)a->work_hint + 255) / 256 + 8);
+    const unsigned blocks = (unsigned)std::min<int64_t>(want, (int64_t)sg_cu_count(dev_id) * 8);
     if (lmax == 8) hipLaunchKernelGGL((k_tier_scan_direct<T, 8>), dim3(blocks), dim3(256), 0, st, *a);
     else if (lmax == 16) hipLaunchKernelGGL((k_tier_scan_direct<T, 16>), dim3(blocks), dim3(256), 0, st, *a);
     else hipLaunchKernelGGL((k_tier_scan_direct<T, SG_LCAP>), dim3(blocks), dim3(256), 0, st, *a);

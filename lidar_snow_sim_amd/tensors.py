@@ -80,6 +80,12 @@ class DeviceResult:
         self.ctx.check_status(st)                              # SnowGPUError with the library's message
         return self
 
+    def join(self, stream=None):
+        """torch's current stream (or `stream`) waits for the call; the host does not.  For results of a lane call (lane=k)."""
+        import torch
+        (stream or torch.cuda.current_stream(self.rows.device)).wait_stream(self.stream)
+        return self
+
     def frames(self, return_src=False):
         """The reference-shaped result: [(stats, aug_pc)] (or (stats, aug_pc, src)), aug_pc / src views of the result tensors."""
         self.wait()
@@ -172,7 +178,7 @@ def table_ids_for(eng, n_frames, particle_file_prefix, root_path, particles, ord
 
 def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, noise_floor=0.7, root_path=None, *, planes=None,
                   orders=None, particles=None, thr_polys=None, device=None, return_src=False, slot=0, calib=None, pre_crop=False,
-                  q8='first', plane_method='reference', plane_seed=0, plane_trials=1000, sync=True, wet=None, out=None, **_ignored):
+                  q8='first', plane_method='reference', plane_seed=0, plane_trials=1000, sync=True, wet=None, out=None, lane=None, **_ignored):
     """augment_batch() of tools/snowfall/simulation.py for torch CUDA tensors (see that docstring for the shared arguments).
 
     frames   a list of N_i x 5 CUDA tensors (concatenated on the device), an F x N x 5 tensor, one N x 5 tensor, or a DeviceBatch
@@ -183,6 +189,13 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
              power_factor, flat_earth, delta, replace, plane): the wet-ground model runs behind the snowfall on the same stream
              (snowgpu_augment_wet_batch_device); the result rows are float64 then (wet_ground/augmentation.py:150).
     out      optional DeviceResult of an earlier call with the same shapes whose tensors are reused (no allocation at all).
+    lane     None (default): the call is part of torch's current stream -- it starts when that stream gets there and whatever the caller
+             queues behind it waits for it.  An integer k: the call runs on compute lane k -- an engine context of its own (streams,
+             scratch, tables) with a torch stream of its own -- which waits for what the caller's stream holds NOW (the inputs) and
+             nothing waits for it: the caller's stream goes on, a call on another lane may run beside this one (the memory-bound sort and
+             compaction of one batch beside the latency-bound per-beam kernels of the other), and the result is claimed through the
+             DeviceResult: .wait() (host), .join() (torch's current stream waits, the host does not).  Keep as many results alive as
+             lanes in flight; `sync=True` with a lane is a plain synchronous call on that lane.
     """
     import torch
     from . import engine as _engine
@@ -196,7 +209,7 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
     dev = rows.device
     if device is not None and int(device) != dev.index:
         raise ValueError(f"the tensors live on {dev}, device={device} was asked for")
-    eng = _engine.get_engine(dev.index, slot)
+    eng = _engine.get_engine(dev.index, slot if lane is None else int(lane))
     nf, n = len(offsets) - 1, int(offsets[-1])
     if nf == 0:
         return []
@@ -241,11 +254,15 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
         # default stream (two event waits): uploads queued before the call are seen, and whoever reads the results on the caller's stream
         # afterwards -- or synchronises it -- waits for the call.
         run = stream
-        if stream.cuda_stream == 0:
+        if stream.cuda_stream == 0 or lane is not None:
             run = eng.__dict__.get("_torch_side_stream")
             if run is None or run.device != dev:
                 run = eng.__dict__["_torch_side_stream"] = torch.cuda.Stream(device=dev)
             run.wait_stream(stream)
+            if lane is not None:                    # (tensors of the caller's stream used on the lane's: the allocator must know)
+                for t in (rows, o_rows, o_src, o_cnt, o_st, o_status, o_flags):
+                    if t is not None:
+                        t.record_stream(run)
         ptr = lambda t: 0 if t is None else t.data_ptr()   # noqa: E731
         with eng.batch_lock:
             if calib is not None:
@@ -273,13 +290,13 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
                                                      w["flat_earth"], w["delta"], w["replace"], o_rows.data_ptr(), o_src.data_ptr(),
                                                      o_cnt.data_ptr(), o_st.data_ptr(), o_flags.data_ptr(), o_status.data_ptr(), run.cuda_stream)
             finally:
-                if run is not stream:
+                if run is not stream and lane is None:
                     stream.wait_stream(run)
                 if calib is not None:
                     eng.ctx.set_fov(None)
                 if plane_method != 'reference':
                     eng.ctx.set_plane_method('reference')
-    res = DeviceResult(eng.ctx, o_rows, o_src, o_cnt, o_st, o_status, offsets, stream, flags=o_flags, keep=(rows, d_off, d_tids, d_poly, d_plane, d_wet_plane))
+    res = DeviceResult(eng.ctx, o_rows, o_src, o_cnt, o_st, o_status, offsets, stream if lane is None else run, flags=o_flags, keep=(rows, d_off, d_tids, d_poly, d_plane, d_wet_plane))
     if not sync:
         return res
     from .tools.snowfall.simulation import _raise_like_reference

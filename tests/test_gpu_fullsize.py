@@ -244,6 +244,37 @@ def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
     assert tot["mismatched_intensity"] == 0 and tot["xyz_over_tol"] == 0 and stat_bad == 0
 
 
+@pytest.mark.parametrize("workload,dtype", [("C2", np.float32), ("C2far", np.float32), ("C2", np.float64)], ids=["C2-float32", "C2far-float32", "C2-float64"])
+def test_cpu_twin_and_hip_path_give_the_same_bytes_at_full_size(workload, dtype, capsys):
+    """libsnowcpu.so (include/snowgpu_cpu.h) is the kernels' per-beam device code compiled for the host; libsnowgpu.so runs it as a launch
+    sequence of wave-level kernels (flattened scan, hand-over queues, capacity tiers, few-flake registers, compaction).  Same source, two
+    builds: four full-size sweeps, threshold polynomials from the device prepass -- identical output rows, source indices and statistics."""
+    import bench
+    from lidar_snow_sim_amd import _cpu_twin, engine
+    tables = _tables(workload)
+    frames, orders = _frames(workload, dtype, 4)
+    eng = engine.Engine(0)
+    try:
+        tids = [eng.table_ids_from_arrays(tables, o) for o in orders]
+        rows = np.concatenate(frames)
+        off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+        out, src, counts, stats, thr = eng.ctx.augment_batch(rows, off, tids, BD, plane=[[*PLANE[0], PLANE[1]]] * 4, want_thr=True)
+    finally:
+        eng.ctx.close()
+    t0 = time.perf_counter()
+    res = _cpu_twin.augment_batch(frames, tables, orders, BD, thr)
+    t_cpu = time.perf_counter() - t0
+    bad = 0
+    for f, (st, aug, sidx) in enumerate(res):
+        a, n = int(off[f]), int(counts[f])
+        same = n == aug.shape[0] and np.array_equal(src[a:a + n], sidx) and out[a:a + n].tobytes() == aug.tobytes() \
+            and tuple(int(v) for v in stats[f]) == tuple(int(v) for v in st)
+        bad += not same
+    _report(capsys, {"test": "cpu twin vs hip path", "workload": workload, "dtype": np.dtype(dtype).name, "frames": 4, "frames_differ": int(bad),
+                     "rows_kept": int(counts.sum()), "cpu_twin_s": round(t_cpu, 3), "cpu_twin_points_per_s": round(float(off[-1]) / t_cpu)})
+    assert bad == 0
+
+
 def test_L5_counts_against_the_native_numpy_flavour(golden, tables, capsys):
     """The reference's own numbers depend on NumPy's SIMD dispatch: the product pins the portable
     flavour by default.  This test REPORTS how far the HIP path is from the AVX-512 flavour of the same reference on the L5
