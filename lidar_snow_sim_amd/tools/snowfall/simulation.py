@@ -129,71 +129,6 @@ class FlatBatch:
         return self.rows[int(self.offsets[i]):int(self.offsets[i + 1])]
 
 
-Q8_CHUNKED_FRAMES = 32       # q8='numpy' batches from this many frames on run as chunks on several engine contexts
-Q8_CHUNK = 12                # frames per chunk (the host pipeline's chunk: 3 * 2^19 rows of 64 x 2048 sweeps)
-Q8_WORKERS = 3               # engine contexts / host threads
-
-
-def _q8_numpy_chunked(eng, device, slot, flat, offsets, order_rows, line_ids, plane_rows, beam_divergence, noise_floor, out_rows, out_src):
-    """q8='numpy' for a large batch.  The one-call path is three serial stages -- upload + device half of the prepass + histogram download
-    (Context.prepass_stats), np.argpartition per histogram row on the host (noise_polys_from_device_stats), per-beam kernels + download
-    (Context.augment_batch on the resident rows) -- so the link idles while the host selects and the host idles while the device computes
-    (0.9 G points/s, half of q8='first').  Here the batch is cut into chunks of Q8_CHUNK frames and Q8_WORKERS host threads, each with an
-    engine context of its own (streams, scratch, page-locked histogram buffer; tables by value), walk the chunks: while one thread selects,
-    the others' chunks are on the link or in the kernels.  Results land in the slices of the batch's result buffers; the selection is
-    still THIS process' np.argpartition, row by row (wet_ground/augmentation.py:232-236).  Returns (counts, stats)."""
-    import threading
-    nf = len(offsets) - 1
-    chunks = [(f, min(f + Q8_CHUNK, nf)) for f in range(0, nf, Q8_CHUNK)]
-    workers = min(Q8_WORKERS, len(chunks))
-    engines = [eng] + [_engine.get_engine(device, slot + 64 * (k + 1)) for k in range(workers - 1)]
-    orders = np.asarray(order_rows, np.int64)
-    ids = []
-    for e in engines:
-        if e is not eng and e.lasers is not eng.lasers:
-            e.set_lasers(eng.lasers)
-        ids.append(np.ascontiguousarray(line_ids(e)[orders.reshape(-1)].reshape(orders.shape), np.int32))
-    planes = np.asarray(plane_rows, np.float64) if plane_rows else None
-    counts = np.zeros(nf, np.int64)
-    stats = np.zeros((nf, 3), np.int64)
-    errors = []
-    cursor = iter(range(len(chunks)))
-    lock = threading.Lock()
-    sel_threads = max(1, 16 // workers)
-
-    def work(w):
-        e = engines[w]
-        try:
-            with e.batch_lock:
-                while not errors:
-                    with lock:
-                        c = next(cursor, None)
-                    if c is None:
-                        return
-                    f0, f1 = chunks[c]
-                    a, b = int(offsets[f0]), int(offsets[f1])
-                    sub, sub_off = flat[a:b], offsets[f0:f1 + 1] - offsets[f0]
-                    hist, rec = e.ctx.prepass_stats(sub, sub_off, plane=None if planes is None else planes[f0:f1], hist_out=e.hist_buffer(f1 - f0))
-                    polys = noise_polys_from_device_stats(hist, rec, noise_floor, threads=sel_threads)
-                    _, _, cn, st, _ = e.ctx.augment_batch(sub, sub_off, ids[w][f0:f1], beam_divergence, thr_poly=polys, noise_floor=noise_floor,
-                                                          out_rows=out_rows[a:b], out_src=None if out_src is None else out_src[a:b],
-                                                          want_src=out_src is not None, rows_resident=True)
-                    counts[f0:f1] = cn
-                    stats[f0:f1] = st
-        except BaseException as ex:          # (handed to the calling thread)
-            errors.append(ex)
-
-    threads = [threading.Thread(target=work, args=(w,)) for w in range(1, workers)]
-    for t in threads:
-        t.start()
-    work(0)
-    for t in threads:
-        t.join()
-    if errors:
-        raise errors[0]
-    return counts, stats
-
-
 def _raise_like_reference(err: _native.SnowGPUError):
     """Map library status codes onto the exception types the reference raises (SURVEY 8 b, 'Errors')."""
     if err.code == _native.E_RANGE:
@@ -281,16 +216,8 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
         fit_rows = [r[get_fov_flag(calib.lidar_to_rect(r[:, 0:3]), (1024, 1920), calib)] for r in rows]
     if host_fit and planes is None:
         planes = _device_planes(eng, fit_rows, dt, plane_method, plane_seed, plane_trials, ncols)
-    table_ids, polys, plane_rows, order_rows = [], [], [], []
+    table_ids, polys, plane_rows = [], [], []
     ids_by_line = None                                                      # device table id of line - 1, looked up once per batch
-
-    def line_ids(e):
-        if isinstance(particles, str):
-            if particles not in ('device', 'missing'):
-                raise ValueError("particles must be a sequence of tables, 'device' or 'missing'")
-            return _LazyFileIds(e, particle_file_prefix, root_path, sample='all' if particles == 'device' else 'missing')
-        return _ArrayIds(e, particles) if particles is not None else _LazyFileIds(e, particle_file_prefix, root_path)
-
     for i, r in enumerate(rows):
         if orders is not None:
             order = list(orders[i])
@@ -299,9 +226,13 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             if shuffle:
                 random.shuffle(order)                                       # simulation.py:485-486
         if ids_by_line is None:
-            ids_by_line = line_ids(eng)
+            if isinstance(particles, str):
+                if particles not in ('device', 'missing'):
+                    raise ValueError("particles must be a sequence of tables, 'device' or 'missing'")
+                ids_by_line = _LazyFileIds(eng, particle_file_prefix, root_path, sample='all' if particles == 'device' else 'missing')
+            else:
+                ids_by_line = _ArrayIds(eng, particles) if particles is not None else _LazyFileIds(eng, particle_file_prefix, root_path)
         table_ids.append(ids_by_line[order[:nl]])                           # channel c reads line order[c] + 1 (simulation.py:78)
-        order_rows.append(order[:nl])
         if thr_polys is not None:
             polys.append(np.asarray(thr_polys[i], np.float64))
         elif planes is not None:
@@ -323,31 +254,6 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
             else:
                 flat[...] = rows[0][:, :5]
         resident = False
-        chunked = None
-        if q8_device and len(rows) >= Q8_CHUNKED_FRAMES and calib is None and not (planes is None and plane_method != 'reference'):
-            # q8='numpy' on a large batch: chunks of a dozen frames on a few engine contexts, one host thread each -- the host's selection of one
-            # chunk beside the kernels and the copies of the others (see _q8_numpy_chunked)
-            out_rows, out_src = eng.result_buffers(int(offsets[-1]), dt)
-            try:
-                chunked = _q8_numpy_chunked(eng, device, slot, flat, offsets, order_rows, line_ids, plane_rows, beam_divergence, noise_floor,
-                                            out_rows, out_src if want_src else None)
-            except _native.SnowGPUError as err:
-                if err.code != _native.E_CHANNELS:
-                    _raise_like_reference(err)
-                chunked = None                                               # channels the device sort does not take: the one-call path sorts here
-        if chunked is not None:
-            counts, stats = chunked
-            out, src = out_rows, (out_src if want_src else None)
-            results = []
-            for i in range(len(rows)):
-                a, n = int(offsets[i]), int(counts[i])
-                aug = out[a:a + n]
-                src_i = None if src is None else src[a:a + n]
-                if rows[i].shape[1] > 5:
-                    aug = np.concatenate((aug, rows[i][src_i, 5:]), axis=1)
-                st = (np.int64(stats[i, 0]), np.int64(stats[i, 1]), int(stats[i, 2]))
-                results.append((st, aug, src_i) if return_src else (st, aug))
-            return results
         if q8_device:
             if planes is None:
                 eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=ncols)

@@ -417,34 +417,6 @@ def test_q8_numpy_device_half_keeps_the_rows_of_the_host_fit_at_full_size(capsys
     assert total["rows_differ"] == 0
 
 
-def test_q8_numpy_in_chunks_on_several_contexts_equals_the_one_call_path(monkeypatch, capsys):
-    """q8='numpy' on a batch of 32 frames or more runs as chunks of a dozen frames on three engine contexts / host threads
-    (simulation._q8_numpy_chunked: one chunk's np.argpartition beside the others' kernels and copies).  Same bytes as the one-call
-    path (upload + device half, selection, per-beam kernels in sequence), frame by frame; channel-major and firing-order sweeps."""
-    from lidar_snow_sim_amd.tools.snowfall import simulation as sim
-    tables = _tables("C2")
-    n = 38                                            # three chunks of twelve and a rest of two
-    total = {"frames": 0, "rows_kept": 0, "frames_differ": 0}
-    for workload in ("C2", "C2fire"):
-        frames, orders = _frames(workload, np.float32, n)
-        kw = dict(planes=[PLANE] * n, orders=orders, particles=tables, return_src=True, q8="numpy")
-        t0 = time.perf_counter()
-        a = sim.augment_batch(frames, "unused", BD, **kw)
-        t_chunked = time.perf_counter() - t0
-        monkeypatch.setattr(sim, "Q8_CHUNKED_FRAMES", 1 << 30)
-        t0 = time.perf_counter()
-        b = sim.augment_batch(frames, "unused", BD, **kw)
-        t_one = time.perf_counter() - t0
-        monkeypatch.undo()
-        for (sa, ra, ia), (sb, rb, ib) in zip(a, b):
-            total["frames"] += 1
-            total["rows_kept"] += int(ia.shape[0])
-            total["frames_differ"] += not (tuple(sa) == tuple(sb) and np.array_equal(ia, ib) and ra.tobytes() == rb.tobytes())
-        total[f"{workload}_chunked_s"], total[f"{workload}_one_call_s"] = round(t_chunked, 3), round(t_one, 3)
-    _report(capsys, dict(total, test="q8_numpy chunked on three contexts vs one call"))
-    assert total["frames_differ"] == 0 and total["rows_kept"] > 0
-
-
 def test_long_tail_order_of_the_received_power_phase_changes_no_byte(monkeypatch, capsys):
     """Large batches run k_power_few first; where k_power<4> goes after it depends on how many beams the 63-entry / global-list tiers held in
     the batches before (page-locked words the device leaves behind: snowgpu_api.cpp, `heavy_tail`): behind k_power_few with those tiers
