@@ -614,10 +614,11 @@ def main():
         traffic, traffic_src, valu = None, None, None
         inner_argv = ["--steps", "2", "--warmup", "1", "--frames", str(F), "--workload", args.workload, "--tables", args.tables]
         if not args.no_pmc and world == 1:
-            fetch = pmc_pass(["FETCH_SIZE"], inner_argv, 3)
-            write = pmc_pass(["WRITE_SIZE"], inner_argv, 3) if fetch else None
+            # (a child runs the first call of the size, one warm-up and two timed steps: four launch sequences per kernel)
+            fetch = pmc_pass(["FETCH_SIZE"], inner_argv, 4)
+            write = pmc_pass(["WRITE_SIZE"], inner_argv, 4) if fetch else None
             sq = pmc_pass(["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"],
-                          inner_argv, 3) if write else None
+                          inner_argv, 4) if write else None
             if fetch and write:
                 in_region = lambda k: k.startswith(REGION_KERNELS)      # noqa: E731
                 fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in fetch.items() if in_region(k)) * 1024 * FETCH_FACTOR

@@ -295,6 +295,21 @@ int snowgpu_estimate_planes_device(snowgpu_ctx *ctx, int n_frames, int64_t n_tot
 int snowgpu_prepass_stats(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                           const double *plane, int32_t *out_hist, double *out_rec);
 
+/*
+ * The same division of labour INSIDE one batch call (round 6): with a callback set, snowgpu_augment_batch calls that bring neither thr_poly
+ * nor a caller permutation compute the device half above per group of frames (a chunk of the pipelined entry), start the per-beam kernels
+ * of the group, and call
+ *     fn(user, first_frame, n_frames, hist, rec, thr_poly_out)
+ * on the CALLING thread as soon as the group's histograms (n_frames x 50 x 2555 int32) and records (n_frames x SNOWGPU_PREPASS_REC) have
+ * landed in page-locked memory -- while those kernels, and the uploads / kernels / downloads of the other groups, run.  fn writes the
+ * groups' polynomials (n_frames x 3, highest power first, np.polyfit's order) and returns 0 (anything else fails the call with
+ * SNOWGPU_E_INVALID); the library uploads them and runs the group's compaction (simulation.py:516-540).  The rows cross the link once
+ * and the host's np.argpartition (wet_ground/augmentation.py:236) hides behind the device's work; the two-call form above costs a second
+ * crossing and runs the three stages in sequence.  fn = NULL switches back to the device's own fit.  Python: augment_batch(q8='numpy').
+ */
+typedef int (*snowgpu_threshold_fn)(void *user, int first_frame, int n_frames, const int32_t *hist, const double *rec, double *thr_poly_out);
+int snowgpu_set_threshold_callback(snowgpu_ctx *ctx, snowgpu_threshold_fn fn, void *user);
+
 /* ---- measurement hooks ------------------------------------------------------------------------ */
 
 /* Record a HIP event pair around every launch of the per-beam kernel (the dominant kernel) on the stream

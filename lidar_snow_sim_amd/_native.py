@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_device_numa_node",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_set_threshold_callback", "snowgpu_device_numa_node",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -95,6 +95,8 @@ def lib():
             L.snowgpu_set_fov_precrop.argtypes = [vp, ctypes.c_int]
             L.snowgpu_last_status.restype = ctypes.c_int
             L.snowgpu_last_status.argtypes = [vp, vp]
+            L.snowgpu_set_threshold_callback.restype = ctypes.c_int
+            L.snowgpu_set_threshold_callback.argtypes = [vp, vp, vp]
             L.snowgpu_status_error.restype = ctypes.c_int
             L.snowgpu_status_error.argtypes = [vp, vp]
             L.snowgpu_set_fov.restype = ctypes.c_int
@@ -273,6 +275,10 @@ class Context:
             rc = self._L.snowgpu_augment_batch(self._h, nf, _p(off), None if rows_resident else _p(rows), code, _p(tids), float(beam_divergence),
                                                _p(thr), _p(pl), float(noise_floor), _p(pm), _p(out_rows), _p(out_src),
                                                _p(counts), _p(stats), _p(out_thr))
+            err = getattr(self, "_thr_error", None)
+            if rc and err is not None:                       # the threshold callback raised: its exception, not the status code
+                self._thr_error = None
+                raise err
             self._check(rc)
         return out_rows, out_src, counts, stats, out_thr
 
@@ -386,6 +392,33 @@ class Context:
         out = np.zeros(8, np.int32)
         self._check(self._L.snowgpu_last_status(self._h, _p(out)))
         return out
+
+    THRESHOLD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int32),
+                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
+
+    def set_threshold_callback(self, fit=None):
+        """fit(first_frame, hist[n, 50, 2555] int32, rec[n, 18] float64) -> n x 3 polynomials, called by the following augment_batch calls
+        (those without thr_poly) once per group of frames while the per-beam kernels of the group run (snowgpu_set_threshold_callback);
+        None: the device fits the threshold itself again.  An exception raised by `fit` fails the call and is re-raised by augment_batch."""
+        self._thr_error = None
+        if fit is None:
+            self._thr_cb = None
+            self._check(self._L.snowgpu_set_threshold_callback(self._h, None, None))
+            return
+
+        def trampoline(_user, first, n, hist_p, rec_p, out_p):
+            try:
+                hist = np.ctypeslib.as_array(hist_p, shape=(n, 50, 2555))
+                rec = np.ctypeslib.as_array(rec_p, shape=(n, 18))
+                out = np.ctypeslib.as_array(out_p, shape=(n, 3))
+                out[...] = np.asarray(fit(int(first), hist, rec), np.float64).reshape(n, 3)
+                return 0
+            except BaseException as ex:      # (no exception may cross the C frames)
+                self._thr_error = ex
+                return 1
+
+        self._thr_cb = self.THRESHOLD_FN(trampoline)             # kept alive as long as the library may call it
+        self._check(self._L.snowgpu_set_threshold_callback(self._h, ctypes.cast(self._thr_cb, ctypes.c_void_p), None))
 
     def check_status(self, status8):
         """Raise what the int32[8] status words of a device-pointer call say (snowgpu_status_error); no-op for status8[0] == 0."""

@@ -306,6 +306,13 @@ struct snowgpu_ctx {
     std::vector<hipEvent_t> pk_ev;        // [2 c] counts of chunk c on the host, [2 c + 1] its packed data
     AsmPool *pool = nullptr;
     double pk_times[4] = {0, 0, 0, 0};    // last packed call: ms until all enqueued, all downloads landed, all rows assembled; host bytes copied
+    // The caller fits the noise threshold (snowgpu_set_threshold_callback): page-locked staging for the device half of the prepass --
+    // histograms | records | status words per group | the polynomials the callback writes -- and one event per group
+    snowgpu_threshold_fn thr_fn = nullptr;
+    void *thr_user = nullptr;
+    char *thr_stage = nullptr;
+    size_t thr_stage_cap = 0;
+    std::vector<hipEvent_t> thr_ev;
 };
 
 #define HIPCHK(ctx, call)                                                                         \
@@ -453,6 +460,8 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (ctx->tier_hint_h) (void)hipHostFree(ctx->tier_hint_h);
+    if (ctx->thr_stage) (void)hipHostFree(ctx->thr_stage);
+    for (hipEvent_t e : ctx->thr_ev) (void)hipEventDestroy(e);
     if (ctx->mail_up_h) (void)hipHostFree(ctx->mail_up_h);
     if (ctx->mail_dn_h) (void)hipHostFree(ctx->mail_dn_h);
     ctx->mail_up_d.release(); ctx->mail_dn_d.release(); ctx->d_wet_lines.release(); ctx->wet_fit.release();
@@ -475,7 +484,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
     ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->ov.release(); ctx->ov_sc.release();
-    ctx->redo_list.release();
+    ctx->redo_list.release(); ctx->back_list.release(); ctx->bbase.release();
     ctx->tier_list.release(); ctx->tier_sparse.release(); ctx->tbase.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -774,7 +783,11 @@ struct BatchDev {
     bool want_perm = false;        // the caller reads perm_out back: the sort writes the permutation of channel-sorted frames too
     SgPackOut *pack = nullptr;     // packed result transfer: the compaction writes these instead of out_rows / out_src (tile scratch filled in here)
     bool serial = false;           // every kernel on `stream`: no fork / join events (chunks of the host pipeline)
+    bool defer_thr = false;        // the caller fits the noise threshold itself while the per-beam kernels run (snowgpu_set_threshold_callback):
+                                   // run_batch stops ahead of the compaction, launches no prepass; run_compaction finishes with b.thr_poly
 };
+
+static int launch_compaction(snowgpu_ctx *ctx, BatchDev &b, const int32_t *perm, const double *thr, size_t regions, int64_t max_tiles);
 
 static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
 {
@@ -806,7 +819,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // The prepass' per-tile statistics ride on the channel sort's first pass over the rows when the plane is known by then: a
     // caller's plane, or the reference-today plane (a constant).  Estimated planes (least squares, RANSAC) come later, on the
     // prepass stream, and the statistics keep their own pass.
-    const bool fuse_stats = !b.thr_poly && !b.perm && (b.plane != nullptr || R->plane_par.method == SG_PLANE_REFERENCE);
+    const bool fuse_stats = !b.thr_poly && !b.defer_thr && !b.perm && (b.plane != nullptr || R->plane_par.method == SG_PLANE_REFERENCE);
     const double *early_plane = b.plane;
     double *lean_part = nullptr;
     if (fuse_stats) {
@@ -843,7 +856,9 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         pre_forked = true;
         return SNOWGPU_OK;
     };
-    if (!thr) {
+    if (!thr && b.defer_thr) {
+        // (no prepass here: the caller fits the polynomial from the device half it already has; run_compaction brings it)
+    } else if (!thr) {
         ENSURE(ctx, ctx->thr_poly, (size_t)b.n_frames * 3);
         thr = ctx->thr_poly.p;
         if (!serial) {           // the prepass' histogram fill runs on ITS stream, beside the sort
@@ -1107,7 +1122,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("beam launch: ") + hipGetErrorString((hipError_t)e));
     // The noise-threshold prepass streams the rows (bandwidth-bound, no LDS): it runs beside the received-power phase and
     // the later tiers (latency-bound, LDS-bound) rather than beside the sort and the scan, which it would slow down.
-    if (!b.thr_poly && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
+    if (!b.thr_poly && !b.defer_thr && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
     // The scan put every over-full beam on the list of its tier (it counted on past a full list, so the beam knows which): the tiers
     // start as soon as it has ended, side by side -- class 0 on the caller's stream, class 1 on a side stream, and the classes from
     // the third on (the 63-entry and the global-list tier: few beams, long dependent chains) behind k_power on ITS stream, which is
@@ -1178,18 +1193,45 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
     // 4. output rows from (sorted) rows + records, round, noise-floor filter, camera crop, compaction, stats
     // (simulation.py:516-540)
     if (pre_forked) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_join0, 0));
+    if (b.defer_thr && !b.thr_poly) return SNOWGPU_OK;           // the caller's polynomial is still being fitted: run_compaction finishes the batch
+    return launch_compaction(ctx, b, perm, thr, regions, max_tiles);
+}
+
+// The batch's last step: output rows from (sorted) rows + records, np.round, noise-floor filter, camera crop, stable compaction,
+// statistics (simulation.py:516-540).  Everything it reads was left by run_batch in the context's scratch.
+static int launch_compaction(snowgpu_ctx *ctx, BatchDev &b, const int32_t *perm, const double *thr, size_t regions, int64_t max_tiles)
+{
+    snowgpu_ctx *R = ctx->root ? ctx->root : ctx;
+    hipStream_t st = b.stream;
     if (b.pack) {
         ENSURE(ctx, ctx->pk_tile_mv, (size_t)b.n_frames * (size_t)max_tiles + 1);
         ENSURE(ctx, ctx->pk_tile_mv_base, (size_t)b.n_frames * (size_t)max_tiles + 1);
         b.pack->tile_mv = ctx->pk_tile_mv.p; b.pack->tile_mv_base = ctx->pk_tile_mv_base.p;
     }
-    e = sg_launch_compact(b.rows, ctx->srows.p, ctx->frame_unsorted.p, b.dtype, ctx->rec.p, ctx->rec_q.p, a.rng, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
-                          ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
-                          a.diff2, b.no_fov ? nullptr : &R->fov, max_tiles, b.pack,
-                          b.n_total <= ((int64_t)1 << 19) ? ctx->qn.p + 3 * regions + (size_t)b.n_frames + 8 : nullptr,      // (small batches: the scan inside the count kernel)
-                          st);
+    int e = sg_launch_compact(b.rows, ctx->srows.p, ctx->frame_unsorted.p, b.dtype, ctx->rec.p, ctx->rec_q.p, ctx->rng.p, thr, ctx->keep.p, perm, b.frame_off, b.n_frames, b.n_total,
+                              ctx->ctile_cnt.p, ctx->ctile_base.p, b.out_rows, b.out_src, b.out_counts, b.out_stats,
+                              ctx->qn.p + 3 * regions, b.no_fov ? nullptr : &R->fov, max_tiles, b.pack,
+                              b.n_total <= ((int64_t)1 << 19) ? ctx->qn.p + 3 * regions + (size_t)b.n_frames + 8 : nullptr,      // (small batches: the scan inside the count kernel)
+                              st);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("compaction launch: ") + hipGetErrorString((hipError_t)e));
     return SNOWGPU_OK;
+}
+
+// ... for a batch whose run_batch stopped ahead of it (defer_thr): b.thr_poly now holds the caller's polynomials (device memory).  The
+// sizes run_batch derived are derived again -- from the same context state: tables, lasers and settings do not change inside a call.
+static int run_compaction(snowgpu_ctx *ctx, BatchDev &b)
+{
+    snowgpu_ctx *R = ctx->root ? ctx->root : ctx;
+    if (!b.thr_poly) return fail(ctx, SNOWGPU_E_INVALID, "run_compaction without threshold polynomials");
+    if (b.n_total == 0) return SNOWGPU_OK;                        // (run_batch filled counts and statistics)
+    const int64_t max_tiles = std::max<int64_t>(1, (b.max_frame + SG_TILE - 1) / SG_TILE);
+    int tiers[4], n_tiers = 0;
+    choose_tiers(R, b.beam_div_deg, tiers, &n_tiers);
+    const size_t q_chunk = 8 * (size_t)sg_beams_block(tiers[0]);
+    const size_t regions = std::max<size_t>((size_t)b.n_frames * 256, (size_t)b.n_total / q_chunk + 2);
+    if (b.out_thr_poly)
+        HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, b.thr_poly, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, b.stream));
+    return launch_compaction(ctx, b, b.perm ? b.perm : ctx->perm.p, b.thr_poly, regions, max_tiles);
 }
 
 static int status_to_error(snowgpu_ctx *ctx, const int32_t st[8])
@@ -1275,12 +1317,16 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     std::vector<int> c_first;
     std::vector<int64_t> h_off;                  // chunk-local offsets: chunk c owns h_off[c_pos[c] .. c_pos[c] + frames + 1)
     std::vector<size_t> c_pos;
+    // (the caller fits the threshold -- snowgpu_set_threshold_callback, below --: groups of twice the rows; the callback's cost per frame
+    // falls with the group's size -- its selection runs on a thread pool -- and the calling thread enqueues nothing while it is inside it:
+    // 256 sweeps, 12 / 24 / 48 sweeps per group: 0.89 / 1.24 / 1.03 G points/s, scripts/probe/q8_cb_probe.py)
+    const int64_t pipe_rows = (ctx->thr_fn != nullptr && !thr_poly && !perm) ? std::max<int64_t>(ctx->pipe_rows, (int64_t)3 << 20) : ctx->pipe_rows;
     for (int f = 0; f < n_frames;) {
         int g = f;
         const int64_t base = frame_offsets[f];
         // (the last chunks are half size: what remains to be done after the last upload has landed -- the last chunk's kernels, its
         // download, the assembly of its rows -- is the part of the call nothing overlaps)
-        const int64_t target = (n_total - base <= 2 * ctx->pipe_rows) ? std::max<int64_t>(ctx->pipe_rows / 2, 1) : ctx->pipe_rows;
+        const int64_t target = (n_total - base <= 2 * pipe_rows) ? std::max<int64_t>(pipe_rows / 2, 1) : pipe_rows;
         while (g < n_frames && (g == f || frame_offsets[g + 1] - base <= target)) ++g;
         c_first.push_back(f);
         c_pos.push_back(h_off.size());
@@ -1477,31 +1523,62 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // A failure inside the loop must not return while copies from / into the caller's buffers (and from h_off) are in flight:
     // every exit goes through the drain below.
 #define PIPECHK(call)                                                                                              \
-    { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e__); rc = SNOWGPU_E_HIP; break; } }
-    for (int c = 0; c < n_chunks && rc == SNOWGPU_OK; ++c) {
+    { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e__); return (int)SNOWGPU_E_HIP; } }
+    // The caller fits the noise threshold (snowgpu_set_threshold_callback): per chunk the device half of the prepass leads the chunk's
+    // kernels, its histograms come down while they run, and the chunk is FINISHED -- callback, polynomials up, compaction, downloads --
+    // when its lane is needed again (L chunks later) or at the end; the host's selection of chunk c thus runs beside the kernels of
+    // chunks c + 1 .. c + L - 1 and beside the link's traffic.
+    const bool cb = ctx->thr_fn != nullptr && !thr_poly && !perm && n_total > 0;
+    constexpr size_t HIST = (size_t)50 * 2555;
+    int32_t *sg_hist = nullptr, *sg_stat = nullptr;
+    double *sg_rec = nullptr, *sg_thr = nullptr;
+    if (cb) {
+        const size_t o_rec = nf * HIST * 4, o_thr = o_rec + nf * SG_PRE_REC * 8, o_stat = o_thr + nf * 3 * 8, need = o_stat + (size_t)n_chunks * 32 + 64;
+        if (need > ctx->thr_stage_cap) {
+            if (ctx->thr_stage) (void)hipHostFree(ctx->thr_stage);
+            ctx->thr_stage = nullptr; ctx->thr_stage_cap = 0;
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->thr_stage, need + need / 8, hipHostMallocDefault));
+            ctx->thr_stage_cap = need + need / 8;
+        }
+        sg_hist = (int32_t *)ctx->thr_stage; sg_rec = (double *)(ctx->thr_stage + o_rec); sg_thr = (double *)(ctx->thr_stage + o_thr);
+        sg_stat = (int32_t *)(ctx->thr_stage + o_stat);
+        while ((int)ctx->thr_ev.size() < 2 * n_chunks) {
+            hipEvent_t e;
+            HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->thr_ev.push_back(e);
+        }
+        ENSURE(ctx, ctx->user_thr, nf * 3);
+    }
+    struct Chunk { BatchDev b; SgPackOut po; snowgpu_ctx *lc; };
+    std::vector<Chunk> chunks((size_t)n_chunks);
+    // chunk c: its kernels (all of them, or everything ahead of the compaction when the caller fits the threshold)
+    auto compute = [&](int c) -> int {
         const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
         const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
         const int64_t *lo = &h_off[c_pos[(size_t)c]];
+        Chunk &k = chunks[(size_t)c];
         snowgpu_ctx *lc = (c % L) == 0 ? ctx : ctx->lanes[(size_t)(c % L) - 1];     // chunk c computes on lane c mod L
+        k.lc = lc;
         hipStream_t cs = lc->stream;
         PIPECHK(hipStreamWaitEvent(cs, ctx->pipe_ev[2 * (size_t)c], 0));
         if (trace) PIPECHK(hipEventRecord(tev[2 + 4 * (size_t)c], cs));
-        BatchDev b{};
+        BatchDev &b = k.b;
+        b = BatchDev{};
         b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = ctx->rows_in.p + (size_t)r0 * rb;
         int64_t mx = 0;
-        for (int k = 0; k < cf; ++k) mx = std::max(mx, lo[k + 1] - lo[k]);
+        for (int q = 0; q < cf; ++q) mx = std::max(mx, lo[q + 1] - lo[q]);
         bool uni = mx > 0;
-        for (int k = 0; k < cf && uni; ++k) uni = (lo[k + 1] - lo[k]) == mx;
+        for (int q = 0; q < cf && uni; ++q) uni = (lo[q + 1] - lo[q]) == mx;
         b.max_frame = mx; b.uniform_rows = uni ? mx : 0;
         b.dtype = dtype; b.table_ids = ctx->table_ids.p + (size_t)f0 * nl; b.beam_div_deg = beam_div_deg;
         b.thr_poly = d_thr ? d_thr + 3 * (size_t)f0 : nullptr;
         b.plane = (!d_thr && plane) ? ctx->plane.p + 4 * (size_t)f0 : nullptr;
         b.noise_floor = noise_floor; b.perm = perm ? ctx->user_perm.p + r0 : nullptr;
-        SgPackOut po{};
+        k.po = SgPackOut{};
         if (packed) {
-            po.meta = ctx->pk_meta.p + r0; po.inten = ctx->pk_int.p + (size_t)r0 * esz; po.mv = ctx->pk_mv.p + (size_t)r0 * 3 * esz;
-            po.mv_counts = ctx->pk_mvcnt.p + f0;
-            b.pack = &po;
+            k.po.meta = ctx->pk_meta.p + r0; k.po.inten = ctx->pk_int.p + (size_t)r0 * esz; k.po.mv = ctx->pk_mv.p + (size_t)r0 * 3 * esz;
+            k.po.mv_counts = ctx->pk_mvcnt.p + f0;
+            b.pack = &k.po;
         } else {
             b.out_rows = ctx->rows_out.p + (size_t)r0 * rb; b.out_src = ctx->out_src.p + r0;
         }
@@ -1512,14 +1589,61 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         // chunk keeps its kernels on one stream: 1.80 instead of 1.76 G points/s (2.09 / 1.96 without source indices), although
         // the same chunk alone is faster with its side streams.
         b.serial = true;
-        rc = run_batch(lc, b);
-        if (rc != SNOWGPU_OK) { if (lc != ctx) ctx->err = lc->err; break; }
+        if (cb && cn > 0) {
+            // the device half of the prepass first (snowgpu_prepass_stats' kernels on the chunk), its results on their way down at once
+            snowgpu_ctx *R = ctx;
+            const double *pl = b.plane;
+            if (!pl) {
+                if (lc->plane_est.ensure((size_t)cf * 4) || lc->plane_info.ensure((size_t)cf * 4)) return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for the plane estimate");
+                int pe = sg_plane_run(&lc->plane_scr, &R->plane_par, b.rows, dtype, b.frame_off, nullptr, cf, cn, mx, lc->plane_est.p, lc->plane_info.p, cs);
+                if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+                pl = lc->plane_est.p;
+            }
+            if (lc->stats_hist.ensure((size_t)cf * HIST) || lc->stats_rec.ensure((size_t)cf * SG_PRE_REC) || (!lc->d_status && hipMalloc((void **)&lc->d_status, 32) != hipSuccess))
+                return fail(ctx, SNOWGPU_E_HIP, "hipMalloc failed for the prepass statistics");
+            PIPECHK(hipMemsetAsync(lc->d_status, 0, 32, cs));
+            int se = sg_prepass_stats_run(&lc->prepass, b.rows, dtype, b.frame_off, cf, cn, mx, pl, lc->stats_hist.p, lc->stats_rec.p, lc->d_status, cs);
+            if (se) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (se > 0 ? hipGetErrorString((hipError_t)se) : "allocation"));
+            PIPECHK(hipEventRecord(ctx->thr_ev[2 * (size_t)c], cs));
+            PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->thr_ev[2 * (size_t)c], 0));
+            PIPECHK(hipMemcpyAsync(sg_hist + (size_t)f0 * HIST, lc->stats_hist.p, (size_t)cf * HIST * 4, hipMemcpyDeviceToHost, ctx->s_d2h));
+            PIPECHK(hipMemcpyAsync(sg_rec + (size_t)f0 * SG_PRE_REC, lc->stats_rec.p, (size_t)cf * SG_PRE_REC * 8, hipMemcpyDeviceToHost, ctx->s_d2h));
+            PIPECHK(hipMemcpyAsync(sg_stat + 8 * (size_t)c, lc->d_status, 32, hipMemcpyDeviceToHost, ctx->s_d2h));
+            PIPECHK(hipEventRecord(ctx->thr_ev[2 * (size_t)c + 1], ctx->s_d2h));
+            b.defer_thr = true;
+        }
+        int brc = run_batch(lc, b);
+        if (brc != SNOWGPU_OK && lc != ctx) ctx->err = lc->err;
+        return brc;
+    };
+    // chunk c: (the caller's threshold fit and the compaction, then) its downloads
+    auto finish = [&](int c) -> int {
+        const int f0 = c_first[(size_t)c], f1 = c_first[(size_t)c + 1], cf = f1 - f0;
+        const int64_t r0 = frame_offsets[f0], cn = frame_offsets[f1] - r0;
+        Chunk &k = chunks[(size_t)c];
+        BatchDev &b = k.b;
+        hipStream_t cs = k.lc->stream;
+        if (b.defer_thr) {
+            PIPECHK(hipEventSynchronize(ctx->thr_ev[2 * (size_t)c + 1]));
+            const int32_t *s8 = sg_stat + 8 * (size_t)c;
+            if (s8[0] != 0) {                                  // (fewer than 3 ground rows in a frame: reported as the device prepass reports it)
+                PIPECHK(hipMemcpyAsync(b.status, k.lc->d_status, 32, hipMemcpyDeviceToDevice, cs));
+                return SNOWGPU_OK;                             // the chunk's status words carry the error to the end of the call
+            }
+            const int crc = ctx->thr_fn(ctx->thr_user, f0, cf, sg_hist + (size_t)f0 * HIST, sg_rec + (size_t)f0 * SG_PRE_REC, sg_thr + 3 * (size_t)f0);
+            if (crc != 0) return fail(ctx, SNOWGPU_E_INVALID, "the threshold callback reported an error");
+            PIPECHK(hipMemcpyAsync(ctx->user_thr.p + 3 * (size_t)f0, sg_thr + 3 * (size_t)f0, sizeof(double) * 3 * (size_t)cf, hipMemcpyHostToDevice, cs));
+            b.thr_poly = ctx->user_thr.p + 3 * (size_t)f0;
+            int crc2 = run_compaction(k.lc, b);
+            if (crc2 != SNOWGPU_OK) { if (k.lc != ctx) ctx->err = k.lc->err; return crc2; }
+        }
         if (packed) {
             // The chunk's words and intensities come down as two copies of its whole row range (the rows of a frame are compacted at the
             // frame's offset: what lies behind a frame's kept rows travels unused -- a copy per frame instead cost ~20 us each, 17 ms per
             // batch), then the head of its list of moved coordinates -- room for one row in eight: the list's length is only known on the
             // device, and a copy sized by it would have to queue behind the copies of every later chunk --, then its counts.  A chunk with
             // more scattered rows than that gets the rest of its list by one more copy (pk_progress).
+            SgPackOut &po = k.po;
             PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
             if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
             PIPECHK(hipStreamWaitEvent(ctx->s_d2h, ctx->pipe_ev[2 * (size_t)c + 1], 0));
@@ -1532,8 +1656,8 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
             PIPECHK(hipMemcpyAsync(st_mvcnt + f0, po.mv_counts, sizeof(int64_t) * (size_t)cf, hipMemcpyDeviceToHost, ctx->s_d2h));
             PIPECHK(hipEventRecord(ctx->pk_ev[2 * (size_t)c], ctx->s_d2h));
             pk_enq = c + 1;
-            if (hipError_t pe = pk_progress(false); pe != hipSuccess) { rc = fail(ctx, SNOWGPU_E_HIP, std::string("packed download: ") + hipGetErrorString(pe)); break; }
-            continue;
+            if (hipError_t pe = pk_progress(false); pe != hipSuccess) return fail(ctx, SNOWGPU_E_HIP, std::string("packed download: ") + hipGetErrorString(pe));
+            return SNOWGPU_OK;
         }
         PIPECHK(hipEventRecord(ctx->pipe_ev[2 * (size_t)c + 1], cs));
         if (trace) PIPECHK(hipEventRecord(tev[3 + 4 * (size_t)c], cs));
@@ -1543,7 +1667,14 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
             if (out_src) PIPECHK(hipMemcpyAsync(out_src + r0, b.out_src, sizeof(int32_t) * (size_t)cn, hipMemcpyDeviceToHost, ctx->s_d2h));
         }
         if (trace) PIPECHK(hipEventRecord(tev[4 + 4 * (size_t)c], ctx->s_d2h));
+        return SNOWGPU_OK;
+    };
+    for (int c = 0; c < n_chunks && rc == SNOWGPU_OK; ++c) {
+        if (cb && c >= L) rc = finish(c - L);                  // (frees the lane chunk c computes on)
+        if (rc == SNOWGPU_OK) rc = compute(c);
+        if (rc == SNOWGPU_OK && !cb) rc = finish(c);
     }
+    for (int c = std::max(0, n_chunks - L); cb && c < n_chunks && rc == SNOWGPU_OK; ++c) rc = finish(c);
 #undef PIPECHK
     if (packed) {
         ctx->pk_times[0] = now() - t_begin;
@@ -1734,7 +1865,63 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
         HIPCHK(ctx, hipMemsetAsync(ctx->dbg_count.p, 0, sizeof(int32_t) * std::max<size_t>(n, 1), st));
         b.dbg_count = ctx->dbg_count.p; b.dbg_rj = ctx->dbg_rj.p; b.dbg_ratio = ctx->dbg_ratio.p; b.dbg_cap = dbg_cap;
     }
-    int rc = run_batch(ctx, b);
+    int rc = SNOWGPU_OK;
+    if (ctx->thr_fn && !thr_poly && !perm && !dbg_count && !precrop && n_used > 0) {
+        // The caller fits the noise threshold (snowgpu_set_threshold_callback), one group = the whole (small) batch: device half of the
+        // prepass, its results down, the per-beam kernels meanwhile, callback, polynomials up, compaction.
+        constexpr size_t HIST = (size_t)50 * 2555;
+        const size_t o_rec = nfz * HIST * 4, o_thr = o_rec + nfz * SG_PRE_REC * 8, o_stat = o_thr + nfz * 24, need = o_stat + 64;
+        if (need > ctx->thr_stage_cap) {
+            if (ctx->thr_stage) (void)hipHostFree(ctx->thr_stage);
+            ctx->thr_stage = nullptr; ctx->thr_stage_cap = 0;
+            HIPCHK(ctx, hipHostMalloc((void **)&ctx->thr_stage, need + need / 8, hipHostMallocDefault));
+            ctx->thr_stage_cap = need + need / 8;
+        }
+        int32_t *sg_hist = (int32_t *)ctx->thr_stage, *sg_stat = (int32_t *)(ctx->thr_stage + o_stat);
+        double *sg_rec = (double *)(ctx->thr_stage + o_rec), *sg_thr = (double *)(ctx->thr_stage + o_thr);
+        ENSURE(ctx, ctx->stats_hist, nfz * HIST);
+        ENSURE(ctx, ctx->stats_rec, nfz * SG_PRE_REC);
+        ENSURE(ctx, ctx->user_thr, nfz * 3);
+        while (ctx->thr_ev.size() < 2) {
+            hipEvent_t ev;
+            HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            ctx->thr_ev.push_back(ev);
+        }
+        const double *pl = d_plane;
+        if (!pl) {
+            ENSURE(ctx, ctx->plane_est, nfz * 4);
+            ENSURE(ctx, ctx->plane_info, nfz * 4);
+            int pe = sg_plane_run(&ctx->plane_scr, &ctx->plane_par, d_rows_used, dtype, d_off_used, nullptr, n_frames, n_used, max_frame_used, ctx->plane_est.p, ctx->plane_info.p, st);
+            if (pe) return fail(ctx, SNOWGPU_E_HIP, std::string("plane estimate: ") + (pe > 0 ? hipGetErrorString((hipError_t)pe) : "allocation"));
+            pl = ctx->plane_est.p;
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_status, 0, 32, st));
+        int se2 = sg_prepass_stats_run(&ctx->prepass, d_rows_used, dtype, d_off_used, n_frames, n_used, max_frame_used, pl, ctx->stats_hist.p, ctx->stats_rec.p, ctx->d_status, st);
+        if (se2) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (se2 > 0 ? hipGetErrorString((hipError_t)se2) : "allocation"));
+        HIPCHK(ctx, hipMemcpyAsync(sg_hist, ctx->stats_hist.p, nfz * HIST * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(sg_rec, ctx->stats_rec.p, nfz * SG_PRE_REC * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(sg_stat, ctx->d_status, 32, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipEventRecord(ctx->thr_ev[1], st));
+        b.defer_thr = true;
+        rc = run_batch(ctx, b);
+        if (rc == SNOWGPU_OK) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->thr_ev[1]));
+            if (sg_stat[0] != 0) {
+                (void)hipStreamSynchronize(st);
+                std::memcpy(ctx->h_status, sg_stat, 32);
+                return status_to_error(ctx, sg_stat);
+            }
+            if (ctx->thr_fn(ctx->thr_user, 0, n_frames, sg_hist, sg_rec, sg_thr) != 0) {
+                (void)hipStreamSynchronize(st);
+                return fail(ctx, SNOWGPU_E_INVALID, "the threshold callback reported an error");
+            }
+            HIPCHK(ctx, hipMemcpyAsync(ctx->user_thr.p, sg_thr, 24 * nfz, hipMemcpyHostToDevice, st));
+            b.thr_poly = ctx->user_thr.p;
+            rc = run_compaction(ctx, b);
+        }
+    } else {
+        rc = run_batch(ctx, b);
+    }
     int32_t status[8] = {0, -1, 0, 0, 0, 0, 0, 0};
     if (rc == SNOWGPU_OK) {
         HIPCHK(ctx, hipMemcpyAsync(ctx->mail_dn_h, ctx->mail_dn_d.p, out_thr_poly ? dn_bytes : dn_thr, hipMemcpyDeviceToHost, st));
@@ -2316,6 +2503,13 @@ extern "C" int snowgpu_estimate_planes(snowgpu_ctx *ctx, int n_frames, const int
 // For a caller that wants the reference's answer on ITS machine (quirk Q8): the 50 x 2555 histogram of (range, I / cos) over the
 // ground rows and the per-frame sums, from the device; the caller takes np.argpartition(hist, 2)[:, 0] itself, fits the noise
 // line and the quadratic from the sums, and hands the polynomials to snowgpu_augment_batch (thr_poly).
+extern "C" int snowgpu_set_threshold_callback(snowgpu_ctx *ctx, snowgpu_threshold_fn fn, void *user)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    ctx->thr_fn = fn; ctx->thr_user = fn ? user : nullptr;
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_prepass_stats(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const void *rows, int dtype,
                                      const double *plane, int32_t *out_hist, double *out_rec)
 {

@@ -255,18 +255,10 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                 flat[...] = rows[0][:, :5]
         resident = False
         if q8_device:
-            if planes is None:
-                eng.ctx.set_plane_method(plane_method, seed=plane_seed, trials=plane_trials, min_rows=ncols)
-            try:
-                hist, rec = eng.ctx.prepass_stats(flat, offsets, plane=np.asarray(plane_rows) if plane_rows else None,
-                                                  hist_out=eng.hist_buffer(len(rows)))
-            except _native.SnowGPUError as err:
-                _raise_like_reference(err)
-            finally:
-                if planes is None and plane_method != 'reference':
-                    eng.ctx.set_plane_method('reference')
-            polys = list(noise_polys_from_device_stats(hist, rec, noise_floor))
-            resident = True                                                      # the rows are on the device already
+            # q8='numpy': the library hands the device half of the prepass (histograms, sums) to this callback group by group WHILE the
+            # per-beam kernels of the group run (snowgpu_set_threshold_callback); the row minima are taken here, with this process' NumPy
+            # (np.argpartition verbatim, quirk Q8), and the polynomials go back for the compaction.  One crossing of the rows, one call.
+            eng.ctx.set_threshold_callback(lambda first, hist, rec: noise_polys_from_device_stats(hist, rec, noise_floor))
         out_rows, out_src = eng.result_buffers(int(offsets[-1]), dt)
         # The device counting sort handles integer channel values 0..255 and reports anything else
         # (SNOWGPU_E_CHANNELS); only then is the batch sorted here and run again with the permutation.
@@ -303,9 +295,16 @@ def augment_batch(frames: Sequence[np.ndarray], particle_file_prefix: str, beam_
                         else:
                             rows_run = rows
                         perm = np.concatenate([np.argsort(r[:, 4], kind="stable") for r in rows_run]).astype(np.int32)
+                        if q8_device and not polys:
+                            # (a caller permutation switches the threshold callback off: fit here, with the local NumPy, from the rows)
+                            pls = planes if planes is not None else _device_planes(eng, rows_run, dt, plane_method, plane_seed, plane_trials, ncols)
+                            polys = [noise_threshold_poly(r[np.argsort(r[:, 4], kind="stable")][:, :5], pls[i][0], pls[i][1], noise_floor, q8='numpy')
+                                     for i, r in enumerate(rows_run)]
                         continue
                     _raise_like_reference(err)
         finally:
+            if q8_device:
+                eng.ctx.set_threshold_callback(None)
             if calib is not None:
                 eng.ctx.set_fov(None)
             if device_plane and plane_method != 'reference':

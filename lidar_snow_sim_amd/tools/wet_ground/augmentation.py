@@ -96,37 +96,38 @@ def noise_polys_from_device_stats(hist, rec, noise_floor=0.7, threads=None):
     xedges = np.linspace(10, 70, 51)                                                # np.histogram2d's edges (:232-233)
     xmid = (xedges[:-1] + xedges[1:]) / 2                                           # :240-241
 
-    def select(lo, hi):
+    n_ground, ymax, p0, p1 = rec[:, 0], rec[:, 4], rec[:, 5], rec[:, 6]
+    step = (np.abs(ymax) - 5.0) / 2555.0
+    m0, m1 = p0.copy(), p1.copy()                                                   # :250-251: too few rows -> the regression line p
+
+    def frames(lo, hi):
         # :234-236 for frames lo .. hi - 1: the device has already put the ground-row count into the empty bins; the histogram
         # becomes the float64 array np.histogram2d returns (one casting copy) and the selection is the reference's expression --
-        # row by row, so a (frames * 50) x 2555 array gives what fifty-row arrays give.  Both release the GIL.
+        # row by row, so a (frames * 50) x 2555 array gives what fifty-row arrays give.  Both release the GIL; the line fit of a
+        # frame follows its selection in the same task, so that one task's Python runs beside the other tasks' selections.
         h = _scratch_f64((hi - lo) * 50 * 2555).reshape(-1, 2555)                  # (reused per thread: no page faults after the first call)
         np.copyto(h, hist[lo:hi].reshape(-1, 2555))
-        return np.argpartition(h, 2)[:, 0].reshape(hi - lo, 50)
+        ymins = np.argpartition(h, 2)[:, 0].reshape(hi - lo, 50)
+        # the noise line per frame (augmentation.py:237-253), on the COMPRESSED arrays x[use], min_vals[use] with the expressions of
+        # scipy.stats.linregress -- np.mean of each, np.cov(x, y, bias=1) -- so that the line is the one the host path
+        # (noise_threshold_poly -> estimate_laser_parameters) fits, operation for operation (a masked sum over all 50 bins adds the
+        # same numbers in another order: last-bit differences that a row sitting on the threshold can see)
+        for f in range(lo, hi):
+            min_vals = ymins[f - lo] * step[f] + 5.0                                # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
+            u = min_vals > 5                                                        # :238
+            if int(u.sum()) > 3:                                                    # :248
+                x, y = xmid[u], min_vals[u]
+                xmean, ymean = np.mean(x), np.mean(y)
+                ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
+                m0[f] = ssxym / ssxm                                                # :249 scipy linregress
+                m1[f] = ymean - m0[f] * xmean
 
     workers = threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     if nf <= 2 or workers <= 1:
-        ymins = select(0, nf)
+        frames(0, nf)
     else:
         per = max(1, -(-nf // workers))
-        ymins = np.concatenate(list(_thread_pool(workers).map(lambda lo: select(lo, min(lo + per, nf)), range(0, nf, per))))
-    # the noise line per frame (augmentation.py:237-253), on the COMPRESSED arrays x[use], min_vals[use] with the expressions of
-    # scipy.stats.linregress -- np.mean of each, np.cov(x, y, bias=1) -- so that the line is the one the host path
-    # (noise_threshold_poly -> estimate_laser_parameters) fits, operation for operation (a masked sum over all 50 bins adds the
-    # same numbers in another order: last-bit differences that a row sitting on the threshold can see)
-    n_ground, ymax, p0, p1 = rec[:, 0], rec[:, 4], rec[:, 5], rec[:, 6]
-    step = (np.abs(ymax) - 5.0) / 2555.0
-    min_vals = ymins * step[:, None] + 5.0                                          # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
-    use = min_vals > 5                                                              # :238
-    m0, m1 = p0.copy(), p1.copy()                                                   # :250-251: too few rows -> the regression line p
-    for f in range(nf):
-        u = use[f]
-        if int(u.sum()) > 3:                                                        # :248
-            x, y = xmid[u], min_vals[f][u]
-            xmean, ymean = np.mean(x), np.mean(y)
-            ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
-            m0[f] = ssxym / ssxm                                                    # :249 scipy linregress
-            m1[f] = ymean - m0[f] * xmean
+        list(_thread_pool(workers).map(lambda lo: frames(lo, min(lo + per, nf)), range(0, nf, per)))
     q = rec[:, 7:18]
     a22, a21, a2, a11, a1, a2gc, a2c, a1gc, a1c, gc, c = (q[:, k] for k in range(11))
     # normal equations of np.polyfit(d, nf (m0 d + m1) c, 2), columns scaled by their norms as polyfit scales them

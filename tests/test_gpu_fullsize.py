@@ -417,6 +417,67 @@ def test_q8_numpy_device_half_keeps_the_rows_of_the_host_fit_at_full_size(capsys
     assert total["rows_differ"] == 0
 
 
+def test_threshold_callback_inside_the_pipelined_call_equals_the_two_call_form(capsys):
+    """snowgpu_set_threshold_callback (q8='numpy' since round 6): 40 full-size sweeps = four chunks of the pipelined host entry on two
+    lanes; per chunk the library hands histograms and sums to the callback while the chunk's per-beam kernels run and finishes the chunk
+    with the callback's polynomials.  Same rows, sources and statistics as the two-call form (snowgpu_prepass_stats, the same selection on
+    the host, snowgpu_augment_batch with thr_poly) -- rows transfer and packed transfer, channel-major and firing-order sweeps; a callback
+    that raises fails the call with its own exception and leaves the context usable."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import noise_polys_from_device_stats
+    tables = _tables("C2")
+    n = 40
+    rec = {"test": "threshold callback vs two calls", "frames": 0, "frames_differ": 0, "callback_groups": 0}
+    eng = engine.Engine(0)
+    try:
+        for workload in ("C2", "C2fire"):
+            frames, orders = _frames(workload, np.float32, n)
+            tids = [eng.table_ids_from_arrays(tables, o) for o in orders]
+            rows = np.concatenate(frames)
+            off = np.concatenate(([0], np.cumsum([f.shape[0] for f in frames]))).astype(np.int64)
+            planes = [[*PLANE[0], PLANE[1]]] * n
+            hist, stats_rec = eng.ctx.prepass_stats(rows, off, plane=planes)
+            polys = noise_polys_from_device_stats(hist, stats_rec, 0.7)
+            want = eng.ctx.augment_batch(rows, off, tids, BD, thr_poly=polys)
+            groups = []
+
+            def fit(first, h, r):
+                groups.append((first, h.shape[0]))
+                return noise_polys_from_device_stats(h, r, 0.7)
+
+            for mode in ("rows", "packed"):
+                eng.ctx.set_result_transfer(mode)
+                eng.ctx.set_threshold_callback(fit)
+                try:
+                    got = eng.ctx.augment_batch(rows, off, tids, BD, plane=planes)
+                finally:
+                    eng.ctx.set_threshold_callback(None)
+                    eng.ctx.set_result_transfer("rows")
+                assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+                for f in range(n):
+                    a, m = int(off[f]), int(want[2][f])
+                    rec["frames"] += 1
+                    rec["frames_differ"] += not (got[0][a:a + m].tobytes() == want[0][a:a + m].tobytes() and np.array_equal(got[1][a:a + m], want[1][a:a + m]))
+            assert sorted(groups)[0][0] == 0 and sum(g[1] for g in groups) == 2 * n and len(groups) >= 2 * 3          # several groups per call
+            rec["callback_groups"] += len(groups)
+
+        def broken(first, h, r):
+            raise KeyError("no fit today")
+
+        eng.ctx.set_threshold_callback(broken)
+        try:
+            with pytest.raises(KeyError):
+                eng.ctx.augment_batch(rows, off, tids, BD, plane=planes)
+        finally:
+            eng.ctx.set_threshold_callback(None)
+        again = eng.ctx.augment_batch(rows, off, tids, BD, thr_poly=polys)                   # the context is still good
+        assert np.array_equal(again[2], want[2]) and again[0][:int(want[2][0])].tobytes() == want[0][:int(want[2][0])].tobytes()
+    finally:
+        eng.ctx.close()
+    _report(capsys, rec)
+    assert rec["frames_differ"] == 0
+
+
 def test_long_tail_order_of_the_received_power_phase_changes_no_byte(monkeypatch, capsys):
     """Large batches run k_power_few first; where k_power<4> goes after it depends on how many beams the 63-entry / global-list tiers held in
     the batches before (page-locked words the device leaves behind: snowgpu_api.cpp, `heavy_tail`): behind k_power_few with those tiers
