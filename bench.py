@@ -220,7 +220,7 @@ def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
     a rank are hard links to 64 distinct sweeps (bounded disk use; every frame is still read, processed and written); outputs
     are unlinked right after they have been written.  One "step" = the whole stream; value = points of all ranks / max time.
     The line carries every rank's stage times (read / gpu / write thread-seconds, wall) and the host-thread budget: the ranks of a node
-    share its cores and its page cache, which is where the scaling curve is expected to bend (DESIGN.md section 7)."""
+    share its cores and its page cache, which is where the scaling curve is expected to bend (DESIGN.md section 8)."""
     import random
     import torch
     from lidar_snow_sim_amd import dist as sdist

@@ -361,7 +361,7 @@ int snowgpu_set_wet_lines(snowgpu_ctx *ctx, int n_frames, const double *lines);
  *                         t = 0.1, d = 15, f = 0.8) for the noise level (:243-246).  The reference draws the RANSAC samples from
  *                         NumPy's process-global UNSEEDED generator (np.random.randint, :183), so it differs from run to run;
  *                         here trial t of frame f draws from Philox4x32-10 keyed by (seed; f, t): same cloud + same seed = same
- *                         curves on every run and GPU.  Parity unpinned by construction (DESIGN.md section 9b).
+ *                         curves on every run and GPU.  Parity unpinned by construction (DESIGN.md section 9).
  * A frame in which NO range row of the 50 x 2555 histogram has its sparsest bin above 5 returns SNOWGPU_E_GROUND under 'poly'
  * (np.polyfit raises TypeError on an empty vector); with one or two such rows the noise curve is np.polyfit's answer to the
  * under-determined system -- the minimum-norm solution of its column-scaled Vandermonde system -- as in the reference, whose RANSAC

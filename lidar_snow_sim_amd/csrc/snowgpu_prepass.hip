@@ -508,7 +508,7 @@ __global__ void k_pre_override_lines(PreArgs a)
 // kept when its summed absolute residual over the inliers undercuts the best so far (the first fit's is summed over ALL points,
 // as in the reference).  The reference draws from NumPy's process-global, unseeded generator (np.random.randint, :183), so two runs
 // of the reference disagree; here trial t of frame f draws from Philox4x32-10 keyed by (seed; f, t): same cloud + same seed = same
-// curve, on every run and GPU.  Parity is therefore unpinned by construction (DESIGN.md section 9b says how it is tested instead).
+// curve, on every run and GPU.  Parity is therefore unpinned by construction (DESIGN.md section 9 says how it is tested instead).
 #define PQ_C 60.0
 #define PQ_S 60.0
 #define PQ_COLS 8      /* sum u^4, u^3, u^2, u, 1, u^2 y, u y, y */

@@ -62,7 +62,7 @@ def main():
     def ransac(x, y, **kw):
         # augmentation.py:240-241 builds x as xedges[[array]]: NumPy < 1.23 read the one-element list as a tuple (x is 1-D, as the
         # author meant); NumPy >= 1.23 makes it a fancy index and x comes out (1, m) -- np.polyfit then raises TypeError("expected 1D
-        # vector for x"), i.e. TODAY the reference's 'poly' branch raises for every cloud (DESIGN.md section 9b).  The fixture holds
+        # vector for x"), i.e. TODAY the reference's 'poly' branch raises for every cloud (DESIGN.md section 9).  The fixture holds
         # the intended computation: x flattened.
         x = np.ravel(x)
         cap["x"], cap["y"] = np.array(x, np.float64), np.array(y, np.float64)

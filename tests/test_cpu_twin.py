@@ -25,6 +25,15 @@ def twin():
     return _cpu_twin
 
 
+def test_cpu_twin_exports_what_its_header_declares(twin):
+    text = (ROOT / "include" / "snowgpu_cpu.h").read_text()
+    names = sorted(set(re.findall(r"\b(snowgpu_cpu_[a-z_]+)\s*\(", text)))
+    assert names == ["snowgpu_cpu_augment_batch", "snowgpu_cpu_version"]
+    for n in names:
+        assert hasattr(twin.lib(), n), n
+    assert twin.lib().snowgpu_cpu_augment_batch(0, None, None, 0, 0, None, None, None, 0, None, None, None, None, 0.1, None, 0.7, 1, None, None, None, None, None) == 1
+
+
 def test_cpu_twin_reproduces_the_reference_L5_fixtures(twin, so, golden, tables):
     """All eight L5 cases (tools/snowfall/simulation.py::augment through the imported reference): kept rows, labels, intensities and
     statistics equal the fixture's; the whole result equals the oracle's byte for byte.  The threshold polynomial is the oracle's

@@ -478,6 +478,31 @@ def test_threshold_callback_inside_the_pipelined_call_equals_the_two_call_form(c
     assert rec["frames_differ"] == 0
 
 
+def test_one_work_queue_for_the_received_power_phase_changes_no_byte(monkeypatch, capsys):
+    """SNOWGPU_KP_ALL=1 (k_power_all: the 16- and 8-entry classes and the closed-up multi-flake beams of the main queue from ONE item space, one
+    persistent kernel) against the default three kernels k_power<4> / <8> / <16>: ten C2far sweeps (ranges x 1.8: a tenth of the beams in the
+    8-entry class, 6 % in the 16-entry one, hundreds in the 63-entry one) as one device batch through the tensor boundary -- striding and the
+    atomic item cursor, six and eight waves per CU -- give the same rows, sources, counts and statistics, byte for byte."""
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    tables = _tables("C2far")
+    frames, orders = _frames("C2far", np.float32, 10)
+    t_frames = [torch.from_numpy(f).cuda() for f in frames]
+    results = []
+    for slot, env in ((301, {"SNOWGPU_KP_ALL": "0"}), (302, {"SNOWGPU_KP_ALL": "1"}), (303, {"SNOWGPU_KP_ALL": "1", "SNOWGPU_KP_ALL_TICKET": "1", "SNOWGPU_KP_ALL_WAVES": "6"})):
+        for k in ("SNOWGPU_KP_ALL", "SNOWGPU_KP_ALL_TICKET", "SNOWGPU_KP_ALL_WAVES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for _ in range(2):                                      # (the second call sizes the rare classes' grids from the first one's counts)
+            res = augment_batch(t_frames, "unused", BD, planes=[PLANE] * 10, orders=orders, particles=tables, return_src=True, slot=slot)
+        results.append([(tuple(int(v) for v in st), aug.cpu().numpy(), src.cpu().numpy()) for st, aug, src in res])
+    same = all(a[0] == b[0] and np.array_equal(a[2], b[2]) and a[1].tobytes() == b[1].tobytes()
+               for other in results[1:] for a, b in zip(results[0], other))
+    kept = int(sum(r[1].shape[0] for r in results[0]))
+    _report(capsys, {"test": "one work queue (k_power_all) vs three kernels", "rows_kept": kept, "same_bytes": bool(same)})
+    assert same and kept > 0
+
+
 def test_long_tail_order_of_the_received_power_phase_changes_no_byte(monkeypatch, capsys):
     """Large batches run k_power_few first; where k_power<4> goes after it depends on how many beams the 63-entry / global-list tiers held in
     the batches before (page-locked words the device leaves behind: snowgpu_api.cpp, `heavy_tail`): behind k_power_few with those tiers
