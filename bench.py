@@ -304,6 +304,237 @@ def run_c5(args, rank, local_rank, world, dist, dev, ranks_seen):
         dist.destroy_process_group()
 
 
+def measure_host_entry(W):
+    """value_pcie_inclusive and single_frame: the same frames through the HOST entry, in a child process without PyTorch and in process."""
+    args, eng, torch, dist, dev, distributed, world, rank, local_rank = W.args, W.eng, W.torch, W.dist, W.dev, W.distributed, W.world, W.rank, W.local_rank
+    F, n_per, n_total, host_rows, table_ids, planes, fused_wet, barrier = W.F, W.n_per, W.n_total, W.host_rows, W.table_ids, W.planes, W.fused_wet, W.barrier
+    out_rows, out_counts, out_stats = W.out_rows, W.out_counts, W.out_stats
+    # ---- the same frames through the HOST entry: H2D + D2H inside the clock (SURVEY 8 d; precompute.py:78 / :106 are the
+    # reference's boundary).  ONE host thread, ONE context: snowgpu_augment_batch pipelines upload / kernels / download in
+    # chunks of whole frames on its own streams.  Measured in a CHILD process that never loads PyTorch (scripts/pcie_bench.py):
+    # the C ABI does not need it, and inside a process that has initialised PyTorch the HIP runtime moves device-to-host copies
+    # with a full-grid blit kernel instead of the DMA engine (traced), which stalls every kernel beside it.  The in-process
+    # figure is reported next to it.
+    pcie, single = None, None
+    if not args.no_pcie and not fused_wet and args.tables == "host":
+        child = None
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+            barrier()
+            r = subprocess.run([sys.executable, str(ROOT / "scripts" / "pcie_bench.py"), "--frames", str(F), "--reps", str(max(1, min(args.steps, 4))),
+                                "--workload", args.workload, "--device", str(local_rank), "--seed-base", str(1000 + rank * F)],
+                               capture_output=True, text=True, timeout=900, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            child = json.loads(lines[-1]) if r.returncode == 0 and lines else None
+        except Exception:
+            child = None
+        # in-process (PyTorch initialised): same call, for comparison and as the fallback
+        pin_in = eng.ctx.pinned_empty((n_total, 5), np.float32)
+        pin_in[...] = host_rows
+        pin_out = eng.ctx.pinned_empty((n_total, 5), np.float32)
+        pin_src = eng.ctx.pinned_empty(n_total, np.int32)
+        h_off = np.arange(F + 1, dtype=np.int64) * n_per
+        h_ids = np.asarray(table_ids, np.int32)
+        h_planes = np.asarray(planes, np.float64)
+
+        def host_call(want_src=True):
+            return eng.ctx.augment_batch(pin_in, h_off, h_ids, BEAM_DIV, plane=h_planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
+
+        host_call(True)
+        barrier()
+        c0 = time.perf_counter()
+        _, _, h_counts, h_stats, _ = host_call(True)
+        inproc_s = time.perf_counter() - c0
+        d_counts = out_counts.cpu().numpy()
+        host_same = bool(np.array_equal(h_counts, d_counts) and np.array_equal(h_stats, out_stats.cpu().numpy())
+                         and all(np.array_equal(pin_out[f * n_per:f * n_per + int(d_counts[f])],
+                                                out_rows[f * n_per:f * n_per + int(d_counts[f])].cpu().numpy()) for f in (0, F // 2, F - 1)))
+        digest = [int(h_counts.sum()), int(h_stats[:, 0].sum()), int(h_stats[:, 1].sum()), int(h_stats[:, 2].sum()),
+                  float(pin_out[:int(h_counts[0]), 3].sum()), int(pin_src[:int(h_counts[0])].astype(np.int64).sum())]
+        dp = (child or {}).get("default_plane") or {}
+        mine = [child["points_per_s"], child["points_per_s_without_src"]] if child else [n_total / inproc_s, n_total / inproc_s]
+        mine += [dp.get("c_abi_points_per_s_reference", 0.0), dp.get("c_abi_points_per_s_lsq", 0.0)]
+        pk_all = (child or {}).get("packed") or {}
+        pk_key = next(iter(pk_all), None)                   # first entry: the library's default thread count
+        pk = pk_all.get(pk_key) if pk_key else None
+        mine += [pk["points_per_s"] if pk else 0.0]
+        if distributed:
+            tt = torch.tensor(mine, dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+            mine = [float(v) for v in tt.tolist()]
+        pcie = {"value": mine[4] if pk else mine[0], "value_rows_transfer": mine[0], "value_rows_transfer_without_src": mine[1],
+                "transfer": ("packed (snowgpu_set_result_transfer(ctx, 1, 0)): per kept row its source row | label and its intensity cross the link, "
+                             "the moved coordinates of scattered rows apart; " + str(pk_key) + " host threads of the library assemble the caller's rows "
+                             "from those and from its input rows -- same bytes in the caller's buffers as the rows transfer") if pk else "rows",
+                "packed_by_host_threads": pk_all or None,
+                "steps": max(1, min(args.steps, 4)),
+                "process_affinity": (child or {}).get("process_affinity"),
+                "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
+                "bytes_per_point": {"h2d": 20, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
+                "link_bound_points_per_s": {"upload_20B": PCIE_PEAK / 20.0 * world, "download_rows_24B": PCIE_PEAK / 24.0 * world,
+                                            "download_rows_without_src_20B": PCIE_PEAK / 20.0 * world},
+                "frac_of_link_bound": {"packed_vs_upload_bound": (mine[4] / (PCIE_PEAK / 20.0 * world)) if pk else None,
+                                       "rows_vs_download_bound": mine[0] / (PCIE_PEAK / 24.0 * world),
+                                       "rows_without_src_vs_download_bound": mine[1] / (PCIE_PEAK / 20.0 * world)},
+                "in_process_with_pytorch": n_total / inproc_s,
+                "matches_device_entry": host_same and (child is None or child["digest"] == digest) and (pk is None or bool(pk.get("same_digest_as_rows_mode"))),
+                "q8_numpy": (child or {}).get("q8_numpy"),
+                "default_plane": dp or None, "default_plane_all_ranks": {"reference": mine[2], "lsq": mine[3]} if dp else None,
+                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
+                        "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
+                        "(snowgpu_set_pipeline); ceilings at 63 GB/s per direction: 20 B per point up; 24 B per point down with the rows "
+                        "transfer (20 with out_src = NULL), ~9.5 with the packed one, which the upload then bounds"}
+        if child and rank == 0:
+            single = {"c_abi_pinned": {"ms": child["single_frame_c_abi_ms"], "min_ms": child["single_frame_c_abi_min_ms"],
+                                       "points_per_s": n_per / (child["single_frame_c_abi_ms"] * 1e-3)},
+                      "python_augment_pageable": {"ms": child["single_frame_python_ms"], "min_ms": child["single_frame_python_min_ms"],
+                                                  "points_per_s": n_per / (child["single_frame_python_ms"] * 1e-3)},
+                      "python_augment_default": {"ms": child.get("single_frame_python_default_ms"), "min_ms": child.get("single_frame_python_default_min_ms"),
+                                                 "note": "augment(pc, prefix, bd, only_camera_fov=False) with no plane and no order: calculate_plane on the "
+                                                         "device by the default method (the plane the reference returns today), random.shuffle on the host"},
+                      "python_augment_lsq_plane": {"ms": child.get("single_frame_python_lsq_ms"), "min_ms": child.get("single_frame_python_lsq_min_ms")},
+                      "points": n_per,
+                      "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock "
+                              "(child process without PyTorch)"}
+
+    return pcie, single
+
+
+def counter_passes(W, alg_bytes):
+    """roofline.traffic / traffic_detail / valu: rocprofv3 --pmc child passes of this command (FETCH_SIZE, WRITE_SIZE, SQ counters), or the committed figures."""
+    args, F, world = W.args, W.F, W.world
+    traffic, traffic_src, valu = None, None, None
+    inner_argv = ["--steps", "2", "--warmup", "1", "--frames", str(F), "--workload", args.workload, "--tables", args.tables]
+    if not args.no_pmc and world == 1:
+        # (a child runs the first call of the size, one warm-up and two timed steps: four launch sequences per kernel)
+        fetch = pmc_pass(["FETCH_SIZE"], inner_argv, 4)
+        write = pmc_pass(["WRITE_SIZE"], inner_argv, 4) if fetch else None
+        sq = pmc_pass(["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"],
+                      inner_argv, 4) if write else None
+        if fetch and write:
+            in_region = lambda k: k.startswith(REGION_KERNELS)      # noqa: E731
+            fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in fetch.items() if in_region(k)) * 1024 * FETCH_FACTOR
+            wb = sum(v.get("WRITE_SIZE", 0.0) for k, v in write.items() if in_region(k)) * 1024 * WRITE_FACTOR
+            traffic = fb + wb
+            whole = (sum(v.get("FETCH_SIZE", 0.0) for v in fetch.values()) * FETCH_FACTOR
+                     + sum(v.get("WRITE_SIZE", 0.0) for v in write.values()) * WRITE_FACTOR) * 1024
+            traffic_src = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes of this command (--steps 2 --warmup 1), "
+                                     "kernels k_beams* / k_power* / k_tier*; counter x 1024 B x calibration factor (FETCH_SIZE x 2.0, "
+                                     "WRITE_SIZE x 1.0: kernels of known byte counts, profiles/r03_pmc_calibration.json)",
+                           "fetch_bytes": fb, "write_bytes": wb, "whole_step_bytes": whole,
+                           "whole_step_over_algorithmic": whole / alg_bytes}
+            dump = os.environ.get("SNOWGPU_BENCH_PMC_DUMP")
+            if dump:                                    # per-kernel table for profiles/ (scripts/collect_profiles.sh)
+                with open(dump, "w") as fh:
+                    fh.write("kernel,FETCH_SIZE_KB_per_step_raw,WRITE_SIZE_KB_per_step_raw,read_bytes_per_step_calibrated,written_bytes_per_step\n")
+                    for k in sorted(set(fetch) | set(write)):
+                        f_kb, w_kb = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
+                        fh.write('"%s",%.1f,%.1f,%.0f,%.0f\n' % (k, f_kb, w_kb, f_kb * 1024 * FETCH_FACTOR, w_kb * 1024 * WRITE_FACTOR))
+        if sq:
+            dom = max((k for k in sq if k.startswith("k_beams")), key=lambda k: sq[k].get("SQ_INSTS_VALU", 0.0), default=None)
+            if dom:
+                d = sq[dom]
+                valu = {"kernel": dom,
+                        "lane_utilisation": d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"]) if d.get("SQ_ACTIVE_INST_VALU") else None,
+                        "valu_instructions_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"] if d.get("SQ_WAVES") else None,
+                        "valu_issue_share_of_wave_cycles": d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"] if d.get("SQ_WAVE_CYCLES") else None,
+                        "note": "SQ counters of the dominant kernel (rocprofv3 --pmc child pass): the path is bound by VALU issue and "
+                                "latency, not by HBM -- these are the figures to read beside frac"}
+    if traffic is None:
+        pmc = ROOT / "profiles" / "hbm_traffic.json"
+        if pmc.exists():
+            try:
+                rec = json.loads(pmc.read_text())
+                if rec.get("frames") == F and rec.get("workload", "C2") == args.workload:
+                    traffic = rec.get("bytes_per_launch")
+                    traffic_src = {"source": "profiles/hbm_traffic.json (committed rocprofv3 passes of this command)"}
+            except Exception:
+                traffic = None
+    return traffic, traffic_src, valu
+
+
+def cpu_legs(W):
+    """cpu_baseline (the oracle, kind "port") and cpu_twin (libsnowcpu.so) on a bounded sample of the batch, and the GPU's frames checked against both."""
+    args, eng, torch = W.args, W.eng, W.torch
+    F, n_per, layers, frames, orders, tables, plane, planes, table_ids, host_rows, fused_wet = W.F, W.n_per, W.layers, W.frames, W.orders, W.tables, W.plane, W.planes, W.table_ids, W.host_rows, W.fused_wet
+    out_rows, out_src, out_counts, out_stats = W.out_rows, W.out_src, W.out_counts, W.out_stats
+    out = {}
+    from oracle import snow_oracle as so
+    # (i) one host core on frame 0; (ii) ALL logical CPUs on frames 0..15 through the pthread driver of
+    # oracle/snow_oracle.c (work item = 256 beams of one (frame, channel); SURVEY 8 d).  The prepass (NumPy, one core,
+    # ~15 ms per frame) is inside both clocks, as it is inside the reference's augment().
+    cores, cpu_info = usable_cpus()
+    n_cpu = min(16, F)
+    las = so.load_lasers() * (layers // 64)
+    c0 = time.perf_counter()
+    so.augment(frames[0], tables, BEAM_DIV, orders[0], plane=plane, lasers=las)
+    one_s = time.perf_counter() - c0
+    c0 = time.perf_counter()
+    refs, used = so.augment_many(frames[:n_cpu], tables, BEAM_DIV, orders[:n_cpu], planes=[plane] * n_cpu, lasers=las, threads=cores)
+    cpu_s = time.perf_counter() - c0
+    same = True
+    for fi in range(min(4, n_cpu)):
+        s_ref, a_ref, src_ref = refs[fi]
+        if fused_wet:
+            a_ref, wsrc = so.ground_water_augmentation(a_ref, water_height=WET["water_height"], pavement_depth=WET["pavement_depth"],
+                                                       noise_floor=WET["noise_floor"], power_factor=WET["power_factor"],
+                                                       flat_earth=WET["flat_earth"], delta=WET["delta"], replace=WET["replace"],
+                                                       plane=plane, return_src=True)
+            src_ref = src_ref[wsrc]
+        n0 = int(out_counts[fi].item())
+        lo = fi * n_per
+        got = out_rows[lo:lo + n0].cpu().numpy()
+        got_src = out_src[lo:lo + n0].cpu().numpy()
+        ok = n0 == a_ref.shape[0] and np.array_equal(got_src, src_ref) and np.array_equal(got[:, 4], a_ref[:, 4]) \
+            and np.allclose(got[:, :3], a_ref[:, :3], rtol=1e-6, atol=0)
+        ok = ok and (np.allclose(got[:, 3], a_ref[:, 3], rtol=1e-6, atol=0) if fused_wet else np.array_equal(got[:, 3], a_ref[:, 3]))
+        if not fused_wet:
+            ok = ok and tuple(int(v) for v in out_stats[fi].cpu().numpy()) == tuple(int(v) for v in s_ref)
+        same = same and bool(ok)
+    # (iii) the build's own CPU twin (libsnowcpu.so: the kernels' per-beam device code compiled for the host, binned tables and all;
+    # include/snowgpu_cpu.h, SURVEY 8 b / 8 d) on the same frames, every usable CPU and one; the polynomials are the device prepass's
+    twin = None
+    if not fused_wet:
+        try:
+            from lidar_snow_sim_amd import _cpu_twin
+            pin_rows = eng.ctx.pinned_empty((n_cpu * n_per, 5), np.float32)
+            pin_rows[...] = host_rows[:n_cpu * n_per]
+            _, _, _, _, thr_dev = eng.ctx.augment_batch(pin_rows, np.arange(n_cpu + 1, dtype=np.int64) * n_per, np.asarray(table_ids[:n_cpu], np.int32), BEAM_DIV,
+                                                        plane=np.asarray(planes[:n_cpu], np.float64), want_thr=True, want_src=False)
+            _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=cores)      # (loads the library, files nothing twice)
+            c0 = time.perf_counter()
+            tw = _cpu_twin.augment_batch(frames[:n_cpu], tables, orders[:n_cpu], BEAM_DIV, thr_dev, lasers=las, threads=cores)
+            tw_s = time.perf_counter() - c0
+            c0 = time.perf_counter()
+            _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=1)
+            tw1_s = time.perf_counter() - c0
+            tw_same = True
+            for fi in range(n_cpu):
+                n0, lo = int(out_counts[fi].item()), fi * n_per
+                tw_same = tw_same and n0 == tw[fi][1].shape[0] and out_rows[lo:lo + n0].cpu().numpy().tobytes() == tw[fi][1].tobytes() \
+                    and np.array_equal(out_src[lo:lo + n0].cpu().numpy(), tw[fi][2])
+            twin = {"value": n_cpu * n_per / tw_s, "unit": "points/s", "cores": cores, "single_core_value": n_per / tw1_s,
+                    "kind": "the build's own restatement: libsnowcpu.so = the HIP kernels' per-beam device code (csrc/sg_beam.h, sg_table_host.h, sg_row.h) "
+                            "compiled for the host, one beam at a time on host threads (include/snowgpu_cpu.h); table filing inside the clock, "
+                            "threshold polynomials given (the device prepass's)",
+                    "sample": f"frames 0..{n_cpu - 1} of the batch, {tw_s:.2f} s on {cores} threads; one thread on frame 0: {tw1_s:.2f} s",
+                    "same_bytes_as_gpu": bool(tw_same)}
+        except Exception as ex:      # the twin is a side measurement: the line does not depend on it
+            twin = {"error": repr(ex)}
+    if twin is not None:
+        out["cpu_twin"] = twin
+    out["cpu_baseline"] = {"value": n_cpu * n_per / cpu_s, "unit": "points/s", "cores": used, "kind": "port",
+                              "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "host_cpus_usable": cpu_info,
+                              "sample": f"frames 0..{n_cpu - 1} of the batch ({n_cpu * n_per} points): oracle/snow_oracle.c (scalar C "
+                                        f"restatement, per-beam scan of the whole table, float64) under its pthread driver -- work item = "
+                                        f"256 beams of one (frame, channel), {used} threads = every CPU this process may use "
+                                        f"(affinity / cgroup quota) -- plus the NumPy frame driver, {cpu_s:.1f} s wall; one core on frame 0: "
+                                        f"{n_per / one_s:.0f} points/s ({one_s:.1f} s)",
+                              "single_core_value": n_per / one_s,
+                              "gpu_output_matches": bool(same)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -512,93 +743,12 @@ def main():
     if args.inner:
         return
 
-    # ---- the same frames through the HOST entry: H2D + D2H inside the clock (SURVEY 8 d; precompute.py:78 / :106 are the
-    # reference's boundary).  ONE host thread, ONE context: snowgpu_augment_batch pipelines upload / kernels / download in
-    # chunks of whole frames on its own streams.  Measured in a CHILD process that never loads PyTorch (scripts/pcie_bench.py):
-    # the C ABI does not need it, and inside a process that has initialised PyTorch the HIP runtime moves device-to-host copies
-    # with a full-grid blit kernel instead of the DMA engine (traced), which stalls every kernel beside it.  The in-process
-    # figure is reported next to it.
-    pcie, single = None, None
-    if not args.no_pcie and not fused_wet and args.tables == "host":
-        child = None
-        try:
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-            barrier()
-            r = subprocess.run([sys.executable, str(ROOT / "scripts" / "pcie_bench.py"), "--frames", str(F), "--reps", str(max(1, min(args.steps, 4))),
-                                "--workload", args.workload, "--device", str(local_rank), "--seed-base", str(1000 + rank * F)],
-                               capture_output=True, text=True, timeout=900, env=env)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            child = json.loads(lines[-1]) if r.returncode == 0 and lines else None
-        except Exception:
-            child = None
-        # in-process (PyTorch initialised): same call, for comparison and as the fallback
-        pin_in = eng.ctx.pinned_empty((n_total, 5), np.float32)
-        pin_in[...] = host_rows
-        pin_out = eng.ctx.pinned_empty((n_total, 5), np.float32)
-        pin_src = eng.ctx.pinned_empty(n_total, np.int32)
-        h_off = np.arange(F + 1, dtype=np.int64) * n_per
-        h_ids = np.asarray(table_ids, np.int32)
-        h_planes = np.asarray(planes, np.float64)
-
-        def host_call(want_src=True):
-            return eng.ctx.augment_batch(pin_in, h_off, h_ids, BEAM_DIV, plane=h_planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
-
-        host_call(True)
-        barrier()
-        c0 = time.perf_counter()
-        _, _, h_counts, h_stats, _ = host_call(True)
-        inproc_s = time.perf_counter() - c0
-        d_counts = out_counts.cpu().numpy()
-        host_same = bool(np.array_equal(h_counts, d_counts) and np.array_equal(h_stats, out_stats.cpu().numpy())
-                         and all(np.array_equal(pin_out[f * n_per:f * n_per + int(d_counts[f])],
-                                                out_rows[f * n_per:f * n_per + int(d_counts[f])].cpu().numpy()) for f in (0, F // 2, F - 1)))
-        digest = [int(h_counts.sum()), int(h_stats[:, 0].sum()), int(h_stats[:, 1].sum()), int(h_stats[:, 2].sum()),
-                  float(pin_out[:int(h_counts[0]), 3].sum()), int(pin_src[:int(h_counts[0])].astype(np.int64).sum())]
-        dp = (child or {}).get("default_plane") or {}
-        mine = [child["points_per_s"], child["points_per_s_without_src"]] if child else [n_total / inproc_s, n_total / inproc_s]
-        mine += [dp.get("c_abi_points_per_s_reference", 0.0), dp.get("c_abi_points_per_s_lsq", 0.0)]
-        pk_all = (child or {}).get("packed") or {}
-        pk_key = next(iter(pk_all), None)                   # first entry: the library's default thread count
-        pk = pk_all.get(pk_key) if pk_key else None
-        mine += [pk["points_per_s"] if pk else 0.0]
-        if distributed:
-            tt = torch.tensor(mine, dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-            mine = [float(v) for v in tt.tolist()]
-        pcie = {"value": mine[4] if pk else mine[0], "value_rows_transfer": mine[0], "value_rows_transfer_without_src": mine[1],
-                "transfer": ("packed (snowgpu_set_result_transfer(ctx, 1, 0)): per kept row its source row | label and its intensity cross the link, "
-                             "the moved coordinates of scattered rows apart; " + str(pk_key) + " host threads of the library assemble the caller's rows "
-                             "from those and from its input rows -- same bytes in the caller's buffers as the rows transfer") if pk else "rows",
-                "packed_by_host_threads": pk_all or None,
-                "steps": max(1, min(args.steps, 4)),
-                "process_affinity": (child or {}).get("process_affinity"),
-                "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
-                "bytes_per_point": {"h2d": 20, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
-                "link_bound_points_per_s": {"upload_20B": PCIE_PEAK / 20.0 * world, "download_rows_24B": PCIE_PEAK / 24.0 * world,
-                                            "download_rows_without_src_20B": PCIE_PEAK / 20.0 * world},
-                "frac_of_link_bound": {"packed_vs_upload_bound": (mine[4] / (PCIE_PEAK / 20.0 * world)) if pk else None,
-                                       "rows_vs_download_bound": mine[0] / (PCIE_PEAK / 24.0 * world),
-                                       "rows_without_src_vs_download_bound": mine[1] / (PCIE_PEAK / 20.0 * world)},
-                "in_process_with_pytorch": n_total / inproc_s,
-                "matches_device_entry": host_same and (child is None or child["digest"] == digest) and (pk is None or bool(pk.get("same_digest_as_rows_mode"))),
-                "q8_numpy": (child or {}).get("q8_numpy"),
-                "default_plane": dp or None, "default_plane_all_ranks": {"reference": mine[2], "lsq": mine[3]} if dp else None,
-                "note": "snowgpu_augment_batch (host pointers) on frames held in page-locked memory, one call per step: the library streams "
-                        "all uploads through one DMA queue, computes chunk after chunk and downloads chunk c while chunk c + 1 computes "
-                        "(snowgpu_set_pipeline); ceilings at 63 GB/s per direction: 20 B per point up; 24 B per point down with the rows "
-                        "transfer (20 with out_src = NULL), ~9.5 with the packed one, which the upload then bounds"}
-        if child and rank == 0:
-            single = {"c_abi_pinned": {"ms": child["single_frame_c_abi_ms"], "min_ms": child["single_frame_c_abi_min_ms"],
-                                       "points_per_s": n_per / (child["single_frame_c_abi_ms"] * 1e-3)},
-                      "python_augment_pageable": {"ms": child["single_frame_python_ms"], "min_ms": child["single_frame_python_min_ms"],
-                                                  "points_per_s": n_per / (child["single_frame_python_ms"] * 1e-3)},
-                      "python_augment_default": {"ms": child.get("single_frame_python_default_ms"), "min_ms": child.get("single_frame_python_default_min_ms"),
-                                                 "note": "augment(pc, prefix, bd, only_camera_fov=False) with no plane and no order: calculate_plane on the "
-                                                         "device by the default method (the plane the reference returns today), random.shuffle on the host"},
-                      "python_augment_lsq_plane": {"ms": child.get("single_frame_python_lsq_ms"), "min_ms": child.get("single_frame_python_lsq_min_ms")},
-                      "points": n_per,
-                      "note": "median of 40 calls, one 64 x 2048 sweep per call, upload + all kernels + download + synchronise inside the clock "
-                              "(child process without PyTorch)"}
+    import types
+    W = types.SimpleNamespace(args=args, eng=eng, torch=torch, dist=dist, dev=dev, distributed=distributed, world=world, rank=rank, local_rank=local_rank,
+                              F=F, n_per=n_per, n_total=n_total, layers=layers, host_rows=host_rows, frames=frames, orders=orders, tables=tables,
+                              table_ids=table_ids, plane=plane, planes=planes, fused_wet=fused_wet, barrier=barrier,
+                              out_rows=out_rows, out_src=out_src, out_counts=out_counts, out_stats=out_stats)
+    pcie, single = measure_host_entry(W)
 
     seen = ranks_seen()
     if rank == 0:
@@ -611,53 +761,7 @@ def main():
         alg_bytes_tables = alg_bytes + 24.0 * ktot * F
         avg_ms = beam_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) if avg_ms > 0 else 0.0
-        traffic, traffic_src, valu = None, None, None
-        inner_argv = ["--steps", "2", "--warmup", "1", "--frames", str(F), "--workload", args.workload, "--tables", args.tables]
-        if not args.no_pmc and world == 1:
-            # (a child runs the first call of the size, one warm-up and two timed steps: four launch sequences per kernel)
-            fetch = pmc_pass(["FETCH_SIZE"], inner_argv, 4)
-            write = pmc_pass(["WRITE_SIZE"], inner_argv, 4) if fetch else None
-            sq = pmc_pass(["SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES"],
-                          inner_argv, 4) if write else None
-            if fetch and write:
-                in_region = lambda k: k.startswith(REGION_KERNELS)      # noqa: E731
-                fb = sum(v.get("FETCH_SIZE", 0.0) for k, v in fetch.items() if in_region(k)) * 1024 * FETCH_FACTOR
-                wb = sum(v.get("WRITE_SIZE", 0.0) for k, v in write.items() if in_region(k)) * 1024 * WRITE_FACTOR
-                traffic = fb + wb
-                whole = (sum(v.get("FETCH_SIZE", 0.0) for v in fetch.values()) * FETCH_FACTOR
-                         + sum(v.get("WRITE_SIZE", 0.0) for v in write.values()) * WRITE_FACTOR) * 1024
-                traffic_src = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate child passes of this command (--steps 2 --warmup 1), "
-                                         "kernels k_beams* / k_power* / k_tier*; counter x 1024 B x calibration factor (FETCH_SIZE x 2.0, "
-                                         "WRITE_SIZE x 1.0: kernels of known byte counts, profiles/r03_pmc_calibration.json)",
-                               "fetch_bytes": fb, "write_bytes": wb, "whole_step_bytes": whole,
-                               "whole_step_over_algorithmic": whole / alg_bytes}
-                dump = os.environ.get("SNOWGPU_BENCH_PMC_DUMP")
-                if dump:                                    # per-kernel table for profiles/ (scripts/collect_profiles.sh)
-                    with open(dump, "w") as fh:
-                        fh.write("kernel,FETCH_SIZE_KB_per_step_raw,WRITE_SIZE_KB_per_step_raw,read_bytes_per_step_calibrated,written_bytes_per_step\n")
-                        for k in sorted(set(fetch) | set(write)):
-                            f_kb, w_kb = fetch.get(k, {}).get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
-                            fh.write('"%s",%.1f,%.1f,%.0f,%.0f\n' % (k, f_kb, w_kb, f_kb * 1024 * FETCH_FACTOR, w_kb * 1024 * WRITE_FACTOR))
-            if sq:
-                dom = max((k for k in sq if k.startswith("k_beams")), key=lambda k: sq[k].get("SQ_INSTS_VALU", 0.0), default=None)
-                if dom:
-                    d = sq[dom]
-                    valu = {"kernel": dom,
-                            "lane_utilisation": d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"]) if d.get("SQ_ACTIVE_INST_VALU") else None,
-                            "valu_instructions_per_wave": d["SQ_INSTS_VALU"] / d["SQ_WAVES"] if d.get("SQ_WAVES") else None,
-                            "valu_issue_share_of_wave_cycles": d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"] if d.get("SQ_WAVE_CYCLES") else None,
-                            "note": "SQ counters of the dominant kernel (rocprofv3 --pmc child pass): the path is bound by VALU issue and "
-                                    "latency, not by HBM -- these are the figures to read beside frac"}
-        if traffic is None:
-            pmc = ROOT / "profiles" / "hbm_traffic.json"
-            if pmc.exists():
-                try:
-                    rec = json.loads(pmc.read_text())
-                    if rec.get("frames") == F and rec.get("workload", "C2") == args.workload:
-                        traffic = rec.get("bytes_per_launch")
-                        traffic_src = {"source": "profiles/hbm_traffic.json (committed rocprofv3 passes of this command)"}
-                except Exception:
-                    traffic = None
+        traffic, traffic_src, valu = counter_passes(W, alg_bytes)
         result = {
             "metric": METRIC,
             "value": value, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -706,79 +810,7 @@ def main():
             result["sampler"] = sampler
             result["config"]["tables"] = "sampled and filed on the device (snowgpu_sample_table, seed = f(prefix, line))"
         if not args.no_cpu_baseline and world == 1:      # rank 0, N = 1 only
-            from oracle import snow_oracle as so
-            # (i) one host core on frame 0; (ii) ALL logical CPUs on frames 0..15 through the pthread driver of
-            # oracle/snow_oracle.c (work item = 256 beams of one (frame, channel); SURVEY 8 d).  The prepass (NumPy, one core,
-            # ~15 ms per frame) is inside both clocks, as it is inside the reference's augment().
-            cores, cpu_info = usable_cpus()
-            n_cpu = min(16, F)
-            las = so.load_lasers() * (layers // 64)
-            c0 = time.perf_counter()
-            so.augment(frames[0], tables, BEAM_DIV, orders[0], plane=plane, lasers=las)
-            one_s = time.perf_counter() - c0
-            c0 = time.perf_counter()
-            refs, used = so.augment_many(frames[:n_cpu], tables, BEAM_DIV, orders[:n_cpu], planes=[plane] * n_cpu, lasers=las, threads=cores)
-            cpu_s = time.perf_counter() - c0
-            same = True
-            for fi in range(min(4, n_cpu)):
-                s_ref, a_ref, src_ref = refs[fi]
-                if fused_wet:
-                    a_ref, wsrc = so.ground_water_augmentation(a_ref, water_height=WET["water_height"], pavement_depth=WET["pavement_depth"],
-                                                               noise_floor=WET["noise_floor"], power_factor=WET["power_factor"],
-                                                               flat_earth=WET["flat_earth"], delta=WET["delta"], replace=WET["replace"],
-                                                               plane=plane, return_src=True)
-                    src_ref = src_ref[wsrc]
-                n0 = int(out_counts[fi].item())
-                lo = fi * n_per
-                got = out_rows[lo:lo + n0].cpu().numpy()
-                got_src = out_src[lo:lo + n0].cpu().numpy()
-                ok = n0 == a_ref.shape[0] and np.array_equal(got_src, src_ref) and np.array_equal(got[:, 4], a_ref[:, 4]) \
-                    and np.allclose(got[:, :3], a_ref[:, :3], rtol=1e-6, atol=0)
-                ok = ok and (np.allclose(got[:, 3], a_ref[:, 3], rtol=1e-6, atol=0) if fused_wet else np.array_equal(got[:, 3], a_ref[:, 3]))
-                if not fused_wet:
-                    ok = ok and tuple(int(v) for v in out_stats[fi].cpu().numpy()) == tuple(int(v) for v in s_ref)
-                same = same and bool(ok)
-            # (iii) the build's own CPU twin (libsnowcpu.so: the kernels' per-beam device code compiled for the host, binned tables and all;
-            # include/snowgpu_cpu.h, SURVEY 8 b / 8 d) on the same frames, every usable CPU and one; the polynomials are the device prepass's
-            twin = None
-            if not fused_wet:
-                try:
-                    from lidar_snow_sim_amd import _cpu_twin
-                    pin_rows = eng.ctx.pinned_empty((n_cpu * n_per, 5), np.float32)
-                    pin_rows[...] = host_rows[:n_cpu * n_per]
-                    _, _, _, _, thr_dev = eng.ctx.augment_batch(pin_rows, np.arange(n_cpu + 1, dtype=np.int64) * n_per, np.asarray(table_ids[:n_cpu], np.int32), BEAM_DIV,
-                                                                plane=np.asarray(planes[:n_cpu], np.float64), want_thr=True, want_src=False)
-                    _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=cores)      # (loads the library, files nothing twice)
-                    c0 = time.perf_counter()
-                    tw = _cpu_twin.augment_batch(frames[:n_cpu], tables, orders[:n_cpu], BEAM_DIV, thr_dev, lasers=las, threads=cores)
-                    tw_s = time.perf_counter() - c0
-                    c0 = time.perf_counter()
-                    _cpu_twin.augment_batch(frames[:1], tables, orders[:1], BEAM_DIV, thr_dev[:1], lasers=las, threads=1)
-                    tw1_s = time.perf_counter() - c0
-                    tw_same = True
-                    for fi in range(n_cpu):
-                        n0, lo = int(out_counts[fi].item()), fi * n_per
-                        tw_same = tw_same and n0 == tw[fi][1].shape[0] and out_rows[lo:lo + n0].cpu().numpy().tobytes() == tw[fi][1].tobytes() \
-                            and np.array_equal(out_src[lo:lo + n0].cpu().numpy(), tw[fi][2])
-                    twin = {"value": n_cpu * n_per / tw_s, "unit": "points/s", "cores": cores, "single_core_value": n_per / tw1_s,
-                            "kind": "the build's own restatement: libsnowcpu.so = the HIP kernels' per-beam device code (csrc/sg_beam.h, sg_table_host.h, sg_row.h) "
-                                    "compiled for the host, one beam at a time on host threads (include/snowgpu_cpu.h); table filing inside the clock, "
-                                    "threshold polynomials given (the device prepass's)",
-                            "sample": f"frames 0..{n_cpu - 1} of the batch, {tw_s:.2f} s on {cores} threads; one thread on frame 0: {tw1_s:.2f} s",
-                            "same_bytes_as_gpu": bool(tw_same)}
-                except Exception as ex:      # the twin is a side measurement: the line does not depend on it
-                    twin = {"error": repr(ex)}
-            if twin is not None:
-                result["cpu_twin"] = twin
-            result["cpu_baseline"] = {"value": n_cpu * n_per / cpu_s, "unit": "points/s", "cores": used, "kind": "port",
-                                      "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "host_cpus_usable": cpu_info,
-                                      "sample": f"frames 0..{n_cpu - 1} of the batch ({n_cpu * n_per} points): oracle/snow_oracle.c (scalar C "
-                                                f"restatement, per-beam scan of the whole table, float64) under its pthread driver -- work item = "
-                                                f"256 beams of one (frame, channel), {used} threads = every CPU this process may use "
-                                                f"(affinity / cgroup quota) -- plus the NumPy frame driver, {cpu_s:.1f} s wall; one core on frame 0: "
-                                                f"{n_per / one_s:.0f} points/s ({one_s:.1f} s)",
-                                      "single_core_value": n_per / one_s,
-                                      "gpu_output_matches": bool(same)}
+            result.update(cpu_legs(W))
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
