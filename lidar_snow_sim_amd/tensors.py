@@ -106,17 +106,22 @@ class _SmallUploads:
     def __init__(self, cap=64):
         self.cap, self.d = cap, OrderedDict()
 
-    def get(self, torch, dev, arr):
+    def get(self, torch, dev, arr, user):
+        """The device copy of `arr`, safe to read on stream `user`: a copy made by an earlier call on another stream is waited for by event."""
         key = (str(dev), arr.dtype.str, arr.shape, arr.tobytes())
-        t = self.d.get(key)
-        if t is None:
-            t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
-            self.d[key] = t
+        hit = self.d.get(key)
+        if hit is None:
+            t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)                # (on torch's current stream)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            hit = self.d[key] = (t, ev)
             while len(self.d) > self.cap:
                 self.d.popitem(last=False)
         else:
             self.d.move_to_end(key)
-        return t
+        if not hit[1].query():
+            user.wait_event(hit[1])
+        return hit[0]
 
 
 def _uploads(eng):
@@ -218,24 +223,41 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
     up = _uploads(eng)
     with torch.cuda.device(dev):
         tids = table_ids_for(eng, nf, particle_file_prefix, root_path, particles, orders, shuffle)
-        d_off = up.get(torch, dev, offsets)
-        d_tids = up.get(torch, dev, tids)
+        if n == 0:                                   # nothing to simulate (the C ABI wants non-null buffers): empty frames come back empty
+            zero = (np.int64(0), np.int64(0), 0)
+            empty = [(zero, rows[:0], torch.empty(0, dtype=torch.int32, device=dev)) if return_src else (zero, rows[:0]) for _ in range(nf)]
+            if sync:
+                return empty
+            z = lambda *shape, dt=torch.int64: torch.zeros(shape, dtype=dt, device=dev)   # noqa: E731
+            return DeviceResult(eng.ctx, rows[:0], z(0, dt=torch.int32), z(nf), z(nf, 3), z(8, dt=torch.int32), offsets, torch.cuda.current_stream(dev))
+        stream = torch.cuda.current_stream(dev)
+        # The C ABI reads stream = NULL as "the context's own stream", which is not ordered against anything of torch's.  torch's legacy
+        # default stream HAS the handle 0, so a call made on it runs on a side stream of the engine, forked from and joined back into the
+        # default stream (two event waits): uploads queued before the call are seen, and whoever reads the results on the caller's stream
+        # afterwards -- or synchronises it -- waits for the call.
+        run = stream
+        if stream.cuda_stream == 0 or lane is not None:
+            run = eng.__dict__.get("_torch_side_stream")
+            if run is None or run.device != dev:
+                run = eng.__dict__["_torch_side_stream"] = torch.cuda.Stream(device=dev)
+        d_off = up.get(torch, dev, offsets, run)
+        d_tids = up.get(torch, dev, tids, run)
         d_poly = d_plane = None
         if thr_polys is not None:
-            d_poly = up.get(torch, dev, np.ascontiguousarray(thr_polys, np.float64).reshape(nf, 3))
+            d_poly = up.get(torch, dev, np.ascontiguousarray(thr_polys, np.float64).reshape(nf, 3), run)
         elif planes is not None:
             if isinstance(planes, np.ndarray) and planes.shape == (nf, 4):          # (wx, wy, wz, h) rows, as the C ABI takes them
                 pl = np.ascontiguousarray(planes, np.float64)
             else:
                 pl = np.asarray([[float(w[0]), float(w[1]), float(w[2]), float(h)] for w, h in planes], np.float64).reshape(nf, 4)
-            d_plane = up.get(torch, dev, pl)
+            d_plane = up.get(torch, dev, pl, run)
         d_wet_plane = None
         if wet is not None:
             wet = dict(wet)
             wp = wet.pop("plane", None)
             if wp is not None:
                 wp = [wp] * nf if len(wp) == 2 and np.ndim(wp[1]) == 0 else wp
-                d_wet_plane = up.get(torch, dev, np.asarray([[float(w[0]), float(w[1]), float(w[2]), float(h)] for w, h in wp], np.float64))
+                d_wet_plane = up.get(torch, dev, np.asarray([[float(w[0]), float(w[1]), float(w[2]), float(h)] for w, h in wp], np.float64), run)
         out_dt = torch.float64 if wet is not None else rows.dtype
         if out is not None and out.rows.shape[0] >= n and out.rows.dtype == out_dt and out.rows.device == dev and out.counts.shape[0] == nf:
             o_rows, o_src, o_cnt, o_st, o_status, o_flags = out.rows, out.src, out.counts, out.stats, out.status, out.flags
@@ -248,16 +270,7 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
             o_flags = None
         if wet is not None and o_flags is None:
             o_flags = torch.empty(nf, dtype=torch.int32, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        # The C ABI reads stream = NULL as "the context's own stream", which is not ordered against anything of torch's.  torch's legacy
-        # default stream HAS the handle 0, so a call made on it runs on a side stream of the engine, forked from and joined back into the
-        # default stream (two event waits): uploads queued before the call are seen, and whoever reads the results on the caller's stream
-        # afterwards -- or synchronises it -- waits for the call.
-        run = stream
-        if stream.cuda_stream == 0 or lane is not None:
-            run = eng.__dict__.get("_torch_side_stream")
-            if run is None or run.device != dev:
-                run = eng.__dict__["_torch_side_stream"] = torch.cuda.Stream(device=dev)
+        if run is not stream:
             run.wait_stream(stream)
             if lane is not None:                    # (tensors of the caller's stream used on the lane's: the allocator must know)
                 for t in (rows, o_rows, o_src, o_cnt, o_st, o_status, o_flags):

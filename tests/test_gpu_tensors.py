@@ -115,6 +115,36 @@ def test_asynchronous_call_on_a_side_stream_and_reused_result_tensors(so, tables
             assert np.array_equal(got[2].cpu().numpy(), src0) and np.array_equal(got[1].cpu().numpy()[:, 3:], a0[:, 3:])
 
 
+def test_two_compute_lanes_in_flight_give_the_results_of_one(so, tables):
+    """lane=k: the call runs on compute lane k (an engine context and stream of its own), the caller's stream does not wait for it, and the
+    result is claimed through the DeviceResult (.join() on the consumer's stream, .wait() on the host).  Four batches alternating between
+    two lanes, results reused per lane: every batch equals the oracle."""
+    from lidar_snow_sim_amd.tensors import augment_batch
+    frames = _ragged_frames()
+    tl = _tables64(tables)
+    orders = [[list(np.random.default_rng(40 + 3 * b + f).permutation(64)) for f in range(3)] for b in range(4)]
+    t_frames = [torch.from_numpy(f).cuda() for f in frames]
+    res, got = [None, None], []
+    for b in range(4):
+        k = b % 2
+        if res[k] is not None:                                  # the lane's earlier batch: claim it before its tensors are reused
+            got.append([(st, a.clone(), i.clone()) for st, a, i in res[k].frames(return_src=True)])
+        res[k] = augment_batch(t_frames, "unused", BD, planes=[PLANE] * 3, orders=orders[b], particles=tl, sync=False, lane=k, out=res[k])
+        assert res[k].stream != torch.cuda.current_stream()
+    res[0].join(); res[1].join()                                # (the consumer's stream waits; the host does not)
+    tail = [[(None, r.rows.clone(), r.src.clone(), r.counts.clone(), r.stats.clone())] for r in res]
+    torch.cuda.current_stream().synchronize()
+    for r in res:
+        got.append([(st, a.clone(), i.clone()) for st, a, i in r.frames(return_src=True)])
+    assert len(got) == 4 and len(tail) == 2
+    for b in range(4):
+        for f in range(3):
+            s0, a0, src0 = so.augment(frames[f], tl, BD, orders[b][f], plane=PLANE)
+            st, aug, src = got[b][f]
+            assert tuple(int(v) for v in st) == tuple(int(v) for v in s0), (b, f)
+            assert np.array_equal(src.cpu().numpy(), src0) and np.array_equal(aug.cpu().numpy()[:, 3:], a0[:, 3:]), (b, f)
+
+
 def test_wet_ground_chained_on_the_device(so, tables):
     """wet=...: snowfall -> ground_water_augmentation with the viewer's keyword arguments (pointcloud_viewer.py:2807-2821), one launch
     sequence, float64 rows out (wet_ground/augmentation.py:150); against the oracle chain."""
@@ -150,3 +180,5 @@ def test_reference_exception_types_from_the_status_words(tables):
         augment_batch([torch.from_numpy(sky).cuda()], "unused", BD, planes=[PLANE], shuffle=False, particles=tl)
     with pytest.raises(ValueError, match="q8"):
         augment_batch([torch.from_numpy(pc).cuda()], "unused", BD, planes=[PLANE], particles=tl, q8="numpy")
+    (st, aug), = augment_batch([torch.empty((0, 5), dtype=torch.float32, device="cuda")], "unused", BD, planes=[PLANE], particles=tl)   # an empty frame
+    assert tuple(int(v) for v in st) == (0, 0, 0) and tuple(aug.shape) == (0, 5) and aug.is_cuda
