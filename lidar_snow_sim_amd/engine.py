@@ -70,15 +70,6 @@ class Engine:
             self._pin_in = buf = self.ctx.pinned_empty(max(need, 1 << 20) * 5 // 4, np.uint8)
         return buf[:need].view(dtype).reshape(int(n_rows), 5)
 
-    def hist_buffer(self, n_frames):
-        """Reused page-locked int32 buffer for the histograms of Context.prepass_stats (130 MB for 256 frames: a fresh pageable
-        array would be page-faulted in on every call)."""
-        need = int(n_frames) * 50 * 2555
-        buf = getattr(self, "_pin_hist", None)
-        if buf is None or buf.size < need:
-            self._pin_hist = buf = self.ctx.pinned_empty(need + need // 4, np.int32)
-        return buf
-
     def result_buffers(self, n_rows, dtype):
         """(out_rows n x 5, out_src n) in page-locked memory from the pool, or pageable arrays past PIN_LIMIT."""
         import ctypes
