@@ -367,10 +367,11 @@ def measure_host_entry(W):
                              "the moved coordinates of scattered rows apart; " + str(pk_key) + " host threads of the library assemble the caller's rows "
                              "from those and from its input rows -- same bytes in the caller's buffers as the rows transfer") if pk else "rows",
                 "packed_by_host_threads": pk_all or None,
+                "compact_input": (child or {}).get("compact_input"),
                 "steps": max(1, min(args.steps, 4)),
                 "process_affinity": (child or {}).get("process_affinity"),
                 "frames_per_call": F, "contexts": 1, "host_threads": 1, "process": "child without PyTorch (scripts/pcie_bench.py)" if child else "in process",
-                "bytes_per_point": {"h2d": 20, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
+                "bytes_per_point": {"h2d": 20, "h2d_compact_input": 17, "d2h_packed": 9.5, "d2h_rows": 24, "d2h_rows_without_src": 20},
                 "link_bound_points_per_s": {"upload_20B": PCIE_PEAK / 20.0 * world, "download_rows_24B": PCIE_PEAK / 24.0 * world,
                                             "download_rows_without_src_20B": PCIE_PEAK / 20.0 * world},
                 "frac_of_link_bound": {"packed_vs_upload_bound": (mine[4] / (PCIE_PEAK / 20.0 * world)) if pk else None,
@@ -803,6 +804,10 @@ def main():
             if pcie.get("default_plane_all_ranks"):
                 result["value_pcie_inclusive_default_plane"] = pcie["default_plane_all_ranks"]["reference"]
                 result["value_pcie_inclusive_lsq_plane"] = pcie["default_plane_all_ranks"]["lsq"]
+            ci = (pcie.get("compact_input") or {}).get("packed") or {}
+            if ci.get("points_per_s") and world == 1:
+                # (x, y, z, intensity) float32 + one channel byte per row up the link (snowgpu_augment_batch_compact), packed transfer down
+                result["value_pcie_inclusive_compact_input"] = ci["points_per_s"]
             result["pcie_inclusive"] = pcie
         if single is not None:
             result["single_frame"] = single

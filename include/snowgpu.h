@@ -203,6 +203,19 @@ int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_o
                           int64_t *out_stats, double *out_thr_poly);
 
 /*
+ * snowgpu_augment_batch for callers bound by the link (round 6): the frames cross it as (x, y, z, intensity) float32 rows plus ONE BYTE per
+ * row for the channel -- 17 bytes per point instead of the 20 of the STF row, which keeps the channel as a fifth float32
+ * (precompute.py:78) -- and a kernel makes the rows on the device (k_expand_rows).  float32, integer channels 0 .. 255, no caller
+ * permutation, no pre-augment crop; everything else -- table ids, plane / polynomial, results, statistics, the pipeline, the packed result
+ * transfer (whose host threads then copy x, y, z from `xyzi`), the threshold callback -- as snowgpu_augment_batch.  out_rows are
+ * (x, y, z, intensity, label) float32 rows: byte for byte what snowgpu_augment_batch returns for the same frames.
+ */
+int snowgpu_augment_batch_compact(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const float *xyzi,
+                                  const uint8_t *channels, const int32_t *table_ids, double beam_divergence_deg,
+                                  const double *thr_poly, const double *plane, double noise_floor, float *out_rows,
+                                  int32_t *out_src, int64_t *out_counts, int64_t *out_stats, double *out_thr_poly);
+
+/*
  * Same computation with every array already in DEVICE memory (hipMalloc'ed by the caller, e.g. a
  * torch tensor's data_ptr) and launched on the caller's stream (hipStream_t passed as void*; NULL =
  * the context's stream).  Nothing is copied to the host and the call does not synchronise: this is

@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_set_threshold_callback", "snowgpu_device_numa_node",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_set_threshold_callback", "snowgpu_augment_batch_compact", "snowgpu_device_numa_node",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -76,6 +76,8 @@ def lib():
             L.snowgpu_augment_batch.restype = ctypes.c_int
             L.snowgpu_augment_batch.argtypes = [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, dbl, vp, vp, dbl, vp,
                                                 vp, vp, vp, vp, vp]
+            L.snowgpu_augment_batch_compact.restype = ctypes.c_int
+            L.snowgpu_augment_batch_compact.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, dbl, vp, vp, dbl, vp, vp, vp, vp, vp]
             L.snowgpu_augment_batch_device.restype = ctypes.c_int
             L.snowgpu_augment_batch_device.argtypes = [vp, ctypes.c_int, i64, i64, vp, vp, ctypes.c_int, vp, dbl, vp, vp,
                                                        dbl, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -277,6 +279,40 @@ class Context:
                                                _p(counts), _p(stats), _p(out_thr))
             err = getattr(self, "_thr_error", None)
             if rc and err is not None:                       # the threshold callback raised: its exception, not the status code
+                self._thr_error = None
+                raise err
+            self._check(rc)
+        return out_rows, out_src, counts, stats, out_thr
+
+    def augment_batch_compact(self, xyzi, channels, frame_offsets, table_ids, beam_divergence, thr_poly=None, plane=None, noise_floor=0.7,
+                              want_thr=False, out_rows=None, out_src=None, want_src=True):
+        """augment_batch for frames given as (x, y, z, intensity) float32 rows + one channel byte per row (17 instead of 20 bytes per point up
+        the link: snowgpu_augment_batch_compact).  Same results as augment_batch on the (x, y, z, intensity, channel) rows."""
+        xyzi = np.ascontiguousarray(xyzi, np.float32)
+        ch = np.ascontiguousarray(channels, np.uint8)
+        off = np.ascontiguousarray(frame_offsets, np.int64)
+        nf, n = len(off) - 1, int(off[-1])
+        if xyzi.ndim != 2 or xyzi.shape[1] != 4 or xyzi.shape[0] < n or ch.shape[0] < n:
+            raise ValueError("xyzi must be N x 4 float32 and channels N uint8")
+        tids = np.ascontiguousarray(table_ids, np.int32).reshape(nf, -1)
+        if tids.shape[1] != self.n_lasers:
+            raise ValueError("table_ids must be n_frames x n_lasers")
+        if out_rows is None:
+            out_rows = np.empty((n, 5), np.float32)
+        if not want_src:
+            out_src = None
+        elif out_src is None:
+            out_src = np.empty(n, np.int32)
+        counts = np.zeros(nf, np.int64)
+        stats = np.zeros((nf, 3), np.int64)
+        thr = None if thr_poly is None else np.ascontiguousarray(thr_poly, np.float64).reshape(nf, 3)
+        pl = None if plane is None else np.ascontiguousarray(plane, np.float64).reshape(nf, 4)
+        out_thr = np.zeros((nf, 3)) if want_thr else None
+        with self._call_lock:
+            rc = self._L.snowgpu_augment_batch_compact(self._h, nf, _p(off), _p(xyzi), _p(ch), _p(tids), float(beam_divergence), _p(thr), _p(pl),
+                                                       float(noise_floor), _p(out_rows), _p(out_src), _p(counts), _p(stats), _p(out_thr))
+            err = getattr(self, "_thr_error", None)
+            if rc and err is not None:
                 self._thr_error = None
                 raise err
             self._check(rc)

@@ -199,6 +199,8 @@ extern "C" {
 // one-wave blocks per CU; ticket: items by an atomic cursor (a->pw_count[3]) instead of striding.  cls8 / cls16: the classes' indices in
 // the tier lists, or -1.
 int sg_launch_power_all(const SgBeamArgs *a, int dtype, int cls8, int cls16, int waves_per_cu, int ticket, void *stream);
+// compact input: (x, y, z, intensity) float32 rows + channel bytes -> (x, y, z, intensity, channel) float32 rows
+int sg_launch_expand_rows(const void *xyzi, const uint8_t *ch, void *rows, int64_t n, void *stream);
 int sg_launch_sort(const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t n_total,
                    int32_t *tile_hist, int32_t *tile_base, uint16_t *rank, uint8_t *ch8, int32_t *perm, int32_t *status,
                    int64_t max_tiles_per_frame, const double *lean_plane, double *lean_part, int32_t *tile_unsorted,

@@ -308,6 +308,9 @@ struct snowgpu_ctx {
     double pk_times[4] = {0, 0, 0, 0};    // last packed call: ms until all enqueued, all downloads landed, all rows assembled; host bytes copied
     // The caller fits the noise threshold (snowgpu_set_threshold_callback): page-locked staging for the device half of the prepass --
     // histograms | records | status words per group | the polynomials the callback writes -- and one event per group
+    // compact input of the call in flight (snowgpu_augment_batch_compact): the channel bytes; `rows` then are (x, y, z, intensity) float32
+    const uint8_t *in_channels = nullptr;
+    DevBuf<uint8_t> rows_c4, rows_ch;     // their device staging (16 + 1 bytes per row), expanded into rows_in by k_expand_rows
     snowgpu_threshold_fn thr_fn = nullptr;
     void *thr_user = nullptr;
     char *thr_stage = nullptr;
@@ -484,7 +487,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->seg_tbl_cnt.release(); ctx->seg_tbl_base.release(); ctx->seg_blk.release(); ctx->seg_cnt.release(); ctx->seg_frame.release();
     ctx->seg_n.release(); ctx->seg_start.release(); ctx->seg_of_blk.release(); ctx->chunk_blk.release();
     ctx->rec.release(); ctx->rec_q.release(); ctx->rng.release(); ctx->dq.release(); ctx->dq_g.release(); ctx->dq_sc.release(); ctx->qn.release(); ctx->pw_items.release(); ctx->ov.release(); ctx->ov_sc.release();
-    ctx->redo_list.release(); ctx->back_list.release(); ctx->bbase.release();
+    ctx->redo_list.release(); ctx->back_list.release(); ctx->bbase.release(); ctx->rows_c4.release(); ctx->rows_ch.release();
     ctx->tier_list.release(); ctx->tier_sparse.release(); ctx->tbase.release(); ctx->h_lists.release();
     for (int k = 0; k < SG_MAX_CLASSES; ++k) { ctx->tq[k].release(); ctx->tq_sc[k].release(); }
     ctx->ctile_cnt.release(); ctx->ctile_base.release(); ctx->table_ids.release(); ctx->out_src.release();
@@ -1348,6 +1351,11 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     ENSURE(ctx, ctx->table_ids, nf * nl);
     ENSURE(ctx, ctx->plane, nf * 4);
     ENSURE(ctx, ctx->rows_in, std::max<size_t>((size_t)n_total * rb, 8));
+    const uint8_t *chn = (rows && dtype == 0) ? ctx->in_channels : nullptr;          // compact input (snowgpu_augment_batch_compact)
+    if (chn) {
+        ENSURE(ctx, ctx->rows_c4, std::max<size_t>((size_t)n_total * 16, 16));
+        ENSURE(ctx, ctx->rows_ch, std::max<size_t>((size_t)n_total, 16));
+    }
     // Packed result transfer: the compaction leaves, per kept row, its source row | label code and its intensity, and the moved
     // coordinates of the label-2 rows apart (SgPackOut); those cross the link in exact sizes once a chunk's counts have landed, and host
     // threads put the caller's rows together -- x, y, z (and the channel of rows without a laser) copied from the caller's INPUT rows.
@@ -1356,7 +1364,7 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     if (packed) {
         // the host threads read the caller's INPUT rows while they write out_rows: the two must not overlap (the rows transfer tolerates
         // rows == out_rows, this one would corrupt frames whose rows do not come channel-sorted); a word holds a 30-bit source row
-        const char *r0 = (const char *)rows, *r1 = r0 + nt * 5 * esz, *o0 = (const char *)out_rows, *o1 = o0 + nt * 5 * esz;
+        const char *r0 = (const char *)rows, *r1 = r0 + nt * (ctx->in_channels ? 4 : 5) * esz, *o0 = (const char *)out_rows, *o1 = o0 + nt * 5 * esz;
         if (r0 < o1 && o0 < r1) return fail(ctx, SNOWGPU_E_INVALID, "packed result transfer: out_rows overlaps rows (the rows are assembled from the input rows)");
         for (int f = 0; f < n_frames; ++f)
             if (frame_offsets[f + 1] - frame_offsets[f] >= ((int64_t)1 << 30))
@@ -1441,7 +1449,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     // ends with a synchronisation)
     for (int c = 0; c < n_chunks; ++c) {
         const int64_t r0 = frame_offsets[c_first[(size_t)c]], cn = frame_offsets[c_first[(size_t)c + 1]] - r0;
-        if (cn && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
+        if (cn && rows && chn) {                       // compact input: 16 + 1 bytes per row up the link (k_expand_rows on the chunk's lane makes the rows)
+            HIPCHK(ctx, hipMemcpyAsync(ctx->rows_c4.p + (size_t)r0 * 16, (const char *)rows + (size_t)r0 * 16, (size_t)cn * 16, hipMemcpyHostToDevice, ctx->s_h2d));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->rows_ch.p + (size_t)r0, chn + r0, (size_t)cn, hipMemcpyHostToDevice, ctx->s_h2d));
+        } else if (cn && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p + (size_t)r0 * rb, (const char *)rows + (size_t)r0 * rb, (size_t)cn * rb, hipMemcpyHostToDevice, ctx->s_h2d));
         HIPCHK(ctx, hipEventRecord(ctx->pipe_ev[2 * (size_t)c], ctx->s_h2d));
         if (trace) HIPCHK(ctx, hipEventRecord(tev[1 + 4 * (size_t)c], ctx->s_h2d));
     }
@@ -1457,7 +1468,23 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         const uint32_t n_rows = (uint32_t)(frame_offsets[f + 1] - o);          // (what came back from the device bounds no host loop or index unchecked)
         const int64_t kept = kept_dev > (int64_t)n_rows ? (int64_t)n_rows : kept_dev;
         const uint32_t *meta = (const uint32_t *)st_meta + o;
-        if (esz == 4) {
+        if (esz == 4 && chn) {                         // compact input: x, y, z from the caller's (x, y, z, intensity) rows, the channel from its bytes
+            const float *in = (const float *)rows + (size_t)o * 4, *it = (const float *)st_int + o, *mv = (const float *)st_mv + (size_t)mv_at * 3;
+            const uint8_t *cb = chn + o;
+            float *out = (float *)out_rows + (size_t)o * 5;
+            for (int64_t j = 0; j < kept; ++j) {
+                const uint32_t m = meta[j], code = m >> 30;
+                uint32_t src = m & 0x3fffffffu;
+                if (src >= n_rows) src = n_rows - 1;
+                const float *ip = in + (size_t)src * 4;
+                float *q = out + (size_t)j * 5;
+                if (code == 2) { q[0] = mv[0]; q[1] = mv[1]; q[2] = mv[2]; mv += 3; }
+                else { q[0] = ip[0]; q[1] = ip[1]; q[2] = ip[2]; }
+                q[3] = it[j];
+                q[4] = code == 3 ? (float)cb[src] : (float)code;
+                if (out_src) out_src[o + j] = (int32_t)src;
+            }
+        } else if (esz == 4) {
             const float *in = (const float *)rows + (size_t)o * 5, *it = (const float *)st_int + o, *mv = (const float *)st_mv + (size_t)mv_at * 3;
             float *out = (float *)out_rows + (size_t)o * 5;
             for (int64_t j = 0; j < kept; ++j) {
@@ -1562,6 +1589,10 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
         hipStream_t cs = lc->stream;
         PIPECHK(hipStreamWaitEvent(cs, ctx->pipe_ev[2 * (size_t)c], 0));
         if (trace) PIPECHK(hipEventRecord(tev[2 + 4 * (size_t)c], cs));
+        if (chn && cn) {
+            int xe = sg_launch_expand_rows(ctx->rows_c4.p + (size_t)r0 * 16, ctx->rows_ch.p + (size_t)r0, ctx->rows_in.p + (size_t)r0 * rb, cn, cs);
+            if (xe) return fail(ctx, SNOWGPU_E_HIP, std::string("expand launch: ") + hipGetErrorString((hipError_t)xe));
+        }
         BatchDev &b = k.b;
         b = BatchDev{};
         b.n_frames = cf; b.n_total = cn; b.frame_off = ctx->pipe_off.p + c_pos[(size_t)c]; b.rows = ctx->rows_in.p + (size_t)r0 * rb;
@@ -1793,7 +1824,14 @@ static int host_batch(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offse
     else if (plane) std::memcpy(ctx->mail_up_h + up_par, plane, 32 * nfz);          // neither: the plane is estimated on the device
     std::memcpy(ctx->mail_up_h + up_ids, table_ids, 4 * nfz * nlz);
     HIPCHK(ctx, hipMemcpyAsync(ctx->mail_up_d.p, ctx->mail_up_h, up_bytes, hipMemcpyHostToDevice, st));
-    if (row_bytes && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
+    if (row_bytes && rows && ctx->in_channels) {       // compact input (snowgpu_augment_batch_compact)
+        ENSURE(ctx, ctx->rows_c4, n * 16);
+        ENSURE(ctx, ctx->rows_ch, n);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->rows_c4.p, rows, n * 16, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->rows_ch.p, ctx->in_channels, n, hipMemcpyHostToDevice, st));
+        int xe = sg_launch_expand_rows(ctx->rows_c4.p, ctx->rows_ch.p, ctx->rows_in.p, n_total, st);
+        if (xe) return fail(ctx, SNOWGPU_E_HIP, std::string("expand launch: ") + hipGetErrorString((hipError_t)xe));
+    } else if (row_bytes && rows) HIPCHK(ctx, hipMemcpyAsync(ctx->rows_in.p, rows, row_bytes, hipMemcpyHostToDevice, st));
     const int64_t *d_frame_off = (const int64_t *)(ctx->mail_up_d.p + up_off);
     const int32_t *d_table_ids = (const int32_t *)(ctx->mail_up_d.p + up_ids);
     const double *d_thr = thr_poly ? (const double *)(ctx->mail_up_d.p + up_par) : nullptr;
@@ -1966,6 +2004,21 @@ extern "C" int snowgpu_augment_batch(snowgpu_ctx *ctx, int n_frames, const int64
 {
     return host_batch(ctx, n_frames, frame_offsets, rows, dtype, table_ids, beam_divergence_deg, thr_poly, plane, noise_floor,
                       perm, out_rows, out_src, out_counts, out_stats, out_thr_poly, 0, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int snowgpu_augment_batch_compact(snowgpu_ctx *ctx, int n_frames, const int64_t *frame_offsets, const float *xyzi, const uint8_t *channels,
+                                             const int32_t *table_ids, double beam_divergence_deg, const double *thr_poly, const double *plane,
+                                             double noise_floor, float *out_rows, int32_t *out_src, int64_t *out_counts, int64_t *out_stats,
+                                             double *out_thr_poly)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    if (!xyzi || !channels) return fail(ctx, SNOWGPU_E_INVALID, "snowgpu_augment_batch_compact: null input");
+    if (ctx->fov.enabled && ctx->fov_pre) return fail(ctx, SNOWGPU_E_INVALID, "the pre-augment crop takes (x, y, z, intensity, channel) rows: snowgpu_augment_batch");
+    ctx->in_channels = channels;
+    const int rc = host_batch(ctx, n_frames, frame_offsets, xyzi, 0, table_ids, beam_divergence_deg, thr_poly, plane, noise_floor, nullptr, out_rows,
+                              out_src, out_counts, out_stats, out_thr_poly, 0, nullptr, nullptr, nullptr, nullptr);
+    ctx->in_channels = nullptr;
+    return rc;
 }
 
 extern "C" int snowgpu_debug_occlusions(snowgpu_ctx *ctx, int64_t n_rows, const void *rows, int dtype, const int32_t *table_ids,

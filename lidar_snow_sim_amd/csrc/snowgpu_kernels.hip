@@ -1736,6 +1736,20 @@ __global__ __launch_bounds__(SG_BLOCK) void k_crop_scatter(const T *__restrict__
         run += wave_cnt[q][0] + wave_cnt[q][1] + wave_cnt[q][2] + wave_cnt[q][3];
     }
 }
+// ------------------------------------------------------------------------------------------------
+// Compact input (snowgpu_augment_batch_compact): rows that crossed the link as (x, y, z, intensity) float32 + one channel BYTE -- 17 bytes
+// per point instead of the STF row's 20 (precompute.py:78 keeps the channel as a fifth float32) -- become the (x, y, z, intensity,
+// channel) rows every kernel reads.  One thread per row; the batch's only pass that exists for the link's sake (0.67 GB written per
+// 256 sweeps, spread over the chunks of the pipeline).
+__global__ __launch_bounds__(256) void k_expand_rows(const float4 *__restrict__ xyzi, const uint8_t *__restrict__ ch, float *__restrict__ rows, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 v = xyzi[i];
+    float *r = rows + i * 5;
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; r[4] = (float)ch[i];
+}
+
 
 // table_ids[frame][channel] -> the table descriptor itself, so that a beam needs one load instead of two dependent ones
 __global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_tables, const int32_t *__restrict__ table_ids,
@@ -1757,6 +1771,14 @@ __global__ void k_resolve_tables(const SgTable *__restrict__ tables, int n_table
         hipError_t e__ = hipGetLastError();                \
         if (e__ != hipSuccess) return (int)e__;            \
     } while (0)
+
+extern "C" int sg_launch_expand_rows(const void *xyzi, const uint8_t *ch, void *rows, int64_t n, void *stream)
+{
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_expand_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)xyzi, ch, (float *)rows, n);
+    SG_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int sg_launch_resolve_tables(const SgTable *tables, int n_tables, const int32_t *table_ids, int64_t n, SgTable *out,
                                         void *stream)

@@ -118,8 +118,38 @@ def main():
                                                "last_call_ms": tt, "same_digest_as_rows_mode": dg == digest}
         finally:
             eng.ctx.set_result_transfer("rows")
+    # compact input (snowgpu_augment_batch_compact): (x, y, z, intensity) float32 + one channel byte per row up the link -- 17 B per point
+    # instead of 20 --, packed result transfer down; the caller's out_rows / out_src receive the same bytes
+    compact = None
+    try:
+        pin_x4 = eng.ctx.pinned_empty((n_total, 4), np.float32)
+        pin_x4[...] = pin_in[:, :4]
+        pin_ch = eng.ctx.pinned_empty(n_total, np.uint8)
+        pin_ch[...] = pin_in[:, 4].astype(np.uint8)
+
+        def call_c(want_src):
+            return eng.ctx.augment_batch_compact(pin_x4, pin_ch, off, h_ids, bench.BEAM_DIV, plane=planes, out_rows=pin_out, out_src=pin_src, want_src=want_src)
+
+        compact = {}
+        for mode in ("rows", "packed"):
+            eng.ctx.set_result_transfer(mode)
+            try:
+                call_c(True)
+                t0 = time.perf_counter()
+                for _ in range(args.reps):
+                    call_c(True)
+                s_c = (time.perf_counter() - t0) / args.reps
+                _, _, c3, st3, _ = call_c(True)
+                dg = [int(c3.sum()), int(st3[:, 0].sum()), int(st3[:, 1].sum()), int(st3[:, 2].sum()),
+                      float(pin_out[:int(c3[0]), 3].sum()), int(pin_src[:int(c3[0])].astype(np.int64).sum())]
+                compact[mode] = {"points_per_s": n_total / s_c, "same_digest_as_rows_mode": dg == digest}
+            finally:
+                eng.ctx.set_result_transfer("rows")
+        compact["bytes_per_point_up"] = 17
+    except Exception as ex:
+        compact = {"error": repr(ex)}
     if args.fast:
-        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc, "packed": packed, "process_affinity": affinity}))
+        print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_without_src": n_total / s_nosrc, "packed": packed, "compact_input": compact, "process_affinity": affinity}))
         return
     # plane = NULL at the C ABI: calculate_plane (simulation.py:449) on the device inside the batch -- the reference's default call
     s_ref, _ = timed(True, "device")                                     # method 'reference': the plane the reference returns today
@@ -187,7 +217,7 @@ def main():
     pyl_ms, pyl_min = med(one_py_lsq)
     print(json.dumps({"points_per_s": n_total / s_src, "points_per_s_best": n_total / b_src, "points_per_s_without_src": n_total / s_nosrc,
                       "points_per_s_without_src_best": n_total / b_nosrc, "frames": F, "reps": args.reps, "points_per_frame": n_per,
-                      "digest": digest, "packed": packed, "process_affinity": affinity, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
+                      "digest": digest, "packed": packed, "compact_input": compact, "process_affinity": affinity, "single_frame_c_abi_ms": abi_ms, "single_frame_c_abi_min_ms": abi_min,
                       "single_frame_python_ms": py_ms, "single_frame_python_min_ms": py_min, "torch_loaded": "torch" in sys.modules,
                       "default_plane": {"c_abi_points_per_s_reference": n_total / s_ref, "c_abi_points_per_s_lsq": n_total / s_lsq,
                                         "python_points_per_s_injected": n_total / py_inj, "python_points_per_s_reference": n_total / py_ref,

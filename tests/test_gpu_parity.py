@@ -780,6 +780,41 @@ def test_device_entry_can_be_captured_into_a_hip_graph(eng, tables):
                 assert torch.equal(src[f * n:f * n + m], want[k][1][f * n:f * n + m]), (k, f)
 
 
+def test_compact_input_gives_the_bytes_of_the_row_entry(tables):
+    """snowgpu_augment_batch_compact: frames as (x, y, z, intensity) float32 rows + one channel byte per row (17 B per point up the link instead
+    of 20; k_expand_rows makes the rows on the device) -- one sweep (single chunk) and 40 sweeps (four chunks of the pipeline on two lanes), rows
+    and packed result transfer, with rows of a channel that has no laser (their output keeps the channel value, quirk Q5): out_rows, out_src,
+    counts and statistics are byte for byte those of snowgpu_augment_batch on the five-column rows."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.synthetic import synthetic_sweep
+    tl = _tables64(tables)
+    eng = engine.Engine(0)
+    try:
+        for n_frames in (1, 40):
+            frames = [synthetic_sweep(64, 2048, seed=1400 + f, intensity="lambert") for f in range(n_frames)]
+            for f in frames:
+                f[5::997, 4] = 200.0                                # a channel without a laser
+            rows = np.concatenate(frames)
+            off = np.arange(n_frames + 1, dtype=np.int64) * frames[0].shape[0]
+            tids = [eng.table_ids_from_arrays(tl, list(np.random.default_rng(f).permutation(64))) for f in range(n_frames)]
+            planes = [[0.0, 0.0, -1.0, -1.7]] * n_frames
+            want = eng.ctx.augment_batch(rows, off, tids, float(np.degrees(3e-3)), plane=planes)
+            xyzi, ch = np.ascontiguousarray(rows[:, :4]), rows[:, 4].astype(np.uint8)
+            for mode in ("rows", "packed"):
+                eng.ctx.set_result_transfer(mode)
+                try:
+                    got = eng.ctx.augment_batch_compact(xyzi, ch, off, tids, float(np.degrees(3e-3)), plane=planes)
+                finally:
+                    eng.ctx.set_result_transfer("rows")
+                assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3]), (n_frames, mode)
+                for f in range(n_frames):
+                    a, m = int(off[f]), int(want[2][f])
+                    assert got[0][a:a + m].tobytes() == want[0][a:a + m].tobytes() and np.array_equal(got[1][a:a + m], want[1][a:a + m]), (n_frames, mode, f)
+            assert (want[0][:int(want[2][0]), 4] == 200.0).sum() > 50
+    finally:
+        eng.ctx.close()
+
+
 def _stretched_subsweep(step=8, scale=1.8, seed=1060):
     from lidar_snow_sim_amd.synthetic import synthetic_sweep
     full = synthetic_sweep(64, 2048, seed=seed, intensity="lambert").reshape(64, 2048, 5)
