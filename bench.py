@@ -532,7 +532,11 @@ def cpu_legs(W):
                                         f"(affinity / cgroup quota) -- plus the NumPy frame driver, {cpu_s:.1f} s wall; one core on frame 0: "
                                         f"{n_per / one_s:.0f} points/s ({one_s:.1f} s)",
                               "single_core_value": n_per / one_s,
-                              "gpu_output_matches": bool(same)}
+                              "gpu_output_matches": bool(same),
+                              # context only (SURVEY 8 d): the reference's own NumPy / Python path cannot run on the GPU box; BASELINE.md holds what it
+                              # measured in the build container (8 vCPU, one 64 x 2048 sweep at 0.5 mm/h)
+                              "reference_numpy_path_in_build_container": {"points_per_s_thread_pool_default": 229, "points_per_s_process_pool_8_vcpu": 5681,
+                                                                           "points_per_s_single_thread_per_beam_loop": 400, "source": "BASELINE.md"}}
     return out
 
 
