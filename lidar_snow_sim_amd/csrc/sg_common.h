@@ -30,8 +30,10 @@ struct SgEntry {      // 64 bytes; the first half decides whether the flake meet
                              this many, leaves ALL of them in the slot of its sorted position and its tier runs no second scan */
 #define SG_OV_STRIDE (2 + 3 * SG_OV_CAP)   /* doubles per overflow slot: range, azimuth, then (a1, a2, rho) per flake -- the plane order of the
                                               hand-over queues, stride 1 */
-#define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m */
+#ifndef SG_QSTEPS
+#define SG_QSTEPS 16     /* coarse range index of a bin: counts below 0, 8, .. 120 m (at most 64: k_table_index is one wave per bin) */
 #define SG_QSTEP_M 8.0
+#endif
 
 struct SgTable {
     const SgEntry *entries;     // bins concatenated, each bin sorted by rho ascending
