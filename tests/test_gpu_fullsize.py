@@ -196,7 +196,7 @@ def test_fullsize_parity_C3_snow_and_wet_fused(dtype, capsys):
 N_BATCH = int(os.environ.get("SNOWGPU_FULLSIZE_BATCH", "32"))
 
 
-@pytest.mark.parametrize("workload", ["C2", "C2fire", "C3"])
+@pytest.mark.parametrize("workload", ["C2", "C2fire", "C3", "C2f64"])
 def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
     """The batch shape of the headline number: N_BATCH (32) full-size float32 sweeps as ONE device-resident batch through the torch-tensor
     boundary (augment_batch on CUDA tensors -> snowgpu_augment_batch_device / snowgpu_augment_wet_batch_device on torch's stream) --
@@ -207,9 +207,10 @@ def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
     from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
     from oracle import snow_oracle as so
     fused = workload == "C3"
-    wl = "C2" if fused else workload
+    dtype = np.float64 if workload == "C2f64" else np.float32          # (C2f64: the same batch as float64 rows)
+    wl = "C2" if workload in ("C3", "C2f64") else workload
     tables = _tables(wl)
-    frames, orders = _frames(wl, np.float32, N_BATCH)
+    frames, orders = _frames(wl, dtype, N_BATCH)
     wet = dict(water_height=0.0008, pavement_depth=0.001, power_factor=15, flat_earth=False, delta=0.5, replace=False)
     dev = torch.device("cuda:0")
     t_frames = [torch.from_numpy(f).to(dev) for f in frames]
@@ -228,7 +229,7 @@ def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
         if fused:
             a0, wsrc0 = so.ground_water_augmentation(a0, noise_floor=0.7, plane=PLANE, return_src=True, **wet)
             src0 = src0[wsrc0]
-        rec = _count_mismatches(got, gsrc, a0, src0, 1e-6)
+        rec = _count_mismatches(got, gsrc, a0, src0, 1e-6 if dtype == np.float32 else 1e-12)
         if fused:                                   # wet-ground intensities are float64 values of a float chain: 1e-6 relative on float32 rows
             _, ig, ir = np.intersect1d(gsrc, src0, return_indices=True)
             rel = np.abs(got[ig, 3] - a0[ir, 3]) / np.maximum(np.abs(a0[ir, 3]), 1e-30)
@@ -237,7 +238,7 @@ def test_fullsize_parity_one_device_batch_of_32(workload, capsys):
         recs.append(rec)
         stat_bad += tuple(int(v) for v in st) != tuple(int(v) for v in s0)
     tot = _sum_counts(recs)
-    tot.update(workload=f"{workload} (one device batch, tensor boundary)", dtype="float32", frames=N_BATCH, points=int(sum(f.shape[0] for f in frames)),
+    tot.update(workload=f"{workload} (one device batch, tensor boundary)", dtype=np.dtype(dtype).name, frames=N_BATCH, points=int(sum(f.shape[0] for f in frames)),
                mismatched_stats=int(stat_bad), gpu_call_s=round(t_gpu, 3), **({"wet_intensity_max_rel": int_max} if fused else {}))
     _report(capsys, tot)
     assert tot["mismatched_src"] == 0 and tot["same_order"] and tot["mismatched_labels"] == 0
