@@ -145,6 +145,35 @@ def test_two_compute_lanes_in_flight_give_the_results_of_one(so, tables):
             assert np.array_equal(src.cpu().numpy(), src0) and np.array_equal(aug.cpu().numpy()[:, 3:], a0[:, 3:]), (b, f)
 
 
+def test_options_of_the_array_boundary_work_on_tensors_with_the_same_bytes(tables):
+    """The keyword options the two boundaries share -- the camera crop inside the compaction (calib=, simulation.py:532-540), calculate_plane on
+    the device by least squares (plane_method='lsq'), tables sampled on the device (particles='device'), caller polynomials (thr_polys=),
+    shuffled permutations from Python's global generator -- give, on CUDA tensors, the bytes the NumPy boundary gives."""
+    import random as pyrandom
+    from lidar_snow_sim_amd.calibration import Calibration
+    from lidar_snow_sim_amd.tools.snowfall import sampling as smp
+    from lidar_snow_sim_amd.tools.snowfall.simulation import augment_batch
+    cal = Calibration(P2=np.array([[700.0, 0, 960, 0], [0, 700.0, 512, 0], [0, 0, 1, 0]]), R0=np.eye(3),
+                      V2C=np.array([[0, -1.0, 0, 0], [0, 0, -1.0, 0], [1.0, 0, 0, 0]]))
+    frames = _ragged_frames()[:2]
+    t_frames = [torch.from_numpy(f).cuda() for f in frames]
+    tl = _tables64(tables)
+    occ, rate = smp.compute_occupancy(2.5, 1.6), smp.snowfall_rate_to_rainfall_rate(2.5, 1.6)
+    cases = [dict(particles=tl, planes=[PLANE] * 2, calib=cal),
+             dict(particles=tl, plane_method="lsq"),
+             dict(particles=tl, thr_polys=[[0.0, 0.01, 2.0]] * 2),
+             dict(particles="device", planes=[PLANE] * 2)]
+    for kw in cases:
+        pyrandom.seed(77)
+        want = augment_batch(frames, f"gunn_{rate}_{occ}", BD, return_src=True, **kw)
+        pyrandom.seed(77)
+        got = augment_batch(t_frames, f"gunn_{rate}_{occ}", BD, return_src=True, **kw)
+        for (s0, a0, i0), (s1, a1, i1) in zip(want, got):
+            assert tuple(int(v) for v in s0) == tuple(int(v) for v in s1), kw.keys()
+            assert np.array_equal(i0, i1.cpu().numpy()) and a0.tobytes() == a1.cpu().numpy().tobytes(), kw.keys()
+    assert want[0][1].shape[0] > 0
+
+
 def test_wet_ground_chained_on_the_device(so, tables):
     """wet=...: snowfall -> ground_water_augmentation with the viewer's keyword arguments (pointcloud_viewer.py:2807-2821), one launch
     sequence, float64 rows out (wet_ground/augmentation.py:150); against the oracle chain."""
