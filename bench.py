@@ -401,6 +401,30 @@ def measure_host_entry(W):
     return pcie, single
 
 
+def batches_in_flight(args, lanes=3):
+    """The same steps with `lanes` batches in flight (compute lanes of the tensor boundary: one engine context and ONE stream each), in a child
+    process whose HIP runtime serves 32 hardware queues (GPU_MAX_HW_QUEUES: with the default of 4, lanes share a queue and run one after the
+    other; with more, ONE batch on its four streams is slower -- so this is a deployment of its own, measured apart from
+    `value`, and BEFORE this process opens the device: two processes' queues on one GPU take turns)."""
+    try:
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        env["GPU_MAX_HW_QUEUES"] = "32"
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--lanes", str(lanes), "--steps", str(20 * lanes), "--warmup", str(4 * lanes),
+               "--workload", args.workload, "--tables", args.tables, "--no-pmc", "--no-pcie", "--no-cpu-baseline"] + (["--frames", str(args.frames)] if args.frames else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        d = json.loads(lines[-1]) if r.returncode == 0 and lines else None
+        if not d:
+            return None
+        return {"lanes": lanes, "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "hw_queues": 32,
+                "note": f"{lanes} batches in flight: step k runs on compute lane k mod {lanes} (augment_batch(..., sync=False, lane=k): an engine context of its own, "
+                        "every kernel of the batch on ONE stream), nothing waits for a step but the next step on the same lane; the memory-bound sort and "
+                        "compaction of one batch run beside the latency-bound per-beam kernels of the others.  Throughput of a pipelined consumer; a batch's "
+                        f"own latency is about {lanes} x ms_per_step.  Child process with GPU_MAX_HW_QUEUES=32 (include/snowgpu.h: snowgpu_set_serial)"}
+    except Exception:
+        return None
+
+
 def counter_passes(W, alg_bytes):
     """roofline.traffic / traffic_detail / valu: rocprofv3 --pmc child passes of this command (FETCH_SIZE, WRITE_SIZE, SQ counters), or the committed figures."""
     args, F, world = W.args, W.F, W.world
@@ -573,6 +597,9 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree")
     distributed = world > 1
+    bif = None
+    if world == 1 and args.lanes == 1 and not (args.no_pcie or args.dry or args.workload == "C5" or args.host_prepass):
+        bif = batches_in_flight(args)
     import torch
     dist = None
     if distributed:
@@ -700,8 +727,9 @@ def main():
     side = torch.cuda.Stream(device=dev)       # (a stream of the caller's: on torch's legacy default stream the boundary forks to one of its own)
     step_no = [0]
     if L > 1 and layers != 64:
-        for k in range(1, L):
-            engine.get_engine(local_rank, k).set_lasers(engine.load_lasers() * (layers // 64))
+        for k in range(L):
+            engine.get_engine(local_rank, snow_tensors.LANE_SLOT0 + k).set_lasers(engine.load_lasers() * (layers // 64))
+    prof_ctx = engine.get_engine(local_rank, snow_tensors.LANE_SLOT0).ctx if L > 1 else eng.ctx       # (the per-beam region's events: lane 0's)
 
     def step():
         k = step_no[0] % L
@@ -715,7 +743,8 @@ def main():
     step()                                                  # (first call of the size: result tensors, library scratch)
     torch.cuda.synchronize()
     out_rows, out_src, out_counts, out_stats, status = res[0].rows, res[0].src, res[0].counts, res[0].stats, res[0].status
-    assert torch.equal(res[0]._keep[2].cpu(), tids.cpu()), "table ids of the tensor boundary differ from the direct lookup"
+    if L == 1:
+        assert torch.equal(res[0]._keep[2].cpu(), tids.cpu()), "table ids of the tensor boundary differ from the direct lookup"
 
     def barrier():
         torch.cuda.synchronize()
@@ -729,7 +758,7 @@ def main():
     st = status.cpu().numpy()
     if st[0] != 0:
         raise RuntimeError(f"device status {st} after warmup")
-    eng.ctx.profile_begin(args.steps)
+    prof_ctx.profile_begin(args.steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -737,7 +766,7 @@ def main():
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    beam_ms, n_launch = eng.ctx.profile_end()
+    beam_ms, n_launch = prof_ctx.profile_end()
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -777,7 +806,7 @@ def main():
                                    f"beam_divergence=3 mrad, noise_floor=0.7, float32 rows resident in HBM"
                                    + ("" if rscale == 1.0 else f", ranges x{rscale} (clipped at 119 m)")
                                    + (", snowfall + wet ground fused (snowgpu_augment_wet_batch_device)" if fused_wet else ""),
-                       "frames_per_step_per_gpu": F, "points_per_frame": n_per,
+                       "frames_per_step_per_gpu": F, "points_per_frame": n_per, "batches_in_flight": max(1, args.lanes),
                        "prepass": "host (outside the timed region)" if args.host_prepass else "device (timed)",
                        "sharding": f"frame-parallel x{world}, no collective", "ranks_seen": seen,
                        "backend": "nccl (RCCL)" if distributed else None,
@@ -815,6 +844,9 @@ def main():
             result["pcie_inclusive"] = pcie
         if single is not None:
             result["single_frame"] = single
+        if bif:
+            result["value_batches_in_flight"] = bif["value"]
+            result["batches_in_flight"] = bif
         if sampler is not None:
             result["sampler"] = sampler
             result["config"]["tables"] = "sampled and filed on the device (snowgpu_sample_table, seed = f(prefix, line))"

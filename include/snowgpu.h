@@ -145,6 +145,16 @@ int snowgpu_set_pipeline(snowgpu_ctx *ctx, int64_t chunk_rows);
  * with the math library's tan, for every flake. */
 int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
 
+/* on = 1: every kernel of a device-pointer batch on the caller's stream -- no side streams, no events (the environment switch SNOWGPU_SERIAL
+ * as a call).  One batch alone is slower that way (4.7 against 4.0 ms per 256 sweeps: the received-power kernels and the prepass no longer
+ * run side by side), but SEVERAL batches in flight on several contexts, one stream each, overlap across batches -- the memory-bound sort and
+ * compaction of one beside the latency-bound per-beam kernels of another: 3.72 - 3.75 ms per batch with three or four in flight (round 6),
+ * PROVIDED every stream has a hardware queue of its own: the HIP runtime serves a process' streams from GPU_MAX_HW_QUEUES (default 4)
+ * queues, and contexts that share a queue run one after the other -- set GPU_MAX_HW_QUEUES=16 or more in the environment before the process
+ * first touches the GPU.  (With more queues ONE batch on its four streams is slower -- 4.8 ms --, so the variable belongs to the
+ * several-batches-in-flight deployment only.)  The Python tensor boundary does this for its compute lanes (augment_batch(..., lane=k)). */
+int snowgpu_set_serial(snowgpu_ctx *ctx, int on);
+
 /* Debug / parity tap: per-flake quantities of a filed table, by table row: range (simulation.py:332), azimuth in
  * [0, 2 pi] (:351-352) and the two tangent angles ordered (right, left) (geometry.py:138-190, :32-80).  out: K x 4 doubles. */
 int snowgpu_debug_table(snowgpu_ctx *ctx, int table_id, double *out, int64_t cap_rows);

@@ -2197,6 +2197,13 @@ extern "C" int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on)
 }
 
 
+extern "C" int snowgpu_set_serial(snowgpu_ctx *ctx, int on)
+{
+    if (!ctx) return SNOWGPU_E_INVALID;
+    ctx->serial = on != 0;
+    return SNOWGPU_OK;
+}
+
 extern "C" int snowgpu_host_alloc(snowgpu_ctx *ctx, size_t bytes, void **ptr)
 {
     if (!ctx || !ptr) return SNOWGPU_E_INVALID;

@@ -25,6 +25,9 @@ import numpy as np
 from . import _native
 
 
+LANE_SLOT0 = 1000           # compute lane k is engine slot LANE_SLOT0 + k: lanes never share a context with plain calls (slot=)
+
+
 def is_device_input(frames) -> bool:
     """True for a torch CUDA tensor, a DeviceBatch, or a non-empty sequence whose first element is a torch CUDA tensor."""
     if isinstance(frames, DeviceBatch):
@@ -200,7 +203,11 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
              nothing waits for it: the caller's stream goes on, a call on another lane may run beside this one (the memory-bound sort and
              compaction of one batch beside the latency-bound per-beam kernels of the other), and the result is claimed through the
              DeviceResult: .wait() (host), .join() (torch's current stream waits, the host does not).  Keep as many results alive as
-             lanes in flight; `sync=True` with a lane is a plain synchronous call on that lane.
+             lanes in flight; `sync=True` with a lane is a plain synchronous call on that lane.  A lane's context runs every kernel of a
+             batch on ONE stream (snowgpu_set_serial); three or four lanes in flight: 3.72 - 3.75 ms per 256-sweep batch against 4.0 for
+             one batch at a time -- if GPU_MAX_HW_QUEUES >= 16 is in the environment before the process first touches the GPU (the
+             runtime's default of 4 hardware queues makes lanes share a queue and run one after the other).  Lanes are engine contexts of
+             their own (slot LANE_SLOT0 + k): a plain call never runs on a lane's context.
     """
     import torch
     from . import engine as _engine
@@ -214,7 +221,12 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
     dev = rows.device
     if device is not None and int(device) != dev.index:
         raise ValueError(f"the tensors live on {dev}, device={device} was asked for")
-    eng = _engine.get_engine(dev.index, slot if lane is None else int(lane))
+    eng = _engine.get_engine(dev.index, slot if lane is None else LANE_SLOT0 + int(lane))
+    if lane is not None and not eng.__dict__.get("_lane_serial"):
+        # a compute lane: its batches overlap OTHER lanes' batches, not their own side streams -- one stream per lane (snowgpu_set_serial; with
+        # GPU_MAX_HW_QUEUES >= 16 in the environment every lane's stream has a hardware queue of its own: include/snowgpu.h)
+        eng.ctx.set_serial(True)
+        eng.__dict__["_lane_serial"] = True
     nf, n = len(offsets) - 1, int(offsets[-1])
     if nf == 0:
         return []
