@@ -401,14 +401,17 @@ def measure_host_entry(W):
     return pcie, single
 
 
-def batches_in_flight(args, lanes=3):
+def batches_in_flight(args, lanes, queues):
     """The same steps with `lanes` batches in flight (compute lanes of the tensor boundary: one engine context and ONE stream each), in a child
-    process whose HIP runtime serves 32 hardware queues (GPU_MAX_HW_QUEUES: with the default of 4, lanes share a queue and run one after the
-    other; with more, ONE batch on its four streams is slower -- so this is a deployment of its own, measured apart from
-    `value`, and BEFORE this process opens the device: two processes' queues on one GPU take turns)."""
+    process.  queues = None: the process as it is -- the HIP runtime serves its default of four hardware queues per stream priority, and the
+    boundary puts its lanes on streams of different priorities so that they do not share one (snowgpu_lane_stream).  queues = 32:
+    GPU_MAX_HW_QUEUES=32, every lane a queue of its own at ONE priority; with that many queues ONE batch on its four streams is slower, so it
+    is a deployment of its own.  Both are measured apart from `value`, and BEFORE this process opens the device: two processes' queues on
+    one GPU take turns."""
     try:
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-        env["GPU_MAX_HW_QUEUES"] = "32"
+        if queues:
+            env["GPU_MAX_HW_QUEUES"] = str(queues)
         cmd = [sys.executable, str(ROOT / "bench.py"), "--lanes", str(lanes), "--steps", str(20 * lanes), "--warmup", str(4 * lanes),
                "--workload", args.workload, "--tables", args.tables, "--no-pmc", "--no-pcie", "--no-cpu-baseline"] + (["--frames", str(args.frames)] if args.frames else [])
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -416,11 +419,8 @@ def batches_in_flight(args, lanes=3):
         d = json.loads(lines[-1]) if r.returncode == 0 and lines else None
         if not d:
             return None
-        return {"lanes": lanes, "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "hw_queues": 32,
-                "note": f"{lanes} batches in flight: step k runs on compute lane k mod {lanes} (augment_batch(..., sync=False, lane=k): an engine context of its own, "
-                        "every kernel of the batch on ONE stream), nothing waits for a step but the next step on the same lane; the memory-bound sort and "
-                        "compaction of one batch run beside the latency-bound per-beam kernels of the others.  Throughput of a pipelined consumer; a batch's "
-                        f"own latency is about {lanes} x ms_per_step.  Child process with GPU_MAX_HW_QUEUES=32 (include/snowgpu.h: snowgpu_set_serial)"}
+        return {"lanes": lanes, "value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "hw_queues": queues or "runtime default (4 per stream priority)"}
     except Exception:
         return None
 
@@ -597,9 +597,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}: the two must agree")
     distributed = world > 1
-    bif = None
+    bif = bif_default = None
     if world == 1 and args.lanes == 1 and not (args.no_pcie or args.dry or args.workload == "C5" or args.host_prepass):
-        bif = batches_in_flight(args)
+        bif = batches_in_flight(args, 3, 32)
+        bif_default = batches_in_flight(args, 2, None)
     import torch
     dist = None
     if distributed:
@@ -846,6 +847,14 @@ def main():
             result["single_frame"] = single
         if bif:
             result["value_batches_in_flight"] = bif["value"]
+            bif["note"] = ("step k runs on compute lane k mod lanes (augment_batch(..., sync=False, lane=k): an engine context of its own, every kernel of "
+                           "the batch on ONE stream), nothing waits for a step but the next step on the same lane; the memory-bound sort and compaction of "
+                           "one batch run beside the latency-bound per-beam kernels of the others.  Throughput of a pipelined consumer; a batch's own "
+                           "latency is about lanes x ms_per_step.  Child processes of this command, run before it opened the device: three lanes with "
+                           "GPU_MAX_HW_QUEUES=32 (`value_batches_in_flight`), two lanes in the unchanged environment (`default_environment`: the lanes' "
+                           "streams differ in priority, include/snowgpu.h: snowgpu_lane_stream)")
+            if bif_default:
+                bif["default_environment"] = bif_default
             result["batches_in_flight"] = bif
         if sampler is not None:
             result["sampler"] = sampler

@@ -148,12 +148,21 @@ int snowgpu_set_exact_math(snowgpu_ctx *ctx, int on);
 /* on = 1: every kernel of a device-pointer batch on the caller's stream -- no side streams, no events (the environment switch SNOWGPU_SERIAL
  * as a call).  One batch alone is slower that way (4.7 against 4.0 ms per 256 sweeps: the received-power kernels and the prepass no longer
  * run side by side), but SEVERAL batches in flight on several contexts, one stream each, overlap across batches -- the memory-bound sort and
- * compaction of one beside the latency-bound per-beam kernels of another: 3.72 - 3.75 ms per batch with three or four in flight (round 6),
- * PROVIDED every stream has a hardware queue of its own: the HIP runtime serves a process' streams from GPU_MAX_HW_QUEUES (default 4)
- * queues, and contexts that share a queue run one after the other -- set GPU_MAX_HW_QUEUES=16 or more in the environment before the process
- * first touches the GPU.  (With more queues ONE batch on its four streams is slower -- 4.8 ms --, so the variable belongs to the
- * several-batches-in-flight deployment only.)  The Python tensor boundary does this for its compute lanes (augment_batch(..., lane=k)). */
+ * compaction of one beside the latency-bound per-beam kernels of another: 3.66 ms per batch with three in flight (round 6),
+ * PROVIDED every stream has a hardware queue of its own: the HIP runtime serves a process' streams of one priority from GPU_MAX_HW_QUEUES
+ * (default 4) queues and hands a new stream the least-used one, so two contexts' streams may share a queue and then run one after the other.
+ * Either give the contexts streams of different priorities (snowgpu_lane_stream below: two lanes 3.8 ms in an unchanged environment) or set
+ * GPU_MAX_HW_QUEUES=32 in the environment before the process first touches the GPU.  (With more than four queues ONE batch on its four
+ * streams is slower -- 4.85 ms: hops between streams wait for queues to be switched in --, so the variable belongs to the
+ * several-batches-in-flight deployment only.)  The Python tensor boundary does all this for its compute lanes (augment_batch(..., lane=k)). */
 int snowgpu_set_serial(snowgpu_ctx *ctx, int on);
+
+/* A stream of the context's for a caller that keeps several batches in flight: level 0 / 1 / 2 = the device's highest / normal / lowest stream
+ * priority (made on the first call, destroyed with the context; *stream is a hipStream_t).  The HIP runtime serves each priority from a
+ * queue pool of its own, so three serial contexts on streams of three DIFFERENT levels run side by side under the runtime's default of four
+ * hardware queues -- streams of one level may be handed the same queue and then run one after the other (scripts/probe/queue_map_probe.hip).
+ * The level only decides whose waves the dispatcher places first when two streams have work ready. */
+int snowgpu_lane_stream(snowgpu_ctx *ctx, int level, void **stream);
 
 /* Debug / parity tap: per-flake quantities of a filed table, by table row: range (simulation.py:332), azimuth in
  * [0, 2 pi] (:351-352) and the two tangent angles ordered (right, left) (geometry.py:138-190, :32-80).  out: K x 4 doubles. */

@@ -26,7 +26,7 @@ EXPORTS = [
     "snowgpu_sample_table", "snowgpu_host_alloc", "snowgpu_host_free", "snowgpu_set_fov",
     "snowgpu_augment_wet_batch_device", "snowgpu_last_status", "snowgpu_free_table", "snowgpu_debug_table", "snowgpu_file_table_device", "snowgpu_set_fov_precrop",
     "snowgpu_set_pipeline", "snowgpu_set_wet_lines", "snowgpu_set_plane_method", "snowgpu_estimate_planes",
-    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_set_threshold_callback", "snowgpu_augment_batch_compact", "snowgpu_set_serial", "snowgpu_device_numa_node",
+    "snowgpu_estimate_planes_device", "snowgpu_prepass_stats", "snowgpu_set_wet_estimation", "snowgpu_wet_last_fit", "snowgpu_debug_ransac_polyfit", "snowgpu_set_result_transfer", "snowgpu_debug_transfer_times", "snowgpu_status_error", "snowgpu_set_threshold_callback", "snowgpu_augment_batch_compact", "snowgpu_set_serial", "snowgpu_lane_stream", "snowgpu_device_numa_node",
 ]
 
 WET_ESTIMATION = {"linear": 0, "poly": 1}
@@ -131,6 +131,8 @@ def lib():
             L.snowgpu_set_pipeline.argtypes = [vp, i64]
             L.snowgpu_set_serial.restype = ctypes.c_int
             L.snowgpu_set_serial.argtypes = [vp, ctypes.c_int]
+            L.snowgpu_lane_stream.restype = ctypes.c_int
+            L.snowgpu_lane_stream.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
             L.snowgpu_set_exact_math.restype = ctypes.c_int
             L.snowgpu_set_exact_math.argtypes = [vp, ctypes.c_int]
             L.snowgpu_profile_begin.restype = ctypes.c_int
@@ -486,6 +488,12 @@ class Context:
         """Every kernel of a device-pointer batch on the caller's stream (snowgpu_set_serial): for contexts that run as one of several compute
         lanes, whose batches overlap each other instead of their own side streams."""
         self._check(self._L.snowgpu_set_serial(self._h, int(bool(on))))
+
+    def lane_stream(self, level: int) -> int:
+        """hipStream_t (as an integer) of the context's stream at priority level 0 / 1 / 2 = highest / normal / lowest (snowgpu_lane_stream)."""
+        h = ctypes.c_void_p(0)
+        self._check(self._L.snowgpu_lane_stream(self._h, int(level), ctypes.byref(h)))
+        return int(h.value or 0)
 
     def set_exact_math(self, on: bool):
         self._check(self._L.snowgpu_set_exact_math(self._h, int(bool(on))))

@@ -237,6 +237,7 @@ struct snowgpu_ctx {
     int per_lane_scan = 0;            // experiments / validation: SNOWGPU_PER_LANE_SCAN=-1 wave scan in the tiers too
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};     // snowgpu_lane_stream: one per priority level, made on demand
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
     DevBuf<uint16_t> rank;
@@ -461,7 +462,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     for (snowgpu_ctx *ln : ctx->lanes) snowgpu_destroy(ln);      // a lane owns a stream, events and scratch only
     ctx->lanes.clear();
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
+    for (hipStream_t w : {ctx->s_h2d, ctx->s_d2h, ctx->lane_stream[0], ctx->lane_stream[1], ctx->lane_stream[2]}) if (w) { (void)hipStreamSynchronize(w); (void)hipStreamDestroy(w); }
     if (ctx->tier_hint_h) (void)hipHostFree(ctx->tier_hint_h);
     if (ctx->thr_stage) (void)hipHostFree(ctx->thr_stage);
     for (hipEvent_t e : ctx->thr_ev) (void)hipEventDestroy(e);
@@ -2201,6 +2202,21 @@ extern "C" int snowgpu_set_serial(snowgpu_ctx *ctx, int on)
 {
     if (!ctx) return SNOWGPU_E_INVALID;
     ctx->serial = on != 0;
+    return SNOWGPU_OK;
+}
+
+extern "C" int snowgpu_lane_stream(snowgpu_ctx *ctx, int level, void **stream)
+{
+    if (!ctx || !stream || level < 0 || level > 2) return SNOWGPU_E_INVALID;
+    *stream = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->lane_stream[level]) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const int prio = level == 0 ? greatest : level == 2 ? least : (least > 0 && greatest < 0 ? 0 : greatest);
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->lane_stream[level], hipStreamNonBlocking, prio));
+    }
+    *stream = (void *)ctx->lane_stream[level];
     return SNOWGPU_OK;
 }
 

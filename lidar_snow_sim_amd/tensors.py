@@ -17,6 +17,7 @@ no arithmetic of the simulation happens in this file.
 """
 from __future__ import annotations
 
+import os
 import random
 from collections import OrderedDict
 
@@ -204,10 +205,12 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
              compaction of one batch beside the latency-bound per-beam kernels of the other), and the result is claimed through the
              DeviceResult: .wait() (host), .join() (torch's current stream waits, the host does not).  Keep as many results alive as
              lanes in flight; `sync=True` with a lane is a plain synchronous call on that lane.  A lane's context runs every kernel of a
-             batch on ONE stream (snowgpu_set_serial); three or four lanes in flight: 3.72 - 3.75 ms per 256-sweep batch against 4.0 for
-             one batch at a time -- if GPU_MAX_HW_QUEUES >= 16 is in the environment before the process first touches the GPU (the
-             runtime's default of 4 hardware queues makes lanes share a queue and run one after the other).  Lanes are engine contexts of
-             their own (slot LANE_SLOT0 + k): a plain call never runs on a lane's context.
+             batch on ONE stream (snowgpu_set_serial) of the context's own (snowgpu_lane_stream); lanes k, k + 1, k + 2 get streams of
+             different priorities -- the HIP runtime keeps a queue pool per priority, so they never share a hardware queue (streams of one
+             priority may, and then run one after the other).  Measured per 256-sweep batch: two lanes 3.8 ms against 4.0 for one batch at
+             a time; with GPU_MAX_HW_QUEUES=32 in the environment before the process first touches the GPU all lanes run at one priority
+             on queues of their own: three lanes 3.66 ms (profiles/r06_lanes_ab.txt).  Lanes are engine contexts of their own (slot
+             LANE_SLOT0 + k): a plain call never runs on a lane's context.
     """
     import torch
     from . import engine as _engine
@@ -251,7 +254,15 @@ def augment_batch(frames, particle_file_prefix, beam_divergence, shuffle=True, n
         if stream.cuda_stream == 0 or lane is not None:
             run = eng.__dict__.get("_torch_side_stream")
             if run is None or run.device != dev:
-                run = eng.__dict__["_torch_side_stream"] = torch.cuda.Stream(device=dev)
+                if lane is not None:
+                    # lanes k, k + 1, k + 2 on streams of three different priorities: three queue pools of the runtime, so three hardware
+                    # queues whatever else the process has created (include/snowgpu.h: snowgpu_lane_stream)
+                    many = int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) >= 16      # (then every stream has a queue anyway: one priority)
+                    order = [int(v) for v in os.environ.get("SNOWGPU_LANE_LEVELS", "1" if many else "2,1,0").split(",")]
+                    run = torch.cuda.ExternalStream(eng.ctx.lane_stream(order[int(lane) % len(order)]), device=dev)
+                else:
+                    run = torch.cuda.Stream(device=dev)
+                eng.__dict__["_torch_side_stream"] = run
         d_off = up.get(torch, dev, offsets, run)
         d_tids = up.get(torch, dev, tids, run)
         d_poly = d_plane = None
