@@ -115,29 +115,36 @@ def test_asynchronous_call_on_a_side_stream_and_reused_result_tensors(so, tables
             assert np.array_equal(got[2].cpu().numpy(), src0) and np.array_equal(got[1].cpu().numpy()[:, 3:], a0[:, 3:])
 
 
-def test_two_compute_lanes_in_flight_give_the_results_of_one(so, tables):
-    """lane=k: the call runs on compute lane k (an engine context and stream of its own), the caller's stream does not wait for it, and the
-    result is claimed through the DeviceResult (.join() on the consumer's stream, .wait() on the host).  Four batches alternating between
-    two lanes, results reused per lane: every batch equals the oracle."""
-    from lidar_snow_sim_amd.tensors import augment_batch
+@pytest.mark.parametrize("n_lanes", [2, 3])
+def test_compute_lanes_in_flight_give_the_results_of_one(so, tables, n_lanes):
+    """lane=k: the call runs on compute lane k (an engine context of its own, every kernel on ONE stream of that context -- lanes 0, 1, 2 on
+    streams of three different priorities: snowgpu_lane_stream), the caller's stream does not wait for it, and the result is claimed through the
+    DeviceResult (.join() on the consumer's stream, .wait() on the host).  Batches dealt round over the lanes, results reused per lane: every
+    batch equals the oracle."""
+    from lidar_snow_sim_amd import engine
+    from lidar_snow_sim_amd.tensors import LANE_SLOT0, augment_batch
     frames = _ragged_frames()
     tl = _tables64(tables)
-    orders = [[list(np.random.default_rng(40 + 3 * b + f).permutation(64)) for f in range(3)] for b in range(4)]
+    nb = 2 * n_lanes
+    orders = [[list(np.random.default_rng(40 + 3 * b + f).permutation(64)) for f in range(3)] for b in range(nb)]
     t_frames = [torch.from_numpy(f).cuda() for f in frames]
-    res, got = [None, None], []
-    for b in range(4):
-        k = b % 2
+    res, got = [None] * n_lanes, []
+    for b in range(nb):
+        k = b % n_lanes
         if res[k] is not None:                                  # the lane's earlier batch: claim it before its tensors are reused
             got.append([(st, a.clone(), i.clone()) for st, a, i in res[k].frames(return_src=True)])
         res[k] = augment_batch(t_frames, "unused", BD, planes=[PLANE] * 3, orders=orders[b], particles=tl, sync=False, lane=k, out=res[k])
         assert res[k].stream != torch.cuda.current_stream()
-    res[0].join(); res[1].join()                                # (the consumer's stream waits; the host does not)
-    tail = [[(None, r.rows.clone(), r.src.clone(), r.counts.clone(), r.stats.clone())] for r in res]
+    assert len({r.stream.cuda_stream for r in res}) == n_lanes   # a stream per lane ...
+    ctxs = [engine.get_engine(0, LANE_SLOT0 + k).ctx for k in range(n_lanes)]
+    assert all(r.stream.cuda_stream in {c.lane_stream(lv) for lv in range(3)} for r, c in zip(res, ctxs))     # ... and it is its context's own
+    for r in res:
+        r.join()                                                # (the consumer's stream waits; the host does not)
     torch.cuda.current_stream().synchronize()
     for r in res:
         got.append([(st, a.clone(), i.clone()) for st, a, i in r.frames(return_src=True)])
-    assert len(got) == 4 and len(tail) == 2
-    for b in range(4):
+    assert len(got) == nb
+    for b in range(nb):
         for f in range(3):
             s0, a0, src0 = so.augment(frames[f], tl, BD, orders[b][f], plane=PLANE)
             st, aug, src = got[b][f]
