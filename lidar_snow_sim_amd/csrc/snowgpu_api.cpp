@@ -2213,7 +2213,7 @@ extern "C" int snowgpu_lane_stream(snowgpu_ctx *ctx, int level, void **stream)
     if (!ctx->lane_stream[level]) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const int prio = level == 0 ? greatest : level == 2 ? least : (least > 0 && greatest < 0 ? 0 : greatest);
+        const int prio = level == 0 ? greatest : level == 2 ? least : (least + greatest) / 2;      // (HIP: 1 low, 0 normal, -1 high)
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->lane_stream[level], hipStreamNonBlocking, prio));
     }
     *stream = (void *)ctx->lane_stream[level];
