@@ -1321,10 +1321,11 @@ static int host_batch_pipelined(snowgpu_ctx *ctx, int n_frames, const int64_t *f
     std::vector<int> c_first;
     std::vector<int64_t> h_off;                  // chunk-local offsets: chunk c owns h_off[c_pos[c] .. c_pos[c] + frames + 1)
     std::vector<size_t> c_pos;
-    // (the caller fits the threshold -- snowgpu_set_threshold_callback, below --: groups of twice the rows; the callback's cost per frame
-    // falls with the group's size -- its selection runs on a thread pool -- and the calling thread enqueues nothing while it is inside it:
-    // 256 sweeps, 12 / 24 / 48 sweeps per group: 0.89 / 1.24 / 1.03 G points/s, scripts/probe/q8_cb_probe.py)
-    const int64_t pipe_rows = (ctx->thr_fn != nullptr && !thr_poly && !perm) ? std::max<int64_t>(ctx->pipe_rows, (int64_t)3 << 20) : ctx->pipe_rows;
+    // (the caller fits the threshold -- snowgpu_set_threshold_callback, below --: groups of 40 sweeps; the callback's cost per frame
+    // falls with the group's size -- its selection runs on a thread pool, every call pays the pool's round trip -- and the calling thread
+    // enqueues nothing while it is inside it: 256 sweeps, 24 / 32 / 40 / 48 / 56 sweeps per group: 1.36 / 1.32 / 1.42 / 1.44 / 1.40 G
+    // points/s with the rows transfer, 1.39 / 1.42 / 1.57 / 1.63 / 1.66 with the packed one, scripts/probe/q8_group_probe.py)
+    const int64_t pipe_rows = (ctx->thr_fn != nullptr && !thr_poly && !perm) ? std::max<int64_t>(ctx->pipe_rows, (int64_t)5 << 20) : ctx->pipe_rows;
     for (int f = 0; f < n_frames;) {
         int g = f;
         const int64_t base = frame_offsets[f];

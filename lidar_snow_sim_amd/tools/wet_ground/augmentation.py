@@ -85,6 +85,40 @@ def _thread_pool(workers):
     return _pool
 
 
+def _usable_cpus():
+    """CPUs this process may keep busy: its affinity mask, cut to the cgroup's CPU quota where one is set (a thread pool wider than the quota
+    is throttled as a whole when the quota of the period is spent)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def _linregress_line(x, y):
+    """Slope and intercept of scipy.stats.linregress(x, y) for float64 vectors: xmean = np.mean(x), ymean = np.mean(y), ssxm, ssxym from
+    np.cov(x, y, bias=1), slope = ssxym / ssxm, intercept = ymean - slope * xmean -- as the ufunc calls np.mean and np.cov make themselves
+    (np.add.reduce / n; the two rows stacked, their means subtracted in place, np.dot(X, X.T.conj()), times np.true_divide(1, n)), without
+    the two functions' argument handling: 10 instead of 37 us per frame, all of it under the GIL, and the same bits
+    (tests/test_host_logic.py::test_line_fit_of_the_threshold_callback_is_numpy_s_own)."""
+    n = x.shape[0]
+    xmean, ymean = np.add.reduce(x) / n, np.add.reduce(y) / n                       # np.mean: umr_sum, true_divide by the count
+    X = np.empty((2, n))
+    X[0] = x
+    X[1] = y                                                                        # np.cov: array(m, ndmin=2), concatenate((X, y))
+    avg = np.add.reduce(X, axis=1)
+    avg /= n                                                                        # np.average(X, axis=1) = X.mean(1)
+    X -= avg[:, None]
+    c = np.dot(X, X.T.conj())
+    c *= np.true_divide(1, n)                                                       # bias=1: ddof = 0, fact = n
+    slope = c[0, 1] / c[0, 0]
+    return slope, ymean - slope * xmean
+
+
 def noise_polys_from_device_stats(hist, rec, noise_floor=0.7, threads=None):
     """Threshold polynomials (n_frames x 3) for q8='numpy' from the device half of the prepass (Context.prepass_stats): the
     histogram's row minima are taken HERE, with this process' NumPy -- np.argpartition(hist, 2)[:, 0] on float64 rows of 2555
@@ -100,34 +134,35 @@ def noise_polys_from_device_stats(hist, rec, noise_floor=0.7, threads=None):
     step = (np.abs(ymax) - 5.0) / 2555.0
     m0, m1 = p0.copy(), p1.copy()                                                   # :250-251: too few rows -> the regression line p
 
-    def frames(lo, hi):
-        # :234-236 for frames lo .. hi - 1: the device has already put the ground-row count into the empty bins; the histogram
-        # becomes the float64 array np.histogram2d returns (one casting copy) and the selection is the reference's expression --
-        # row by row, so a (frames * 50) x 2555 array gives what fifty-row arrays give.  Both release the GIL; the line fit of a
-        # frame follows its selection in the same task, so that one task's Python runs beside the other tasks' selections.
-        h = _scratch_f64((hi - lo) * 50 * 2555).reshape(-1, 2555)                  # (reused per thread: no page faults after the first call)
-        np.copyto(h, hist[lo:hi].reshape(-1, 2555))
-        ymins = np.argpartition(h, 2)[:, 0].reshape(hi - lo, 50)
-        # the noise line per frame (augmentation.py:237-253), on the COMPRESSED arrays x[use], min_vals[use] with the expressions of
-        # scipy.stats.linregress -- np.mean of each, np.cov(x, y, bias=1) -- so that the line is the one the host path
-        # (noise_threshold_poly -> estimate_laser_parameters) fits, operation for operation (a masked sum over all 50 bins adds the
-        # same numbers in another order: last-bit differences that a row sitting on the threshold can see)
-        for f in range(lo, hi):
-            min_vals = ymins[f - lo] * step[f] + 5.0                                # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
-            u = min_vals > 5                                                        # :238
-            if int(u.sum()) > 3:                                                    # :248
-                x, y = xmid[u], min_vals[u]
-                xmean, ymean = np.mean(x), np.mean(y)
-                ssxm, ssxym, _, _ = np.cov(x, y, bias=1).flat
-                m0[f] = ssxym / ssxm                                                # :249 scipy linregress
-                m1[f] = ymean - m0[f] * xmean
+    # :234-236: the device has already put the ground-row count into the empty bins; the histogram becomes the float64 array
+    # np.histogram2d returns (one casting copy) and the selection is the reference's expression -- row by row, so any run of rows of the
+    # (frames * 50) x 2555 array gives what fifty-row arrays give: the rows are dealt out in equal runs, whatever frame they belong to (24
+    # frames on 16 threads: one and a half frames each instead of two for some and none for others).  Both steps release the GIL.
+    rows_all = hist.reshape(-1, 2555)
+    ymins = np.empty(nf * 50, np.intp)
 
-    workers = threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    def select(lo, hi):
+        h = _scratch_f64((hi - lo) * 2555).reshape(-1, 2555)                       # (reused per thread: no page faults after the first call)
+        np.copyto(h, rows_all[lo:hi])
+        ymins[lo:hi] = np.argpartition(h, 2)[:, 0]
+
+    workers = threads or int(os.environ.get("SNOWGPU_Q8_THREADS", "0")) or min(16, _usable_cpus())
     if nf <= 2 or workers <= 1:
-        frames(0, nf)
+        select(0, nf * 50)
     else:
-        per = max(1, -(-nf // workers))
-        list(_thread_pool(workers).map(lambda lo: frames(lo, min(lo + per, nf)), range(0, nf, per)))
+        per = -(-nf * 50 // workers)
+        list(_thread_pool(workers).map(lambda lo: select(lo, min(lo + per, nf * 50)), range(0, nf * 50, per)))
+    # the noise line per frame (augmentation.py:237-253), on the COMPRESSED arrays x[use], min_vals[use] with the expressions of
+    # scipy.stats.linregress -- np.mean of each, np.cov(x, y, bias=1) -- so that the line is the one the host path
+    # (noise_threshold_poly -> estimate_laser_parameters) fits, operation for operation (a masked sum over all 50 bins adds the
+    # same numbers in another order: last-bit differences that a row sitting on the threshold can see)
+    min_all = ymins.reshape(nf, 50) * step[:, None] + 5.0                           # yedges[ymins] with yedges = np.linspace(5, ymax, 2556) (:237)
+    use_all = min_all > 5                                                           # :238
+    enough = np.add.reduce(use_all, axis=1) > 3                                     # :248
+    for f in range(nf):                                                             # (element by element the expressions of one frame)
+        if enough[f]:
+            u = use_all[f]
+            m0[f], m1[f] = _linregress_line(xmid[u], min_all[f][u])                 # :249 scipy linregress
     q = rec[:, 7:18]
     a22, a21, a2, a11, a1, a2gc, a2c, a1gc, a1c, gc, c = (q[:, k] for k in range(11))
     # normal equations of np.polyfit(d, nf (m0 d + m1) c, 2), columns scaled by their norms as polyfit scales them

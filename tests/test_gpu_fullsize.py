@@ -459,7 +459,7 @@ def test_threshold_callback_inside_the_pipelined_call_equals_the_two_call_form(c
                     a, m = int(off[f]), int(want[2][f])
                     rec["frames"] += 1
                     rec["frames_differ"] += not (got[0][a:a + m].tobytes() == want[0][a:a + m].tobytes() and np.array_equal(got[1][a:a + m], want[1][a:a + m]))
-            assert sorted(groups)[0][0] == 0 and sum(g[1] for g in groups) == 2 * n and len(groups) >= 2 * 3          # several groups per call
+            assert sorted(groups)[0][0] == 0 and sum(g[1] for g in groups) == 2 * n and len(groups) >= 2 * 2          # several groups per call
             rec["callback_groups"] += len(groups)
 
         def broken(first, h, r):

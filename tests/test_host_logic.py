@@ -877,3 +877,21 @@ def test_stream_run_refuses_a_sharded_run_without_a_common_listing(tmp_path):
     (tmp_path / "lidar").mkdir()
     with pytest.raises(ValueError, match="existing"):
         stream.run(tmp_path / "lidar", ["a,1"], rank=1, world=2, modes=("gunn",), combos=[(1.0, 0.1)])
+
+
+def test_line_fit_of_the_threshold_callback_is_numpy_s_own():
+    """The threshold callback fits its noise line with the ufunc calls np.mean and np.cov make themselves (_linregress_line): same bits as
+    scipy.stats.linregress, which the host path and the reference call (wet_ground/augmentation.py:248-249), for every length the 50-bin
+    histogram can leave."""
+    from scipy.stats import linregress
+    from lidar_snow_sim_amd.tools.wet_ground.augmentation import _linregress_line
+    rng = np.random.default_rng(77)
+    xmid = (np.linspace(10, 70, 51)[:-1] + np.linspace(10, 70, 51)[1:]) / 2
+    for trial in range(400):
+        n = 4 + trial % 47
+        u = np.zeros(50, bool)
+        u[rng.choice(50, n, replace=False)] = True
+        x, y = xmid[u], 5.0 + rng.integers(1, 2555, n) * rng.uniform(0.01, 0.2)
+        ref = linregress(x, y)
+        slope, intercept = _linregress_line(x, y)
+        assert slope == ref.slope and intercept == ref.intercept, (trial, n)
