@@ -414,7 +414,7 @@ def batches_in_flight(args, lanes, queues):
             env["GPU_MAX_HW_QUEUES"] = str(queues)
         cmd = [sys.executable, str(ROOT / "bench.py"), "--lanes", str(lanes), "--steps", str(20 * lanes), "--warmup", str(4 * lanes),
                "--workload", args.workload, "--tables", args.tables, "--no-pmc", "--no-pcie", "--no-cpu-baseline"] + (["--frames", str(args.frames)] if args.frames else [])
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         d = json.loads(lines[-1]) if r.returncode == 0 and lines else None
         if not d:
