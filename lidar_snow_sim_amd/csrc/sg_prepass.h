@@ -15,6 +15,8 @@ struct SgWetParams {
     int estimation;             // 0: 'linear' (augmentation.py:215-221, :247-253), 1: 'poly' (:223-229, :243-246; seeded RANSAC)
     uint64_t seed;              // 'poly': seed of the RANSAC draws
     double *fit_out;            // optional DEVICE array n_frames x 8: the fitted curves (k_pre_export_fit)
+    const int32_t *src_first;   // optional DEVICE array, indexed like the rows: out_src gets src_first[row] instead of the row's index in its
+                                // frame (a chained call: the rows are an earlier stage's output, src_first its source rows)
 };
 
 #define SG_PRE_REC 18      /* doubles per frame of sg_prepass_stats_run's record */

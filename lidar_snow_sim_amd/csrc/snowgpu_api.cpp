@@ -260,7 +260,7 @@ struct snowgpu_ctx {
     DevBuf<double> stats_rec;
     // fused snow + wet (snowgpu_augment_wet_batch*): the snowfall result stays here
     DevBuf<uint8_t> snow_rows;
-    DevBuf<int32_t> snow_src, wet_src, wet_flags;
+    DevBuf<int32_t> snow_src, wet_flags;
     DevBuf<int64_t> snow_counts, wet_counts;
     DevBuf<double> wet_rows, wet_plane;
     // measurement hooks (snowgpu_profile_begin / _end)
@@ -496,7 +496,7 @@ extern "C" void snowgpu_destroy(snowgpu_ctx *ctx)
     ctx->frame_off.release(); ctx->out_counts.release(); ctx->out_stats.release();
     ctx->thr_poly.release(); ctx->plane.release(); ctx->dbg_rj.release(); ctx->dbg_ratio.release();
     ctx->dbg_count.release(); ctx->frame_tables.release(); ctx->user_thr.release(); ctx->out_thr.release(); ctx->user_perm.release();
-    ctx->snow_rows.release(); ctx->snow_src.release(); ctx->wet_src.release(); ctx->wet_flags.release(); ctx->snow_counts.release();
+    ctx->snow_rows.release(); ctx->snow_src.release(); ctx->wet_flags.release(); ctx->snow_counts.release();
     ctx->wet_counts.release(); ctx->wet_rows.release(); ctx->wet_plane.release();
     ctx->rows_crop.release(); ctx->crop_src.release(); ctx->crop_out_src.release(); ctx->crop_counts.release(); ctx->crop_off.release(); ctx->crop_stats.release();
     sg_prepass_release(&ctx->prepass);
@@ -2295,7 +2295,6 @@ extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, 
     const size_t esz = dtype == 0 ? 4 : 8, n = (size_t)n_total;
     ENSURE(ctx, ctx->snow_rows, std::max<size_t>(n * 5 * esz, 8));
     ENSURE(ctx, ctx->snow_src, std::max<size_t>(n, 1));
-    ENSURE(ctx, ctx->wet_src, std::max<size_t>(n, 1));
     ENSURE(ctx, ctx->snow_counts, (size_t)n_frames);
     BatchDev b{};
     b.n_frames = n_frames; b.n_total = n_total; b.max_frame = (max_frame_rows > 0 && max_frame_rows <= n_total) ? max_frame_rows : n_total;
@@ -2325,9 +2324,10 @@ extern "C" int snowgpu_augment_wet_batch_device(snowgpu_ctx *ctx, int n_frames, 
                          ctx->wet_plane_est.p, nullptr, b.stream);
         d_wet_plane = ctx->wet_plane_est.p;
     }
+    // (the source rows of the chained result -- final row -> snowfall row -> input row -- are composed as the wet scatter writes them)
+    wp.src_first = ctx->snow_src.p;
     if (!e) e = sg_wet_run(&ctx->prepass, ctx->snow_rows.p, dtype, d_frame_offsets, ctx->snow_counts.p, n_frames, n_total, b.max_frame,
-                       d_wet_plane, &wp, d_out_rows, ctx->wet_src.p, d_out_counts, d_out_flags, d_status, b.stream);
-    if (!e) e = sg_launch_compose_src(d_frame_offsets, d_out_counts, n_frames, b.max_frame, ctx->wet_src.p, ctx->snow_src.p, d_out_src, b.stream);
+                       d_wet_plane, &wp, d_out_rows, d_out_src, d_out_counts, d_out_flags, d_status, b.stream);
     if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("wet ground: ") + (e > 0 ? hipGetErrorString((hipError_t)e) : "allocation"));
     return SNOWGPU_OK;
 }

@@ -18,6 +18,7 @@
 #include "sg_prepass.h"
 #include "sg_lean.h"
 #include "sg_philox.h"
+#include "sg_math.h"
 
 #define PB 256
 #define HX 50     /* range rows of the histogram (augmentation.py:232) */
@@ -1042,20 +1043,27 @@ __global__ __launch_bounds__(PB) void k_lean_rowmin_solve(PreArgs a, int xmean_f
 // ================================================================================================================
 // wet ground (augmentation.py:88-159; phy_equations.py:35-108)
 
-struct Fresnel { double rs, ts, rp, tp, aout; };
-__device__ __forceinline__ Fresnel fresnel_power(double ain, double n_in, double n_out)   // phy_equations.py:35-67
+// phy_equations.py:35-67 fresnel_power(ain, n_in, n_out), from the sine and cosine of the incidence angle instead of the angle: the
+// refraction angle only ever enters as its sine -- n_in / n_out sin(ain), clipped (:41-43) -- and its cosine, the root of 1 - sin^2
+// (cos(arcsin(s)), :44-46), and the angle the chain hands on (total_transmittance, :81-83) is used the same way, so no arcsin, sine or
+// cosine is taken here at all; the two amplitude pairs share their denominators' reciprocals, and `frac` (:47) enters as its reciprocal.
+// The same numbers to a few 1e-16 (the wet path's intensities are float64 values compared at 1e-9 / 1e-7: tests/test_gpu_parity.py
+// ::test_L6_wet_ground, test_gpu_fullsize.py) -- the library sin / arcsin / cos and 18 divisions per row were 0.88 ms of a fused
+// 256-sweep step.
+struct Fresnel { double rs, ts, rp, tp, s_out, c_out; };
+__device__ __forceinline__ Fresnel fresnel_power(double si, double ci, double n_in, double n_out)
 {
     Fresnel r;
-    double s = sin(ain) * n_in / n_out;
-    s = s < -1 ? -1 : (s > 1 ? 1 : s);
-    r.aout = asin(s);
-    const double ci = cos(ain), co = cos(r.aout);
-    const double frac = ci * n_in / n_out / co;
-    const double rs = (n_in * ci - n_out * co) / (n_in * ci + n_out * co);
-    const double ts = 2 * n_in * ci / (n_in * ci + n_out * co);
-    const double rp = (n_out * ci - n_in * co) / (n_out * ci + n_in * co);
-    const double tp = 2 * n_in * ci / (n_out * ci + n_in * co);
-    r.rs = rs * rs; r.ts = ts * ts / frac; r.rp = rp * rp; r.tp = tp * tp / frac;
+    double s = si * n_in / n_out;                                    // :41
+    s = s < -1 ? -1 : (s > 1 ? 1 : s);                               // :42-43
+    const double co = sqrt(1.0 - s * s);                             // cos(aout), aout = arcsin(s) (:44-46)
+    r.s_out = s; r.c_out = co;
+    const double a = n_in * ci, b = n_out * co, c = n_out * ci, d = n_in * co;
+    const double i1 = 1.0 / (a + b), i2 = 1.0 / (c + d);
+    const double rs = (a - b) * i1, ts = 2 * a * i1;                 // :49-50
+    const double rp = (c - d) * i2, tp = 2 * a * i2;                 // :51-52
+    const double inv_frac = (n_out * co) / (ci * n_in);              // 1 / (cos(ain) n_in / n_out / cos(aout)) (:47)
+    r.rs = rs * rs; r.ts = ts * ts * inv_frac; r.rp = rp * rp; r.tp = tp * tp * inv_frac;   // :54-57
     return r;
 }
 
@@ -1071,6 +1079,7 @@ struct WetArgs {
     int32_t *out_src;
     int64_t *out_counts;
     int32_t *out_flags;
+    const int32_t *src_first;   // SgWetParams::src_first
 };
 
 template <typename T>
@@ -1084,18 +1093,31 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
     const PreFrame fr = a.fr[f];
     const T *rows = (const T *)a.rows;
     int cnt_a = 0, cnt_b = 0;
+    double gns[4], gds[4], angs[4], ins[4];                              // the thread's four rows side by side: every load first
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const bool in = r < n && !fr.unchanged;
+        gns[q] = in ? a.g_norm[base + r] : NAN;
+        const bool ground = gns[q] == gns[q];
+        gds[q] = ground ? a.g_dist[base + r] : 0.0;
+        angs[q] = ground ? a.g_ang[base + r] : 1.0;
+        ins[q] = ground ? (double)rows[(base + r) * 5 + 3] : 0.0;
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int64_t r = tile0 + q * PB + threadIdx.x;
         if (r >= n) continue;
         uint8_t cls;
         double ni = 0.0;
-        const double gn = a.g_norm[base + r];
+        const double gn = gns[q];
         if (fr.unchanged) { cls = 1; }                                   // frame returned as is (augmentation.py:51-52)
         else if (gn != gn) { cls = 1; }
         else {
-            const double gd = a.g_dist[base + r], ang = a.g_ang[base + r];
-            const double gc = cos(ang);
-            const double inten = (double)rows[(base + r) * 5 + 3];
+            const double gd = gds[q], ang = angs[q];
+            double gs, gc;
+            sg_sincos_0_2pi(ang, gs, gc);                                // the incidence angle lies in [0, pi] (an arccos)
+            const double inten = ins[q];
             double rel, thr;
             if (fr.quad) {                                               // estimation_method = 'poly'
                 const double gd2 = gd * gd;
@@ -1107,8 +1129,8 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
             }
             const double refl = inten / gc / rel;                        // :90
             double rho = refl < 0.05 ? 0.05 : (refl > 1 ? 1 : refl);     // :109 np.clip(reflectivities, 0.05, 1)
-            const Fresnel aw = fresnel_power(ang, 1.0003, 1.33);         // phy_equations.py:81
-            const Fresnel wa = fresnel_power(aw.aout, 1.33, 1.0003);     // :83
+            const Fresnel aw = fresnel_power(gs, gc, 1.0003, 1.33);      // phy_equations.py:81
+            const Fresnel wa = fresnel_power(aw.s_out, aw.c_out, 1.33, 1.0003);   // :83 (the angle inside the water)
             const double ts = aw.ts * rho * wa.ts / (1 - rho * wa.rs);   // :86
             const double tp = aw.tp * rho * wa.tp / (1 - rho * wa.rp);   // :89
             const double t = fmax(tp, ts);                               // augmentation.py:119
@@ -1137,22 +1159,33 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
     }
 }
 
-__global__ void k_wet_scan(WetArgs w)
+// per frame: tile offsets of the two output runs ([non-ground ; kept ground], augmentation.py:147-150).  One WAVE per frame: lane l takes
+// tiles l, l + 64, .. (a thread per frame walked its 128 tiles twice, load after load: 52 us of a 256-sweep step).
+__global__ __launch_bounds__(64) void k_wet_scan(WetArgs w)
 {
     const PreArgs &a = w.p;
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= a.n_frames) return;
+    const int f = blockIdx.x, lane = threadIdx.x;
     const int64_t n = pre_rows(a, f);
     const int64_t tiles = (n + SG_TILE - 1) / SG_TILE;
+    const int32_t *c = w.tile_cnt + (int64_t)f * a.max_tiles * 2;
+    int32_t *b = w.tile_base + (int64_t)f * a.max_tiles * 2;
     int na = 0, nb = 0;
-    for (int64_t t = 0; t < tiles; ++t) {
-        const int32_t *c = w.tile_cnt + ((int64_t)f * a.max_tiles + t) * 2;
-        int32_t *b = w.tile_base + ((int64_t)f * a.max_tiles + t) * 2;
-        b[0] = na; b[1] = nb; na += c[0]; nb += c[1];
+    for (int64_t t0 = 0; t0 < tiles; t0 += 64) {
+        const int64_t t = t0 + lane;
+        const int ca = t < tiles ? c[2 * t] : 0, cb = t < tiles ? c[2 * t + 1] : 0;
+        int ia = ca, ib = cb;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int x = __shfl_up(ia, o), y = __shfl_up(ib, o);
+            if (lane >= o) { ia += x; ib += y; }
+        }
+        if (t < tiles) { b[2 * t] = na + ia - ca; b[2 * t + 1] = nb + ib - cb; }
+        na += __shfl(ia, 63); nb += __shfl(ib, 63);
     }
-    for (int64_t t = 0; t < tiles; ++t) w.tile_base[((int64_t)f * a.max_tiles + t) * 2 + 1] += na;   // ground after non-ground
-    w.out_counts[f] = na + nb;
-    w.out_flags[f] = a.fr[f].unchanged;
+    for (int64_t t = lane; t < tiles; t += 64) b[2 * t + 1] += na;                    // ground after non-ground (same lane wrote it)
+    if (lane == 0) {
+        w.out_counts[f] = na + nb;
+        w.out_flags[f] = a.fr[f].unchanged;
+    }
 }
 
 template <typename T>
@@ -1197,7 +1230,7 @@ __global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
                 if (c[q] == 2) lab = 1.0;                                // :159
             }
             d[4] = lab;
-            w.out_src[dst] = (int32_t)(r - base);
+            w.out_src[dst] = w.src_first ? w.src_first[r] : (int32_t)(r - base);
         }
         for (int k = 0; k < 2; ++k) run[k] += wc[q][0][k] + wc[q][1][k] + wc[q][2][k] + wc[q][3][k];
     }
@@ -1474,12 +1507,12 @@ extern "C" int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, cons
     w.water_height = wp->water_height; w.pavement_depth = wp->pavement_depth; w.replace = wp->replace;
     w.cls = (uint8_t *)s->buf[B_CLS]; w.new_i = (double *)s->buf[B_NEWI];
     w.tile_cnt = (int32_t *)s->buf[B_TCNT]; w.tile_base = (int32_t *)s->buf[B_TBASE];
-    w.out_rows = out_rows; w.out_src = out_src; w.out_counts = out_counts; w.out_flags = out_flags;
+    w.out_rows = out_rows; w.out_src = out_src; w.out_counts = out_counts; w.out_flags = out_flags; w.src_first = wp->src_first;
     dim3 grid((unsigned)a.max_tiles, (unsigned)n_frames);
     if (dtype == 0) hipLaunchKernelGGL(k_wet_apply<float>, grid, dim3(PB), 0, st, w);
     else hipLaunchKernelGGL(k_wet_apply<double>, grid, dim3(PB), 0, st, w);
     LCHK();
-    hipLaunchKernelGGL(k_wet_scan, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, w);
+    hipLaunchKernelGGL(k_wet_scan, dim3((unsigned)n_frames), dim3(64), 0, st, w);
     LCHK();
     if (dtype == 0) hipLaunchKernelGGL(k_wet_scatter<float>, grid, dim3(PB), 0, st, w);
     else hipLaunchKernelGGL(k_wet_scatter<double>, grid, dim3(PB), 0, st, w);
