@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(PB) void k_wet_apply(WetArgs w)
             cls = (v > lim) ? 2 : 0;                                     // :146
         }
         w.cls[base + r] = cls;
-        w.new_i[base + r] = ni;
+        if (cls == 2) w.new_i[base + r] = ni;                            // (read back for kept ground rows only: k_wet_scatter)
         cnt_a += cls == 1; cnt_b += cls == 2;
     }
     __shared__ int sa[4], sb[4];
@@ -1213,24 +1213,36 @@ __global__ __launch_bounds__(PB) void k_wet_scatter(WetArgs w)
     __syncthreads();
     const int32_t *tb = w.tile_base + ((int64_t)f * a.max_tiles + blockIdx.x) * 2;
     int run[2] = {tb[0], tb[1]};
+    // every load of the thread's four rows before the first store (the argument struct carries no `restrict`: behind a store to out_rows the
+    // compiler may not start the next row's loads, and the kernel was a chain of four round trips per thread: 0.59 ms per 256 sweeps)
+    T sx[4], sy[4], sz[4], si[4], sl[4];
+    double nw[4];
+    int32_t sf[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t r = base + tile0 + q * PB + tid;
+        const T *s = rows + (c[q] ? r : base) * 5;
+        sx[q] = s[0]; sy[q] = s[1]; sz[q] = s[2]; si[q] = s[3]; sl[q] = s[4];
+        nw[q] = c[q] == 2 ? w.new_i[r] : 0.0;
+        sf[q] = (c[q] && w.src_first) ? w.src_first[r] : (int32_t)(r - base);
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (c[q]) {
             const int k = c[q] - 1;
             int off = run[k];
             for (int ww = 0; ww < wv; ++ww) off += wc[q][ww][k];
-            const int64_t r = base + tile0 + q * PB + tid;
             const int64_t dst = base + off + pre[q];
-            const T *s = rows + r * 5;
             double *d = w.out_rows + dst * 5;
-            d[0] = (double)s[0]; d[1] = (double)s[1]; d[2] = (double)s[2];
-            d[3] = (c[q] == 2) ? w.new_i[r] : (double)s[3];              // augmentation.py:151-153
-            double lab = (double)s[4];
+            d[0] = (double)sx[q]; d[1] = (double)sy[q]; d[2] = (double)sz[q];
+            d[3] = (c[q] == 2) ? nw[q] : (double)si[q];                  // augmentation.py:151-153
+            double lab = (double)sl[q];
             if (!unchanged) {
                 if (w.replace) lab = 0.0;                                // :155-156
                 if (c[q] == 2) lab = 1.0;                                // :159
             }
             d[4] = lab;
-            w.out_src[dst] = w.src_first ? w.src_first[r] : (int32_t)(r - base);
+            w.out_src[dst] = sf[q];
         }
         for (int k = 0; k < 2; ++k) run[k] += wc[q][0][k] + wc[q][1][k] + wc[q][2][k] + wc[q][3][k];
     }
