@@ -166,8 +166,9 @@ def main():
         orders.append(o)
     fb = FlatBatch(pin_in, off)
 
-    def py_batch(**kw):
-        augment_batch(fb, "unused", bench.BEAM_DIV, particles=tables, orders=orders, **kw)
+    def py_batch(warm=1, **kw):
+        for _ in range(warm):
+            augment_batch(fb, "unused", bench.BEAM_DIV, particles=tables, orders=orders, **kw)
         t0 = time.perf_counter()
         for _ in range(args.reps):
             augment_batch(fb, "unused", bench.BEAM_DIV, particles=tables, orders=orders, **kw)
@@ -178,7 +179,9 @@ def main():
     py_lsq = py_batch(plane_method="lsq")
     # q8='numpy': the histogram's row minima from THIS process' NumPy (quirk Q8); the device makes histogram and sums (prepass_stats),
     # the rows cross the link twice
-    py_q8 = py_batch(planes=[([0.0, 0.0, -1.0], -1.7)] * F, q8="numpy")
+    # (six untimed calls first: the selection's thread pool, its per-thread scratch and the allocator's thresholds for NumPy's 1 MB index
+    # arrays settle over the first few calls -- scripts/probe/q8_group_probe.py shows the first timed run of a process 20 % below the later ones)
+    py_q8 = py_batch(warm=6, planes=[([0.0, 0.0, -1.0], -1.7)] * F, q8="numpy")
     # one sweep end to end through the C ABI (page-locked) and through the Python augment() (pageable input)
     one_off = np.array([0, n_per], np.int64)
 
