@@ -66,6 +66,12 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 // List views: element j of this thread's private array lives at base[j * stride + tid] -- LDS, strided by the block
 // size (STRIDE > 0, a compile-time constant), or global memory strided by the lane count of the global-list tier
 // (STRIDE == 0: run-time stride `rstride`).
+#ifndef SG_DICT_SWEEP
+#define SG_DICT_SWEEP 8      /* list capacities up to this one build the dict from sorted endpoints (0: the walk everywhere).  Same box, ms per
+                                256 sweeps, 0 / 4 / 8 / 16: C2 3.99 / 3.95 / 3.92 / 3.95, C2far 8.37 / 8.36 / 8.24 / 8.36, C1 7.78 / 7.77 / 7.65 / 7.85 -- at 16
+                                entries the intervals no longer fit in registers beside the 34 endpoints and the owner test reads LDS again */
+#endif
+#include "sg_sortnet.h"
 #define SG_IDX(j) ((STRIDE) ? ((j) * (STRIDE) + tid) : (int)((long long)(j) * rstride + tid))
 #define SG_A1(j) s_a1[SG_IDX(j)]
 #define SG_A2(j) s_a2[SG_IDX(j)]
@@ -565,6 +571,47 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
     unsigned long long cnt = 0;
     if constexpr (HUGE_TIER) for (int j = 0; j < L; ++j) SG_RATIO(j) = -1.0;
     acc.reset();
+#if SG_DICT_SWEEP
+    if constexpr (!HUGE_TIER && LMAX <= SG_DICT_SWEEP) {
+        // The same slots, left to right, without the walk's search for the next endpoint: the 2 LMAX + 2 endpoints (unused list entries
+        // and nothing else stand in as e_max) sorted once by a fixed compare-exchange network in registers (sg_sortnet.h), then every
+        // pair of neighbours that differ is a slot [e, nxt) -- np.unique's (:265) --, its owner the first list entry that covers it
+        // (:284).  Every lane runs the same instructions whatever its list: the walk's trip count varied from lane to lane.
+        constexpr int NE = 2 * LMAX + 2;
+        constexpr bool IN_REGS = LMAX <= 8;                     // the intervals too stay in registers for the owner test (32 of them at 8 entries)
+        double s[NE];
+        [[maybe_unused]] double qa[IN_REGS ? LMAX : 1], qb[IN_REGS ? LMAX : 1];
+#pragma unroll
+        for (int q = 0; q < LMAX; ++q) {
+            const double q1 = SG_A1(q), q2 = SG_A2(q);
+            s[2 * q] = q < L ? q1 : e_max; s[2 * q + 1] = q < L ? q2 : e_max;
+            if constexpr (IN_REGS) { qa[q] = q < L ? q1 : INFINITY; qb[q] = q2; }     // (an unused entry covers nothing)
+        }
+        s[2 * LMAX] = ra; s[2 * LMAX + 1] = la;
+        sg_sort_net<NE>(s);
+#pragma unroll
+        for (int i = 0; i + 1 < NE; ++i) {
+            const double e = s[i], nxt = s[i + 1];
+            if (!(e < nxt)) continue;                           // equal neighbours: one endpoint
+            int own = -1;
+            if constexpr (IN_REGS) {
+#pragma unroll
+                for (int q = LMAX - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = q;      // nearest flake covering the slot (:284)
+            } else {
+                for_entries([&](int q, double q1, double q2) {
+                    if (own < 0 && q1 <= e && e < q2) own = q;
+                });
+            }
+            const double w = nxt - e;
+            if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)
+            else {
+                const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
+                SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
+                if (c < 8) cnt += 1ull << (4 * own);
+            }
+        }
+    } else
+#endif
     {
         double e = e_min;
         while (e < e_max) {

@@ -895,3 +895,15 @@ def test_line_fit_of_the_threshold_callback_is_numpy_s_own():
         ref = linregress(x, y)
         slope, intercept = _linregress_line(x, y)
         assert slope == ref.slope and intercept == ref.intercept, (trial, n)
+
+
+def test_sorting_networks_of_the_dict_are_the_generator_s_and_sort():
+    """csrc/sg_sortnet.h is what scripts/gen_sortnet.py writes (nothing edited by hand), and its comparator lists sort: every 0 / 1 input of 10
+    and 18 values (the zero-one principle), random inputs with ties for 34."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    import gen_sortnet as gen
+    assert (ROOT / "lidar_snow_sim_amd" / "csrc" / "sg_sortnet.h").read_text() == gen.header_text()
+    for n in gen.SIZES:
+        net = gen.network(n)
+        assert all(0 <= i < j < n for i, j in net)
+        gen.check(n, net)
