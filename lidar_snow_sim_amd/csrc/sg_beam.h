@@ -67,9 +67,10 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 // size (STRIDE > 0, a compile-time constant), or global memory strided by the lane count of the global-list tier
 // (STRIDE == 0: run-time stride `rstride`).
 #ifndef SG_DICT_SWEEP
-#define SG_DICT_SWEEP 8      /* list capacities up to this one build the dict from sorted endpoints (0: the walk everywhere).  Same box, ms per
-                                256 sweeps, 0 / 4 / 8 / 16: C2 3.99 / 3.95 / 3.92 / 3.95, C2far 8.37 / 8.36 / 8.24 / 8.36, C1 7.78 / 7.77 / 7.65 / 7.85 -- at 16
-                                entries the intervals no longer fit in registers beside the 34 endpoints and the owner test reads LDS again */
+#define SG_DICT_SWEEP 16     /* list capacities up to this one build the dict from sorted endpoints (0: the walk everywhere).  Same box, ms per
+                                256 sweeps, 0 / 4 / 8: C2 3.99 / 3.95 / 3.92, C2far 8.37 / 8.36 / 8.24, C1 7.78 / 7.77 / 7.65; 8 / 16 with the 16-entry
+                                kernel held to two waves per SIMD (SG_KP_WAVES_TIERS = 2: 59 registers spilled): C2 3.96 / 3.94, C2far 8.27 / 7.66,
+                                C1 7.71 / 7.49, C4 18.23 / 18.15 -- at one wave per SIMD (no spills) C2far loses instead: 8.71 */
 #endif
 #include "sg_sortnet.h"
 #define SG_IDX(j) ((STRIDE) ? ((j) * (STRIDE) + tid) : (int)((long long)(j) * rstride + tid))
@@ -578,29 +579,52 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         // pair of neighbours that differ is a slot [e, nxt) -- np.unique's (:265) --, its owner the first list entry that covers it
         // (:284).  Every lane runs the same instructions whatever its list: the walk's trip count varied from lane to lane.
         constexpr int NE = 2 * LMAX + 2;
-        constexpr bool IN_REGS = LMAX <= 8;                     // the intervals too stay in registers for the owner test (32 of them at 8 entries)
+        // The owner test reads the intervals from registers: all of them at up to 8 entries (32 registers), eight at a time beyond that --
+        // a first round leaves, per slot, the nearest covering entry among the first eight in five bits of three 64-bit words, the second
+        // round looks among the rest only where the first found none, and adds the slots up (in slot order, as ever).
+        constexpr int HALF = LMAX <= 8 ? LMAX : 8;
+        static_assert(LMAX <= 8 || LMAX == 16, "two rounds of eight entries");
         double s[NE];
-        [[maybe_unused]] double qa[IN_REGS ? LMAX : 1], qb[IN_REGS ? LMAX : 1];
+        double qa[HALF], qb[HALF];
 #pragma unroll
         for (int q = 0; q < LMAX; ++q) {
             const double q1 = SG_A1(q), q2 = SG_A2(q);
             s[2 * q] = q < L ? q1 : e_max; s[2 * q + 1] = q < L ? q2 : e_max;
-            if constexpr (IN_REGS) { qa[q] = q < L ? q1 : INFINITY; qb[q] = q2; }     // (an unused entry covers nothing)
+            if (q < HALF) { qa[q] = q < L ? q1 : INFINITY; qb[q] = q2; }              // (an unused entry covers nothing)
         }
         s[2 * LMAX] = ra; s[2 * LMAX + 1] = la;
         sg_sort_net<NE>(s);
+        [[maybe_unused]] unsigned long long first8[3] = {0ull, 0ull, 0ull};           // 5 bits per slot: 0 .. 7, or 31 = none of the first eight
+        if constexpr (LMAX > 8) {
+#pragma unroll
+            for (int i = 0; i + 1 < NE; ++i) {
+                const double e = s[i];
+                unsigned own = 31u;
+#pragma unroll
+                for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = (unsigned)q;
+                first8[i / 12] |= (unsigned long long)own << (5 * (i % 12));
+            }
+#pragma unroll
+            for (int q = 0; q < HALF; ++q) {
+                const double q1 = SG_A1(HALF + q), q2 = SG_A2(HALF + q);
+                qa[q] = HALF + q < L ? q1 : INFINITY; qb[q] = q2;
+            }
+        }
 #pragma unroll
         for (int i = 0; i + 1 < NE; ++i) {
             const double e = s[i], nxt = s[i + 1];
             if (!(e < nxt)) continue;                           // equal neighbours: one endpoint
             int own = -1;
-            if constexpr (IN_REGS) {
+            if constexpr (LMAX > 8) {
+                const unsigned f8 = (unsigned)(first8[i / 12] >> (5 * (i % 12))) & 31u;
+                if (f8 != 31u) own = (int)f8;
+                else {
 #pragma unroll
-                for (int q = LMAX - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = q;      // nearest flake covering the slot (:284)
+                    for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = HALF + q;
+                }
             } else {
-                for_entries([&](int q, double q1, double q2) {
-                    if (own < 0 && q1 <= e && e < q2) own = q;
-                });
+#pragma unroll
+                for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = q;      // nearest flake covering the slot (:284)
             }
             const double w = nxt - e;
             if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)

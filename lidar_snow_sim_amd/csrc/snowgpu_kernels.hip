@@ -40,7 +40,10 @@
 #define SG_KP_THREE_MIN 8     /* (the 4-entry k_power gains no occupancy from it -- it takes half of each CU by design -- and pays for the ranges' second trip: 5.17 vs 4.90 ms per C2 step) */
 #endif
 #ifndef SG_KP_WAVES_TIERS
-#define SG_KP_WAVES_TIERS 1   /* waves per SIMD the 8- and 16-entry k_power are compiled for: 2 and 3 (<= 168 VGPRs, a few spilled) measured the same */
+#define SG_KP_WAVES_TIERS 2   /* waves per SIMD the 8- and 16-entry k_power are compiled for.  With the dict's endpoints sorted in registers (sg_beam.h:
+                                 SG_DICT_SWEEP) the 16-entry kernel wants 315 registers: held to 256 -- 59 spilled, 204 B of scratch per lane -- it keeps
+                                 its two waves per SIMD and C2far gains 7 %; left alone it drops to one wave and C2far loses 5 %.  (Round 5, before that
+                                 dict: 1, 2 and 3 measured the same) */
 #endif
 #ifndef SG_KP_WAVES
 #define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
