@@ -69,7 +69,7 @@ __device__ __forceinline__ int sg_bin_of(double theta, double inv_w, int nb)
 #ifndef SG_DICT_SWEEP
 #define SG_DICT_SWEEP 16     /* list capacities up to this one build the dict from sorted endpoints (0: the walk everywhere).  Same box, ms per
                                 256 sweeps, 0 / 4 / 8: C2 3.99 / 3.95 / 3.92, C2far 8.37 / 8.36 / 8.24, C1 7.78 / 7.77 / 7.65; 8 / 16 with the 16-entry
-                                kernel held to two waves per SIMD (SG_KP_WAVES_TIERS = 2: 59 registers spilled): C2 3.96 / 3.94, C2far 8.27 / 7.66,
+                                kernel held to two waves per SIMD (SG_KP_WAVES_TIERS = 2: 18 registers spilled): C2 3.96 / 3.94, C2far 8.27 / 7.66,
                                 C1 7.71 / 7.49, C4 18.23 / 18.15 -- at one wave per SIMD (no spills) C2far loses instead: 8.71 */
 #endif
 #include "sg_sortnet.h"
@@ -580,8 +580,9 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         // (:284).  Every lane runs the same instructions whatever its list: the walk's trip count varied from lane to lane.
         constexpr int NE = 2 * LMAX + 2;
         // The owner test reads the intervals from registers: all of them at up to 8 entries (32 registers), eight at a time beyond that --
-        // a first round leaves, per slot, the nearest covering entry among the first eight in five bits of three 64-bit words, the second
-        // round looks among the rest only where the first found none, and adds the slots up (in slot order, as ever).
+        // a first round gives every slot one of the first eight entries covers to the nearest of them and marks it, the second round looks
+        // among the other eight for the slots left and sends what nobody covers to the hard target.  Each owner's slots, and the hard
+        // target's, still arrive in slot order: an owner belongs to one round.
         constexpr int HALF = LMAX <= 8 ? LMAX : 8;
         static_assert(LMAX <= 8 || LMAX == 16, "two rounds of eight entries");
         double s[NE];
@@ -594,15 +595,22 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         }
         s[2 * LMAX] = ra; s[2 * LMAX + 1] = la;
         sg_sort_net<NE>(s);
-        [[maybe_unused]] unsigned long long first8[3] = {0ull, 0ull, 0ull};           // 5 bits per slot: 0 .. 7, or 31 = none of the first eight
+        // one slot to its owner's running sum (the ratio column; 4 bits of `cnt` count the owner's slots, saturating at 8)
+        auto credit = [&](int own, double w) {
+            const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
+            SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
+            if (c < 8) cnt += 1ull << (4 * own);
+        };
+        [[maybe_unused]] unsigned long long claimed = 0ull;       // 16 entries: the slots the first round gave to one of the first eight
         if constexpr (LMAX > 8) {
 #pragma unroll
             for (int i = 0; i + 1 < NE; ++i) {
-                const double e = s[i];
-                unsigned own = 31u;
+                const double e = s[i], nxt = s[i + 1];
+                if (!(e < nxt)) continue;
+                int own = -1;
 #pragma unroll
-                for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = (unsigned)q;
-                first8[i / 12] |= (unsigned long long)own << (5 * (i % 12));
+                for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = q;
+                if (own >= 0) { credit(own, nxt - e); claimed |= 1ull << i; }
             }
 #pragma unroll
             for (int q = 0; q < HALF; ++q) {
@@ -614,25 +622,13 @@ __device__ __forceinline__ int sg_beam_dict(int L, double theta_c, double d, dou
         for (int i = 0; i + 1 < NE; ++i) {
             const double e = s[i], nxt = s[i + 1];
             if (!(e < nxt)) continue;                           // equal neighbours: one endpoint
+            if constexpr (LMAX > 8) { if ((claimed >> i) & 1ull) continue; }
             int own = -1;
-            if constexpr (LMAX > 8) {
-                const unsigned f8 = (unsigned)(first8[i / 12] >> (5 * (i % 12))) & 31u;
-                if (f8 != 31u) own = (int)f8;
-                else {
 #pragma unroll
-                    for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = HALF + q;
-                }
-            } else {
-#pragma unroll
-                for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = q;      // nearest flake covering the slot (:284)
-            }
+            for (int q = HALF - 1; q >= 0; --q) if (qa[q] <= e && e < qb[q]) own = (LMAX > 8 ? HALF : 0) + q;   // nearest flake covering the slot (:284)
             const double w = nxt - e;
             if (own < 0) acc.push(w);                           // nobody claimed it: hard target (:292-293)
-            else {
-                const unsigned c = (unsigned)(cnt >> (4 * own)) & 15u;
-                SG_RATIO(own) = c ? SG_RATIO(own) + w : w;
-                if (c < 8) cnt += 1ull << (4 * own);
-            }
+            else credit(own, w);
         }
     } else
 #endif

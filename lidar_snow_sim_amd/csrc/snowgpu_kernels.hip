@@ -41,7 +41,7 @@
 #endif
 #ifndef SG_KP_WAVES_TIERS
 #define SG_KP_WAVES_TIERS 2   /* waves per SIMD the 8- and 16-entry k_power are compiled for.  With the dict's endpoints sorted in registers (sg_beam.h:
-                                 SG_DICT_SWEEP) the 16-entry kernel wants 315 registers: held to 256 -- 59 spilled, 204 B of scratch per lane -- it keeps
+                                 SG_DICT_SWEEP) the 16-entry kernel wants more than 256 registers: held to 256 -- 18 spilled, 44 B of scratch per lane -- it keeps
                                  its two waves per SIMD and C2far gains 7 %; left alone it drops to one wave and C2far loses 5 %.  (Round 5, before that
                                  dict: 1, 2 and 3 measured the same) */
 #endif
