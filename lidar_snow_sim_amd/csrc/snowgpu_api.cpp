@@ -238,6 +238,7 @@ struct snowgpu_ctx {
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};     // snowgpu_lane_stream: one per priority level, made on demand
+    int prepass_with_few = -1;        // SNOWGPU_PREPASS_WITH_FEW=0 / 1: never / always start the prepass beside k_power_few (default: long-tail batches only)
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
     DevBuf<uint16_t> rank;
@@ -429,6 +430,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
     { const char *v = std::getenv("SNOWGPU_HEAVY_TAIL"); ctx->heavy_tail = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_PREPASS_WITH_FEW"); ctx->prepass_with_few = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_KP_ALL"); if (v) ctx->kp_all = v[0] != '0'; }
     { const char *v = std::getenv("SNOWGPU_KP_ALL_WAVES"); if (v) ctx->kp_all_waves = std::min(std::max(std::atoi(v), 1), 8); }
     { const char *v = std::getenv("SNOWGPU_KP_ALL_TICKET"); if (v) ctx->kp_all_ticket = v[0] == '1'; }
@@ -1119,6 +1121,12 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             // k_tier_gather stays BEHIND this wait although it needs nothing of k_power_few: with it ahead the tiers and the prepass start
             // the moment k_power_few ends, together with k_power<4>, and take the CUs its persistent blocks would have taken -- 4.43 - 4.49
             // against 4.22 - 4.24 ms per step on one box (round 5); the 30 us it costs give k_power<4> its head start.
+            // Long-tail batches (heavy_tail: the 63-entry chain outlasts everything) start the prepass beside k_power_few instead of behind
+            // it: with the chain and three persistent kernels on the chip its small kernels wait for CUs (C1: k_pre_mean32 1.1 ms, k_lean_gather
+            // 0.11 ms) and stand in the chain's way -- C1 7.39 -> 7.14 ms; where the tail is short the prepass is better off behind
+            // k_power_few (C2 3.91 -> 3.95 the other way, C2far the same).  SNOWGPU_PREPASS_WITH_FEW=0 / 1 overrides.
+            const bool pre_with_few = R->prepass_with_few < 0 ? heavy_tail : R->prepass_with_few == 1;
+            if (pre_with_few && few_first && !kp_all && !b.thr_poly && !b.defer_thr && !pre_forked) { int prc = launch_prepass(); if (prc) return prc; }
             if (few_first && !kp_all) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->ev_few, 0));
             if (!kp_all) e = sg_launch_tier_gather(&a, st);
         }

@@ -517,11 +517,16 @@ def test_long_tail_order_of_the_received_power_phase_changes_no_byte(monkeypatch
     rows = np.concatenate(frames)
     assert rows.shape[0] > (1 << 19)
     results = []
-    for v in ("0", "1", None):
+    for v in ("0", "1", None, "0+prepass", "1-prepass"):
+        # ("0+prepass" / "1-prepass": the prepass beside k_power_few -- the long-tail order's companion -- forced on in the short-tail order and
+        # off in the long-tail one: SNOWGPU_PREPASS_WITH_FEW)
+        monkeypatch.delenv("SNOWGPU_PREPASS_WITH_FEW", raising=False)
         if v is None:
             monkeypatch.delenv("SNOWGPU_HEAVY_TAIL", raising=False)
         else:
-            monkeypatch.setenv("SNOWGPU_HEAVY_TAIL", v)
+            monkeypatch.setenv("SNOWGPU_HEAVY_TAIL", v[0])
+            if len(v) > 1:
+                monkeypatch.setenv("SNOWGPU_PREPASS_WITH_FEW", "1" if v[1] == "+" else "0")
         e = engine.Engine(0)
         try:
             tids = [e.table_ids_from_arrays(tl, o) for o in orders]
