@@ -992,13 +992,41 @@ __device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
 }
 
-// lines and (unless the frame needs NumPy's float32 mean first) the quadratic, one thread per frame, after k_pre_rowmin (large batches)
+// lines and (unless the frame needs NumPy's float32 mean first) the quadratic after k_pre_rowmin (large batches).  One WAVE per frame: the
+// lanes fetch the frame's 50 row minima in one round and squeeze out the rows without one (augmentation.py:238) by a ballot, in row order,
+// into LDS; lane 0 then runs the fits on them -- lean_lines_frame's statements.  (A thread per frame read the minima one after the other,
+// 50 round trips, into arrays that lived in scratch memory: 46 us at the end of the prepass chain, which ends the step's side branch.)
 __global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f32, double *thr_poly)
 {
-    const int f = blockIdx.x * 64 + threadIdx.x;
+    const int f = blockIdx.x, lane = threadIdx.x;
     if (f >= a.n_frames) return;
-    lean_lines_frame(a, f, xmean_f32);
-    if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
+    __shared__ double xs[HX], ys[HX];
+    static_assert(HX <= 64, "one lane per range row");
+    const double mv = lane < HX ? a.rowmin[(int64_t)f * HX + lane] : 0.0;
+    const bool keep = lane < HX && mv > 5;                               // augmentation.py:238
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+        const double xstep = (70.0 - 10.0) / HX;
+        const double e0 = (double)lane * xstep + 10.0;
+        const double e1 = (lane + 1 == HX) ? 70.0 : (double)(lane + 1) * xstep + 10.0;
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        xs[pos] = (e0 + e1) / 2; ys[pos] = mv;                           // :240-241
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    const int m = __popcll(mask);
+    PreFrame &fr = a.fr[f];
+    const double ng = fr.n_ground;
+    double slope = 0, icpt = 0;
+    if (ng >= 3) {
+        slope = (fr.sxy / ng) / (fr.sxx / ng);                           // scipy linregress: ssxym / ssxm
+        const double xm = xmean_f32 ? fr.xmean32 : fr.xmean;             // np.mean of a float32 column is a float32 (augmentation.py:216)
+        icpt = fr.ymean - slope * xm;
+    }
+    fr.p0 = slope; fr.p1 = icpt;
+    if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
+    else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
+    if (!fr.need_mean32) lean_solve_frame(a, f, thr_poly);
 }
 
 // Small batches (up to 16 frames: bound by their chain of dependent launches): row minima of a frame's histogram (one block per range
@@ -1384,7 +1412,7 @@ static int lean_run(SgPrepassScratch *s, const void *rows, int dtype, const int6
     } else {
         hipLaunchKernelGGL(k_pre_rowmin, dim3(HX, (unsigned)n_frames), dim3(PB), 0, st, a);
         LCHK();
-        hipLaunchKernelGGL(k_lean_lines_solve, dim3((unsigned)((n_frames + 63) / 64)), dim3(64), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
+        hipLaunchKernelGGL(k_lean_lines_solve, dim3((unsigned)n_frames), dim3(64), 0, st, a, dtype == 0 ? 1 : 0, thr_poly);
         LCHK();
     }
     if (dtype == 0) {
