@@ -460,7 +460,23 @@ __global__ __launch_bounds__(64) void k_pre_lines(PreArgs a, int xmean_f32)
     const int cols[2] = {4, 5};
     double mom[2];
     frame_sums<2>(a.part + (int64_t)f * a.max_tiles * 12, tiles, cols, mom);
+    // min_vals > 5 (augmentation.py:238), x = centres of the surviving range rows (:240-241): the lanes fetch the 50 row minima in one round
+    // and squeeze them, in row order, into LDS by a ballot (thread 0 reading them one after the other into scratch arrays: 37 us)
+    __shared__ double xs[HX], ys[HX];
+    const int lane = threadIdx.x;
+    const double mv = lane < HX ? a.rowmin[(int64_t)f * HX + lane] : 0.0;
+    const bool keep = lane < HX && mv > 5;
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+        const double xstep = (70.0 - 10.0) / HX;
+        const double e0 = (double)lane * xstep + 10.0;
+        const double e1 = (lane + 1 == HX) ? 70.0 : (double)(lane + 1) * xstep + 10.0;
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        xs[pos] = (e0 + e1) / 2; ys[pos] = mv;
+    }
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    const int m = __popcll(mask);
     const double sxx = mom[0], sxy = mom[1];
     const double ng = fr.n_ground;
     double slope = 0, icpt = 0;
@@ -471,18 +487,6 @@ __global__ __launch_bounds__(64) void k_pre_lines(PreArgs a, int xmean_f32)
         icpt = fr.ymean - slope * xm;
     }
     fr.p0 = slope; fr.p1 = icpt;
-    // min_vals > 5 (augmentation.py:238), x = centres of the surviving range rows (:240-241)
-    double xs[HX], ys[HX];
-    int m = 0;
-    const double xstep = (70.0 - 10.0) / HX;
-    for (int r = 0; r < HX; ++r) {
-        const double mv = a.rowmin[(int64_t)f * HX + r];
-        if (mv > 5) {
-            const double e0 = (double)r * xstep + 10.0;
-            const double e1 = (r + 1 == HX) ? 70.0 : (double)(r + 1) * xstep + 10.0;
-            xs[m] = (e0 + e1) / 2; ys[m] = mv; ++m;
-        }
-    }
     if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
     else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
 }
