@@ -996,17 +996,18 @@ __device__ __forceinline__ void lean_solve_frame(const PreArgs &a, int f, double
     a.fr[f].poly[0] = out[0]; a.fr[f].poly[1] = out[1]; a.fr[f].poly[2] = out[2];
 }
 
-// lines and (unless the frame needs NumPy's float32 mean first) the quadratic after k_pre_rowmin (large batches).  One WAVE per frame: the
+// The two lines and (unless the frame needs NumPy's float32 mean first) the quadratic of one frame by ONE WAVE (all 64 lanes call it): the
 // lanes fetch the frame's 50 row minima in one round and squeeze out the rows without one (augmentation.py:238) by a ballot, in row order,
-// into LDS; lane 0 then runs the fits on them -- lean_lines_frame's statements.  (A thread per frame read the minima one after the other,
-// 50 round trips, into arrays that lived in scratch memory: 46 us at the end of the prepass chain, which ends the step's side branch.)
-__global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f32, double *thr_poly)
+// into LDS (xs, ys: HX doubles each); lane 0 then runs the fits on them -- lean_lines_frame's statements.  (A thread per frame read the
+// minima one after the other, 50 round trips, into arrays that lived in scratch memory: 46 us at the end of the prepass chain of a
+// 256-sweep step, which ends the step's side branch.)  VOL: the minima were written by other blocks of the running launch -- read past the L1.
+template <bool VOL>
+__device__ __forceinline__ void lean_lines_wave(const PreArgs &a, int f, int xmean_f32, double *xs, double *ys, double *thr_poly)
 {
-    const int f = blockIdx.x, lane = threadIdx.x;
-    if (f >= a.n_frames) return;
-    __shared__ double xs[HX], ys[HX];
     static_assert(HX <= 64, "one lane per range row");
-    const double mv = lane < HX ? a.rowmin[(int64_t)f * HX + lane] : 0.0;
+    const int lane = threadIdx.x & 63;
+    double mv = 0.0;
+    if (lane < HX) mv = VOL ? ((const volatile double *)a.rowmin)[(int64_t)f * HX + lane] : a.rowmin[(int64_t)f * HX + lane];
     const bool keep = lane < HX && mv > 5;                               // augmentation.py:238
     const unsigned long long mask = __ballot(keep);
     if (keep) {
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f3
         const int pos = __popcll(mask & ((1ull << lane) - 1ull));
         xs[pos] = (e0 + e1) / 2; ys[pos] = mv;                           // :240-241
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // written and read by the lanes of one wave: no barrier, but keep the order
     if (lane != 0) return;
     const int m = __popcll(mask);
     PreFrame &fr = a.fr[f];
@@ -1031,6 +1032,15 @@ __global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f3
     if (m > 3) small_linregress(xs, ys, m, fr.pmin0, fr.pmin1);         // augmentation.py:248-249
     else { fr.pmin0 = slope; fr.pmin1 = icpt; fr.need_mean32 = xmean_f32; }   // :250-251
     if (!fr.need_mean32) lean_solve_frame(a, f, thr_poly);
+}
+
+// ... after k_pre_rowmin (large batches): one wave per frame
+__global__ __launch_bounds__(64) void k_lean_lines_solve(PreArgs a, int xmean_f32, double *thr_poly)
+{
+    const int f = blockIdx.x;
+    if (f >= a.n_frames) return;
+    __shared__ double xs[HX], ys[HX];
+    lean_lines_wave<false>(a, f, xmean_f32, xs, ys, thr_poly);
 }
 
 // Small batches (up to 16 frames: bound by their chain of dependent launches): row minima of a frame's histogram (one block per range
@@ -1055,8 +1065,10 @@ __global__ __launch_bounds__(PB) void k_lean_rowmin_solve(PreArgs a, int xmean_f
         const int ob = __shfl_down(best, o), oi = __shfl_down(bidx, o);
         if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
     }
-    __shared__ int sb[4], si[4];
+    __shared__ int sb[4], si[4], s_last;
+    __shared__ double s_xs[HX], s_ys[HX];
     if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bidx; }
+    if (threadIdx.x == 0) s_last = 0;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
@@ -1064,12 +1076,11 @@ __global__ __launch_bounds__(PB) void k_lean_rowmin_solve(PreArgs a, int xmean_f
         const double step = (fr.ymax - 5.0) / HY;
         a.rowmin[(int64_t)f * HX + row] = (bidx == HY) ? fr.ymax : (double)bidx * step + 5.0;   // yedges[ymins] (:237)
         __threadfence();                                                     // the row's minimum before the count that announces it
-        if (atomicAdd(&fr.rows_done, 1) == HX - 1) {                         // this block completed the frame
-            __threadfence();
-            lean_lines_frame(a, f, xmean_f32);
-            if (!a.fr[f].need_mean32) lean_solve_frame(a, f, thr_poly);
-        }
+        s_last = atomicAdd(&fr.rows_done, 1) == HX - 1;                      // this block completed the frame
+        if (s_last) __threadfence();
     }
+    __syncthreads();
+    if (s_last && threadIdx.x < 64) lean_lines_wave<true>(a, f, xmean_f32, s_xs, s_ys, thr_poly);   // (one thread did this: 50 loads in a row)
 }
 
 // ================================================================================================================
