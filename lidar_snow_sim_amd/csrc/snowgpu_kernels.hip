@@ -31,7 +31,8 @@
 #define SG_FP_WAVES 6     /* waves per SIMD the pass over all rows is compiled for (<= 80 VGPRs; its LDS -- 19 KB per block -- would allow 8) */
 #endif
 #ifndef SG_NB_TIERS
-#define SG_NB_TIERS 8     /* ... and by the later tiers */
+#define SG_NB_TIERS 4     /* ... and by the later tiers (8 until the dict's endpoints moved into registers; since then, same box, 8 / 4 / 3 / 2:
+                             C2 3.96 / 3.90 / 3.93 / 3.93 ms, C2far 7.61 / 7.53 - 7.59 / 7.53 / 7.63, C1 7.21 / 7.16) */
 #endif
 #ifndef SG_KP_THREE_MAX
 #define SG_KP_THREE_MAX 16    /* k_power keeps three list columns in LDS (not four) for capacities SG_KP_THREE_MIN .. SG_KP_THREE_MAX; 0: never */
