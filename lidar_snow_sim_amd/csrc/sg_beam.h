@@ -292,6 +292,25 @@ __device__ __forceinline__ int sg_beam_scan(T px, T py, T pz, const SgTable tab,
     return L;
 }
 
+// The last 16 bytes of a record -- range, bin flag, source row -- as ONE load issued where sg_tail_load stands and pinned where
+// sg_tail_pin stands (a plain member read that only a branch uses is moved into that branch by the compiler, behind the wait for
+// what decides the branch: a second round trip).
+struct SgTail { double rho; uint32_t flags; };
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef unsigned int SgTailRaw __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ SgTailRaw sg_tail_load(const SG_GLOBAL SgEntry *fp) { return *reinterpret_cast<const SG_GLOBAL SgTailRaw *>(&fp->rho); }
+__device__ __forceinline__ SgTail sg_tail_pin(SgTailRaw v)
+{
+    asm volatile("" : "+v"(v));
+    SgTail t; t.rho = __hiloint2double((int)v.y, (int)v.x); t.flags = v.z;
+    return t;
+}
+#else
+typedef SgTail SgTailRaw;
+__device__ __forceinline__ SgTailRaw sg_tail_load(const SgEntry *fp) { SgTail t; t.rho = fp->rho; t.flags = fp->flags; return t; }
+__device__ __forceinline__ SgTail sg_tail_pin(SgTailRaw v) { return v; }
+#endif
+
 // COMPACT lists (sg_wave_scan): one word per intersecting flake instead of its two interval angles -- the record's index | bit 30: a limit
 // ray cuts the disk on the right | bit 31: on the left (geometry.py:26-27: that ray's angle then replaces the tangent angle)
 __device__ __forceinline__ uint32_t sg_hit_word(uint32_t e, bool hit_r, bool hit_l)
@@ -303,6 +322,30 @@ __device__ __forceinline__ void sg_hit_angles(uint32_t w, const SgEntry *__restr
     const SG_GLOBAL SgEntry *f = sg_gptr(entries) + (w & 0x3fffffffu);
     a1 = (w & 0x40000000u) ? theta_r : f->t0;                   // geometry.py:26
     a2 = (w & 0x80000000u) ? theta_l : f->t1;                   // geometry.py:27
+}
+
+// The same for a whole short list with ONE round of loads: the tangent angles of every listed record (16 bytes each, one load) are
+// requested before the first is used, whether the word's bits will want them or not -- with the loads under those bits the compiler
+// waited for each entry's pair before it asked for the next (four round trips for a four-entry list).  w[j], j >= L: any word (entry 0 is read).
+template <int N>
+__device__ __forceinline__ void sg_hit_angles_all(const uint32_t (&w)[N], int L, const SgEntry *__restrict__ entries, double theta_r, double theta_l,
+                                                  double (&a1)[N], double (&a2)[N])
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    SgTailRaw raw[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const SG_GLOBAL SgEntry *f = sg_gptr(entries) + (j < L ? (w[j] & 0x3fffffffu) : 0u);
+        raw[j] = *reinterpret_cast<const SG_GLOBAL SgTailRaw *>(&f->t0);
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        a1[j] = (w[j] & 0x40000000u) ? theta_r : __hiloint2double((int)raw[j].y, (int)raw[j].x);      // geometry.py:26
+        a2[j] = (w[j] & 0x80000000u) ? theta_l : __hiloint2double((int)raw[j].w, (int)raw[j].z);      // geometry.py:27
+    }
+#else
+    for (int j = 0; j < N; ++j) if (j < L) sg_hit_angles(w[j], entries, theta_r, theta_l, a1[j], a2[j]);
+#endif
 }
 
 // ---- the same scan, one WAVE for its 64 beams ---------------------------------------------------------------------------
@@ -346,18 +389,25 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
         const int b_nx = (b_lo + 1 == nb) ? 0 : b_lo + 1;
         const SG_GLOBAL uint32_t *g_start = sg_gptr(tab.bin_start);
         const SG_GLOBAL SgEntry *g_ent = sg_gptr(tab.entries);
-        st0 = g_start[b_lo];
-        uint32_t hi0 = g_start[b_lo + 1];
-        st2 = g_start[b_nx];
-        uint32_t hi1 = span >= 1 ? g_start[b_nx + 1] : st2;
-        uint32_t lo0 = st0, lo1 = st2;                          // records with rho < d: a prefix of each (sorted) bin
-        if (tab.bin_q) {   // the coarse range index brackets the prefix (counts below the multiples of SG_QSTEP_M around d): the search
+        // Bin starts and the coarse range index: EIGHT independent loads, every one issued before the first is used -- no load
+        // under a condition of its own (the compiler kept such a load behind a wait for the earlier ones: bin starts, then the
+        // second bin's end, then the index -- three round trips where the addresses need none of the loaded values).
+        const uint32_t s0 = g_start[b_lo], s0e = g_start[b_lo + 1], s1 = g_start[b_nx], s1e = g_start[b_nx + 1];
+        const bool has_q = tab.bin_q != nullptr;
+        uint32_t c0 = 0, c1 = 0, u0 = 0, u1 = 0;
+        int kk = 0;
+        if (has_q) {       // the coarse range index brackets the prefix (counts below the multiples of SG_QSTEP_M around d): the search
             // below then looks at the one or two records in between instead of halving the whole bin
             const double dq = g.d * (1.0 / SG_QSTEP_M);
-            const int kk = dq < (double)(SG_QSTEPS - 1) ? (int)dq : SG_QSTEPS - 1;
-            const SG_GLOBAL uint32_t *q0 = sg_gptr(tab.bin_q) + (size_t)b_lo * SG_QSTEPS + kk, *q1 = sg_gptr(tab.bin_q) + (size_t)b_nx * SG_QSTEPS + kk;
-            const uint32_t c0 = q0[0], c1 = q1[0];
-            const uint32_t u0 = kk < SG_QSTEPS - 1 ? q0[1] : 0u, u1 = kk < SG_QSTEPS - 1 ? q1[1] : 0u;
+            kk = dq < (double)(SG_QSTEPS - 1) ? (int)dq : SG_QSTEPS - 1;
+            const int k1 = kk < SG_QSTEPS - 1 ? kk + 1 : kk;      // (the last step has no upper count: its load repeats the lower one)
+            const SG_GLOBAL uint32_t *q0 = sg_gptr(tab.bin_q) + (size_t)b_lo * SG_QSTEPS, *q1 = sg_gptr(tab.bin_q) + (size_t)b_nx * SG_QSTEPS;
+            c0 = q0[kk]; u0 = q0[k1]; c1 = q1[kk]; u1 = q1[k1];
+        }
+        st0 = s0; st2 = s1;
+        uint32_t hi0 = s0e, hi1 = span >= 1 ? s1e : s1;
+        uint32_t lo0 = st0, lo1 = st2;                          // records with rho < d: a prefix of each (sorted) bin
+        if (has_q) {
             lo0 = st0 + c0;
             if (kk < SG_QSTEPS - 1) hi0 = st0 + u0;
             if (span >= 1) { lo1 = st2 + c1; if (kk < SG_QSTEPS - 1) hi1 = st2 + u1; }
@@ -405,10 +455,15 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
             sg_geo_limits(og, beam_div_deg);
             const SG_GLOBAL SgEntry *fp = sg_gptr(oent) + e;
             const double phi = fp->phi, fx = fp->x, fy = fp->y, fr = fp->r;         // the record's first half
+            // ... and its last 16 bytes (range, bin flag) in the SAME round of loads: read only by the half that intersect, they cost a
+            // second round trip per trip of this loop when they wait for the test's outcome (sg_tail_load / sg_tail_pin)
+            const SgTailRaw tl_raw = sg_tail_load(fp);
             bool und = false, hit_r, hit_l;
-            if (sg_flake_test<DEFER>(og, phi, fx, fy, fr, hit_r, hit_l, und)) {
-                const double rho = fp->rho;                                         // ... and, for the half that intersect, (part of) its second
-                const uint32_t flags = fp->flags;
+            const bool hit = sg_flake_test<DEFER>(og, phi, fx, fy, fr, hit_r, hit_l, und);
+            const SgTail tl = sg_tail_pin(tl_raw);
+            if (hit) {
+                const double rho = tl.rho;
+                const uint32_t flags = tl.flags;
                 if (!(j >= n0o && !(flags & 1u))) {                                 // a flake filed under both bins counts once
                     const int col = wbase + o;
                     const int pos = und ? LMAX + ov_cap : atomicAdd(&s_cnt[col], 1);

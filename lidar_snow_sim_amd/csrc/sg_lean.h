@@ -17,13 +17,37 @@ struct SgLeanTile {
     int64_t max_tiles;
 };
 
+// v + (v of the lane N places up in the same row of 16 lanes), N = 8, 4, 2, 1: a DPP move per half of the double instead of a
+// cross-lane read through the LDS pipeline.  What the lanes whose partner lies outside the row get is not used by the callers.
+template <int N>
+__device__ __forceinline__ double lean_row_shl(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, 0x100 | N, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x100 | N, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// wave reduction, the sum in lane 0: the tree of `v += __shfl_down(v, o)`, o = 32 .. 1, bit for bit (lane 0 adds the same pairs in
+// the same order); the four steps inside a row of 16 lanes as DPP moves
+__device__ __forceinline__ double lean_wave_sum(double v)
+{
+    v += __shfl_down(v, 32);
+    v += __shfl_down(v, 16);
+    v += lean_row_shl<8>(v);
+    v += lean_row_shl<4>(v);
+    v += lean_row_shl<2>(v);
+    v += lean_row_shl<1>(v);
+    return v;
+}
+
 // block reduction of K values in a fixed order: lanes -> waves -> thread 0 (256 threads)
 template <int K>
 __device__ __forceinline__ void lean_block_sum(double (&v)[K], double *smem /* 4 * K */)
 {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int k = 0; k < K; ++k)
-        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o);
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = lean_wave_sum(v[k]);
     __syncthreads();
     if (lane == 0) for (int k = 0; k < K; ++k) smem[w * K + k] = v[k];
     __syncthreads();
@@ -69,7 +93,8 @@ __device__ __forceinline__ void lean_tile_stats(const SgLeanTile &a, int f, int6
     }
     double *smax = sm + 52, *s_mean = sm + 56;
     lean_block_sum<3>(v, sm);
-    for (int o = 32; o > 0; o >>= 1) ymax = fmax(ymax, __shfl_down(ymax, o));
+    ymax = fmax(ymax, __shfl_down(ymax, 32)); ymax = fmax(ymax, __shfl_down(ymax, 16));
+    ymax = fmax(ymax, lean_row_shl<8>(ymax)); ymax = fmax(ymax, lean_row_shl<4>(ymax)); ymax = fmax(ymax, lean_row_shl<2>(ymax)); ymax = fmax(ymax, lean_row_shl<1>(ymax));
     if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = ymax;
     if (threadIdx.x == 0) { s_mean[0] = v[0] > 0 ? v[1] / v[0] : 0.0; s_mean[1] = v[0] > 0 ? v[2] / v[0] : 0.0; }
     __syncthreads();

@@ -507,9 +507,10 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
                 sg_beam_limits(theta_c, a.beam_div_deg, th_r, th_l);
                 if constexpr (LMAX <= 4) {
                     double x1[LMAX], x2[LMAX];
+                    uint32_t hw[LMAX];
 #pragma unroll
-                    for (int j = 0; j < LMAX; ++j)
-                        if (j < L) sg_hit_angles(reinterpret_cast<const uint32_t *>(s_a1)[j * BLOCK + tid], tab.entries, th_r, th_l, x1[j], x2[j]);
+                    for (int j = 0; j < LMAX; ++j) hw[j] = reinterpret_cast<const uint32_t *>(s_a1)[j * BLOCK + tid];
+                    sg_hit_angles_all<LMAX>(hw, L, tab.entries, th_r, th_l, x1, x2);
 #pragma unroll
                     for (int j = 0; j < LMAX; ++j)
                         if (j < L) {
