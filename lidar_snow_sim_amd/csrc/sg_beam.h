@@ -30,6 +30,55 @@
 #endif
 template <typename P> __device__ __forceinline__ const SG_GLOBAL P *sg_gptr(const P *p) { return (const SG_GLOBAL P *)p; }
 
+// Scans over the 64 lanes of a wave as DPP operations (row shifts inside a row of 16 lanes, then the last lane of a row broadcast to the
+// rows after it): six VALU instructions and no trip through the LDS pipeline, where `__shfl_up` costs a cross-lane read, a wait, a compare
+// and a select per step.  Every lane of the wave must be active.  The host harness runs waves of one lane: the identity.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int sg_dpp(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int sg_wave_incl_add(int v)          // inclusive prefix sum
+{
+    v += sg_dpp<0x111, 0xf>(0, v); v += sg_dpp<0x112, 0xf>(0, v); v += sg_dpp<0x114, 0xf>(0, v); v += sg_dpp<0x118, 0xf>(0, v);   // row_shr:1, 2, 4, 8
+    v += sg_dpp<0x142, 0xa>(0, v);                                   // row_bcast:15 into rows 1 and 3
+    v += sg_dpp<0x143, 0xc>(0, v);                                   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int sg_wave_incl_max(int v)          // inclusive prefix maximum
+{
+    constexpr int I = (int)0x80000000;
+    v = max(v, sg_dpp<0x111, 0xf>(I, v)); v = max(v, sg_dpp<0x112, 0xf>(I, v)); v = max(v, sg_dpp<0x114, 0xf>(I, v)); v = max(v, sg_dpp<0x118, 0xf>(I, v));
+    v = max(v, sg_dpp<0x142, 0xa>(I, v));
+    v = max(v, sg_dpp<0x143, 0xc>(I, v));
+    return v;
+}
+__device__ __forceinline__ int sg_wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }   // lane 63's value, in a scalar register
+#else
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int sg_dpp(int, int v) { return v; }
+__device__ __forceinline__ int sg_wave_incl_add(int v) { return v; }
+__device__ __forceinline__ int sg_wave_incl_max(int v) { return v; }
+__device__ __forceinline__ int sg_wave_last(int v) { return v; }
+#endif
+
+// Owner of pair p = base + lane when the lanes' beams hold [excl, incl) of the wave's pair numbers: the first lane whose inclusive count
+// exceeds p.  Every beam with pairs leaves its lane number at its first pair's place in the window (s_mark: one int per lane of the
+// block), a beam that began before the window leads it, and a prefix maximum carries the marks forward: two LDS writes, one read and
+// six DPP steps instead of a binary search of six dependent cross-lane reads.  Lanes past the wave's last pair get its last owner.
+__device__ __forceinline__ int sg_pair_owner(int *s_mark, int tid, int base, int excl, int incl)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = tid & 63, wbase = tid & ~63;
+    s_mark[tid] = -1;
+    asm volatile("" ::: "memory");
+    if (incl > excl && excl >= base && excl < base + 64) s_mark[wbase + (excl - base)] = lane;
+    asm volatile("" ::: "memory");
+    int m = ((volatile int *)s_mark)[tid];
+    const unsigned long long cm = __ballot(excl < base && base < incl);
+    if (lane == 0 && m < 0) m = cm ? __ffsll((long long)cm) - 1 : 0;
+    return sg_wave_incl_max(m) & 63;
+#else
+    return 0;
+#endif
+}
+
 // (beam, record) pairs a wave of sg_wave_scan takes per trip: its 64 lanes.  The host harness runs the scan as a wave of one lane
 // (tests/host_harness/wave_vs_lane.cpp) and sets 1.
 #ifndef SG_PAIR_WINDOW
@@ -356,7 +405,8 @@ __device__ __forceinline__ void sg_hit_angles_all(const uint32_t (&w)[N], int L,
 // pairs at a time whichever beams they belong to -- the owner's geometry travels by cross-lane reads.  A hit is appended to
 // its owner's list through an LDS counter; every beam sorts its few entries by (range, scan order) afterwards, which is the
 // order the per-lane scan produces.  Bins beyond the second (wedges wider than a bin) keep the per-lane loop.
-// s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries); s_st: two ints per lane.
+// s_cnt: one int per lane of the block; s_key: LMAX ints per lane (the scan order of the stored entries); s_st: two ints per lane; s_mark: one
+// int per lane (sg_pair_owner; the host harness passes none).
 // DEFER (the pass over all rows in the default arithmetic): a beam one of whose distance tests falls inside the band of
 // sg_near_ray is not decided here: SG_HITS_UNDECIDED is set in its flake count (with `overflow`), nothing is kept of its list, and the
 // caller sends it to the global-list tier, whose scan carries the reference's expression.  About one test in 1e8 on ordinary input.
@@ -367,7 +417,7 @@ __device__ __forceinline__ void sg_hit_angles_all(const uint32_t (&w)[N], int L,
 template <typename T, int LMAX, int STRIDE, bool DEFER = false, bool COMPACT = false>
 __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const SgTable tab, double beam_div_deg, double *s_a1, double *s_a2,
                                             double *s_rho, int *s_cnt, int *s_key, int *s_st, int tid, SgBeamOut &out, T &d_t, double &theta_c,
-                                            bool EXACT_TAN, double *ov_blk = nullptr, int ov_cap = 0)
+                                            bool EXACT_TAN, double *ov_blk = nullptr, int ov_cap = 0, int *s_mark = nullptr)
 {
     // ov_blk: overflow slot of the block's column 0 (the slots follow the columns), or null.  Flakes LMAX .. ov_cap - 1 of a beam go
     // to its slot as they are met (the caller adds the first LMAX and the header if the beam ends up within ov_cap).
@@ -427,14 +477,18 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
     s_st[2 * tid] = (int)st0; s_st[2 * tid + 1] = (int)st2;
     asm volatile("" ::: "memory");
     const int cnt = n0 + n1;
-    int incl = cnt;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int incl = sg_wave_incl_add(cnt);
     const int excl = incl - cnt;
-    const int total = __shfl(incl, 63);
+    const int total = sg_wave_last(incl);
     const unsigned long long ent_bits = (unsigned long long)tab.entries;
     for (int base = 0; base < total; base += SG_PAIR_WINDOW) {
         const int p = base + lane;
         const bool valid = p < total;
+#if defined(SG_SCAN_OWNER_MARKS)
+        const int o = sg_pair_owner(s_mark, tid, base, excl, incl);    // first lane whose inclusive count exceeds p
+#else
+        // (sg_pair_owner here -- marks and a prefix maximum instead of the search -- was measured: the pass 6 % slower; the search's cross-lane
+        // reads overlap the record loads of the trip before, the marks' LDS writes and 24 B of spilled registers did not pay for them)
         int lo = 0, hi = 63;                                    // owner = first lane whose inclusive count exceeds p
         for (int it = 0; it < 6; ++it) {
             const int mid = (lo + hi) >> 1;
@@ -442,6 +496,7 @@ __device__ __forceinline__ int sg_wave_scan(bool act, T px, T py, T pz, const Sg
             if (v > p) hi = mid; else lo = mid + 1;
         }
         const int o = lo & 63;
+#endif
         const int j = p - __shfl(excl, o);
         const int n0o = __shfl(n0, o);
         const uint32_t st0o = (uint32_t)s_st[2 * (wbase + o)], st2o = (uint32_t)s_st[2 * (wbase + o) + 1];
@@ -1069,12 +1124,10 @@ __device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__rest
 {
     static_assert(STRIDE > 0, "LDS lists only");
     const int lane = (int)(threadIdx.x & 63);
-    int incl = nw;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    const int incl = sg_wave_incl_add(nw);
     const int excl = incl - nw;
-    const int total = __shfl(incl, 63);
-    int maxn = nw;
-    for (int o = 32; o > 0; o >>= 1) { const int v = __shfl_xor(maxn, o); maxn = v > maxn ? v : maxn; }
+    const int total = sg_wave_last(incl);
+    const int maxn = sg_wave_last(sg_wave_incl_max(nw));
     for (int base = 0; base < total; base += 64) {
         const int p = base + lane;
         const bool valid = p < total;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "sg_common.h"
+#include "sg_beam.h"
 
 __device__ __forceinline__ int sg_find_frame(const int64_t *__restrict__ off, int n_frames, int64_t g)
 {
@@ -45,12 +46,20 @@ __device__ __forceinline__ const T *sg_row(const SgBeamArgs &a, int f, int64_t g
 __device__ __forceinline__ void sg_add_diff2(unsigned long long *diff2, bool live, int f, long long d2)
 {
     unsigned long long todo = __ballot(live && d2 != 0);
+    if (!todo) return;
+    // addends below 2^24 in size (they are: twice an intensity difference): the wave's sum fits an int and a DPP prefix sum folds it;
+    // anything else takes the 64-bit butterfly
+    const bool small = __ballot(live && (d2 >= (1 << 24) || d2 <= -(1 << 24))) == 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
-        const int fl = __shfl(f, leader);
+        const int fl = __builtin_amdgcn_readlane(f, leader);
         const bool mine = live && f == fl;
-        long long part = mine ? d2 : 0;
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        long long part;
+        if (small) part = (long long)__builtin_amdgcn_readlane(sg_wave_incl_add(mine ? (int)d2 : 0), 63);
+        else {
+            part = mine ? d2 : 0;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        }
         if ((int)(threadIdx.x & 63) == leader && part != 0) atomicAdd(&diff2[fl], (unsigned long long)part);
         todo &= ~__ballot(mine);
     }

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
     int *s_cnt = DICT ? (COMPACT ? (int *)(reinterpret_cast<uint32_t *>(s_a1) + ROWS * BLOCK) : (int *)(s_rho + ROWS * BLOCK)) : nullptr;   // wave scan: flakes met per beam ...
     int *s_key = DICT ? s_cnt + (BLOCK < 64 ? 64 : BLOCK) : nullptr;      // ... and the scan order of the stored ones
     int *s_st = DICT ? s_key + LMAX * BLOCK : nullptr;                    // ... and where its two bins start (two ints per lane)
+    int *s_mark = DICT ? s_st + 2 * (BLOCK < 64 ? 64 : BLOCK) : nullptr;  // ... and the owner marks of a trip of its pair loop (sg_pair_owner)
     const int tid = threadIdx.x;
     const int n_las = a.las->n;
     int64_t work_n = 0, work_off = 0;
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, (!LIST && DICT == 1 && BLO
             // DICT == 1: distance tests too close to call are not decided here (sg_beam.h: sg_near_ray); DICT == 2 (exact-math mode) and the
             // wave scan in a tier: every test by the reference's expression, in place
             L = sg_wave_scan<T, LMAX, BLOCK, !LIST && DICT == 1, COMPACT>(act, px, py, pz, tab, a.beam_div_deg, s_a1, s_a2, s_rho, s_cnt, s_key, s_st, tid, o, d_t, theta_c,
-                                                                          a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0);
+                                                                          a.exact_math != 0, ov_blk, ov_blk ? a.ov_cap : 0, s_mark);
             if (ov_blk && act && o.overflow && o.n_hits <= a.ov_cap) {   // header and the flakes the LDS list holds: the slot is complete
                 double *sp = ov_blk + (size_t)tid * SG_OV_STRIDE;
                 sp[0] = (double)d_t; sp[1] = theta_c;
@@ -1087,11 +1088,23 @@ __global__ __launch_bounds__(64, 2) void k_power_all(SgBeamArgs a, SgKpAll u)
 // 9.58 / 11.03 without any such kernel); N = 3: 4.32, 9.77, 9.48 (and C1: 8.98 without, 8.58 with N = 2, 8.78 with N = 3).
 // Tried and dropped: the kernel beside k_power on another stream, two or three blocks per CU instead of four (all 1 - 10 % slower:
 // the persistent kernels of this phase do best when each has the chip to itself for its turn).
+// one step of the segmented fold of k_power_few's pair loop: take (sum, bin) of the lane the DPP control names if it belongs to the same beam
+// and holds the larger sum (equal sums: the smaller bin)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void sg_fold_step(double &sm, int &kk, int oo)
+{
+    const int o2 = sg_dpp<CTRL, ROW_MASK>(oo, oo), k2 = sg_dpp<CTRL, ROW_MASK>(kk, kk);
+    const int lo = sg_dpp<CTRL, ROW_MASK>(__double2loint(sm), __double2loint(sm)), hi = sg_dpp<CTRL, ROW_MASK>(__double2hiint(sm), __double2hiint(sm));
+    const double s2 = __hiloint2double(hi, lo);
+    if (o2 == oo && (s2 > sm || (s2 == sm && k2 < kk))) { sm = s2; kk = k2; }
+}
+
 template <typename T, int N>
 __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)   // (N = 3: 127 registers and eight spilled; at three waves per SIMD, 143 registers, it was slower on every workload)
 {
     __shared__ double s_amp[N + 1][256], s_rho[N + 1][256], s_best[256];      // scatterer N: the hard target
     __shared__ int s_win[N + 1][256], s_zone[N + 1][256], s_k[256];           // k0 | k1 << 16;  first bin | bins << 16
+    __shared__ int s_mark[256];                                               // owner marks of a trip of the pair loop (sg_pair_owner)
     const int tid = (int)threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int n_items = a.pw_count[1];
     const int step = (int)gridDim.x * 4;
@@ -1138,20 +1151,13 @@ __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)
         for (int z = 0; z <= N; ++z) s_zone[z][tid] = zone[z];
         s_best[tid] = 0.0; s_k[tid] = 0;
         asm volatile("" ::: "memory");                // written and read by the lanes of one wave: LDS keeps a wave's operations in order
-        int incl = n;
-        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        const int incl = sg_wave_incl_add(n);
         const int excl = incl - n;
-        const int total = __shfl(incl, 63);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         for (int base = 0; base < total; base += 64) {
             const int p = base + lane;
             const bool valid = p < total;
-            int lo = 0, hi = 63;                      // owner = first lane whose inclusive count exceeds p
-            for (int s6 = 0; s6 < 6; ++s6) {
-                const int mid = (lo + hi) >> 1;
-                const int v = __shfl(incl, mid);
-                if (v > p) hi = mid; else lo = mid + 1;
-            }
-            const int ow = lo & 63;
+            const int ow = sg_pair_owner(s_mark, tid, base, excl, incl);   // first lane whose inclusive count exceeds p
             int j = p - __shfl(excl, ow);
             double sm = -1.0;
             int kk = 0x7fffffff, oo = 64 + lane;      // (a lane without a pair: a run of its own)
@@ -1178,12 +1184,12 @@ __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)
                 kk = k; oo = ow;
             }
             // the pairs of one beam are neighbours: fold them towards the last lane of the run (larger sum; equal sums: smaller bin)
-            for (int off = 1; off < 64; off <<= 1) {
-                const double s2 = __shfl_up(sm, off);
-                const int k2 = __shfl_up(kk, off), o2 = __shfl_up(oo, off);
-                if (lane >= off && o2 == oo && (s2 > sm || (s2 == sm && k2 < kk))) { sm = s2; kk = k2; }
-            }
-            const int on = __shfl_down(oo, 1);
+            // (a segmented prefix maximum: DPP row shifts, then the last lane of a row to the rows after it -- a lane whose source does not
+            // exist reads its own values back, which changes nothing; the result in the last lane of a run is the run's first maximum
+            // whatever the tree, the runs being contiguous)
+            sg_fold_step<0x111, 0xf>(sm, kk, oo); sg_fold_step<0x112, 0xf>(sm, kk, oo); sg_fold_step<0x114, 0xf>(sm, kk, oo); sg_fold_step<0x118, 0xf>(sm, kk, oo);
+            sg_fold_step<0x142, 0xa>(sm, kk, oo); sg_fold_step<0x143, 0xc>(sm, kk, oo);
+            const int on = sg_dpp<0x130, 0xf>(oo, oo);      // wave_shl:1 -- the next lane's owner (lane 63: its own, and the test below knows)
             if (valid && (lane == 63 || on != oo)) {  // ... which folds it into the beam's cell (its bins may come in two rounds)
                 volatile double *vb = s_best;
                 volatile int *vk = s_k;
@@ -1864,7 +1870,7 @@ static int launch_beams_t(const SgBeamArgs *a, hipStream_t st)
 {
     // (the pass over all rows: ranges + one word per listed flake; a list-mode scan: three double columns -- see k_beams)
     const size_t lds = DICT ? (LIST ? sizeof(double) * (size_t)BLOCK * 3 * (size_t)LMAX : (sizeof(double) + sizeof(uint32_t)) * (size_t)BLOCK * (size_t)LMAX)
-                                  + sizeof(int) * (3 * (size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
+                                  + sizeof(int) * (4 * (size_t)(BLOCK < 64 ? 64 : BLOCK) + (size_t)LMAX * BLOCK)
                             : sizeof(double) * (size_t)BLOCK * 4 * ((size_t)LMAX + 1);
     static bool attr_set[64] = {};
     if (int e = sg_set_lds(k_beams<T, LMAX, BLOCK, LIST, DICT>, lds, attr_set)) return e;
