@@ -58,6 +58,26 @@ __device__ __forceinline__ int sg_wave_incl_max(int v) { return v; }
 __device__ __forceinline__ int sg_wave_last(int v) { return v; }
 #endif
 
+// one step of the segmented fold of a pair loop (k_power_few, sg_wave_eval): take (sum, bin) of the lane the DPP control names if it belongs to the same beam
+// and holds the larger sum (equal sums: the smaller bin)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void sg_fold_step(double &sm, int &kk, int oo)
+{
+    const int o2 = sg_dpp<CTRL, ROW_MASK>(oo, oo), k2 = sg_dpp<CTRL, ROW_MASK>(kk, kk);
+    const int lo = sg_dpp<CTRL, ROW_MASK>(__double2loint(sm), __double2loint(sm)), hi = sg_dpp<CTRL, ROW_MASK>(__double2hiint(sm), __double2hiint(sm));
+    const double s2 = __hiloint2double(hi, lo);
+    if (o2 == oo && (s2 > sm || (s2 == sm && k2 < kk))) { sm = s2; kk = k2; }
+}
+
+// the whole fold: a segmented prefix maximum -- DPP row shifts, then the last lane of a row to the rows after it.  A lane whose source does
+// not exist reads its own values back, which changes nothing; the last lane of a run of equal `oo` ends up with the run's first maximum
+// whatever the tree, the runs being contiguous.  Every lane of the wave must be active.
+__device__ __forceinline__ void sg_fold_runs(double &sm, int &kk, int oo)
+{
+    sg_fold_step<0x111, 0xf>(sm, kk, oo); sg_fold_step<0x112, 0xf>(sm, kk, oo); sg_fold_step<0x114, 0xf>(sm, kk, oo); sg_fold_step<0x118, 0xf>(sm, kk, oo);
+    sg_fold_step<0x142, 0xa>(sm, kk, oo); sg_fold_step<0x143, 0xc>(sm, kk, oo);
+}
+
 // Owner of pair p = base + lane when the lanes' beams hold [excl, incl) of the wave's pair numbers: the first lane whose inclusive count
 // exceeds p.  Every beam with pairs leaves its lane number at its first pair's place in the window (s_mark: one int per lane of the
 // block), a beam that began before the window leads it, and a prefix maximum carries the marks forward: two LDS writes, one read and
@@ -1127,7 +1147,7 @@ __device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__rest
     const int incl = sg_wave_incl_add(nw);
     const int excl = incl - nw;
     const int total = sg_wave_last(incl);
-    const int maxn = sg_wave_last(sg_wave_incl_max(nw));
+    [[maybe_unused]] const int maxn = sg_wave_last(sg_wave_incl_max(nw));
     for (int base = 0; base < total; base += 64) {
         const int p = base + lane;
         const bool valid = p < total;
@@ -1150,12 +1170,24 @@ __device__ __forceinline__ void sg_wave_eval(int nw, int S, const double *__rest
             sg_eval_group<STRIDE, EXACT, NB>(g, 0, So, rgrid, s_a1, s_a2, s_rho, tid, sg_kp_k0(tpk), sg_kp_k1(tpk),
                                              s_a1[SG_IDX(So)], s_rho[SG_IDX(So)], gbest, gk, 0);
         }
+#if !defined(SG_EVAL_FOLD_LOOP)
+        // a beam's groups are neighbouring pairs: fold every run towards its last lane (sg_fold_runs), and the owner reads that one lane --
+        // three cross-lane reads per trip instead of three per group of the wave's longest list
+        sg_fold_runs(gbest, gk, valid ? o : 64 + lane);
+        {
+            const int qs = excl - base, qe = incl - 1 - base < 63 ? incl - 1 - base : 63;   // my run inside this window
+            const double gb = __shfl(gbest, qe & 63);
+            const int k = __shfl(gk, qe & 63);
+            if (nw > 0 && qe >= 0 && qs < 64 && (gb > best || (gb == best && k < k_best))) { best = gb; k_best = k; }
+        }
+#else
         for (int r = 0; r < maxn; ++r) {                        // (cross-lane reads outside divergent code)
             const int q = excl + r - base;
             const double gb = __shfl(gbest, q & 63);
             const int k = __shfl(gk, q & 63);
             if (r < nw && q >= 0 && q < 64 && (gb > best || (gb == best && k < k_best))) { best = gb; k_best = k; }
         }
+#endif
     }
 }
 

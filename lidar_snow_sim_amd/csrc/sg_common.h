@@ -9,6 +9,8 @@
 #define SG_NBINS 2048           /* azimuth bins per table: 3.07 mrad, one beam width at 3 mrad */
 #define SG_BIN_MARGIN 1e-6      /* rad; flakes are filed under every bin their angular interval +- margin touches */
 #define SG_BEAM_MARGIN 1e-9     /* rad; a beam scans every bin its wedge +- margin touches */
+#define SG_TBL_STRIDE 16     /* 64-bit words between the per-table counters of the segment builder: one 128-byte line each -- the 16 384 atomics of a
+                               256-sweep batch fall on 64 tables, and sixteen counters to a line queued them behind one another (k_seg_count 30 us) */
 #define SG_BLKREC 8          /* int32 words per block record of the segment order (five used) */
 #define SG_HITS_UNDECIDED 0x40000000   /* in a beam's flake count: a distance test of the pass over all rows was too close to call (sg_beam.h: sg_near_ray) */
 #define SG_MAX_LASERS 256

@@ -918,7 +918,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
                          && b.n_total < ((int64_t)1 << 31);
     if (use_seg) {
         const size_t P = (size_t)b.n_frames * 256;
-        ENSURE(ctx, ctx->seg_tbl_cnt, R->tables.size() + 1); ENSURE(ctx, ctx->seg_tbl_base, R->tables.size() + 1);
+        ENSURE(ctx, ctx->seg_tbl_cnt, (R->tables.size() + 1) * SG_TBL_STRIDE); ENSURE(ctx, ctx->seg_tbl_base, R->tables.size() + 1);
         ENSURE(ctx, ctx->seg_blk, P); ENSURE(ctx, ctx->seg_cnt, P);
         ENSURE(ctx, ctx->seg_frame, P); ENSURE(ctx, ctx->seg_start, P); ENSURE(ctx, ctx->seg_n, 2);
         ENSURE(ctx, ctx->seg_of_blk, ((size_t)((b.n_total + first_block - 1) / first_block) + P) * SG_BLKREC);

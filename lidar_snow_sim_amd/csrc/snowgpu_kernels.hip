@@ -1088,17 +1088,6 @@ __global__ __launch_bounds__(64, 2) void k_power_all(SgBeamArgs a, SgKpAll u)
 // 9.58 / 11.03 without any such kernel); N = 3: 4.32, 9.77, 9.48 (and C1: 8.98 without, 8.58 with N = 2, 8.78 with N = 3).
 // Tried and dropped: the kernel beside k_power on another stream, two or three blocks per CU instead of four (all 1 - 10 % slower:
 // the persistent kernels of this phase do best when each has the chip to itself for its turn).
-// one step of the segmented fold of k_power_few's pair loop: take (sum, bin) of the lane the DPP control names if it belongs to the same beam
-// and holds the larger sum (equal sums: the smaller bin)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void sg_fold_step(double &sm, int &kk, int oo)
-{
-    const int o2 = sg_dpp<CTRL, ROW_MASK>(oo, oo), k2 = sg_dpp<CTRL, ROW_MASK>(kk, kk);
-    const int lo = sg_dpp<CTRL, ROW_MASK>(__double2loint(sm), __double2loint(sm)), hi = sg_dpp<CTRL, ROW_MASK>(__double2hiint(sm), __double2hiint(sm));
-    const double s2 = __hiloint2double(hi, lo);
-    if (o2 == oo && (s2 > sm || (s2 == sm && k2 < kk))) { sm = s2; kk = k2; }
-}
-
 template <typename T, int N>
 __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)   // (N = 3: 127 registers and eight spilled; at three waves per SIMD, 143 registers, it was slower on every workload)
 {
@@ -1157,7 +1146,17 @@ __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)
         for (int base = 0; base < total; base += 64) {
             const int p = base + lane;
             const bool valid = p < total;
+#if !defined(SG_FEW_OWNER_SEARCH)
             const int ow = sg_pair_owner(s_mark, tid, base, excl, incl);   // first lane whose inclusive count exceeds p
+#else
+            int lo = 0, hi = 63;                      // owner = first lane whose inclusive count exceeds p
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(incl, mid);
+                if (v > p) hi = mid; else lo = mid + 1;
+            }
+            const int ow = lo & 63;
+#endif
             int j = p - __shfl(excl, ow);
             double sm = -1.0;
             int kk = 0x7fffffff, oo = 64 + lane;      // (a lane without a pair: a run of its own)
@@ -1184,11 +1183,7 @@ __global__ __launch_bounds__(256, 4) void k_power_few(SgBeamArgs a, int qplanes)
                 kk = k; oo = ow;
             }
             // the pairs of one beam are neighbours: fold them towards the last lane of the run (larger sum; equal sums: smaller bin)
-            // (a segmented prefix maximum: DPP row shifts, then the last lane of a row to the rows after it -- a lane whose source does not
-            // exist reads its own values back, which changes nothing; the result in the last lane of a run is the run's first maximum
-            // whatever the tree, the runs being contiguous)
-            sg_fold_step<0x111, 0xf>(sm, kk, oo); sg_fold_step<0x112, 0xf>(sm, kk, oo); sg_fold_step<0x114, 0xf>(sm, kk, oo); sg_fold_step<0x118, 0xf>(sm, kk, oo);
-            sg_fold_step<0x142, 0xa>(sm, kk, oo); sg_fold_step<0x143, 0xc>(sm, kk, oo);
+            sg_fold_runs(sm, kk, oo);
             const int on = sg_dpp<0x130, 0xf>(oo, oo);      // wave_shl:1 -- the next lane's owner (lane 63: its own, and the test below knows)
             if (valid && (lane == 63 || on != oo)) {  // ... which folds it into the beam's cell (its bins may come in two rounds)
                 volatile double *vb = s_best;
@@ -1323,7 +1318,7 @@ __global__ __launch_bounds__(256) void k_seg_count(const int64_t *__restrict__ f
         resolved[i] = d;
     }
     const SgPair r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
-    if (r.rows > 0) atomicAdd(&tbl_cnt[r.key], (1ull << 32) | (unsigned long long)((r.rows + blk - 1) / blk));
+    if (r.rows > 0) atomicAdd(&tbl_cnt[(size_t)r.key * SG_TBL_STRIDE], (1ull << 32) | (unsigned long long)((r.rows + blk - 1) / blk));
 }
 
 // exclusive scan of the packed per-table counts (both halves at once: neither overflows 32 bits); leaves the counts zero
@@ -1335,12 +1330,12 @@ __global__ __launch_bounds__(1024) void k_seg_scan(unsigned long long *__restric
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024, b0 = t * per, b1 = b0 + per < n ? b0 + per : n;
     unsigned long long sum = 0;
-    for (int k = b0; k < b1; ++k) sum += tbl_cnt[k];
+    for (int k = b0; k < b1; ++k) sum += tbl_cnt[(size_t)k * SG_TBL_STRIDE];
     sc[t] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) { const unsigned long long add = t >= d ? sc[t - d] : 0; __syncthreads(); sc[t] += add; __syncthreads(); }
     unsigned long long run = sc[t] - sum;
-    for (int k = b0; k < b1; ++k) { const unsigned long long c = tbl_cnt[k]; tbl_base[k] = run; run += c; tbl_cnt[k] = 0; }
+    for (int k = b0; k < b1; ++k) { const unsigned long long c = tbl_cnt[(size_t)k * SG_TBL_STRIDE]; tbl_base[k] = run; run += c; tbl_cnt[(size_t)k * SG_TBL_STRIDE] = 0; }
     if (t == 1023) {
         seg_n[0] = (int32_t)(sc[1023] >> 32); seg_n[1] = (int32_t)(sc[1023] & 0xffffffffull);
         if (one_chunk_blk) { one_chunk_blk[0] = 0; one_chunk_blk[1] = (int32_t)(sc[1023] & 0xffffffffull); }   // the pass as ONE launch: all blocks
@@ -1358,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_seg_place(const int64_t *__restrict__ f
     const SgPair r = sg_pair(p, frame_off, tile_base, max_tiles, table_ids, n_las, n_tables);
     if (r.rows <= 0) return;
     const int nb = (r.rows + blk - 1) / blk;
-    const unsigned long long c = atomicAdd(&tbl_cur[r.key], (1ull << 32) | (unsigned long long)nb), base = tbl_base[r.key];
+    const unsigned long long c = atomicAdd(&tbl_cur[(size_t)r.key * SG_TBL_STRIDE], (1ull << 32) | (unsigned long long)nb), base = tbl_base[r.key];
     const int slot = (int)(base >> 32) + (int)(c >> 32);
     const int b0 = (int)(base & 0xffffffffull) + (int)(c & 0xffffffffull);
     seg_start[slot] = r.start; seg_cnt[slot] = r.rows; seg_frame[slot] = (p >> 8) | ((p & 255) << 22); seg_blk[slot] = b0;
@@ -2097,7 +2092,7 @@ extern "C" int sg_launch_segments(const int64_t *frame_off, int n_frames, const 
 {
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)n_frames;         // 256 pairs per frame, one thread each
-    if (hipMemsetAsync(tbl_cnt, 0, sizeof(unsigned long long) * ((size_t)n_tables + 1), st) != hipSuccess) return (int)hipGetLastError();
+    if (hipMemsetAsync(tbl_cnt, 0, sizeof(unsigned long long) * ((size_t)n_tables + 1) * SG_TBL_STRIDE, st) != hipSuccess) return (int)hipGetLastError();
     hipLaunchKernelGGL(k_seg_count, dim3(grid), dim3(256), 0, st, frame_off, n_frames, tile_base, max_tiles, table_ids, n_las, n_tables, block, tbl_cnt,
                        tables, resolved);
     SG_CHECK_LAUNCH();

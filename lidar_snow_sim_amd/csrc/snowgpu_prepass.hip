@@ -416,10 +416,19 @@ __global__ __launch_bounds__(PB) void k_pre_rowmin(PreArgs a)
     const PreFrame fr = a.fr[f];
     const int ng = (int)fr.n_ground;
     int best = 0x7fffffff, bidx = 0x7fffffff;
-    for (int b = threadIdx.x; b < HY; b += PB) {
-        int c = h[b];
+    constexpr int TRIPS = (HY + PB - 1) / PB;
+    int cs[TRIPS];
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {                                    // the row's counts in one round of loads (a load per trip of a loop waited for each)
+        const int b = threadIdx.x + i * PB;
+        cs[i] = b < HY ? h[b] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < TRIPS; ++i) {
+        int c = cs[i];
+        if (c < 0) continue;
         if (c == 0) c = ng;
-        if (c < best) { best = c; bidx = b; }                            // ascending b per thread: first minimum
+        if (c < best) { best = c; bidx = threadIdx.x + i * PB; }         // ascending b per thread: first minimum
     }
     for (int o = 32; o > 0; o >>= 1) {
         const int ob = __shfl_down(best, o), oi = __shfl_down(bidx, o);
