@@ -607,6 +607,9 @@ template <typename T, int LMAX>
 __global__ __launch_bounds__(256, 4) void k_tier_scan_direct(SgBeamArgs a)
 {
     constexpr int P = SG_QPLANES(LMAX);
+    // The rare long-list class: a handful of beams, each a chain of dependent record loads, beside persistent kernels that fill every SIMD --
+    // and everything behind this chain (the step's last link since the prepass got shorter) waits for it.  Its waves go first.
+    if constexpr (LMAX > 16) __builtin_amdgcn_s_setprio(3);
     const int n_las = a.las->n;
     int64_t work_n = a.tier_info[a.cls];
     if (work_n > a.work_hi) work_n = a.work_hi;
@@ -985,6 +988,7 @@ __global__ __launch_bounds__(BLOCK < 64 ? 64 : BLOCK, LMAX <= 4 ? SG_KP_WAVES : 
     constexpr int THREADS = BLOCK < 64 ? 64 : BLOCK, WAVES = THREADS / 64, LANES = BLOCK < 64 ? BLOCK : 64;
     constexpr int WIN = BLOCK < 64 ? 1 : SG_KP_WIN;       // waves' worth of slots per work item
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if constexpr (LMAX > 16) __builtin_amdgcn_s_setprio(3);   // (the rare long-list class: see k_tier_scan_direct)
     const int tid = threadIdx.x;
     int64_t work_n = 0, work_off = 0;
     int n_items;
