@@ -47,7 +47,9 @@
                                  dict: 1, 2 and 3 measured the same) */
 #endif
 #ifndef SG_KP_WAVES
-#define SG_KP_WAVES 2     /* waves per SIMD k_power<4> is compiled for: it runs on half of each CU (two 256-thread blocks), so up to 256 VGPRs cost no residency -- at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
+#define SG_KP_WAVES 3     /* waves per SIMD k_power<4> is compiled for.  3 = 168 VGPRs, 10 spilled (40 B of scratch per lane): same box, against 2 (184 VGPRs,
+                             none spilled) C2 3.71 -> 3.67 ms, C1 6.92 -> 6.86, C2far the same -- the kernel waits on latency, and a third wave per SIMD is worth
+                             more than the spill costs; at 4 (128 VGPRs) it spilled 33 registers and wrote 0.65 GB of scratch per step */
 #endif
 // Beams per wave of the per-beam kernels by list capacity (the LDS lists are strided by it).  The first capacity fills
 // whole 256-thread blocks; 8 and 16 entries run full 64-lane waves; the 63-entry tier runs 16 live lanes per wave (32 KB of
