@@ -1039,7 +1039,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         const int lanes = first_block < 64 ? first_block : 64;
         a.n_regions_ub = use_seg ? (int64_t)b.n_frames * 256 : (b.n_total + a.q_chunk - 1) / a.q_chunk;
         a.blk_rows = first_block;
-        a.kp_lds_quarters = 2;     // k_power's persistent blocks take half of each CU: the later tiers and the prepass run beside it
+        a.kp_lds_quarters = 2;     // k_power's persistent blocks take half of each CU: the later tiers and the prepass run beside it (3 and 4 quarters, with the kernel at 168 VGPRs: C2 + 1 %, C2far + 8 %, C1 + 2 %)
         const size_t items_cap = n / (size_t)lanes + 2 * (size_t)a.n_regions_ub + 64;
         ENSURE(ctx, ctx->pw_items, 2 * items_cap);
         a.pw_items = ctx->pw_items.p;
