@@ -814,15 +814,30 @@ __device__ __forceinline__ void sg_kp_item(const SgBeamArgs &a, char *smem, cons
     if constexpr (WIN > 1) {
         if (sorted) {
             int key[WIN], rank[WIN];
+            // the window's flake counts in one round of loads per level of indirection: every lane reads a valid slot (slot 0 of the window
+            // stands in for those past its end) -- under `idx < cnt` each of the WIN loads waited for the one before
+            int64_t at[WIN];
+            unsigned scw[WIN];
+#pragma unroll
+            for (int r = 0; r < WIN; ++r) { const int idx = r * 64 + lane; at[r] = (int64_t)start + (idx < cnt ? idx : 0); }
+            if (LISTQ && ov_list) {                       // (the branch outside the loops: a branch per slot put a wait behind every load)
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) at[r] = (int64_t)a.tier_list[work_off + at[r]];
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) scw[r] = (unsigned)a.ov_sc[at[r]];
+            } else {
+                if (!LISTQ && slot_list) {
+#pragma unroll
+                    for (int r = 0; r < WIN; ++r) at[r] = (int64_t)slot_list[at[r]];
+                }
+#pragma unroll
+                for (int r = 0; r < WIN; ++r) scw[r] = (unsigned)scs[at[r]];
+            }
 #pragma unroll
             for (int r = 0; r < WIN; ++r) {
                 const int idx = r * 64 + lane;
                 key[r] = 255;                             // past the end of the window: last
-                if (idx < cnt) {
-                    const unsigned sc = (LISTQ && ov_list) ? a.ov_sc[a.tier_list[work_off + start + idx]]
-                                                           : scs[(!LISTQ && slot_list) ? (int64_t)slot_list[start + idx] : (int64_t)start + idx];
-                    key[r] = sc == 0xffffu ? 254 : (int)(sc & 255u);
-                }
+                if (idx < cnt) key[r] = scw[r] == 0xffffu ? 254 : (int)(scw[r] & 255u);
                 rank[r] = 0;
             }
             int base = 0;
@@ -919,10 +934,20 @@ __device__ __forceinline__ void sg_kp_item(const SgBeamArgs &a, char *smem, cons
             } else {
                 s_a1[ltid] = f_a1; s_a2[ltid] = f_a2;
                 if constexpr (!THREE) s_rho[ltid] = f_rho;
-                for (int j = 1; j < L; ++j) {
-                    s_a1[j * BLOCK + ltid] = qb[(2 + 3 * j) * qs];
-                    s_a2[j * BLOCK + ltid] = qb[(3 + 3 * j) * qs];
-                    if constexpr (!THREE) s_rho[j * BLOCK + ltid] = qb[(4 + 3 * j) * qs];
+                if constexpr (LMAX <= 4 && !THREE) {
+                    // every plane of a slot exists, filled or not: the whole list in ONE round of loads (a loop of L - 1 trips waited for each trip's three)
+                    double xa[LMAX - 1], xb[LMAX - 1], xr[LMAX - 1];
+#pragma unroll
+                    for (int j = 1; j < LMAX; ++j) { xa[j - 1] = qb[(2 + 3 * j) * qs]; xb[j - 1] = qb[(3 + 3 * j) * qs]; xr[j - 1] = qb[(4 + 3 * j) * qs]; }
+#pragma unroll
+                    for (int j = 1; j < LMAX; ++j)
+                        if (j < L) { s_a1[j * BLOCK + ltid] = xa[j - 1]; s_a2[j * BLOCK + ltid] = xb[j - 1]; s_rho[j * BLOCK + ltid] = xr[j - 1]; }
+                } else {
+                    for (int j = 1; j < L; ++j) {
+                        s_a1[j * BLOCK + ltid] = qb[(2 + 3 * j) * qs];
+                        s_a2[j * BLOCK + ltid] = qb[(3 + 3 * j) * qs];
+                        if constexpr (!THREE) s_rho[j * BLOCK + ltid] = qb[(4 + 3 * j) * qs];
+                    }
                 }
             }
             auto queue_rho = [&](int j) -> double {       // range of list entry j (THREE: from the queue)
