@@ -907,11 +907,18 @@ __device__ __forceinline__ void sg_kp_item(const SgBeamArgs &a, char *smem, cons
                 if constexpr (THREE) ord = 0;
                 // first every flake into the columns as it lies in the queue -- independent loads, all in flight together --, then
                 // the insertion sort on LDS alone (a load per step of the sort would put a memory latency into every step)
-#pragma unroll 4
-                for (int h = 1; h < L; ++h) {
-                    s_a1[h * BLOCK + ltid] = qb[(2 + 3 * h) * qs];
-                    s_a2[h * BLOCK + ltid] = qb[(3 + 3 * h) * qs];
-                    s_rho[h * BLOCK + ltid] = qb[(4 + 3 * h) * qs];
+                // (eight flakes per round, every load of a round issued before its first store: `#pragma unroll 4` left a remainder loop of up to
+                // three trips that waited for each trip's loads -- seven flakes took four rounds, the 63-entry class up to eighteen)
+                for (int h0 = 1; h0 < L; h0 += 8) {
+                    double xa[8], xb[8], xr[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const int h = h0 + c < L ? h0 + c : 0;     // (past the list: plane 0 again, not stored)
+                        xa[c] = qb[(2 + 3 * h) * qs]; xb[c] = qb[(3 + 3 * h) * qs]; xr[c] = qb[(4 + 3 * h) * qs];
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (h0 + c < L) { s_a1[(h0 + c) * BLOCK + ltid] = xa[c]; s_a2[(h0 + c) * BLOCK + ltid] = xb[c]; s_rho[(h0 + c) * BLOCK + ltid] = xr[c]; }
                 }
                 for (int h = 1; h < L; ++h) {
                     const double x1 = s_a1[h * BLOCK + ltid], x2 = s_a2[h * BLOCK + ltid], r = s_rho[h * BLOCK + ltid];
