@@ -1198,12 +1198,13 @@ __device__ __forceinline__ void sg_beam_decide(double d, int channel, const SgLa
                                                SgBeamOut &out)
 {
     const int max_i = las->max_i[channel], min_i = las->min_i[channel];
+    const double f_slope = las->focal_slope[channel], f_offset = las->focal_offset[channel];   // (the laser's four constants in one round of loads)
     const double c_tau = 299792458.0 * 1e-8;
-    const double i_snow = 0.9 * max_i;
     double i_max = best;                                        // :152
     const double d_max = ((double)k_best / 10) - (c_tau / 2);   // :153
     const double t1 = 1 - d_max / 120;
-    i_max += max_i * las->focal_slope[channel] * fabs(las->focal_offset[channel] - t1 * t1);   // :155
+    const double i_snow = 0.9 * max_i;
+    i_max += max_i * f_slope * fabs(f_offset - t1 * t1);        // :155
     if (i_max < min_i) i_max = min_i;                           // :156
     if (i_max > max_i) i_max = max_i;
     long long new_i = (long long)i_max;                         // :162 / :182

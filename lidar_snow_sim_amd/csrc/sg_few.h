@@ -30,6 +30,7 @@ __device__ __forceinline__ int sg_few_prep(double d, double theta_c, int L, cons
 {
     constexpr bool F32 = SgReal<T>::is_f32;
     static_assert(N >= 1 && N <= 3, "an owner must stay below eight slots (2 N + 1 <= 7)");
+    const int max_i = las->max_i[channel];                     // (asked for here, used in phase 3a: the load flies while phase 2 computes)
     // -- phase 2
     double a1[N], a2[N];
     double theta_r, theta_l;
@@ -79,7 +80,6 @@ __device__ __forceinline__ int sg_few_prep(double d, double theta_c, int L, cons
         e = nxt;
     }
     // -- phase 3a for the owners, closed up near -> far (simulation.py:137-146)
-    const int max_i = las->max_i[channel];
     const double c_tau = 299792458.0 * 1e-8;
     const double beta_0 = 1 * 1e-6 / SG_PI;
     const double i_snow = 0.9 * max_i;
