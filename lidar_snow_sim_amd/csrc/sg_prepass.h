@@ -34,6 +34,8 @@ int sg_prepass_run(SgPrepassScratch *s, const void *rows, int dtype, const int64
                    void *stream, int tiles_done, const void *srows, const int32_t *frame_unsorted, int hist_cleared);
 // clears the prepass' histogram on `stream` ahead of time (independent of the batch's data): sg_prepass_run(.., hist_cleared = 1) then skips its fill
 int sg_prepass_clear_hist(SgPrepassScratch *s, int n_frames, void *stream);
+int sg_prepass_stats_early(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t max_frame,
+                           const double *plane, void *stream);
 double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, int64_t max_frame);
 int sg_wet_run(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off,
                const int64_t *frame_cnt, int n_frames, int64_t n_total, int64_t max_frame, const double *plane, const SgWetParams *wp, double *out_rows, int32_t *out_src,

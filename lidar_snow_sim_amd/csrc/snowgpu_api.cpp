@@ -238,6 +238,7 @@ struct snowgpu_ctx {
     bool tier_rows_auto = true;       // row kernels for the tiers of small batches (SNOWGPU_TIER_ROWS=0 switches that off too)
     bool tier_rows = false;           // SNOWGPU_TIER_ROWS=1: the later tiers as row kernels (snowgpu_rows.hip: G lanes per beam) -- measured slower, kept for A/B
     hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};     // snowgpu_lane_stream: one per priority level, made on demand
+    int stats_early = -1;             // SNOWGPU_STATS_EARLY=0 / 1: the prepass' per-tile statistics inside the sort's first pass / as a kernel of their own on the prepass stream (default: the latter for batches of more than 16 frames)
     int prepass_with_few = -1;        // SNOWGPU_PREPASS_WITH_FEW=0 / 1: never / always start the prepass beside k_power_few (default: long-tail batches only)
     bool serial = false;              // experiments: SNOWGPU_SERIAL=1 keeps every kernel on the caller's stream (pure kernel times)
     DevBuf<int32_t> chunk_blk;
@@ -430,6 +431,7 @@ extern "C" int snowgpu_create(int device, snowgpu_ctx **out)
     { const char *v = std::getenv("SNOWGPU_FEW"); ctx->few = v ? std::max(0, std::min(3, std::atoi(v))) : 2; }
     { const char *v = std::getenv("SNOWGPU_HEAVY_TAIL"); ctx->heavy_tail = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_SERIAL"); ctx->serial = v && v[0] == '1'; }
+    { const char *v = std::getenv("SNOWGPU_STATS_EARLY"); ctx->stats_early = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_PREPASS_WITH_FEW"); ctx->prepass_with_few = v ? (v[0] == '1' ? 1 : 0) : -1; }
     { const char *v = std::getenv("SNOWGPU_KP_ALL"); if (v) ctx->kp_all = v[0] != '0'; }
     { const char *v = std::getenv("SNOWGPU_KP_ALL_WAVES"); if (v) ctx->kp_all_waves = std::min(std::max(std::atoi(v), 1), 8); }
@@ -841,6 +843,11 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         if (!lean_part) return fail(ctx, SNOWGPU_E_HIP, "prepass: allocation");
     }
     bool hist_early = false;
+    // Large batches take the statistics out of the sort again: as a kernel of their own on the prepass stream, behind the histogram fill, they
+    // run beside the sort and the scan (the sort's first pass 0.33 -> 0.20 ms on the step's critical path, the scan a little slower for the
+    // company: C2 - 0.7 %, C2fire - 0.8 %, C3 - 0.9 % on one box).  Same sums in the same order as inside the sort (k_lean_stats deals the
+    // rows to its threads as k_sort_hist does): same bits.  Only with a caller's plane -- nothing on `st` has to make it first.
+    const bool stats_early = fuse_stats && !serial && early_plane == b.plane && (R->stats_early < 0 ? b.n_frames > 16 : R->stats_early == 1);
     auto launch_prepass = [&]() -> int {
         HIPCHK(ctx, hipEventRecord(ctx->ev_fork0, st));
         HIPCHK(ctx, hipStreamWaitEvent(s_aux2, ctx->ev_fork0, 0));
@@ -877,6 +884,10 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
             int he = sg_prepass_clear_hist(&ctx->prepass, b.n_frames, s_aux2);
             if (he) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass: ") + (he > 0 ? hipGetErrorString((hipError_t)he) : "allocation"));
             hist_early = true;
+            if (fuse_stats && stats_early) {
+                int se = sg_prepass_stats_early(&ctx->prepass, b.rows, b.dtype, b.frame_off, b.n_frames, b.max_frame, early_plane, s_aux2);
+                if (se) return fail(ctx, SNOWGPU_E_HIP, std::string("prepass statistics: ") + (se > 0 ? hipGetErrorString((hipError_t)se) : "allocation"));
+            }
         }
     } else if (b.out_thr_poly) {
         HIPCHK(ctx, hipMemcpyAsync(b.out_thr_poly, thr, sizeof(double) * 3 * (size_t)b.n_frames, hipMemcpyDeviceToDevice, st));
@@ -897,7 +908,7 @@ static int run_batch(snowgpu_ctx *ctx, BatchDev &b)
         // (first pass and per-frame scan here; the second pass -- the sorted copy of unsorted frames -- further down, so that the segment
         // builder, which needs the scan only, runs on its side stream beside it)
         int e = sg_launch_sort(b.rows, b.dtype, b.frame_off, b.n_frames, b.n_total, ctx->tile_hist.p, ctx->tile_base.p,
-                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, fuse_stats ? early_plane : nullptr, lean_part,
+                               ctx->rank.p, ctx->keep.p, ctx->perm.p, b.status, max_tiles, (fuse_stats && !stats_early) ? early_plane : nullptr, (fuse_stats && !stats_early) ? lean_part : nullptr,
                                ctx->tile_unsorted.p, ctx->frame_unsorted.p, ctx->srows.p, b.want_perm ? 1 : 0, 1, st);
         if (e) return fail(ctx, SNOWGPU_E_HIP, std::string("sort launch: ") + hipGetErrorString((hipError_t)e));
         perm = ctx->perm.p;

@@ -770,8 +770,11 @@ __global__ __launch_bounds__(PB) void k_lean_stats(PreArgs a)
     const T *rows = (const T *)a.rows;
     T rx[4], ry[4], rz[4], ri[4];                // all loads of the tile in flight before the first use
     bool valid[4];
+    // rows to threads as the channel sort's first kernel deals them (wave w: rows [256 w, 256 w + 256) of the tile in four rounds of 64): the
+    // statistics taken there and here are then the same sums in the same order -- the same bits whichever kernel a call uses
+    const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
     for (int q = 0; q < 4; ++q) {
-        const int64_t r = tile0 + q * PB + threadIdx.x;
+        const int64_t r = tile0 + w * 256 + q * 64 + lane;
         valid[q] = r < n;
         const T *p = rows + (base + (valid[q] ? r : 0)) * 5;
         rx[q] = p[0]; ry[q] = p[1]; rz[q] = p[2]; ri[q] = p[3];
@@ -1388,6 +1391,24 @@ extern "C" double *sg_prepass_reserve_tiles(SgPrepassScratch *s, int n_frames, i
     const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
     if (ensure(s, B_PART, (size_t)n_frames * (size_t)max_tiles * LP_COLS * 8)) return nullptr;
     return (double *)s->buf[B_PART];
+}
+
+// The per-tile statistics as a kernel of their own, ahead of the prepass proper (the tiles are reserved: sg_prepass_reserve_tiles; the plane is
+// known): on the prepass stream beside the sort and the scan instead of inside the sort's first pass.  sg_prepass_run is then told tiles_done = 1.
+extern "C" int sg_prepass_stats_early(SgPrepassScratch *s, const void *rows, int dtype, const int64_t *frame_off, int n_frames, int64_t max_frame,
+                                      const double *plane, void *stream)
+{
+    PreArgs a{};
+    a.rows = rows; a.frame_off = frame_off; a.n_frames = n_frames; a.plane = plane; a.delta = 0.5; a.flat_earth = 0; a.cos_only = 1;
+    const int64_t max_tiles = (max_frame + SG_TILE - 1) / SG_TILE > 0 ? (max_frame + SG_TILE - 1) / SG_TILE : 1;
+    a.max_tiles = max_tiles;
+    a.part = (double *)s->buf[B_PART];
+    if (!a.part) return -1;
+    dim3 grid((unsigned)max_tiles, (unsigned)n_frames);
+    if (dtype == 0) hipLaunchKernelGGL(k_lean_stats<float>, grid, dim3(PB), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_lean_stats<double>, grid, dim3(PB), 0, (hipStream_t)stream, a);
+    LCHK();
+    return 0;
 }
 
 // The histogram of the snowfall prepass, cleared ahead of time: the fill depends on nothing of the batch, so it can run on the prepass
